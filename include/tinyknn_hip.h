@@ -1,0 +1,154 @@
+/*
+ * tinyknn_hip.h — C ABI of libtinyknn_hip.so, the MI355X (gfx950) implementation
+ * of the ONE hot path of thomasahle/tinyknn: the Quick-ADC 4-bit PQ code scan, the
+ * bounded order-dependent top-R heap, the per-query distance table and the exact
+ * rescoring that sit behind FastPQ / _FastDistanceTable / IVF.query.
+ *
+ * Every entry point names the reference interface it replaces (file:line relative
+ * to the reference repository).  Plain pointers and sizes only; no torch types.
+ * Conventions
+ *   - return value: 0 = ok, <0 = error; tk_last_error() gives the text
+ *     (the reference kernels are void/nogil and cannot fail; its Python layer
+ *     raises AssertionError — the Python binding maps error codes to that).
+ *   - pointers are HOST pointers unless the parameter name ends in _dev;
+ *     buffers are caller-owned, written in place, nothing is retained
+ *     (same ownership rule as the Cython memoryview arguments).
+ *   - `order`: accumulation order of the saturating int8 sum.
+ *     TK_ORDER_SSE = _fast_pq.pyx:209-236 (one accumulator),
+ *     TK_ORDER_AVX = _fast_pq_256.pyx:126-156 (two accumulators, merged last);
+ *     the reference's public API uses AVX (fast_pq.py:21-24).
+ *   - `stream`: a hipStream_t passed as void* (NULL = the default stream).  Device
+ *     entry points only enqueue work; host-pointer entry points synchronise.
+ * There is no CPU fallback: without a usable GPU every compute call fails.
+ */
+#ifndef TINYKNN_HIP_H
+#define TINYKNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TK_ORDER_SSE 0
+#define TK_ORDER_AVX 1
+
+#define TK_OK 0
+#define TK_ERR_ARG (-1)     /* bad argument (shape/size contract violated)   */
+#define TK_ERR_HIP (-2)     /* HIP runtime error                              */
+#define TK_ERR_STATE (-3)   /* index not fully populated for this call        */
+
+/* ---- library -------------------------------------------------------------- */
+const char *tk_last_error(void);
+int tk_version(void);
+/* number of visible GPUs; 0 when there is none (compute calls then fail) */
+int tk_device_count(void);
+int tk_set_device(int device);
+
+/* ---- drop-in kernels on host buffers -------------------------------------- */
+
+/* estimate_pq_sse(data, tables, out, signd)  _fast_pq.pyx:101-111
+ * estimate_pq_avx(...)                       _fast_pq_256.pyx:52-62
+ * data: uint64 (chunks, M) Quick-ADC layout (_transform.py:4-77); tables: uint64
+ * (2M,) (_transform.py:114-138); out: uint64 (>= 2*chunks,), 16 int8/uint8 per chunk. */
+int tk_estimate_pq(const uint64_t *data, int64_t chunks, int M, const uint64_t *tables,
+                   uint64_t *out, int signd, int order);
+
+/* Batched form of the same call: nq tables (nq, 2M) against one code array,
+ * out (nq, 2*chunks).  What examples/example.py:60-66 does in a Python loop. */
+int tk_estimate_pq_batch(const uint64_t *data, int64_t chunks, int M,
+                         const uint64_t *tables, int64_t nq, uint64_t *out, int signd,
+                         int order);
+
+/* query_pq_sse(data, n, tables, indices, vals, signd, labels=None)  _fast_pq.pyx:114-206
+ * query_pq_avx(...)                                                 _fast_pq_256.pyx:65-123
+ * indices int64 (R,), vals int32 (R,) are read AND written (one heap is threaded
+ * through several calls, ivf.py:137-150).  labels: int64 (>= n,) or NULL. */
+int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t n,
+                const uint64_t *tables, int64_t *indices, int32_t *vals, int R, int signd,
+                const int64_t *labels, int order);
+
+/* init_heap(indices, vals, signd)   _fast_pq.pyx:240-252 */
+int tk_init_heap(int64_t *indices, int32_t *vals, int R, int signd);
+/* insert(indices, vals, i, v)       _fast_pq.pyx:274-307 */
+int tk_heap_insert(int64_t *indices, int32_t *vals, int R, int64_t i, int32_t v);
+/* insert_is(indices, vals, i, v)    _fast_pq.pyx:256-271 */
+int tk_heap_insert_is(int64_t *indices, int32_t *vals, int R, int64_t i, int32_t v);
+
+/* FastPQ.distance_table / udistance_table   fast_pq.py:186-222 / :224-252
+ * centers: float32 (16, dq) row-major; f_order != 0 when the caller's array was
+ * F-ordered (dims_per_block == 1 leaves such a view, fast_pq.py:99-101; numpy then
+ * sums the mean in that order).  q: (nq, dq) padded (and rotated) queries, float32
+ * (q_is_f64 == 0) or float64.  aux0/aux1: signed: sqrt_n_blocks, unused;
+ * unsigned: log(n_blocks), sqrt(n_blocks).  Outputs: tables uint8 (nq, M, 16) (the
+ * transform_tables byte image), shift (nq,) in q's dtype, scale float64 (nq,). */
+int tk_build_tables(const float *centers, int dq, int dpb, int f_order, const void *q,
+                    int q_is_f64, int64_t nq, double aux0, double aux1, int signd,
+                    uint8_t *tables, void *shift, double *scale);
+
+/* knn_brute1(x, Y, k)  utils.py:89-92 (+ bottom_k :22-25): squared distances of
+ * the n rows of Y (n, d) float32 to x (d,), positions of the k smallest in
+ * ascending order (ties: lower position first).  k >= n returns arange(n).
+ * out_pos: int64 (min(k, n),).  Returns the count written, or <0. */
+int64_t tk_knn_brute1(const float *x, const float *Y, int64_t n, int d, int64_t k,
+                      int64_t *out_pos);
+
+/* ---- device-resident IVF index --------------------------------------------
+ * Holds what the reference's IVF object holds after fit+build (ivf.py:14-17,
+ * 77-102) in HBM, re-tiled for coalesced scans, and answers batches of queries
+ * with the kernel pipeline that replaces IVF.query (ivf.py:106-163). */
+typedef struct tk_index tk_index;
+
+tk_index *tk_index_create(void);
+void tk_index_destroy(tk_index *ix);
+
+/* FastPQ state: centers (16, dq) float32, dims_per_block, sqrt_n_blocks
+ * (fast_pq.py:99-102); f_order as in tk_build_tables; order = TK_ORDER_*. */
+int tk_index_set_pq(tk_index *ix, const float *centers, int dq, int dpb, int f_order,
+                    double sqrt_n_blocks, int order);
+/* active_centers (n_lists, d) float32 and their packed codes
+ * pq_transformed_centers.packed (center_chunks, M)   ivf.py:91-96 */
+int tk_index_set_centers(tk_index *ix, const float *active_centers, int64_t n_lists, int d,
+                         const uint64_t *center_codes, int64_t center_chunks);
+/* pq_transformed_points / ids (ivf.py:100-102) flattened list-major:
+ * list_sizes (n_lists,) true rows; codes (sum ceil(size/16), M) packed chunks;
+ * ids (sum size,) labels. */
+int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const uint64_t *codes,
+                       const int64_t *ids);
+/* IVF.data: the (normalised) float32 vectors used for rescoring  ivf.py:77-79 */
+int tk_index_set_data(tk_index *ix, const float *data, int64_t N, int d);
+
+/* Largest batch the workspace is currently sized for grows on demand; this call
+ * pre-sizes it (so that tk_index_query_batch_dev never allocates, e.g. under
+ * stream capture). */
+int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, int pass_1);
+
+/* IVF.query for a batch  ivf.py:106-163.
+ * q: (nq, d) float32 queries AFTER the metric's normalisation (ivf.py:125-127 is
+ * done by the host binding with numpy, as the reference does);
+ * q_pq: (nq, dq) padded (rotated) queries for the table build, float32 or float64.
+ * pass_1 <= 0 selects (n_probes+1)*k+1 (ivf.py:135-136).
+ * out_ids: int64 (nq, k), rows padded with -1 when fewer than k ids exist.
+ * Optional debug outputs (NULL to skip): out_probes int64 (nq, min(n_probes,n_lists)),
+ * out_heap_idx int64 (nq, pass_1), out_heap_val int32 (nq, pass_1). */
+int tk_index_query_batch(tk_index *ix, const float *q, const void *q_pq, int q_pq_is_f64,
+                         int64_t nq, int k, int n_probes, int pass_1, int64_t *out_ids,
+                         int64_t *out_probes, int64_t *out_heap_idx, int32_t *out_heap_val);
+
+/* Same with device-resident inputs/outputs, enqueued on `stream`, no sync. */
+int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_dev,
+                             int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                             int64_t *out_ids_dev, void *stream);
+
+/* Timing of the stages of the last tk_index_query_batch[_dev] call when profiling
+ * was switched on with tk_index_set_profiling(ix, 1): milliseconds per stage
+ * [tables, coarse_scan, coarse_heap, coarse_rescore, scan, heap, rescore] and the
+ * algorithmic bytes the list-scan kernel was asked to stream.
+ * Synchronises the stream. */
+int tk_index_set_profiling(tk_index *ix, int on);
+int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

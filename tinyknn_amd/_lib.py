@@ -1,0 +1,104 @@
+"""ctypes loader of libtinyknn_hip.so (C ABI: include/tinyknn_hip.h).
+
+The HIP library is the only implementation of the hot path; there is no CPU
+fallback.  Loading fails loudly if the shared object is missing, and every
+compute call fails loudly if no GPU is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+ORDER_SSE, ORDER_AVX = 0, 1
+
+
+class TinyKnnHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.environ.get("TINYKNN_HIP_LIB", os.path.join(_HERE, "libtinyknn_hip.so"))
+
+
+_lib = None
+
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/tinyknn_hip.h one to one
+SIGNATURES = {
+    "tk_last_error": (C.c_char_p, []),
+    "tk_version": (C.c_int, []),
+    "tk_device_count": (C.c_int, []),
+    "tk_set_device": (C.c_int, [C.c_int]),
+    "tk_estimate_pq": (C.c_int, [_u64p, C.c_int64, C.c_int, _u64p, _u64p, C.c_int, C.c_int]),
+    "tk_estimate_pq_batch": (C.c_int, [_u64p, C.c_int64, C.c_int, _u64p, C.c_int64, _u64p,
+                                       C.c_int, C.c_int]),
+    "tk_query_pq": (C.c_int, [_u64p, C.c_int64, C.c_int, C.c_int64, _u64p, _i64p, _i32p, C.c_int,
+                              C.c_int, _i64p, C.c_int]),
+    "tk_init_heap": (C.c_int, [_i64p, _i32p, C.c_int, C.c_int]),
+    "tk_heap_insert": (C.c_int, [_i64p, _i32p, C.c_int, C.c_int64, C.c_int32]),
+    "tk_heap_insert_is": (C.c_int, [_i64p, _i32p, C.c_int, C.c_int64, C.c_int32]),
+    "tk_build_tables": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64,
+                                  C.c_double, C.c_double, C.c_int, _u8p, C.c_void_p, _f64p]),
+    "tk_knn_brute1": (C.c_int64, [_f32p, _f32p, C.c_int64, C.c_int, C.c_int64, _i64p]),
+    "tk_index_create": (C.c_void_p, []),
+    "tk_index_destroy": (None, [C.c_void_p]),
+    "tk_index_set_pq": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
+    "tk_index_set_centers": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _u64p, C.c_int64]),
+    "tk_index_set_lists": (C.c_int, [C.c_void_p, _i64p, _u64p, _i64p]),
+    "tk_index_set_data": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int]),
+    "tk_index_reserve": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "tk_index_query_batch": (C.c_int, [C.c_void_p, _f32p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                       C.c_int, C.c_int, _i64p, _i64p, _i64p, _i32p]),
+    "tk_index_query_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tk_index_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "tk_index_last_profile": (C.c_int, [C.c_void_p, _f32p, _f64p]),
+}
+
+
+def lib():
+    """The loaded library.  Raises TinyKnnHipError when it is not built."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise TinyKnnHipError(
+                f"{path} not found: build it with `make -C tinyknn_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). "
+                "tinyknn_amd has no CPU fallback for the PQ scan path.")
+        try:
+            handle = C.CDLL(path)
+        except OSError as e:
+            raise TinyKnnHipError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Map a C-ABI return code to an exception.  Argument errors become
+    AssertionError, the convention of the reference's Python layer
+    (fast_pq.py:66,161,290,295; ivf.py:10,13,73-75)."""
+    if rc >= 0:
+        return rc
+    msg = lib().tk_last_error().decode()
+    if rc == -1:
+        raise AssertionError(msg)
+    raise TinyKnnHipError(msg)
+
+
+def device_count():
+    return lib().tk_device_count()
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(t)

@@ -1,0 +1,240 @@
+// adc_scan.hip — the Quick-ADC 4-bit PQ code scan for gfx950 (CDNA4).
+//
+// Replaces compute_block_dists (_fast_pq.pyx:209-236) and compute_block_dists_avx
+// (_fast_pq_256.pyx:126-156) of the reference and the loops that call them
+// (estimate_pq_* and the distance half of query_pq_*).
+//
+// Mapping.  One lane owns one 16-row chunk (the reference's __m128i), a wave 64
+// consecutive chunks.  Per block pair p the lane loads the chunk's 16-byte group
+// (global_load_dwordx4; the tiled layout of kernels.h makes 8 neighbouring lanes
+// share one 128-byte line) and looks every nibble up in the query's 16-entry
+// table with v_perm_b32 — the CDNA byte shuffle, used exactly as the reference
+// uses pshufb: the table row is wave-uniform (it arrives through the scalar
+// cache), the selector is the per-lane code.  A 16-entry table is two 8-byte
+// halves, so a lookup of 4 rows is perm(lo half), perm(hi half), perm(select by
+// code bit 3).  No LDS and no MFMA: the path is a gather/reduce.
+//
+// Exact int8 saturation.  Accumulators are int16 pairs holding value<<8; a
+// v_pk_add_i16 with clamp then saturates at 127<<8|0xff / -128<<8, which is
+// _mm_adds_epi8 bit for bit in the high byte (SURVEY §7 hard part 2); unsigned
+// mode uses v_pk_add_u16 clamp.  One VGPR carries two rows; the AVX order keeps
+// two such accumulator sets (block pairs p even / p odd) and merges them with
+// one final saturating add, the SSE order keeps one.
+#include "kernels.h"
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+template <bool SIGNED>
+__device__ __forceinline__ uint32_t sat_add2(uint32_t a, uint32_t b)
+{
+    if (SIGNED) {
+        v2s r = __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, a),
+                                              __builtin_bit_cast(v2s, b));
+        return __builtin_bit_cast(uint32_t, r);
+    } else {
+        v2u r = __builtin_elementwise_add_sat(__builtin_bit_cast(v2u, a),
+                                              __builtin_bit_cast(v2u, b));
+        return __builtin_bit_cast(uint32_t, r);
+    }
+}
+
+// 4 rows (the 4 bytes of `sel3`, each a 3-bit index) looked up in one 16-entry
+// byte table t; `pick` holds, per byte i, i or 4+i according to code bit 3.
+// Result is added, value<<8, into the two row-pair accumulators.
+template <bool SIGNED>
+__device__ __forceinline__ void lut4(uint32_t sel3, uint32_t pick, const uint4 t,
+                                     uint32_t &acc01, uint32_t &acc23)
+{
+    uint32_t lo = __builtin_amdgcn_perm(t.y, t.x, sel3);  // entries 0..7
+    uint32_t hi = __builtin_amdgcn_perm(t.w, t.z, sel3);  // entries 8..15
+    uint32_t r = __builtin_amdgcn_perm(hi, lo, pick);     // byte i = T[code_i]
+    uint32_t w01 = __builtin_amdgcn_perm(0u, r, 0x010c000cu);  // [r1,0,r0,0]
+    uint32_t w23 = __builtin_amdgcn_perm(0u, r, 0x030c020cu);  // [r3,0,r2,0]
+    acc01 = sat_add2<SIGNED>(acc01, w01);
+    acc23 = sat_add2<SIGNED>(acc23, w23);
+}
+
+// (a & b) | c in one VALU op.  VOP3 on gfx9 takes no literal and one SGPR, so the
+// mask rides in an SGPR and the byte-index constant in a VGPR; hipcc otherwise
+// splits this into v_and + v_or.
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask_s, uint32_t c_v)
+{
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask_s), "v"(c_v));
+    return r;
+}
+
+// One block pair: 16 rows x 2 blocks.  Low nibble = block 2p first, then the high
+// nibble = block 2p+1, into the same accumulator set (the order of both reference
+// kernels inside a 128-bit lane).
+template <bool SIGNED>
+__device__ __forceinline__ void pair_step(const uint4 x, const uint4 tl, const uint4 th,
+                                          uint32_t (&acc)[8])
+{
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t v = xs[j];
+        uint32_t s_lo = v & 0x07070707u;
+        uint32_t k_lo = and_or(v >> 1, 0x04040404u, 0x03020100u);
+        uint32_t vh = v >> 4;
+        uint32_t s_hi = vh & 0x07070707u;
+        uint32_t k_hi = and_or(v >> 5, 0x04040404u, 0x03020100u);
+        lut4<SIGNED>(s_lo, k_lo, tl, acc[2 * j], acc[2 * j + 1]);
+        lut4<SIGNED>(s_hi, k_hi, th, acc[2 * j], acc[2 * j + 1]);
+    }
+}
+
+// All M blocks of chunk c against table `tab` (M uint4, wave-uniform address).
+// Returns the chunk's 16 int8/uint8 distances.
+template <int ORDER, bool SIGNED>
+__device__ __forceinline__ uint4 scan_chunk(const uint4 *__restrict__ codes, int64_t c, int P,
+                                            const uint4 *__restrict__ tab)
+{
+    const uint4 *src = codes + ((c >> 3) * (int64_t)P) * 8 + (c & 7);
+    uint32_t a0[8], a1[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a0[i] = a1[i] = 0;
+
+    if (ORDER == TK_ORDER_AVX) {
+        // _fast_pq_256.pyx:135-149: 4 blocks per step, pairs p even -> lane 0 of the
+        // ymm (a0), p odd -> lane 1 (a1); a trailing odd pair is not read there.
+        const int steps = P >> 1;
+#pragma unroll 2
+        for (int j = 0; j < steps; j++) {
+            uint4 x0 = src[(2 * j) * 8];
+            uint4 x1 = src[(2 * j + 1) * 8];
+            pair_step<SIGNED>(x0, tab[4 * j], tab[4 * j + 1], a0);
+            pair_step<SIGNED>(x1, tab[4 * j + 2], tab[4 * j + 3], a1);
+        }
+#pragma unroll
+        // :152-156.  A clamped accumulator carries 0xff in its low byte; clear it in
+        // one operand so the two low bytes cannot carry into the value byte.
+        for (int i = 0; i < 8; i++) a0[i] = sat_add2<SIGNED>(a0[i], a1[i] & 0xff00ff00u);
+    } else {
+#pragma unroll 2
+        for (int p = 0; p < P; p++) {
+            uint4 x = src[p * 8];
+            pair_step<SIGNED>(x, tab[2 * p], tab[2 * p + 1], a0);
+        }
+    }
+    uint4 o;
+    o.x = __builtin_amdgcn_perm(a0[1], a0[0], 0x07050301u);
+    o.y = __builtin_amdgcn_perm(a0[3], a0[2], 0x07050301u);
+    o.z = __builtin_amdgcn_perm(a0[5], a0[4], 0x07050301u);
+    o.w = __builtin_amdgcn_perm(a0[7], a0[6], 0x07050301u);
+    return o;
+}
+
+// ---------------------------------------------------------------------------
+// reference layout -> tiled layout
+__global__ void retile_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                              int64_t chunks, int64_t chunks_pad, int P)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (c_pad, p)
+    int64_t total = chunks_pad * P;
+    if (i >= total) return;
+    // iterate in destination order so that stores are coalesced
+    int64_t tile = i / (8 * (int64_t)P);
+    int rem = (int)(i - tile * 8 * P);
+    int p = rem >> 3, cl = rem & 7;
+    int64_t c = tile * 8 + cl;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c < chunks) v = src[c * P + p];
+    dst[i] = v;
+}
+
+void tk_launch_retile(const uint4 *src_ref, uint4 *dst_tiled, int64_t chunks, int P,
+                      hipStream_t s)
+{
+    int64_t chunks_pad = (chunks + 7) / 8 * 8;
+    int64_t total = chunks_pad * P;
+    if (total == 0) return;
+    int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src_ref, dst_tiled,
+                       chunks, chunks_pad, P);
+}
+
+// ---------------------------------------------------------------------------
+template <int ORDER, bool SIGNED>
+__global__ __launch_bounds__(256) void scan_flat_kernel(const uint4 *__restrict__ codes,
+                                                        int64_t chunks, int P,
+                                                        const uint4 *__restrict__ tables, int M,
+                                                        uint4 *__restrict__ out,
+                                                        int64_t out_stride)
+{
+    const int q = blockIdx.y;
+    const uint4 *tab = tables + (int64_t)q * M;
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool active = c < chunks;
+    // inactive lanes of the last wave read chunk 0 (in bounds) and drop the result
+    uint4 o = scan_chunk<ORDER, SIGNED>(codes, active ? c : 0, P, tab);
+    if (active) out[(int64_t)q * out_stride + c] = o;
+}
+
+void tk_launch_scan_flat(const uint4 *codes, int64_t chunks, int M, const uint4 *tables,
+                         int64_t nq, uint4 *out, int64_t out_stride, int signd, int order,
+                         hipStream_t s)
+{
+    if (chunks == 0 || nq == 0) return;
+    dim3 grid((unsigned)((chunks + 255) / 256), (unsigned)nq);
+    int P = M / 2;
+#define TK_LAUNCH(O, S_)                                                                      \
+    hipLaunchKernelGGL((scan_flat_kernel<O, S_>), grid, dim3(256), 0, s, codes, chunks, P,    \
+                       tables, M, out, out_stride)
+    if (order == TK_ORDER_AVX) {
+        if (signd) TK_LAUNCH(TK_ORDER_AVX, true); else TK_LAUNCH(TK_ORDER_AVX, false);
+    } else {
+        if (signd) TK_LAUNCH(TK_ORDER_SSE, true); else TK_LAUNCH(TK_ORDER_SSE, false);
+    }
+#undef TK_LAUNCH
+}
+
+// ---------------------------------------------------------------------------
+// Probed lists of one query, concatenated in probe order into a flat chunk
+// range [0, prefix[S]); lane f of the grid owns flat chunk f.
+template <int ORDER, bool SIGNED>
+__global__ __launch_bounds__(256) void scan_probes_kernel(
+    const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
+    const int *__restrict__ slot_prefix, const int64_t *__restrict__ slot_chunk0, int S,
+    uint4 *__restrict__ dist, int64_t cap)
+{
+    const int q = blockIdx.y;
+    const int *prefix = slot_prefix + (int64_t)q * (S + 1);
+    const int total = prefix[S];
+    const int f0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+    if (f0 >= total) return;  // whole wave beyond this query's work
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool active = f < total;
+    const int ff = active ? f : total - 1;
+    // largest s with prefix[s] <= ff  (prefix is non-decreasing, prefix[0] = 0)
+    int lo = 0, hi = S;  // invariant: prefix[lo] <= ff < prefix[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= ff) lo = mid; else hi = mid;
+    }
+    const int64_t c = slot_chunk0[(int64_t)q * S + lo] + (ff - prefix[lo]);
+    const uint4 *tab = tables + (int64_t)q * M;
+    uint4 o = scan_chunk<ORDER, SIGNED>(codes, c, P, tab);
+    if (active) dist[(int64_t)q * cap + f] = o;
+}
+
+void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
+                           const int *slot_prefix, const int64_t *slot_chunk0, int S,
+                           int max_flat_chunks, uint4 *dist, int64_t cap, int signd,
+                           int order, hipStream_t s)
+{
+    if (nq == 0 || max_flat_chunks == 0 || S == 0) return;
+    dim3 grid((unsigned)((max_flat_chunks + 255) / 256), (unsigned)nq);
+    int P = M / 2;
+#define TK_LAUNCH(O, S_)                                                                      \
+    hipLaunchKernelGGL((scan_probes_kernel<O, S_>), grid, dim3(256), 0, s, codes, P, tables,  \
+                       M, slot_prefix, slot_chunk0, S, dist, cap)
+    if (order == TK_ORDER_AVX) {
+        if (signd) TK_LAUNCH(TK_ORDER_AVX, true); else TK_LAUNCH(TK_ORDER_AVX, false);
+    } else {
+        if (signd) TK_LAUNCH(TK_ORDER_SSE, true); else TK_LAUNCH(TK_ORDER_SSE, false);
+    }
+#undef TK_LAUNCH
+}

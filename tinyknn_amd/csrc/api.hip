@@ -1,0 +1,656 @@
+// api.hip — the C ABI of libtinyknn_hip.so (declared in include/tinyknn_hip.h).
+// Host-pointer entry points stage their arguments into HBM, run the gfx950
+// kernels and copy results back; the tk_index_* entry points keep the index
+// resident and only enqueue kernels.  There is no CPU implementation behind any of
+// these calls.
+#include <mutex>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/tinyknn_hip.h"
+#include "kernels.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHECK(x)                                                                          \
+    do {                                                                                     \
+        hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) {                                                              \
+            char b_[512];                                                                    \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                                    \
+            return fail(TK_ERR_HIP, b_);                                                     \
+        }                                                                                    \
+    } while (0)
+
+#define ARGCHECK(cond, msg)                                                                  \
+    do {                                                                                     \
+        if (!(cond)) return fail(TK_ERR_ARG, std::string("bad argument: ") + msg);           \
+    } while (0)
+
+extern "C" const char *tk_last_error(void) { return g_err.c_str(); }
+extern "C" int tk_version(void) { return 1; }
+
+extern "C" int tk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int tk_set_device(int device)
+{
+    HIPCHECK(hipSetDevice(device));
+    return TK_OK;
+}
+
+static int require_gpu()
+{
+    if (tk_device_count() <= 0)
+        return fail(TK_ERR_HIP, "no HIP device visible: libtinyknn_hip has no CPU fallback");
+    return TK_OK;
+}
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return TK_OK;
+        if (p) HIPCHECK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIPCHECK(hipMalloc(&p, want));
+        cap = want;
+        return TK_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T *as() const { return (T *)p; }
+};
+
+#define TRY(x)                         \
+    do {                               \
+        int r_ = (x);                  \
+        if (r_ != TK_OK) return r_;    \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// scratch of the host-pointer entry points
+struct Scratch {
+    std::mutex mu;
+    DevBuf ref, tiled, tables, out, hidx, hval, labels, slots_i, slots_l, q, rows, cand, pos,
+        centers, shift, scale, tabs8;
+};
+static Scratch &scratch()
+{
+    static Scratch s;
+    return s;
+}
+
+static int stage_codes(Scratch &S, const uint64_t *data, int64_t chunks, int M, hipStream_t st)
+{
+    const int P = M / 2;
+    size_t ref_bytes = (size_t)chunks * M * 8;
+    TRY(S.ref.ensure(ref_bytes));
+    TRY(S.tiled.ensure((size_t)tk_tiled_uint4s(chunks, P) * 16));
+    HIPCHECK(hipMemcpyAsync(S.ref.p, data, ref_bytes, hipMemcpyHostToDevice, st));
+    tk_launch_retile(S.ref.as<uint4>(), S.tiled.as<uint4>(), chunks, P, st);
+    return TK_OK;
+}
+
+extern "C" int tk_estimate_pq_batch(const uint64_t *data, int64_t chunks, int M,
+                                    const uint64_t *tables, int64_t nq, uint64_t *out, int signd,
+                                    int order)
+{
+    TRY(require_gpu());
+    ARGCHECK(chunks >= 0 && nq >= 0, "negative size");
+    ARGCHECK(M >= 2 && M % 2 == 0, "M must be even");
+    ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
+    ARGCHECK(nq <= 65535, "at most 65535 tables per call");
+    if (chunks == 0 || nq == 0) return TK_OK;
+    Scratch &S = scratch();
+    std::lock_guard<std::mutex> lk(S.mu);
+    hipStream_t st = 0;
+    TRY(stage_codes(S, data, chunks, M, st));
+    TRY(S.tables.ensure((size_t)nq * M * 16));
+    TRY(S.out.ensure((size_t)nq * chunks * 16));
+    HIPCHECK(hipMemcpyAsync(S.tables.p, tables, (size_t)nq * M * 16, hipMemcpyHostToDevice, st));
+    tk_launch_scan_flat(S.tiled.as<uint4>(), chunks, M, S.tables.as<uint4>(), nq,
+                        S.out.as<uint4>(), chunks, signd, order, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(out, S.out.p, (size_t)nq * chunks * 16, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return TK_OK;
+}
+
+extern "C" int tk_estimate_pq(const uint64_t *data, int64_t chunks, int M, const uint64_t *tables,
+                              uint64_t *out, int signd, int order)
+{
+    return tk_estimate_pq_batch(data, chunks, M, tables, 1, out, signd, order);
+}
+
+extern "C" int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t n,
+                           const uint64_t *tables, int64_t *indices, int32_t *vals, int R,
+                           int signd, const int64_t *labels, int order)
+{
+    TRY(require_gpu());
+    ARGCHECK(chunks >= 0 && R >= 1, "sizes");
+    ARGCHECK(M >= 2 && M % 2 == 0, "M must be even");
+    ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
+    ARGCHECK(chunks < (1ll << 31) / 16, "list too long");
+    ARGCHECK((size_t)R * 12 <= 64 * 1024, "heap larger than 64 KiB of LDS");
+    if (chunks == 0) return TK_OK;
+    Scratch &S = scratch();
+    std::lock_guard<std::mutex> lk(S.mu);
+    hipStream_t st = 0;
+    TRY(stage_codes(S, data, chunks, M, st));
+    TRY(S.tables.ensure((size_t)M * 16));
+    TRY(S.out.ensure((size_t)chunks * 16));
+    TRY(S.hidx.ensure((size_t)R * 8));
+    TRY(S.hval.ensure((size_t)R * 4));
+    TRY(S.slots_i.ensure(3 * sizeof(int)));
+    TRY(S.slots_l.ensure(sizeof(int64_t)));
+    // labels beyond n are never read (pos < n is tested first, _fast_pq_256.pyx:111-114)
+    int64_t nlab = n < 16 * chunks ? n : 16 * chunks;
+    if (nlab < 0) nlab = 0;
+    if (labels && nlab > 0) {
+        TRY(S.labels.ensure((size_t)nlab * 8));
+        HIPCHECK(hipMemcpyAsync(S.labels.p, labels, (size_t)nlab * 8, hipMemcpyHostToDevice, st));
+    }
+    HIPCHECK(hipMemcpyAsync(S.tables.p, tables, (size_t)M * 16, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.hidx.p, indices, (size_t)R * 8, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.hval.p, vals, (size_t)R * 4, hipMemcpyHostToDevice, st));
+    int64_t nclamp = n > (int64_t)0x7fffffff ? 0x7fffffff : (n < 0 ? 0 : n);
+    int si[3] = {0, (int)chunks, (int)nclamp};
+    int64_t sl[1] = {labels ? 0 : -1};
+    HIPCHECK(hipMemcpyAsync(S.slots_i.p, si, sizeof si, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.slots_l.p, sl, sizeof sl, hipMemcpyHostToDevice, st));
+    tk_launch_scan_flat(S.tiled.as<uint4>(), chunks, M, S.tables.as<uint4>(), 1, S.out.as<uint4>(),
+                        chunks, signd, order, st);
+    tk_launch_heap_replay(S.out.as<uint4>(), chunks, 1, S.slots_i.as<int>(),
+                          S.slots_i.as<int>() + 2, S.slots_l.as<int64_t>(), 1,
+                          S.labels.as<int64_t>(), S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R,
+                          signd, 1, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(indices, S.hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(vals, S.hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return TK_OK;
+}
+
+extern "C" int tk_init_heap(int64_t *indices, int32_t *vals, int R, int signd)
+{
+    TRY(require_gpu());
+    ARGCHECK(R >= 0, "R");
+    if (R == 0) return TK_OK;
+    Scratch &S = scratch();
+    std::lock_guard<std::mutex> lk(S.mu);
+    hipStream_t st = 0;
+    TRY(S.hidx.ensure((size_t)R * 8));
+    TRY(S.hval.ensure((size_t)R * 4));
+    tk_launch_heap_fill(S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R, signd ? 127 : 255, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(indices, S.hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(vals, S.hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return TK_OK;
+}
+
+static int heap_insert_host(int64_t *indices, int32_t *vals, int R, int64_t i, int32_t v, int is)
+{
+    TRY(require_gpu());
+    ARGCHECK(R >= 1, "R");
+    ARGCHECK((size_t)R * 12 <= 64 * 1024, "heap larger than 64 KiB of LDS");
+    Scratch &S = scratch();
+    std::lock_guard<std::mutex> lk(S.mu);
+    hipStream_t st = 0;
+    TRY(S.hidx.ensure((size_t)R * 8));
+    TRY(S.hval.ensure((size_t)R * 4));
+    HIPCHECK(hipMemcpyAsync(S.hidx.p, indices, (size_t)R * 8, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.hval.p, vals, (size_t)R * 4, hipMemcpyHostToDevice, st));
+    tk_launch_heap_insert(S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R, i, v, is, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(indices, S.hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(vals, S.hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return TK_OK;
+}
+
+extern "C" int tk_heap_insert(int64_t *indices, int32_t *vals, int R, int64_t i, int32_t v)
+{
+    return heap_insert_host(indices, vals, R, i, v, 0);
+}
+extern "C" int tk_heap_insert_is(int64_t *indices, int32_t *vals, int R, int64_t i, int32_t v)
+{
+    return heap_insert_host(indices, vals, R, i, v, 1);
+}
+
+extern "C" int tk_build_tables(const float *centers, int dq, int dpb, int f_order, const void *q,
+                               int q_is_f64, int64_t nq, double aux0, double aux1, int signd,
+                               uint8_t *tables, void *shift, double *scale)
+{
+    TRY(require_gpu());
+    ARGCHECK(dpb >= 1 && dpb <= 32, "dims_per_block must be in 1..32");
+    ARGCHECK(dq >= dpb && dq % dpb == 0, "dq must be a multiple of dims_per_block");
+    ARGCHECK(nq >= 0, "nq");
+    const int M = dq / dpb;
+    const size_t esz = q_is_f64 ? 8 : 4;
+    ARGCHECK((size_t)16 * M * esz <= 60 * 1024, "too many blocks for the LDS table");
+    if (nq == 0) return TK_OK;
+    Scratch &S = scratch();
+    std::lock_guard<std::mutex> lk(S.mu);
+    hipStream_t st = 0;
+    TRY(S.centers.ensure((size_t)16 * dq * 4));
+    TRY(S.q.ensure((size_t)nq * dq * esz));
+    TRY(S.tabs8.ensure((size_t)nq * M * 16));
+    TRY(S.shift.ensure((size_t)nq * esz));
+    TRY(S.scale.ensure((size_t)nq * 8));
+    HIPCHECK(hipMemcpyAsync(S.centers.p, centers, (size_t)16 * dq * 4, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.q.p, q, (size_t)nq * dq * esz, hipMemcpyHostToDevice, st));
+    tk_launch_build_tables(S.centers.as<float>(), dq, dpb, f_order, S.q.p, q_is_f64, nq, aux0, aux1,
+                           signd, S.tabs8.as<uint8_t>(), S.shift.p, S.scale.as<double>(), st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(tables, S.tabs8.p, (size_t)nq * M * 16, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(shift, S.shift.p, (size_t)nq * esz, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(scale, S.scale.p, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return TK_OK;
+}
+
+extern "C" int64_t tk_knn_brute1(const float *x, const float *Y, int64_t n, int d, int64_t k,
+                                 int64_t *out_pos)
+{
+    int r = require_gpu();
+    if (r != TK_OK) return r;
+    if (n < 0 || d < 1 || k < 0) return fail(TK_ERR_ARG, "bad argument: sizes");
+    if (n > 4096) return fail(TK_ERR_ARG, "bad argument: at most 4096 candidate rows");
+    int64_t kk = k < n ? k : n;
+    if (kk == 0) return 0;
+    Scratch &S = scratch();
+    std::lock_guard<std::mutex> lk(S.mu);
+    hipStream_t st = 0;
+    std::vector<int64_t> cand((size_t)n);
+    for (int64_t i = 0; i < n; i++) cand[i] = i;
+#define HC(x)                                                                      \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) return fail(TK_ERR_HIP, hipGetErrorString(e_));      \
+    } while (0)
+    if ((r = S.q.ensure((size_t)d * 4)) || (r = S.rows.ensure((size_t)n * d * 4)) ||
+        (r = S.cand.ensure((size_t)n * 8)) || (r = S.pos.ensure((size_t)kk * 8)))
+        return r;
+    HC(hipMemcpyAsync(S.q.p, x, (size_t)d * 4, hipMemcpyHostToDevice, st));
+    HC(hipMemcpyAsync(S.rows.p, Y, (size_t)n * d * 4, hipMemcpyHostToDevice, st));
+    HC(hipMemcpyAsync(S.cand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    tk_launch_rescore(S.q.as<float>(), d, S.rows.as<float>(), n, S.cand.as<int64_t>(), (int)n, 1,
+                      (int)kk, 0, S.pos.as<int64_t>(), nullptr, st);
+    HC(hipGetLastError());
+    HC(hipMemcpyAsync(out_pos, S.pos.p, (size_t)kk * 8, hipMemcpyDeviceToHost, st));
+    HC(hipStreamSynchronize(st));
+#undef HC
+    return kk;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident index
+struct tk_index {
+    // FastPQ
+    DevBuf pq_centers;
+    int dq = 0, dpb = 0, M = 0, f_order = 0, order = TK_ORDER_AVX;
+    double sqrt_nb = 0;
+    // coarse
+    DevBuf active_centers, center_codes;
+    int64_t n_lists = 0, center_chunks = 0;
+    int d = 0;
+    // lists
+    DevBuf list_chunk_off, list_n, ids_off, ids, codes;
+    int64_t total_chunks = 0, total_ids = 0;
+    int max_list_chunks = 0;
+    bool have_pq = false, have_centers = false, have_lists = false, have_data = false;
+    // vectors
+    DevBuf data;
+    int64_t N = 0;
+    // workspace
+    DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
+        slot_n, slot_loff, dist, heap_idx, heap_val, cslots_i, cslots_l, q, qpq, out, stage;
+    // profiling
+    int profiling = 0;
+    hipEvent_t ev[8] = {};
+    bool ev_made = false;
+    float last_ms[7] = {};
+    double last_scan_bytes = 0;
+};
+
+extern "C" tk_index *tk_index_create(void)
+{
+    if (require_gpu() != TK_OK) return nullptr;
+    return new tk_index();
+}
+
+extern "C" void tk_index_destroy(tk_index *ix)
+{
+    if (!ix) return;
+    DevBuf *bufs[] = {&ix->pq_centers, &ix->active_centers, &ix->center_codes, &ix->list_chunk_off,
+                      &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->data, &ix->tables,
+                      &ix->shift, &ix->scale, &ix->cdist, &ix->cheap_idx, &ix->cheap_val,
+                      &ix->probes, &ix->slot_prefix, &ix->slot_chunk0, &ix->slot_n, &ix->slot_loff,
+                      &ix->dist, &ix->heap_idx, &ix->heap_val, &ix->cslots_i, &ix->cslots_l, &ix->q,
+                      &ix->qpq, &ix->out, &ix->stage};
+    for (DevBuf *b : bufs) b->release();
+    if (ix->ev_made)
+        for (auto &e : ix->ev) (void)hipEventDestroy(e);
+    delete ix;
+}
+
+extern "C" int tk_index_set_pq(tk_index *ix, const float *centers, int dq, int dpb, int f_order,
+                               double sqrt_n_blocks, int order)
+{
+    ARGCHECK(ix, "null index");
+    ARGCHECK(dpb >= 1 && dpb <= 32 && dq % dpb == 0, "dq/dpb");
+    ARGCHECK((dq / dpb) % 2 == 0, "number of blocks must be even");
+    ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
+    TRY(ix->pq_centers.ensure((size_t)16 * dq * 4));
+    HIPCHECK(hipMemcpy(ix->pq_centers.p, centers, (size_t)16 * dq * 4, hipMemcpyHostToDevice));
+    ix->dq = dq; ix->dpb = dpb; ix->M = dq / dpb; ix->f_order = f_order;
+    ix->sqrt_nb = sqrt_n_blocks; ix->order = order;
+    ix->have_pq = true;
+    return TK_OK;
+}
+
+static int upload_tiled(DevBuf &dst, DevBuf &stage, const uint64_t *codes, int64_t chunks, int M)
+{
+    const int P = M / 2;
+    size_t tiled_bytes = (size_t)tk_tiled_uint4s(chunks, P) * 16;
+    TRY(dst.ensure(tiled_bytes > 0 ? tiled_bytes : 16));
+    if (chunks == 0) return TK_OK;
+    size_t ref_bytes = (size_t)chunks * M * 8;
+    TRY(stage.ensure(ref_bytes));
+    HIPCHECK(hipMemcpy(stage.p, codes, ref_bytes, hipMemcpyHostToDevice));
+    tk_launch_retile(stage.as<uint4>(), dst.as<uint4>(), chunks, P, 0);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    return TK_OK;
+}
+
+extern "C" int tk_index_set_centers(tk_index *ix, const float *active_centers, int64_t n_lists,
+                                    int d, const uint64_t *center_codes, int64_t center_chunks)
+{
+    ARGCHECK(ix && ix->have_pq, "set_pq first");
+    ARGCHECK(n_lists >= 1 && d >= 1, "sizes");
+    ARGCHECK(center_chunks == (n_lists + 15) / 16, "center_chunks must be ceil(n_lists/16)");
+    TRY(ix->active_centers.ensure((size_t)n_lists * d * 4));
+    HIPCHECK(hipMemcpy(ix->active_centers.p, active_centers, (size_t)n_lists * d * 4,
+                       hipMemcpyHostToDevice));
+    TRY(upload_tiled(ix->center_codes, ix->stage, center_codes, center_chunks, ix->M));
+    ix->n_lists = n_lists; ix->d = d; ix->center_chunks = center_chunks;
+    int ci[3] = {0, (int)center_chunks, (int)n_lists};
+    int64_t cl[1] = {-1};
+    TRY(ix->cslots_i.ensure(sizeof ci));
+    TRY(ix->cslots_l.ensure(sizeof cl));
+    HIPCHECK(hipMemcpy(ix->cslots_i.p, ci, sizeof ci, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ix->cslots_l.p, cl, sizeof cl, hipMemcpyHostToDevice));
+    ix->have_centers = true;
+    return TK_OK;
+}
+
+extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const uint64_t *codes,
+                                  const int64_t *ids)
+{
+    ARGCHECK(ix && ix->have_centers, "set_centers first");
+    const int64_t L = ix->n_lists;
+    std::vector<int64_t> coff(L + 1, 0), ioff(L + 1, 0);
+    int64_t maxc = 0;
+    for (int64_t i = 0; i < L; i++) {
+        ARGCHECK(list_sizes[i] >= 0, "negative list size");
+        int64_t c = (list_sizes[i] + 15) / 16;
+        coff[i + 1] = coff[i] + c;
+        ioff[i + 1] = ioff[i] + list_sizes[i];
+        if (c > maxc) maxc = c;
+    }
+    ARGCHECK(maxc < (1ll << 26), "list too long");
+    TRY(upload_tiled(ix->codes, ix->stage, codes, coff[L], ix->M));
+    TRY(ix->list_chunk_off.ensure((size_t)(L + 1) * 8));
+    TRY(ix->ids_off.ensure((size_t)(L + 1) * 8));
+    TRY(ix->list_n.ensure((size_t)L * 8));
+    TRY(ix->ids.ensure((size_t)(ioff[L] > 0 ? ioff[L] : 1) * 8));
+    HIPCHECK(hipMemcpy(ix->list_chunk_off.p, coff.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ix->ids_off.p, ioff.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ix->list_n.p, list_sizes, (size_t)L * 8, hipMemcpyHostToDevice));
+    if (ioff[L] > 0)
+        HIPCHECK(hipMemcpy(ix->ids.p, ids, (size_t)ioff[L] * 8, hipMemcpyHostToDevice));
+    ix->total_chunks = coff[L];
+    ix->total_ids = ioff[L];
+    ix->max_list_chunks = (int)maxc;
+    ix->have_lists = true;
+    return TK_OK;
+}
+
+extern "C" int tk_index_set_data(tk_index *ix, const float *data, int64_t N, int d)
+{
+    ARGCHECK(ix && ix->have_centers, "set_centers first");
+    ARGCHECK(d == ix->d, "data dimension differs from the centres'");
+    ARGCHECK(N >= 1, "N");
+    TRY(ix->data.ensure((size_t)N * d * 4));
+    HIPCHECK(hipMemcpy(ix->data.p, data, (size_t)N * d * 4, hipMemcpyHostToDevice));
+    ix->N = N;
+    ix->have_data = true;
+    return TK_OK;
+}
+
+struct Plan {
+    int kc, rescore, R, S;
+    int64_t cap;  // uint4 per query in the distance buffer
+};
+
+static int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &p)
+{
+    ARGCHECK(ix && ix->have_pq && ix->have_centers && ix->have_lists && ix->have_data,
+             "index not fully populated (pq, centers, lists, data)");
+    ARGCHECK(k >= 1 && n_probes >= 1, "k and n_probes must be >= 1");
+    int64_t kc = n_probes < ix->n_lists ? n_probes : ix->n_lists;              // fast_pq.py:291
+    int64_t rescore = 2 * kc + 10 < ix->n_lists ? 2 * kc + 10 : ix->n_lists;   // :293-294
+    int64_t R = pass_1 > 0 ? pass_1 : (int64_t)(n_probes + 1) * k + 1;         // ivf.py:135-136
+    ARGCHECK(R * 12 <= 64 * 1024 && rescore * 12 <= 64 * 1024, "heap larger than 64 KiB of LDS");
+    ARGCHECK(R * 12 + (int64_t)ix->d * 4 <= 64 * 1024, "rescoring tile larger than 64 KiB of LDS");
+    p.kc = (int)kc; p.rescore = (int)rescore; p.R = (int)R; p.S = (int)kc;
+    p.cap = (int64_t)kc * ix->max_list_chunks;
+    if (p.cap < 1) p.cap = 1;
+    ARGCHECK(p.cap < (1ll << 31), "probed chunk range overflows int32");
+    return TK_OK;
+}
+
+static int reserve(tk_index *ix, int64_t nq, int k, const Plan &p)
+{
+    const int M = ix->M;
+    TRY(ix->tables.ensure((size_t)nq * M * 16));
+    TRY(ix->shift.ensure((size_t)nq * 8));
+    TRY(ix->scale.ensure((size_t)nq * 8));
+    TRY(ix->cdist.ensure((size_t)nq * ix->center_chunks * 16));
+    TRY(ix->cheap_idx.ensure((size_t)nq * p.rescore * 8));
+    TRY(ix->cheap_val.ensure((size_t)nq * p.rescore * 4));
+    TRY(ix->probes.ensure((size_t)nq * p.kc * 8));
+    TRY(ix->slot_prefix.ensure((size_t)nq * (p.S + 1) * 4));
+    TRY(ix->slot_chunk0.ensure((size_t)nq * p.S * 8));
+    TRY(ix->slot_n.ensure((size_t)nq * p.S * 4));
+    TRY(ix->slot_loff.ensure((size_t)nq * p.S * 8));
+    TRY(ix->dist.ensure((size_t)nq * p.cap * 16));
+    TRY(ix->heap_idx.ensure((size_t)nq * p.R * 8));
+    TRY(ix->heap_val.ensure((size_t)nq * p.R * 4));
+    TRY(ix->out.ensure((size_t)nq * k * 8));
+    return TK_OK;
+}
+
+static const int64_t MAX_SUB = 32768;  // gridDim.y limit of the scan kernels is 65535
+
+extern "C" int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, int pass_1)
+{
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    return reserve(ix, nq < MAX_SUB ? nq : MAX_SUB, k, p);
+}
+
+// one sub-batch, everything on device
+static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int qpq_f64, int64_t nq,
+                     int k, const Plan &p, int64_t *out_dev, hipStream_t st)
+{
+    const int M = ix->M;
+    const bool prof = ix->profiling != 0;
+    if (prof && !ix->ev_made) {
+        for (auto &e : ix->ev) HIPCHECK(hipEventCreate(&e));
+        ix->ev_made = true;
+    }
+    int evi = 0;
+#define MARK()                                                     \
+    do {                                                           \
+        if (prof) HIPCHECK(hipEventRecord(ix->ev[evi++], st));     \
+    } while (0)
+    MARK();
+    // 1. distance tables                                   fast_pq.py:186-222
+    tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
+                           qpq_f64, nq, ix->sqrt_nb, 0.0, 1, ix->tables.as<uint8_t>(), ix->shift.p,
+                           ix->scale.as<double>(), st);
+    MARK();
+    // 2. coarse stage = dtable.top(centers)                 ivf.py:131, fast_pq.py:284-312
+    tk_launch_scan_flat(ix->center_codes.as<uint4>(), ix->center_chunks, M, ix->tables.as<uint4>(),
+                        nq, ix->cdist.as<uint4>(), ix->center_chunks, 1, ix->order, st);
+    MARK();
+    tk_launch_heap_fill(ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
+                        nq * p.rescore, 127, st);
+    tk_launch_heap_replay(ix->cdist.as<uint4>(), ix->center_chunks, nq, ix->cslots_i.as<int>(),
+                          ix->cslots_i.as<int>() + 2, ix->cslots_l.as<int64_t>(), 1, nullptr,
+                          ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(), p.rescore, 1, 1,
+                          st);
+    MARK();
+    tk_launch_rescore(q_dev, ix->d, ix->active_centers.as<float>(), ix->n_lists,
+                      ix->cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0,
+                      ix->probes.as<int64_t>(), nullptr, st);
+    tk_launch_make_slots(ix->probes.as<int64_t>(), nullptr, p.S, nq, ix->n_lists,
+                         ix->list_chunk_off.as<int64_t>(), ix->list_n.as<int64_t>(),
+                         ix->ids_off.as<int64_t>(), ix->slot_prefix.as<int>(),
+                         ix->slot_chunk0.as<int64_t>(), ix->slot_n.as<int>(),
+                         ix->slot_loff.as<int64_t>(), st);
+    MARK();
+    // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
+    tk_launch_scan_probes(ix->codes.as<uint4>(), M, ix->tables.as<uint4>(), nq,
+                          ix->slot_prefix.as<int>(), ix->slot_chunk0.as<int64_t>(), p.S,
+                          (int)p.cap, ix->dist.as<uint4>(), p.cap, 1, ix->order, st);
+    MARK();
+    tk_launch_heap_fill(ix->heap_idx.as<int64_t>(), ix->heap_val.as<int32_t>(), nq * p.R, 127, st);
+    tk_launch_heap_replay(ix->dist.as<uint4>(), p.cap, nq, ix->slot_prefix.as<int>(),
+                          ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
+                          ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
+                          ix->heap_val.as<int32_t>(), p.R, 1, 0, st);
+    MARK();
+    // 4. strip sentinels, exact rescoring                   ivf.py:154-163
+    tk_launch_rescore(q_dev, ix->d, ix->data.as<float>(), ix->N, ix->heap_idx.as<int64_t>(), p.R,
+                      nq, k, 1, out_dev, nullptr, st);
+    MARK();
+#undef MARK
+    HIPCHECK(hipGetLastError());
+    if (prof) {
+        HIPCHECK(hipEventSynchronize(ix->ev[7]));
+        for (int i = 0; i < 7; i++) {
+            float ms = 0;
+            HIPCHECK(hipEventElapsedTime(&ms, ix->ev[i], ix->ev[i + 1]));
+            ix->last_ms[i] += ms;
+        }
+        // algorithmic bytes of the list scan: code bytes + table + heap out
+        std::vector<int> pre((size_t)nq * (p.S + 1));
+        HIPCHECK(hipMemcpy(pre.data(), ix->slot_prefix.p, pre.size() * 4, hipMemcpyDeviceToHost));
+        double bytes = 0;
+        for (int64_t i = 0; i < nq; i++)
+            bytes += (double)pre[(size_t)i * (p.S + 1) + p.S] * M * 8 + 16.0 * M + 12.0 * p.R;
+        ix->last_scan_bytes += bytes;
+    }
+    return TK_OK;
+}
+
+extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_dev,
+                                        int q_pq_is_f64, int64_t nq, int k, int n_probes,
+                                        int pass_1, int64_t *out_ids_dev, void *stream)
+{
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    ARGCHECK(nq >= 0, "nq");
+    hipStream_t st = (hipStream_t)stream;
+    if (ix->profiling) {
+        for (float &m : ix->last_ms) m = 0;
+        ix->last_scan_bytes = 0;
+    }
+    const size_t esz = q_pq_is_f64 ? 8 : 4;
+    for (int64_t o = 0; o < nq; o += MAX_SUB) {
+        int64_t sub = nq - o < MAX_SUB ? nq - o : MAX_SUB;
+        TRY(reserve(ix, sub, k, p));
+        TRY(run_batch(ix, q_dev + o * ix->d, (const char *)q_pq_dev + (size_t)o * ix->dq * esz,
+                      q_pq_is_f64, sub, k, p, out_ids_dev + o * k, st));
+    }
+    return TK_OK;
+}
+
+extern "C" int tk_index_query_batch(tk_index *ix, const float *q, const void *q_pq,
+                                    int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                                    int64_t *out_ids, int64_t *out_probes, int64_t *out_heap_idx,
+                                    int32_t *out_heap_val)
+{
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    ARGCHECK(nq >= 0, "nq");
+    if (nq == 0) return TK_OK;
+    ARGCHECK(!(out_probes || out_heap_idx || out_heap_val) || nq <= MAX_SUB,
+             "debug outputs need nq <= 32768");
+    const size_t esz = q_pq_is_f64 ? 8 : 4;
+    TRY(ix->q.ensure((size_t)nq * ix->d * 4));
+    TRY(ix->qpq.ensure((size_t)nq * ix->dq * esz));
+    DevBuf outbuf;  // separate from the sub-batch `out` workspace
+    TRY(outbuf.ensure((size_t)nq * k * 8));
+    HIPCHECK(hipMemcpy(ix->q.p, q, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ix->qpq.p, q_pq, (size_t)nq * ix->dq * esz, hipMemcpyHostToDevice));
+    int r = tk_index_query_batch_dev(ix, ix->q.as<float>(), ix->qpq.p, q_pq_is_f64, nq, k, n_probes,
+                                     pass_1, outbuf.as<int64_t>(), nullptr);
+    if (r == TK_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(out_ids, outbuf.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_probes)
+            e = hipMemcpy(out_probes, ix->probes.p, (size_t)nq * p.kc * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_heap_idx)
+            e = hipMemcpy(out_heap_idx, ix->heap_idx.p, (size_t)nq * p.R * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_heap_val)
+            e = hipMemcpy(out_heap_val, ix->heap_val.p, (size_t)nq * p.R * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) r = fail(TK_ERR_HIP, hipGetErrorString(e));
+    }
+    outbuf.release();
+    return r;
+}
+
+extern "C" int tk_index_set_profiling(tk_index *ix, int on)
+{
+    ARGCHECK(ix, "null index");
+    ix->profiling = on;
+    return TK_OK;
+}
+
+extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes)
+{
+    ARGCHECK(ix, "null index");
+    for (int i = 0; i < 7; i++) ms7[i] = ix->last_ms[i];
+    *scan_bytes = ix->last_scan_bytes;
+    return TK_OK;
+}

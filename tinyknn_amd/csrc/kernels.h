@@ -1,0 +1,75 @@
+// kernels.h — launch wrappers of the gfx950 kernels (internal to libtinyknn_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TK_ORDER_SSE 0
+#define TK_ORDER_AVX 1
+
+// Device code layout ("tiled"): chunk c (16 rows), block pair p (16 bytes holding
+// code[16c+r][2p] | code[16c+r][2p+1] << 4 for r = 0..15, i.e. the reference's
+// 16-byte group, _transform.py:4-77) lives at uint4 index
+//     ((c / 8) * P + p) * 8 + (c % 8),      P = M / 2
+// so that 8 consecutive chunks share one 128-byte line per pair and a wave whose
+// lanes own consecutive chunks reads whole lines.  The chunk count is padded to a
+// multiple of 8 with zero chunks.
+static inline int64_t tk_tiled_uint4s(int64_t chunks, int P)
+{
+    return ((chunks + 7) / 8) * 8 * (int64_t)P;
+}
+
+// reference layout (chunks, M) uint64  ->  tiled layout, `chunk0` = first
+// destination chunk (must be a multiple of 8 unless the caller owns the tile)
+void tk_launch_retile(const uint4 *src_ref, uint4 *dst_tiled, int64_t chunks, int P,
+                      hipStream_t s);
+
+// Flat scan: every chunk of one code array against nq tables.
+// tables: (nq, M) uint4 (16 table bytes per block); out: (nq, out_stride) uint4,
+// 16 int8/uint8 distances per chunk.
+void tk_launch_scan_flat(const uint4 *codes, int64_t chunks, int M, const uint4 *tables,
+                         int64_t nq, uint4 *out, int64_t out_stride, int signd, int order,
+                         hipStream_t s);
+
+// Probed-list scan: query q scans the lists slot 0..S-1 named by
+// slot_chunk0[q][s] (first global chunk) and slot_prefix[q][s..s+1] (flat chunk
+// range inside the query's distance row).  dist: (nq, cap) uint4.
+void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
+                           const int *slot_prefix, const int64_t *slot_chunk0, int S,
+                           int max_flat_chunks, uint4 *dist, int64_t cap, int signd,
+                           int order, hipStream_t s);
+
+// Exact replay of the reference's sequential heap over precomputed distances.
+// One wave per query.  slot_n: true rows per slot; slot_label_off: offset into
+// `labels` or -1 (label = position).  heap_idx/heap_val: (nq, R) in/out.
+// slots_uniform: the slot arrays hold ONE row that every query uses.
+void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
+                           const int *slot_n, const int64_t *slot_label_off, int S,
+                           const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
+                           int signd, int slots_uniform, hipStream_t s);
+
+void tk_launch_heap_fill(int64_t *heap_idx, int32_t *heap_val, int64_t count, int32_t v,
+                         hipStream_t s);
+// single insert on a device heap (insertion-sort variant when `is`)
+void tk_launch_heap_insert(int64_t *heap_idx, int32_t *heap_val, int R, int64_t i, int32_t v,
+                           int is, hipStream_t s);
+
+// Distance tables (fast_pq.py:186-252).  q: (nq, dq) float or double.
+void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, const void *q,
+                            int q_is_f64, int64_t nq, double aux0, double aux1, int signd,
+                            uint8_t *tables, void *shift, double *scale, hipStream_t s);
+
+// Exact rescoring + ascending top-k.
+// cand: (nq, R) int64 candidate ids (heap order).  strip: drop -1 entries first
+// (ivf.py:154-155) — without it, negative ids address rows from the end
+// (fast_pq.py:311).  If the candidate count <= k the ids are returned in heap
+// order (ivf.py:158-159 / fast_pq.py:307-308).  out: (nq, k) padded with -1;
+// out_count (nq,) optional.
+void tk_launch_rescore(const float *q, int d, const float *rows, int64_t n_rows,
+                       const int64_t *cand, int R, int64_t nq, int k, int strip,
+                       int64_t *out, int *out_count, hipStream_t s);
+
+// probes (nq, kc) list ids -> per-slot scan descriptors
+void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,
+                          int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
+                          const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
+                          int *slot_n, int64_t *slot_label_off, hipStream_t s);

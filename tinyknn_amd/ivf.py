@@ -1,0 +1,225 @@
+"""IVF with the reference's API (tinyknn/ivf.py); queries run on the MI355X.
+
+fit / build are offline host code with the reference's semantics.  After build the
+index (PQ codebook, coded coarse centres, inverted lists, ids, rescoring vectors)
+is uploaded once into HBM (`DeviceIndex`); `query` and `query_batch` then run the
+kernel pipeline of libtinyknn_hip.so: distance tables -> coarse scan + heap +
+rescoring -> probed-list scan -> exact heap replay -> exact rescoring.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .fast_pq import FastPQ, avx, dpad
+from .utils import group_data_by_indices, knn_brute, timer
+
+
+class DeviceIndex:
+    """HBM-resident copy of a built IVF (C ABI: tk_index_*)."""
+
+    def __init__(self, ivf):
+        L = _lib.lib()
+        pq = ivf.pq
+        self._h = L.tk_index_create()
+        if not self._h:
+            raise _lib.TinyKnnHipError(L.tk_last_error().decode() or "tk_index_create failed")
+        centers = pq.centers
+        f_order = int(not centers.flags.c_contiguous)
+        c32 = np.ascontiguousarray(centers, dtype=np.float32)
+        self.dq = c32.shape[1]
+        self.dpb = pq.dims_per_block
+        order = _lib.ORDER_AVX if avx else _lib.ORDER_SSE
+        _lib.check(L.tk_index_set_pq(self._h, _lib.ptr(c32, _lib._f32p), self.dq, self.dpb,
+                                     f_order, float(pq.sqrt_n_blocks), order))
+        ac = np.ascontiguousarray(ivf.active_centers, dtype=np.float32)
+        self.n_lists, self.d = ac.shape
+        csize, cpacked = ivf.pq_transformed_centers
+        assert csize == self.n_lists
+        cpacked = np.ascontiguousarray(cpacked, dtype=np.uint64)
+        _lib.check(L.tk_index_set_centers(self._h, _lib.ptr(ac, _lib._f32p), self.n_lists, self.d,
+                                          _lib.ptr(cpacked, _lib._u64p), cpacked.shape[0]))
+        M = self.dq // self.dpb
+        sizes, packed, ids = [], [], []
+        for i in range(self.n_lists):
+            td = ivf.pq_transformed_points[i]
+            if isinstance(td, np.ndarray):      # FastPQ.transform(empty) returns the raw array
+                sizes.append(0)
+                continue
+            sizes.append(td.size)
+            packed.append(np.ascontiguousarray(td.packed, dtype=np.uint64))
+            ids.append(np.asarray(ivf.ids[i], dtype=np.int64)[:td.size])
+        sizes = np.array(sizes, dtype=np.int64)
+        codes = (np.ascontiguousarray(np.concatenate(packed)) if packed
+                 else np.zeros((1, M), dtype=np.uint64))
+        allids = (np.ascontiguousarray(np.concatenate(ids)) if ids else np.zeros(1, np.int64))
+        _lib.check(L.tk_index_set_lists(self._h, _lib.ptr(sizes, _lib._i64p),
+                                        _lib.ptr(codes, _lib._u64p), _lib.ptr(allids, _lib._i64p)))
+        if ivf.data.dtype != np.float32:
+            raise TypeError("tinyknn_amd rescoring runs in float32 on the GPU; build the index "
+                            f"from float32 vectors (got {ivf.data.dtype})")
+        data = np.ascontiguousarray(ivf.data)
+        _lib.check(L.tk_index_set_data(self._h, _lib.ptr(data, _lib._f32p), data.shape[0],
+                                       data.shape[1]))
+        self.code_bytes = int(codes.nbytes)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().tk_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def query_batch(self, qn, q_pq, k, n_probes, pass_1=None, debug=False):
+        """qn: (nq, d) float32 normalised queries; q_pq: (nq, dq) table-build queries."""
+        qn = np.ascontiguousarray(qn, dtype=np.float32)
+        is64 = q_pq.dtype != np.float32
+        q_pq = np.ascontiguousarray(q_pq, dtype=np.float64 if is64 else np.float32)
+        nq = qn.shape[0]
+        assert qn.shape[1] == self.d and q_pq.shape == (nq, self.dq)
+        out = np.full((nq, k), -1, dtype=np.int64)
+        R = pass_1 if pass_1 else (n_probes + 1) * k + 1
+        probes = hidx = hval = None
+        if debug:
+            probes = np.zeros((nq, min(n_probes, self.n_lists)), dtype=np.int64)
+            hidx = np.zeros((nq, R), dtype=np.int64)
+            hval = np.zeros((nq, R), dtype=np.int32)
+        _lib.check(_lib.lib().tk_index_query_batch(
+            self._h, _lib.ptr(qn, _lib._f32p), q_pq.ctypes.data, int(is64), nq, int(k),
+            int(n_probes), int(pass_1 or 0), _lib.ptr(out, _lib._i64p),
+            None if probes is None else _lib.ptr(probes, _lib._i64p),
+            None if hidx is None else _lib.ptr(hidx, _lib._i64p),
+            None if hval is None else _lib.ptr(hval, _lib._i32p)))
+        if debug:
+            return out, dict(probes=probes, heap_idx=hidx, heap_val=hval)
+        return out
+
+    def query_batch_dev(self, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, out_ptr,
+                        pass_1=None, stream=0):
+        """Device pointers in, device pointer out, enqueued on `stream` (no sync)."""
+        _lib.check(_lib.lib().tk_index_query_batch_dev(
+            self._h, qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
+            int(pass_1 or 0), out_ptr, stream))
+
+    def reserve(self, nq, k, n_probes, pass_1=None):
+        _lib.check(_lib.lib().tk_index_reserve(self._h, nq, int(k), int(n_probes), int(pass_1 or 0)))
+
+    def set_profiling(self, on):
+        _lib.check(_lib.lib().tk_index_set_profiling(self._h, int(on)))
+
+    def last_profile(self):
+        ms = (C.c_float * 7)()
+        b = C.c_double()
+        _lib.check(_lib.lib().tk_index_last_profile(self._h, ms, C.byref(b)))
+        names = ["tables", "coarse_scan", "coarse_heap", "coarse_rescore", "scan", "heap", "rescore"]
+        return dict(zip(names, list(ms))), b.value
+
+
+class IVF:
+    """reference: ivf.py:8-163"""
+
+    def __init__(self, metric, n_clusters, pq=None):
+        assert metric in ["euclidean", "angular"]
+        self.metric = metric
+        self.pq = FastPQ(dims_per_block=2) if pq is None else pq
+        assert self.pq.centers is None, "PQ should not be pre-fitted"
+        self.pq_transformed_points = [None] * n_clusters
+        self.pq_transformed_centers = [None] * n_clusters
+        self.n_clusters = n_clusters
+        self.ids = [None] * n_clusters
+        self._dev = None
+
+    # device handles are not picklable (the reference pickles (pq, ivf), bench.py:88-103)
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_dev"] = None
+        return st
+
+    # ---- offline ---------------------------------------------------------
+    def fit(self, X, verbose=False):
+        """Coarse k-means centres + PQ codebook.  reference: ivf.py:19-51"""
+        import sklearn.cluster
+        n, d = X.shape
+        assert n >= 1
+        with timer(verbose, "Fitting IVF cluster centers..."):
+            km = sklearn.cluster.KMeans(n_clusters=self.n_clusters, n_init=1, verbose=verbose)
+            if self.metric == "angular":
+                # spherical data: normalise the points, then the centres (ivf.py:38-45)
+                X = X / np.linalg.norm(X, axis=1, keepdims=True)
+                self.all_centers = km.fit(X).cluster_centers_
+                self.all_centers /= np.linalg.norm(self.all_centers, axis=1, keepdims=True)
+            else:
+                self.all_centers = km.fit(X).cluster_centers_
+        with timer(verbose, "Fitting PQ to data..."):
+            self.pq.fit(X, verbose=verbose)
+        return self
+
+    def build(self, X, n_probes=2, verbose=False):
+        """Assign every point to its n_probes nearest centres and encode the lists.
+        reference: ivf.py:53-104"""
+        assert n_probes <= self.n_clusters, (
+            f"Can't assign points to {n_probes} clusters, as index only has {self.n_clusters}")
+        self._dev = None
+        self.data = data = X.copy()
+        if self.metric == "angular":
+            data /= np.linalg.norm(data, axis=1, keepdims=True)
+        with timer(verbose, "Computing nearest clusters..."):
+            nearest = knn_brute(data, self.all_centers, k=n_probes, metric=self.metric)
+        with timer(verbose, "PQ Transforming active centers..."):
+            self.active_centers = np.ascontiguousarray(
+                self.all_centers[np.unique(nearest)], dtype=np.float32)
+            self.pq_transformed_centers = self.pq.transform(self.active_centers)
+        with timer(verbose, "Transforming points..."):
+            n_active = self.active_centers.shape[0]
+            groups, self.ids = group_data_by_indices(data, nearest, n_active)
+            for i in range(n_active):
+                self.pq_transformed_points[i] = self.pq.transform(groups[i])
+        return self
+
+    # ---- queries (GPU) -----------------------------------------------------
+    def device_index(self):
+        if self._dev is None:
+            self._dev = DeviceIndex(self)
+        return self._dev
+
+    def _prepare(self, qs):
+        """Host side of ivf.py:125-128: float32, metric normalisation (numpy, in
+        place for a contiguous float32 input as in the reference), padding and the
+        optional float64 rotation of the table-build query."""
+        pq = self.pq
+        dq = pq.centers.shape[1]
+        d = qs.shape[1]
+        pad = (-d) % (dpad * pq.dims_per_block)
+        if self.metric == "angular":
+            for row in qs:
+                row /= np.linalg.norm(row)
+        qp = qs if pad == 0 else np.concatenate([qs, np.zeros((len(qs), pad), qs.dtype)], axis=1)
+        if pq.R is not None:
+            qp = np.stack([row @ pq.R.T for row in qp])   # per-row GEMV, as the reference
+        assert qp.shape[1] == dq
+        return qs, qp
+
+    def query(self, q, k, n_probes=1, pass_1=None):
+        """Top-k ids for one query.  reference: ivf.py:106-163"""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        assert self.data.shape[1] == q.shape[0]
+        qn, qp = self._prepare(q[None, :])
+        out = self.device_index().query_batch(qn, qp, k, n_probes, pass_1)[0]
+        return out[out != -1] if out[-1] == -1 else out
+
+    def query_batch(self, qs, k, n_probes=1, pass_1=None):
+        """(nq, d) queries -> (nq, k) int64 ids, rows padded with -1 when the
+        reference would return fewer than k ids.  (The reference's README shows a
+        2-d `ivf.query(queries, ...)` that its code does not support; this is that
+        call.)"""
+        qs = np.array(qs, dtype=np.float32, order="C", copy=True)
+        qn, qp = self._prepare(qs)
+        return self.device_index().query_batch(qn, qp, k, n_probes, pass_1)
