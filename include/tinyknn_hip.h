@@ -140,13 +140,15 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
                              int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                              int64_t *out_ids_dev, void *stream);
 
-/* Timing of the stages of the last tk_index_query_batch[_dev] call when profiling
- * was switched on with tk_index_set_profiling(ix, 1): milliseconds per stage
- * [tables, coarse_scan, coarse_heap, coarse_rescore, scan, heap, rescore] and the
- * algorithmic bytes the list-scan kernel was asked to stream.
- * Synchronises the stream. */
+/* Stage timing.  With profiling on, every (sub-)batch records HIP events on its
+ * stream around the stages (no synchronisation in the query call).
+ * tk_index_last_profile synchronises that stream and returns the mean
+ * milliseconds per stage over the batches recorded since the last read
+ * [tables, coarse_scan, coarse_heap, coarse_rescore+slots, scan, heap, rescore],
+ * their count, and the algorithmic bytes the list-scan kernel streamed for the
+ * most recent batch (code bytes + table + heap per query). */
 int tk_index_set_profiling(tk_index *ix, int on);
-int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes);
+int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches);
 
 #ifdef __cplusplus
 }

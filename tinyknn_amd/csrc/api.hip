@@ -331,12 +331,13 @@ struct tk_index {
     // workspace
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, cslots_i, cslots_l, q, qpq, out, stage;
-    // profiling
+    // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
-    hipEvent_t ev[8] = {};
-    bool ev_made = false;
-    float last_ms[7] = {};
-    double last_scan_bytes = 0;
+    std::vector<hipEvent_t> evs;   // 8 per set
+    size_t ev_used = 0;            // sets recorded since the last read
+    hipStream_t ev_stream = 0;
+    int last_S = 0, last_R = 0;
+    int64_t last_nq = 0;
 };
 
 extern "C" tk_index *tk_index_create(void)
@@ -355,8 +356,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->dist, &ix->heap_idx, &ix->heap_val, &ix->cslots_i, &ix->cslots_l, &ix->q,
                       &ix->qpq, &ix->out, &ix->stage};
     for (DevBuf *b : bufs) b->release();
-    if (ix->ev_made)
-        for (auto &e : ix->ev) (void)hipEventDestroy(e);
+    for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
 }
 
@@ -512,15 +512,23 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
                      int k, const Plan &p, int64_t *out_dev, hipStream_t st)
 {
     const int M = ix->M;
-    const bool prof = ix->profiling != 0;
-    if (prof && !ix->ev_made) {
-        for (auto &e : ix->ev) HIPCHECK(hipEventCreate(&e));
-        ix->ev_made = true;
+    const bool prof = ix->profiling != 0 && ix->ev_used < 4096;
+    hipEvent_t *ev = nullptr;
+    if (prof) {
+        while (ix->evs.size() < (ix->ev_used + 1) * 8) {
+            hipEvent_t e;
+            HIPCHECK(hipEventCreate(&e));
+            ix->evs.push_back(e);
+        }
+        ev = &ix->evs[ix->ev_used * 8];
+        ix->ev_used++;
+        ix->ev_stream = st;
+        ix->last_S = p.S; ix->last_R = p.R; ix->last_nq = nq;
     }
     int evi = 0;
-#define MARK()                                                     \
-    do {                                                           \
-        if (prof) HIPCHECK(hipEventRecord(ix->ev[evi++], st));     \
+#define MARK()                                                 \
+    do {                                                       \
+        if (prof) HIPCHECK(hipEventRecord(ev[evi++], st));     \
     } while (0)
     MARK();
     // 1. distance tables                                   fast_pq.py:186-222
@@ -565,21 +573,6 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
     MARK();
 #undef MARK
     HIPCHECK(hipGetLastError());
-    if (prof) {
-        HIPCHECK(hipEventSynchronize(ix->ev[7]));
-        for (int i = 0; i < 7; i++) {
-            float ms = 0;
-            HIPCHECK(hipEventElapsedTime(&ms, ix->ev[i], ix->ev[i + 1]));
-            ix->last_ms[i] += ms;
-        }
-        // algorithmic bytes of the list scan: code bytes + table + heap out
-        std::vector<int> pre((size_t)nq * (p.S + 1));
-        HIPCHECK(hipMemcpy(pre.data(), ix->slot_prefix.p, pre.size() * 4, hipMemcpyDeviceToHost));
-        double bytes = 0;
-        for (int64_t i = 0; i < nq; i++)
-            bytes += (double)pre[(size_t)i * (p.S + 1) + p.S] * M * 8 + 16.0 * M + 12.0 * p.R;
-        ix->last_scan_bytes += bytes;
-    }
     return TK_OK;
 }
 
@@ -591,10 +584,6 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     ARGCHECK(nq >= 0, "nq");
     hipStream_t st = (hipStream_t)stream;
-    if (ix->profiling) {
-        for (float &m : ix->last_ms) m = 0;
-        ix->last_scan_bytes = 0;
-    }
     const size_t esz = q_pq_is_f64 ? 8 : 4;
     for (int64_t o = 0; o < nq; o += MAX_SUB) {
         int64_t sub = nq - o < MAX_SUB ? nq - o : MAX_SUB;
@@ -644,13 +633,33 @@ extern "C" int tk_index_set_profiling(tk_index *ix, int on)
 {
     ARGCHECK(ix, "null index");
     ix->profiling = on;
+    ix->ev_used = 0;
     return TK_OK;
 }
 
-extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes)
+extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches)
 {
     ARGCHECK(ix, "null index");
-    for (int i = 0; i < 7; i++) ms7[i] = ix->last_ms[i];
-    *scan_bytes = ix->last_scan_bytes;
+    for (int i = 0; i < 7; i++) ms7[i] = 0;
+    *scan_bytes = 0;
+    *batches = (int)ix->ev_used;
+    if (ix->ev_used == 0) return TK_OK;
+    HIPCHECK(hipStreamSynchronize(ix->ev_stream));
+    for (size_t b = 0; b < ix->ev_used; b++)
+        for (int i = 0; i < 7; i++) {
+            float ms = 0;
+            HIPCHECK(hipEventElapsedTime(&ms, ix->evs[b * 8 + i], ix->evs[b * 8 + i + 1]));
+            ms7[i] += ms / (float)ix->ev_used;
+        }
+    // algorithmic bytes of the list scan of the most recent sub-batch:
+    // per query  sum over probed lists ceil(n/16)*M*8  +  16*M (table)  +  12*R (heap)
+    const int S = ix->last_S;
+    std::vector<int> pre((size_t)ix->last_nq * (S + 1));
+    HIPCHECK(hipMemcpy(pre.data(), ix->slot_prefix.p, pre.size() * 4, hipMemcpyDeviceToHost));
+    double bytes = 0;
+    for (int64_t i = 0; i < ix->last_nq; i++)
+        bytes += (double)pre[(size_t)i * (S + 1) + S] * ix->M * 8 + 16.0 * ix->M + 12.0 * ix->last_R;
+    *scan_bytes = bytes;
+    ix->ev_used = 0;
     return TK_OK;
 }

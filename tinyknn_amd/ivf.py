@@ -118,9 +118,10 @@ class DeviceIndex:
     def last_profile(self):
         ms = (C.c_float * 7)()
         b = C.c_double()
-        _lib.check(_lib.lib().tk_index_last_profile(self._h, ms, C.byref(b)))
+        n = C.c_int32()
+        _lib.check(_lib.lib().tk_index_last_profile(self._h, ms, C.byref(b), C.byref(n)))
         names = ["tables", "coarse_scan", "coarse_heap", "coarse_rescore", "scan", "heap", "rescore"]
-        return dict(zip(names, list(ms))), b.value
+        return dict(zip(names, list(ms))), b.value, n.value
 
 
 class IVF:
