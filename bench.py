@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--recall-sample", type=int, default=1000)
     ap.add_argument("--cache-dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -181,6 +182,7 @@ def main():
     out_dev = torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)
     stream = torch.cuda.current_stream().cuda_stream
     dev.reserve(args.nq, args.k, args.n_probes)
+    dev.set_heap_mode(args.heap_mode)
 
     def step():
         dev.query_batch_dev(q_dev.data_ptr(), qp_dev.data_ptr(), False, args.nq, args.k,

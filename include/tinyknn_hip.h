@@ -140,6 +140,17 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
                              int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                              int64_t *out_ids_dev, void *stream);
 
+/* Heap replay strategy.  0 = automatic: when the replay can skip `insert`'s
+ * duplicate-label scan without changing the result (fresh heaps and pairwise
+ * distinct labels, i.e. IVF.build(n_probes=1)) each LANE replays one query (64
+ * queries per wave, heap columns in LDS; pass_1 <= 574), or, for larger heaps, a
+ * wave replays one query on packed 32-bit entries; otherwise the general kernel
+ * (int64 labels + duplicate scan, one query per wave) runs.  1 = always the
+ * general kernel.  2 = the packed wave kernel instead of the lane kernel.  All are
+ * bit-exact replays of _fast_pq_256.pyx:73-123; the switch exists for A/B timing
+ * and for the parity tests. */
+int tk_index_set_heap_mode(tk_index *ix, int mode);
+
 /* Stage timing.  With profiling on, every (sub-)batch records HIP events on its
  * stream around the stages (no synchronisation in the query call).
  * tk_index_last_profile synchronises that stream and returns the mean

@@ -262,6 +262,9 @@ void tko_heap_insert_is(i64 *indices, int32_t *vals, int R, i64 i, int32_t v)
  * every lane that passes is inserted without re-checking (:111-118); the bound
  * is refreshed once per block that had a hit (:123).
  * Optional counters: n_ins[0] += inserts attempted, n_ins[1] += blocks with hit. */
+static int32_t *g_block_trace = NULL;   /* optional: inserts attempted per block */
+void tko_set_block_trace(int32_t *buf) { g_block_trace = buf; }
+
 void tko_query_pq_stats(const uint64_t *data, i64 chunks, int M, i64 n,
                         const uint64_t *tables, i64 *indices, int32_t *vals, int R,
                         int signd, const i64 *labels, int order, i64 *n_ins)
@@ -286,6 +289,7 @@ void tko_query_pq_stats(const uint64_t *data, i64 chunks, int M, i64 n,
                 i64 label = labels ? labels[pos] : pos;
                 int32_t v = signd ? (int32_t)(int8_t)dist[r] : (int32_t)dist[r];
                 if (n_ins) n_ins[0]++;
+                if (g_block_trace) g_block_trace[c]++;
                 tko_heap_insert(indices, vals, R, label, v);
             }
         }

@@ -340,7 +340,8 @@ def test_ivf_vs_oracle_larger(tk, oracle):
                             [ivf.pq_transformed_points[i].size for i in range(L)],
                             [ivf.ids[i] for i in range(L)], ivf.data)
     qn, qp = ivf._prepare(qs.copy())
-    for n_probes in (1, 5, 10, 20):
+    for n_probes, heap_mode in ((1, 0), (5, 0), (10, 0), (10, 1), (10, 2), (20, 0), (50, 0), (50, 1), (50, 2)):
+        ivf.device_index().set_heap_mode(heap_mode)   # lane-per-query / wave-per-query replay
         out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)
         for qi in range(nq):
             ids, odbg = ox.query(qn[qi], 10, n_probes=n_probes, debug=True)
@@ -348,3 +349,42 @@ def test_ivf_vs_oracle_larger(tk, oracle):
             np.testing.assert_array_equal(dbg["heap_idx"][qi], odbg["heap_idx"], err_msg=f"q{qi}")
             np.testing.assert_array_equal(dbg["heap_val"][qi], odbg["heap_val"], err_msg=f"q{qi}")
             np.testing.assert_array_equal(out[qi][out[qi] != -1] if len(ids) < 10 else out[qi], ids)
+
+
+def _oracle_index(oracle, ivf):
+    L = len(ivf.active_centers)
+    return oracle.OracleIndex(ivf.pq.centers, 2, ivf.pq.R, ivf.pq.sqrt_n_blocks, ivf.active_centers,
+                              ivf.pq_transformed_centers.packed,
+                              [ivf.pq_transformed_points[i].packed for i in range(L)],
+                              [ivf.pq_transformed_points[i].size for i in range(L)],
+                              [ivf.ids[i] for i in range(L)], ivf.data)
+
+
+@pytest.mark.parametrize("build_probes", [1, 2])
+def test_ivf_saturating_and_duplicates(tk, oracle, build_probes):
+    """Far-apart clusters: int8 sums hit both rails, coarse heaps keep -1 sentinels
+    (which wrap to the last list, fast_pq.py:311 / ivf.py:141), and with
+    build_probes=2 every point sits in two lists (dedupe across lists)."""
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(3)
+    n, d, nq = 6000, 20, 200
+    cent = np.random.randn(12, d) * 8
+    X = (cent[np.random.randint(12, size=n)] + 0.5 * np.random.randn(n, d)).astype(np.float32)
+    qs = (cent[np.random.randint(12, size=nq)] + 0.5 * np.random.randn(nq, d)).astype(np.float32)
+    ivf = IVF("euclidean", 40, FastPQ(2))
+    ivf.fit(X).build(X, n_probes=build_probes)
+    ox = _oracle_index(oracle, ivf)
+    qn, qp = ivf._prepare(qs.copy())
+    saw_sentinel = 0
+    for n_probes in (3, 8, 20):
+        for heap_mode in (0, 1, 2):
+            ivf.device_index().set_heap_mode(heap_mode)
+            out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)
+            for qi in range(nq):
+                ids, odbg = ox.query(qn[qi], 10, n_probes=n_probes, debug=True)
+                saw_sentinel += int((odbg["probes"] < 0).any())
+                np.testing.assert_array_equal(dbg["probes"][qi], odbg["probes"], err_msg=f"q{qi}")
+                np.testing.assert_array_equal(dbg["heap_idx"][qi], odbg["heap_idx"], err_msg=f"q{qi} p{n_probes} m{heap_mode}")
+                np.testing.assert_array_equal(dbg["heap_val"][qi], odbg["heap_val"], err_msg=f"q{qi}")
+                np.testing.assert_array_equal(out[qi][out[qi] != -1] if len(ids) < 10 else out[qi], ids)
+    print("queries with a -1 probe:", saw_sentinel)

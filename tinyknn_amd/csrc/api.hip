@@ -3,7 +3,9 @@
 // kernels and copy results back; the tk_index_* entry points keep the index
 // resident and only enqueue kernels.  There is no CPU implementation behind any of
 // these calls.
+#include <algorithm>
 #include <mutex>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -156,7 +158,7 @@ extern "C" int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t 
     ARGCHECK(M >= 2 && M % 2 == 0, "M must be even");
     ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
     ARGCHECK(chunks < (1ll << 31) / 16, "list too long");
-    ARGCHECK((size_t)R * 12 <= 64 * 1024, "heap larger than 64 KiB of LDS");
+    ARGCHECK((size_t)R * 12 <= 15 * 1024, "heap larger than 15 KiB of LDS (R <= 1280)");
     if (chunks == 0) return TK_OK;
     Scratch &S = scratch();
     std::lock_guard<std::mutex> lk(S.mu);
@@ -188,7 +190,7 @@ extern "C" int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t 
     tk_launch_heap_replay(S.out.as<uint4>(), chunks, 1, S.slots_i.as<int>(),
                           S.slots_i.as<int>() + 2, S.slots_l.as<int64_t>(), 1,
                           S.labels.as<int64_t>(), S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R,
-                          signd, 1, st);
+                          signd, 1, nullptr, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(indices, S.hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(vals, S.hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
@@ -218,7 +220,7 @@ static int heap_insert_host(int64_t *indices, int32_t *vals, int R, int64_t i, i
 {
     TRY(require_gpu());
     ARGCHECK(R >= 1, "R");
-    ARGCHECK((size_t)R * 12 <= 64 * 1024, "heap larger than 64 KiB of LDS");
+    ARGCHECK((size_t)R * 12 <= 15 * 1024, "heap larger than 15 KiB of LDS (R <= 1280)");
     Scratch &S = scratch();
     std::lock_guard<std::mutex> lk(S.mu);
     hipStream_t st = 0;
@@ -324,13 +326,16 @@ struct tk_index {
     DevBuf list_chunk_off, list_n, ids_off, ids, codes;
     int64_t total_chunks = 0, total_ids = 0;
     int max_list_chunks = 0;
+    bool ids_unique = false;   // no label occurs twice => the lane-per-query replay is exact
+    int heap_mode = 0;         // 0 auto (lanes, else packed wave), 1 general wave, 2 packed wave
     bool have_pq = false, have_centers = false, have_lists = false, have_data = false;
     // vectors
     DevBuf data;
     int64_t N = 0;
     // workspace
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
-        slot_n, slot_loff, dist, heap_idx, heap_val, cslots_i, cslots_l, q, qpq, out, stage;
+        slot_n, slot_loff, dist, heap_idx, heap_val, cslots_i, cslots_l, q, qpq, out, stage,
+        repeat_flag;
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
     std::vector<hipEvent_t> evs;   // 8 per set
@@ -354,7 +359,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->shift, &ix->scale, &ix->cdist, &ix->cheap_idx, &ix->cheap_val,
                       &ix->probes, &ix->slot_prefix, &ix->slot_chunk0, &ix->slot_n, &ix->slot_loff,
                       &ix->dist, &ix->heap_idx, &ix->heap_val, &ix->cslots_i, &ix->cslots_l, &ix->q,
-                      &ix->qpq, &ix->out, &ix->stage};
+                      &ix->qpq, &ix->out, &ix->stage, &ix->repeat_flag};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
@@ -426,6 +431,30 @@ extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const
         if (c > maxc) maxc = c;
     }
     ARGCHECK(maxc < (1ll << 26), "list too long");
+    // are the labels pairwise distinct?  (IVF.build(n_probes=1): every point in one list)
+    {
+        bool uniq = true;
+        const int64_t T = ioff[L];
+        int64_t mn = 0, mx = -1;
+        for (int64_t i = 0; i < T; i++) {
+            if (i == 0 || ids[i] < mn) mn = ids[i];
+            if (i == 0 || ids[i] > mx) mx = ids[i];
+        }
+        if (T > 0 && mn >= 0 && mx < 64 * T + 1024) {
+            std::vector<uint64_t> seen((size_t)(mx / 64 + 1), 0);
+            for (int64_t i = 0; i < T && uniq; i++) {
+                uint64_t bit = 1ull << (ids[i] & 63);
+                if (seen[(size_t)(ids[i] >> 6)] & bit) uniq = false;
+                seen[(size_t)(ids[i] >> 6)] |= bit;
+            }
+        } else if (T > 0) {
+            std::vector<int64_t> tmp(ids, ids + T);
+            std::sort(tmp.begin(), tmp.end());
+            for (int64_t i = 1; i < T && uniq; i++) uniq = tmp[i] != tmp[i - 1];
+            if (mn < 0) uniq = false;  // a label -1 would match the heap's sentinel
+        }
+        ix->ids_unique = uniq;
+    }
     TRY(upload_tiled(ix->codes, ix->stage, codes, coff[L], ix->M));
     TRY(ix->list_chunk_off.ensure((size_t)(L + 1) * 8));
     TRY(ix->ids_off.ensure((size_t)(L + 1) * 8));
@@ -468,7 +497,7 @@ static int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &
     int64_t kc = n_probes < ix->n_lists ? n_probes : ix->n_lists;              // fast_pq.py:291
     int64_t rescore = 2 * kc + 10 < ix->n_lists ? 2 * kc + 10 : ix->n_lists;   // :293-294
     int64_t R = pass_1 > 0 ? pass_1 : (int64_t)(n_probes + 1) * k + 1;         // ivf.py:135-136
-    ARGCHECK(R * 12 <= 64 * 1024 && rescore * 12 <= 64 * 1024, "heap larger than 64 KiB of LDS");
+    ARGCHECK(R * 12 <= 15 * 1024 && rescore * 12 <= 15 * 1024, "heap larger than 15 KiB of LDS (R <= 1280)");
     ARGCHECK(R * 12 + (int64_t)ix->d * 4 <= 64 * 1024, "rescoring tile larger than 64 KiB of LDS");
     p.kc = (int)kc; p.rescore = (int)rescore; p.R = (int)R; p.S = (int)kc;
     p.cap = (int64_t)kc * ix->max_list_chunks;
@@ -495,6 +524,7 @@ static int reserve(tk_index *ix, int64_t nq, int k, const Plan &p)
     TRY(ix->heap_idx.ensure((size_t)nq * p.R * 8));
     TRY(ix->heap_val.ensure((size_t)nq * p.R * 4));
     TRY(ix->out.ensure((size_t)nq * k * 8));
+    TRY(ix->repeat_flag.ensure((size_t)nq));
     return TK_OK;
 }
 
@@ -540,12 +570,30 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
     tk_launch_scan_flat(ix->center_codes.as<uint4>(), ix->center_chunks, M, ix->tables.as<uint4>(),
                         nq, ix->cdist.as<uint4>(), ix->center_chunks, 1, ix->order, st);
     MARK();
-    tk_launch_heap_fill(ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
-                        nq * p.rescore, 127, st);
-    tk_launch_heap_replay(ix->cdist.as<uint4>(), ix->center_chunks, nq, ix->cslots_i.as<int>(),
-                          ix->cslots_i.as<int>() + 2, ix->cslots_l.as<int64_t>(), 1, nullptr,
-                          ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(), p.rescore, 1, 1,
-                          st);
+    // positions of one list against a fresh heap are distinct labels: lane-per-query
+    const bool fast_c = ix->heap_mode != 1 && ix->center_chunks * 16 <= 0xffffff;
+    const bool lanes_c = fast_c && ix->heap_mode == 0 && p.rescore <= TK_LANES_MAX_R;
+    if (fast_c && !lanes_c) {
+        tk_launch_heap_replay_packed(ix->cdist.as<uint4>(), ix->center_chunks, nq,
+                                     ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
+                                     ix->cslots_l.as<int64_t>(), 1, nullptr,
+                                     ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
+                                     p.rescore, 1, 1, nullptr, st);
+    } else if (lanes_c) {
+        if (tk_launch_heap_replay_lanes(ix->cdist.as<uint4>(), ix->center_chunks, nq,
+                                        ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
+                                        ix->cslots_l.as<int64_t>(), 1, nullptr,
+                                        ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
+                                        p.rescore, 1, 1, nullptr, st))
+            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
+    } else {
+        tk_launch_heap_fill(ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
+                            nq * p.rescore, 127, st);
+        tk_launch_heap_replay(ix->cdist.as<uint4>(), ix->center_chunks, nq,
+                              ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
+                              ix->cslots_l.as<int64_t>(), 1, nullptr, ix->cheap_idx.as<int64_t>(),
+                              ix->cheap_val.as<int32_t>(), p.rescore, 1, 1, nullptr, st);
+    }
     MARK();
     tk_launch_rescore(q_dev, ix->d, ix->active_centers.as<float>(), ix->n_lists,
                       ix->cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0,
@@ -554,18 +602,43 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
                          ix->list_chunk_off.as<int64_t>(), ix->list_n.as<int64_t>(),
                          ix->ids_off.as<int64_t>(), ix->slot_prefix.as<int>(),
                          ix->slot_chunk0.as<int64_t>(), ix->slot_n.as<int>(),
-                         ix->slot_loff.as<int64_t>(), st);
+                         ix->slot_loff.as<int64_t>(), ix->repeat_flag.as<unsigned char>(), st);
     MARK();
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
     tk_launch_scan_probes(ix->codes.as<uint4>(), M, ix->tables.as<uint4>(), nq,
                           ix->slot_prefix.as<int>(), ix->slot_chunk0.as<int64_t>(), p.S,
                           (int)p.cap, ix->dist.as<uint4>(), p.cap, 1, ix->order, st);
     MARK();
-    tk_launch_heap_fill(ix->heap_idx.as<int64_t>(), ix->heap_val.as<int32_t>(), nq * p.R, 127, st);
-    tk_launch_heap_replay(ix->dist.as<uint4>(), p.cap, nq, ix->slot_prefix.as<int>(),
-                          ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
-                          ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
-                          ix->heap_val.as<int32_t>(), p.R, 1, 0, st);
+    const bool fast = ix->heap_mode != 1 && ix->ids_unique && p.cap * 16 <= 0xffffff;
+    const bool lanes = fast && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
+    if (fast) {
+        if (!lanes)
+            tk_launch_heap_replay_packed(ix->dist.as<uint4>(), p.cap, nq,
+                                         ix->slot_prefix.as<int>(), ix->slot_n.as<int>(),
+                                         ix->slot_loff.as<int64_t>(), p.S, ix->ids.as<int64_t>(),
+                                         ix->heap_idx.as<int64_t>(), ix->heap_val.as<int32_t>(),
+                                         p.R, 1, 0, ix->repeat_flag.as<unsigned char>(), st);
+        else if (tk_launch_heap_replay_lanes(ix->dist.as<uint4>(), p.cap, nq, ix->slot_prefix.as<int>(),
+                                        ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
+                                        ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
+                                        ix->heap_val.as<int32_t>(), p.R, 1, 0,
+                                        ix->repeat_flag.as<unsigned char>(), st))
+            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
+        // queries whose probe list wrapped (-1 from an unfilled coarse heap) may scan a
+        // list twice; they take the wave kernel with the duplicate-label scan
+        tk_launch_heap_replay(ix->dist.as<uint4>(), p.cap, nq, ix->slot_prefix.as<int>(),
+                              ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
+                              ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
+                              ix->heap_val.as<int32_t>(), p.R, 1, 0,
+                              ix->repeat_flag.as<unsigned char>(), st);
+    } else {
+        tk_launch_heap_fill(ix->heap_idx.as<int64_t>(), ix->heap_val.as<int32_t>(), nq * p.R, 127,
+                            st);
+        tk_launch_heap_replay(ix->dist.as<uint4>(), p.cap, nq, ix->slot_prefix.as<int>(),
+                              ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
+                              ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
+                              ix->heap_val.as<int32_t>(), p.R, 1, 0, nullptr, st);
+    }
     MARK();
     // 4. strip sentinels, exact rescoring                   ivf.py:154-163
     tk_launch_rescore(q_dev, ix->d, ix->data.as<float>(), ix->N, ix->heap_idx.as<int64_t>(), p.R,
@@ -627,6 +700,14 @@ extern "C" int tk_index_query_batch(tk_index *ix, const float *q, const void *q_
     }
     outbuf.release();
     return r;
+}
+
+extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
+{
+    ARGCHECK(ix, "null index");
+    ARGCHECK(mode >= 0 && mode <= 2, "mode");
+    ix->heap_mode = mode;
+    return TK_OK;
 }
 
 extern "C" int tk_index_set_profiling(tk_index *ix, int on)

@@ -25,6 +25,16 @@
 //     64-lane compare + ballot, the sift-down runs wave-uniformly.
 #include "kernels.h"
 
+// Heap state shared by the lanes of a wave lives in LDS and is accessed through
+// address-space-3 volatile pointers: volatile keeps every access in program order
+// (one lane stores, all lanes load), and the explicit address space keeps them
+// ds_read/ds_write — a volatile access through a generic pointer compiles to
+// flat_load/flat_store sc0 sc1 with a vmcnt(0) wait each, ~10x slower.
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) volatile int32_t lds_vi32;
+typedef __attribute__((address_space(3))) volatile int64_t lds_vi64;
+#define LDS_PTR(T, p) ((T *)(__attribute__((address_space(3))) unsigned char *)(p))
+
 template <bool SIGNED>
 __device__ __forceinline__ bool byte_lt(uint32_t d, uint32_t bound8)
 {
@@ -46,11 +56,11 @@ __device__ __forceinline__ bool any_lt16(const uint4 v, uint32_t bound8)
 
 // The heap arrays are wave-uniform state; reading them through readfirstlane keeps
 // the replay's control flow on the scalar unit.
-__device__ __forceinline__ int32_t lds_i32(volatile int32_t *p)
+__device__ __forceinline__ int32_t lds_i32(lds_vi32 *p)
 {
     return __builtin_amdgcn_readfirstlane(*p);
 }
-__device__ __forceinline__ int64_t lds_i64(volatile int64_t *p)
+__device__ __forceinline__ int64_t lds_i64(lds_vi64 *p)
 {
     int64_t v = *p;
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -59,9 +69,10 @@ __device__ __forceinline__ int64_t lds_i64(volatile int64_t *p)
 }
 
 // insert (_fast_pq.pyx:274-307).  Called by all 64 lanes with wave-uniform
-// arguments; every lane performs the same LDS writes so that the heap is
-// coherent in each lane's own program order.
-__device__ __forceinline__ void heap_insert(volatile int64_t *hidx, volatile int32_t *hval, int R,
+// arguments.  Only lane 0 stores: 64 lanes storing to one address serialise in the
+// LDS pipe (a 64-way same-bank write), and the accesses are volatile and
+// in-order per wave, so every lane's later loads see lane 0's stores.
+__device__ __forceinline__ void heap_insert(lds_vi64 *hidx, lds_vi32 *hval, int R,
                                             int64_t label, int32_t v, int lane)
 {
     bool dup = false;
@@ -81,18 +92,17 @@ __device__ __forceinline__ void heap_insert(volatile int64_t *hidx, volatile int
             if (vr > nxt_val) { nxt = r; nxt_val = vr; }
         }
         if (nxt == j) {
-            hval[j] = v;
-            hidx[j] = label;
+            if (lane == 0) { hval[j] = v; hidx[j] = label; }
             break;
         }
-        hval[j] = nxt_val;
-        hidx[j] = lds_i64(&hidx[nxt]);
+        const int64_t moved = lds_i64(&hidx[nxt]);
+        if (lane == 0) { hval[j] = nxt_val; hidx[j] = moved; }
         j = nxt;
     }
 }
 
 // insert_is (_fast_pq.pyx:256-271)
-__device__ __forceinline__ void heap_insert_is(volatile int64_t *hidx, volatile int32_t *hval,
+__device__ __forceinline__ void heap_insert_is(lds_vi64 *hidx, lds_vi32 *hval,
                                                int R, int64_t label, int32_t v, int lane)
 {
     bool dup = false;
@@ -102,30 +112,47 @@ __device__ __forceinline__ void heap_insert_is(volatile int64_t *hidx, volatile 
     while (j + 1 != R) {
         int32_t nv = lds_i32(&hval[j + 1]);
         if (!(nv > v)) break;
-        hidx[j] = lds_i64(&hidx[j + 1]);
-        hval[j] = nv;
+        const int64_t moved = lds_i64(&hidx[j + 1]);
+        if (lane == 0) { hidx[j] = moved; hval[j] = nv; }
         j++;
     }
-    hidx[j] = label;
-    hval[j] = v;
+    if (lane == 0) { hidx[j] = label; hval[j] = v; }
 }
 
+// Workgroup = 4 independent waves (4 queries): gfx950 admits only ~8 workgroups
+// per CU, so single-wave workgroups would cap residency at 2 waves per SIMD.
+#define TK_HEAP_WAVES 4
+
 template <bool SIGNED>
-__global__ __launch_bounds__(64) void heap_replay_kernel(
+__global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_kernel(
     const uint4 *__restrict__ dist, int64_t cap, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
-    int32_t *__restrict__ heap_val, int R, int slots_uniform)
+    int32_t *__restrict__ heap_val, int R, int slots_uniform,
+    const unsigned char *__restrict__ only_flagged, int64_t nq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    volatile int64_t *hidx = (volatile int64_t *)smem;
-    volatile int32_t *hval = (volatile int32_t *)(smem + (size_t)R * 8);
-    const int lane = threadIdx.x;
-    const int64_t q = blockIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const size_t wstride = ((size_t)R * 12 + 15) & ~(size_t)15;
+    lds_vi64 *hidx = LDS_PTR(lds_vi64, smem + wave * wstride);
+    lds_vi32 *hval = LDS_PTR(lds_vi32, smem + wave * wstride + (size_t)R * 8);
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * TK_HEAP_WAVES + wave;
+    if (q >= nq) return;   // wave-uniform; the kernel uses no workgroup barrier
 
-    for (int t = lane; t < R; t += 64) {
-        hidx[t] = heap_idx[q * R + t];
-        hval[t] = heap_val[q * R + t];
+    if (only_flagged) {
+        // second pass behind the lane-per-query kernel: only the queries it skipped,
+        // starting from a fresh heap
+        if (!only_flagged[q]) return;
+        for (int t = lane; t < R; t += 64) {
+            hidx[t] = -1;
+            hval[t] = SIGNED ? 127 : 255;
+        }
+    } else {
+        for (int t = lane; t < R; t += 64) {
+            hidx[t] = heap_idx[q * R + t];
+            hval[t] = heap_val[q * R + t];
+        }
     }
     // Is the incoming array a max-heap of values in the 8-bit range?  Then the
     // bound (low 8 bits of the root) can only go down and stale votes are safe.
@@ -202,18 +229,359 @@ __global__ __launch_bounds__(64) void heap_replay_kernel(
 void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                            const int *slot_n, const int64_t *slot_label_off, int S,
                            const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
-                           int signd, int slots_uniform, hipStream_t s)
+                           int signd, int slots_uniform, const unsigned char *only_flagged,
+                           hipStream_t s)
 {
     if (nq == 0 || R == 0) return;
-    size_t lds = (size_t)R * 12;
+    size_t lds = (((size_t)R * 12 + 15) & ~(size_t)15) * TK_HEAP_WAVES;
+    dim3 grid((unsigned)((nq + TK_HEAP_WAVES - 1) / TK_HEAP_WAVES)), block(64 * TK_HEAP_WAVES);
     if (signd)
-        hipLaunchKernelGGL(heap_replay_kernel<true>, dim3((unsigned)nq), dim3(64), lds, s, dist,
-                           cap, slot_prefix, slot_n, slot_label_off, S, labels, heap_idx,
-                           heap_val, R, slots_uniform);
+        hipLaunchKernelGGL(heap_replay_kernel<true>, grid, block, lds, s, dist, cap, slot_prefix,
+                           slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform,
+                           only_flagged, nq);
     else
-        hipLaunchKernelGGL(heap_replay_kernel<false>, dim3((unsigned)nq), dim3(64), lds, s, dist,
-                           cap, slot_prefix, slot_n, slot_label_off, S, labels, heap_idx,
-                           heap_val, R, slots_uniform);
+        hipLaunchKernelGGL(heap_replay_kernel<false>, grid, block, lds, s, dist, cap, slot_prefix,
+                           slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform,
+                           only_flagged, nq);
+}
+
+// ---------------------------------------------------------------------------
+// Lane-per-query replay (the throughput path of IVF.query batches).
+//
+// The wave-per-query kernel above spends 64 lanes on one scalar heap.  When
+//   (a) every heap starts fresh (ivf.py:137-138 / init_heap),
+//   (b) no label can occur twice among the lists a query scans (ids are globally
+//       unique, i.e. IVF.build(n_probes=1), or positions of one list), so the
+//       duplicate test of `insert` can never fire,
+// each LANE can replay one query: same blocks, same stale-bound test, same
+// unconditional inserts, same sift-down — 64 queries per wave in SIMT.
+//   * heap entry = one dword (value8 << 24 | flat position24) in LDS, laid out
+//     [slot j][lane]: a lane only touches its own column and bank = lane % 32, so
+//     the divergent sift-down addresses are conflict-free by construction;
+//   * the distance rows are staged 16 blocks per lane at a time by LDS-DMA
+//     (global_load_lds_dwordx4: each lane's 16 bytes from its own row land in
+//     ST[k][lane]), double-buffered, so that no lane ever waits on a dependent
+//     global load; inside a segment lanes are decoupled: each walks to its next
+//     block with a byte below its bound, then all lanes with a pending candidate
+//     perform one insert together; a bound is refreshed when its block is done;
+//   * labels are resolved from the flat positions once, at the end.
+template <bool SIGNED>
+__device__ __forceinline__ int entry_val(uint32_t e)
+{
+    return SIGNED ? ((int32_t)e >> 24) : (int)(e >> 24);
+}
+
+template <bool SIGNED>
+__device__ __forceinline__ uint32_t mask_lt16(const uint4 v, uint32_t bound8)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            m |= (uint32_t)byte_lt<SIGNED>((w[i] >> (8 * b)) & 0xffu, bound8) << (4 * i + b);
+    return m;
+}
+
+template <bool SIGNED>
+__global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
+    const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
+    const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
+    const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
+    int32_t *__restrict__ heap_val, int R, int slots_uniform,
+    const unsigned char *__restrict__ skip, int nbuf)
+{
+    // LDS: H[R+2][64] heap columns (+2 sentinel rows) | ST[nbuf][16][64] staged blocks
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *H = (uint32_t *)smem;
+    uint4 *ST = (uint4 *)(smem + (size_t)(R + 2) * 256);
+    const int lane = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x * 64 + lane;
+    // `skip`: queries whose probe list may repeat a list (left to the wave kernel)
+    const bool valid = q < nq && !(skip && skip[q]);
+    const int64_t qc = q < nq ? q : nq - 1;
+    const int64_t qs = slots_uniform ? 0 : qc;
+    const int *prefix = slot_prefix + qs * (S + 1);
+    const int *sn = slot_n + qs * S;
+    const uint4 *drow = dist + qc * cap;
+
+    const uint32_t fresh = (SIGNED ? 0x7f000000u : 0xff000000u) | 0x00ffffffu;
+    for (int j = 0; j < R; j++) H[j * 64 + lane] = fresh;
+    H[R * 64 + lane] = H[(R + 1) * 64 + lane] = SIGNED ? 0x80000000u : 0u;  // never > anything
+    uint32_t bound = SIGNED ? 0x7fu : 0xffu;
+
+    const int total = (valid && S > 0) ? prefix[S] : 0;   // flat chunks of this lane's query
+    int nseg = (total + 15) >> 4;
+    int max_nseg = nseg;
+    for (int o = 32; o > 0; o >>= 1) {
+        int other = __shfl_xor(max_nseg, o, 64);
+        max_nseg = other > max_nseg ? other : max_nseg;
+    }
+    max_nseg = __builtin_amdgcn_readfirstlane(max_nseg);
+
+    // slot cursor (monotonic): flat chunks [s_begin, s_end) belong to slot s with n rows
+    int s = 0, s_begin = 0, s_end = 0, n = 0;
+    if (total > 0) { s_end = prefix[1]; n = sn[0]; }
+
+    // stage segment g (16 blocks per lane, each lane from its own row) by LDS-DMA:
+    // one global_load_lds_dwordx4 per block row k writes ST[buf][k][0..63]
+    auto stage = [&](int g, int buf) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int blk = 16 * g + k;
+            if (blk < total)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(drow + blk),
+                    (__attribute__((address_space(3))) void *)(ST + (buf * 16 + k) * 64), 16, 0, 0);
+        }
+    };
+
+    if (max_nseg > 0) stage(0, 0);
+    for (int g = 0; g < max_nseg; g++) {
+        const int buf = nbuf > 1 ? (g & 1) : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // segment g has landed
+        if (nbuf > 1 && g + 1 < max_nseg) stage(g + 1, buf ^ 1);
+        int k = 0;
+        int kmax = total - 16 * g;
+        kmax = kmax < 0 ? 0 : (kmax > 16 ? 16 : kmax);
+        uint32_t bits = 0;
+        uint4 dd = make_uint4(0, 0, 0, 0);
+        int cur = 0;
+        for (;;) {
+            // next block of this segment with a byte below the live bound
+            while (bits == 0 && k < kmax) {
+                dd = ST[(buf * 16 + k) * 64 + lane];
+                cur = 16 * g + k;
+                while (cur >= s_end) {   // next probed list (empty lists are stepped over)
+                    s++;
+                    s_begin = s_end;
+                    s_end = prefix[s + 1];
+                    n = sn[s];
+                }
+                bits = mask_lt16<SIGNED>(dd, bound);          // cmp_mask, _fast_pq_256.pyx:81-90
+                const int rows = n - 16 * (cur - s_begin);    // `pos < n`, :111
+                if (rows < 16) bits &= rows > 0 ? ((1u << rows) - 1u) : 0u;
+                k++;
+            }
+            if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
+            if (bits) {   // one insert per lane with a pending candidate
+                const int r = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const uint32_t w = r < 4 ? dd.x : r < 8 ? dd.y : r < 12 ? dd.z : dd.w;
+                const uint32_t by = (w >> (8 * (r & 3))) & 0xffu;
+                const uint32_t entry = (by << 24) | (uint32_t)(16 * cur + r);
+                const int v = entry_val<SIGNED>(entry);
+                // insert, _fast_pq.pyx:291-307, branch-free per level: H[R] and H[R+1]
+                // hold a value no entry exceeds, so children beyond the heap (clamped
+                // to R) are never taken; el/er are 256 B apart (one ds_read2st64).
+                int j = 0;
+                bool go = true;
+                do {
+                    const int l = 2 * j + 1;
+                    const int lc = l < R ? l : R;
+                    const uint32_t el = H[lc * 64 + lane];
+                    const uint32_t er = H[(lc + 1) * 64 + lane];
+                    const int vl = entry_val<SIGNED>(el), vr = entry_val<SIGNED>(er);
+                    const bool cl = vl > v;                 // vals[l] > nxt_val
+                    const int nv = cl ? vl : v;
+                    uint32_t ne = cl ? el : entry;
+                    int nxt = cl ? l : j;
+                    const bool cr = vr > nv;                // vals[r] > nxt_val
+                    ne = cr ? er : ne;
+                    nxt = cr ? l + 1 : nxt;
+                    H[j * 64 + lane] = ne;                  // entry itself when nxt == j
+                    go = nxt != j;
+                    j = nxt;
+                } while (go);
+                if (bits == 0) bound = H[lane] >> 24;     // refresh after the block, :123
+            }
+        }
+        if (nbuf == 1 && g + 1 < max_nseg) stage(g + 1, 0);
+    }
+    if (!valid) return;
+    // ---- resolve flat positions to labels
+    const int64_t *loffs = slot_label_off + qs * S;
+    for (int j = 0; j < R; j++) {
+        const uint32_t e = H[j * 64 + lane];
+        const uint32_t pos = e & 0x00ffffffu;
+        int64_t label = -1;
+        if (pos != 0x00ffffffu) {
+            const int f = (int)(pos >> 4);
+            int lo = 0, hi = S;  // prefix[lo] <= f < prefix[hi]
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (prefix[mid] <= f) lo = mid; else hi = mid;
+            }
+            const int64_t inlist = (int64_t)pos - 16 * (int64_t)prefix[lo];
+            const int64_t loff = loffs[lo];
+            label = loff < 0 ? inlist : labels[loff + inlist];
+        }
+        heap_idx[q * R + j] = label;
+        heap_val[q * R + j] = entry_val<SIGNED>(e);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wave-per-query replay on packed entries: same preconditions as the
+// lane-per-query kernel (fresh heap, labels cannot repeat), same entry format
+// (value8 << 24 | flat position24), but the 64 lanes of a wave cooperate on ONE
+// query: coalesced 1 KiB loads of 64 blocks, a ballot vote, the exact per-block
+// mask from lanes 0..15, and a scalar-controlled sift-down over a heap that is R
+// dwords of LDS (children l, l+1 are adjacent dwords).  Far fewer instructions per
+// insert than heap_replay_kernel (no label array, no duplicate scan, one LDS word
+// per node), which is what bounds that kernel at 10^4 concurrent queries.
+template <bool SIGNED>
+__global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
+    const uint4 *__restrict__ dist, int64_t cap, const int *__restrict__ slot_prefix,
+    const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
+    const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
+    int32_t *__restrict__ heap_val, int R, int slots_uniform,
+    const unsigned char *__restrict__ skip, int64_t nq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6;
+    lds_vu32 *H = LDS_PTR(lds_vu32, smem + (size_t)wave * R * 4);  // [R] per wave
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * TK_HEAP_WAVES + wave;
+    if (q >= nq) return;   // wave-uniform; no workgroup barrier below
+    if (skip && skip[q]) return;
+    const int64_t qs = slots_uniform ? 0 : q;
+    const int *prefix = slot_prefix + qs * (S + 1);
+    const uint4 *drow = dist + q * cap;
+
+    const uint32_t fresh = (SIGNED ? 0x7f000000u : 0xff000000u) | 0x00ffffffu;
+    for (int t = lane; t < R; t += 64) H[t] = fresh;
+    uint32_t bound = SIGNED ? 0x7fu : 0xffu;
+    const uint4 never = SIGNED ? make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu)
+                               : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    for (int s = 0; s < S; s++) {
+        const int c0 = prefix[s];
+        const int nchunks = prefix[s + 1] - c0;
+        const int n = slot_n[qs * S + s];
+        for (int base = 0; base < nchunks; base += 64) {
+            const int b = base + lane;
+            const bool have = b < nchunks;
+            uint4 dd = never;
+            if (have) dd = drow[c0 + b];
+            bool vote = have && any_lt16<SIGNED>(dd, bound);
+            uint64_t mask = __builtin_amdgcn_ballot_w64(vote);
+            while (mask) {
+                const int j = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint32_t d0 = __builtin_amdgcn_readlane(dd.x, j);
+                const uint32_t d1 = __builtin_amdgcn_readlane(dd.y, j);
+                const uint32_t d2 = __builtin_amdgcn_readlane(dd.z, j);
+                const uint32_t d3 = __builtin_amdgcn_readlane(dd.w, j);
+                // lane r < 16 tests row r against the live bound (= block-start bound)
+                const uint32_t w = lane < 4 ? d0 : lane < 8 ? d1 : lane < 12 ? d2 : d3;
+                const uint32_t by = (w >> (8 * (lane & 3))) & 0xffu;
+                const int rows = n - 16 * (base + j);   // `pos < n`
+                const bool lt = lane < 16 && lane < rows && byte_lt<SIGNED>(by, bound);
+                uint32_t bits = (uint32_t)__builtin_amdgcn_ballot_w64(lt);
+                if (!bits) continue;
+                const uint32_t pos0 = (uint32_t)(16 * (c0 + base + j));
+                while (bits) {
+                    const int r = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const uint32_t byr = __builtin_amdgcn_readlane(by, r);
+                    const uint32_t entry = (byr << 24) | (pos0 + (uint32_t)r);
+                    const int v = entry_val<SIGNED>(entry);
+                    int jn = 0;
+                    for (;;) {  // insert, _fast_pq.pyx:291-307
+                        const int l = 2 * jn + 1;
+                        if (l >= R) { if (lane == 0) H[jn] = entry; break; }
+                        uint32_t el = H[l];
+                        uint32_t er = (l + 1 < R) ? H[l + 1] : 0u;
+                        el = __builtin_amdgcn_readfirstlane(el);
+                        er = __builtin_amdgcn_readfirstlane(er);
+                        int nxt = jn, nv = v;
+                        uint32_t ne = entry;
+                        if (entry_val<SIGNED>(el) > nv) { nxt = l; nv = entry_val<SIGNED>(el); ne = el; }
+                        if (l + 1 < R && entry_val<SIGNED>(er) > nv) { nxt = l + 1; ne = er; }
+                        if (nxt == jn) { if (lane == 0) H[jn] = entry; break; }
+                        if (lane == 0) H[jn] = ne;  // one lane: same-address stores serialise
+                        jn = nxt;
+                    }
+                }
+                bound = __builtin_amdgcn_readfirstlane(H[0]) >> 24;  // :123
+                if (mask) {
+                    vote = vote && any_lt16<SIGNED>(dd, bound);
+                    mask &= __builtin_amdgcn_ballot_w64(vote);
+                }
+            }
+        }
+    }
+    // resolve flat positions to labels
+    const int64_t *loffs = slot_label_off + qs * S;
+    for (int t = lane; t < R; t += 64) {
+        const uint32_t e = H[t];
+        const uint32_t pos = e & 0x00ffffffu;
+        int64_t label = -1;
+        if (pos != 0x00ffffffu) {
+            const int f = (int)(pos >> 4);
+            int lo = 0, hi = S;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (prefix[mid] <= f) lo = mid; else hi = mid;
+            }
+            const int64_t inlist = (int64_t)pos - 16 * (int64_t)prefix[lo];
+            const int64_t loff = loffs[lo];
+            label = loff < 0 ? inlist : labels[loff + inlist];
+        }
+        heap_idx[q * R + t] = label;
+        heap_val[q * R + t] = entry_val<SIGNED>(e);
+    }
+}
+
+void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
+                                  const int *slot_n, const int64_t *slot_label_off, int S,
+                                  const int64_t *labels, int64_t *heap_idx, int32_t *heap_val,
+                                  int R, int signd, int slots_uniform, const unsigned char *skip,
+                                  hipStream_t s)
+{
+    if (nq == 0 || R == 0) return;
+    size_t lds = (size_t)R * 4 * TK_HEAP_WAVES;
+    dim3 grid((unsigned)((nq + TK_HEAP_WAVES - 1) / TK_HEAP_WAVES)), block(64 * TK_HEAP_WAVES);
+    if (signd)
+        hipLaunchKernelGGL(heap_replay_packed_kernel<true>, grid, block, lds, s, dist, cap,
+                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
+                           slots_uniform, skip, nq);
+    else
+        hipLaunchKernelGGL(heap_replay_packed_kernel<false>, grid, block, lds, s, dist, cap,
+                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
+                           slots_uniform, skip, nq);
+}
+
+int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
+                                const int *slot_n, const int64_t *slot_label_off, int S,
+                                const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
+                                int signd, int slots_uniform, const unsigned char *skip,
+                                hipStream_t s)
+{
+    if (nq == 0 || R == 0) return 0;
+    // heap columns + 16 staged blocks per lane, double-buffered when it fits
+    int nbuf = ((size_t)(R + 2) * 256 + 2 * 16384 <= 160 * 1024) ? 2 : 1;
+    size_t lds = (size_t)(R + 2) * 256 + (size_t)nbuf * 16384;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void *)heap_replay_lanes_kernel<true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e2 = hipFuncSetAttribute((const void *)heap_replay_lanes_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e1 != hipSuccess || e2 != hipSuccess) return -1;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((nq + 63) / 64));
+    if (signd)
+        hipLaunchKernelGGL(heap_replay_lanes_kernel<true>, grid, dim3(64), lds, s, dist, cap, nq,
+                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
+                           slots_uniform, skip, nbuf);
+    else
+        hipLaunchKernelGGL(heap_replay_lanes_kernel<false>, grid, dim3(64), lds, s, dist, cap, nq,
+                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
+                           slots_uniform, skip, nbuf);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -238,8 +606,8 @@ __global__ __launch_bounds__(64) void heap_insert_kernel(int64_t *heap_idx, int3
                                                          int R, int64_t i, int32_t v, int is)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    volatile int64_t *hidx = (volatile int64_t *)smem;
-    volatile int32_t *hval = (volatile int32_t *)(smem + (size_t)R * 8);
+    lds_vi64 *hidx = LDS_PTR(lds_vi64, smem);
+    lds_vi32 *hval = LDS_PTR(lds_vi32, smem + (size_t)R * 8);
     const int lane = threadIdx.x;
     for (int t = lane; t < R; t += 64) {
         hidx[t] = heap_idx[t];

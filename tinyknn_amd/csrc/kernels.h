@@ -42,10 +42,33 @@ void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64
 // One wave per query.  slot_n: true rows per slot; slot_label_off: offset into
 // `labels` or -1 (label = position).  heap_idx/heap_val: (nq, R) in/out.
 // slots_uniform: the slot arrays hold ONE row that every query uses.
+// only_flagged (nq bytes or NULL): replay only the flagged queries, each from a
+// fresh heap (the second pass behind tk_launch_heap_replay_lanes).
 void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                            const int *slot_n, const int64_t *slot_label_off, int S,
                            const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
-                           int signd, int slots_uniform, hipStream_t s);
+                           int signd, int slots_uniform, const unsigned char *only_flagged,
+                           hipStream_t s);
+
+// Lane-per-query form of the same replay: 64 queries per wave.  Preconditions
+// (checked by the caller): heaps start fresh (-1 / 127|255), no label can repeat
+// among a query's lists (so `insert`'s duplicate test cannot fire), R*256 B of LDS
+// <= 160 KiB, cap*16 < 2^24 codes per query.  Writes (nq, R) heaps.  Returns 0.
+// skip (nq bytes or NULL): queries to leave untouched.
+#define TK_LANES_MAX_R 574
+int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
+                                const int *slot_n, const int64_t *slot_label_off, int S,
+                                const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
+                                int signd, int slots_uniform, const unsigned char *skip,
+                                hipStream_t s);
+
+// Wave-per-query replay on packed entries; same preconditions and outputs as the
+// lane-per-query kernel (R*4 B of LDS).
+void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
+                                  const int *slot_n, const int64_t *slot_label_off, int S,
+                                  const int64_t *labels, int64_t *heap_idx, int32_t *heap_val,
+                                  int R, int signd, int slots_uniform, const unsigned char *skip,
+                                  hipStream_t s);
 
 void tk_launch_heap_fill(int64_t *heap_idx, int32_t *heap_val, int64_t count, int32_t v,
                          hipStream_t s);
@@ -72,4 +95,5 @@ void tk_launch_rescore(const float *q, int d, const float *rows, int64_t n_rows,
 void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
-                          int *slot_n, int64_t *slot_label_off, hipStream_t s);
+                          int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
+                          hipStream_t s);

@@ -117,15 +117,17 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
                                   const int64_t *__restrict__ list_n,
                                   const int64_t *__restrict__ ids_off, int *__restrict__ slot_prefix,
                                   int64_t *__restrict__ slot_chunk0, int *__restrict__ slot_n,
-                                  int64_t *__restrict__ slot_label_off)
+                                  int64_t *__restrict__ slot_label_off,
+                                  unsigned char *__restrict__ repeat_flag)
 {
     int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     int acc = 0;
+    bool wrapped = false;  // a wrapped id may name a list that is probed twice
     slot_prefix[qi * (S + 1)] = 0;
     for (int s = 0; s < S; s++) {
         int64_t cl = probes[qi * S + s];
-        if (cl < 0) cl += n_lists;
+        if (cl < 0) { cl += n_lists; wrapped = true; }
         int64_t c0 = list_chunk_off[cl];
         acc += (int)(list_chunk_off[cl + 1] - c0);
         slot_prefix[qi * (S + 1) + s + 1] = acc;
@@ -133,16 +135,18 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
         slot_n[qi * S + s] = (int)list_n[cl];
         slot_label_off[qi * S + s] = ids_off[cl];
     }
+    if (repeat_flag) repeat_flag[qi] = wrapped;
 }
 
 void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
-                          int *slot_n, int64_t *slot_label_off, hipStream_t s)
+                          int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
+                          hipStream_t s)
 {
     (void)probe_count;
     if (nq == 0) return;
     hipLaunchKernelGGL(make_slots_kernel, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, s,
                        probes, kc, nq, n_lists, list_chunk_off, list_n, ids_off, slot_prefix,
-                       slot_chunk0, slot_n, slot_label_off);
+                       slot_chunk0, slot_n, slot_label_off, repeat_flag);
 }
