@@ -1,0 +1,119 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol,
+compute calls fail loudly without a GPU, host-side layout code matches the
+golden vectors, and the offline fit/build code keeps the reference's contracts."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import golden, ROOT
+
+
+def _have_gpu():
+    from tinyknn_amd import _lib
+    return _lib.device_count() > 0
+
+
+def test_abi_exports_every_declared_symbol():
+    from tinyknn_amd import _lib
+    lib = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "tinyknn_hip.h")).read()
+    declared = set(re.findall(r"\b(tk_[a-z0-9_]+)\s*\(", header))
+    declared.discard("tk_index")
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in tinyknn_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.tk_version() >= 1
+
+
+def test_no_cpu_fallback():
+    if _have_gpu():
+        pytest.skip("GPU present")
+    from tinyknn_amd import _lib
+    from tinyknn_amd._fast_pq import init_heap
+    from tinyknn_amd._fast_pq_avx import estimate_pq_avx
+    with pytest.raises(_lib.TinyKnnHipError):
+        init_heap(np.zeros(3, np.int64), np.zeros(3, np.int32), True)
+    with pytest.raises(_lib.TinyKnnHipError):
+        estimate_pq_avx(np.zeros((1, 4), np.uint64), np.zeros(8, np.uint64), np.zeros(2, np.uint64), True)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tinyknn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_layout_golden(tag):
+    from tinyknn_amd._transform import transform_data, unpack, transform_tables
+    g = golden("g1_layout.npz")
+    packed = transform_data(g[f"codes_{tag}"])
+    np.testing.assert_array_equal(packed, g[f"packed_{tag}"])
+    np.testing.assert_array_equal(unpack(packed), g[f"codes_{tag}"])
+    np.testing.assert_array_equal(transform_tables(g[f"table_{tag}"]), g[f"ttable_{tag}"])
+    with pytest.raises(AssertionError):
+        transform_data(np.zeros((15, 4), np.uint8))
+    with pytest.raises(AssertionError):
+        transform_data(np.full((16, 4), 16, np.uint8))
+
+
+def test_typed_buffer_errors():
+    from tinyknn_amd._fast_pq import init_heap, estimate_pq_sse
+    with pytest.raises(ValueError):
+        init_heap(np.zeros(3, np.int32), np.zeros(3, np.int32), True)
+    with pytest.raises(ValueError):
+        estimate_pq_sse(np.zeros((1, 4), np.uint32), np.zeros(8, np.uint64), np.zeros(2, np.uint64), True)
+    with pytest.raises(ValueError):
+        estimate_pq_sse(np.zeros((2, 8), np.uint64)[:, ::2], np.zeros(8, np.uint64), np.zeros(4, np.uint64), True)
+
+
+def test_fit_contracts():
+    from tinyknn_amd import FastPQ, IVF
+    with pytest.raises(AssertionError):                       # reference tests/test_pq.py:93-97
+        FastPQ(2).fit(np.zeros((0, 8), np.float32))
+    with pytest.raises(AssertionError):
+        IVF("manhattan", 4)
+    pq = FastPQ(2)
+    with pytest.raises(AssertionError):
+        pq.transform(np.zeros((4, 8), np.float32))
+    np.random.seed(1)
+    X = np.random.randn(100, 10).astype(np.float32)
+    pq.fit(X)
+    assert pq.centers.shape == (16, 16) and pq.centers.dtype == np.float32   # 10 -> 16 = 2 * (4*dpb)
+    assert pq.R is not None and pq.R.shape == (16, 16)
+    td = pq.transform(X)
+    assert td.size == 100 and td.packed.shape == (7, 8) and td.packed.dtype == np.uint64
+    td2 = pq.transform(X)
+    np.testing.assert_array_equal(td.packed, td2.packed)     # test_pq.py:100-108
+    pq100 = FastPQ(2).fit(np.random.randn(64, 100).astype(np.float32))
+    assert pq100.R is None and pq100.centers.shape == (16, 104)   # the 100-d special case
+    assert not FastPQ(1).fit(np.random.randn(64, 100).astype(np.float32)).centers.flags.c_contiguous
+
+
+def test_build_contracts():
+    from tinyknn_amd import FastPQ, IVF
+    from tinyknn_amd.utils import group_data_by_indices
+    np.random.seed(2)
+    X = np.random.randn(300, 8).astype(np.float32)
+    ivf = IVF("angular", 6, FastPQ(2))
+    ivf.fit(X).build(X, n_probes=2)
+    L = len(ivf.active_centers)
+    assert sum(ivf.pq_transformed_points[i].size for i in range(L)) == 2 * len(X)
+    assert all(ivf.ids[i].dtype == np.int64 for i in range(L))
+    np.testing.assert_allclose(np.linalg.norm(ivf.data, axis=1), 1, rtol=1e-5)
+    import pickle
+    ivf2 = pickle.loads(pickle.dumps(ivf))                    # examples/bench.py:88-103
+    assert ivf2._dev is None and ivf2.n_clusters == 6
+    # reference tests/test_utils.py:50-72
+    idx = np.random.randint(0, 5, size=(50, 2))
+    parts, ids = group_data_by_indices(X[:50], idx, 5)
+    for g in range(5):
+        mask = (idx == g).any(axis=1)
+        assert sorted(map(tuple, parts[g])) == sorted(map(tuple, np.vstack([X[:50][idx[:, j] == g] for j in range(2)])))
+        assert set(ids[g]) == set(np.nonzero(mask)[0])
