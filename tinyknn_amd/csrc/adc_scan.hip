@@ -86,11 +86,24 @@ __device__ __forceinline__ void pair_step(const uint4 x, const uint4 tl, const u
     }
 }
 
+template <bool SIGNED>
+__device__ __forceinline__ uint32_t pk_min2(uint32_t a, uint32_t b)
+{
+    if (SIGNED) {
+        v2s r = __builtin_elementwise_min(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b));
+        return __builtin_bit_cast(uint32_t, r);
+    } else {
+        v2u r = __builtin_elementwise_min(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b));
+        return __builtin_bit_cast(uint32_t, r);
+    }
+}
+
 // All M blocks of chunk c against table `tab` (M uint4, wave-uniform address).
-// Returns the chunk's 16 int8/uint8 distances.
+// Returns the chunk's 16 int8/uint8 distances and, in `mn`, their minimum (the
+// heap replay uses it to skip blocks without reading them).
 template <int ORDER, bool SIGNED>
 __device__ __forceinline__ uint4 scan_chunk(const uint4 *__restrict__ codes, int64_t c, int P,
-                                            const uint4 *__restrict__ tab)
+                                            const uint4 *__restrict__ tab, uint32_t &mn)
 {
     const uint4 *src = codes + ((c >> 3) * (int64_t)P) * 8 + (c & 7);
     uint32_t a0[8], a1[8];
@@ -118,6 +131,14 @@ __device__ __forceinline__ uint4 scan_chunk(const uint4 *__restrict__ codes, int
             uint4 x = src[p * 8];
             pair_step<SIGNED>(x, tab[2 * p], tab[2 * p + 1], a0);
         }
+    }
+    {   // minimum over the 16 rows: the value<<8 halves order like the values
+        uint32_t m = pk_min2<SIGNED>(pk_min2<SIGNED>(pk_min2<SIGNED>(a0[0], a0[1]),
+                                                     pk_min2<SIGNED>(a0[2], a0[3])),
+                                     pk_min2<SIGNED>(pk_min2<SIGNED>(a0[4], a0[5]),
+                                                     pk_min2<SIGNED>(a0[6], a0[7])));
+        m = pk_min2<SIGNED>(m, m >> 16);
+        mn = (m >> 8) & 0xffu;
     }
     uint4 o;
     o.x = __builtin_amdgcn_perm(a0[1], a0[0], 0x07050301u);
@@ -162,27 +183,33 @@ __global__ __launch_bounds__(256) void scan_flat_kernel(const uint4 *__restrict_
                                                         int64_t chunks, int P,
                                                         const uint4 *__restrict__ tables, int M,
                                                         uint4 *__restrict__ out,
-                                                        int64_t out_stride)
+                                                        int64_t out_stride,
+                                                        uint8_t *__restrict__ mins,
+                                                        int64_t min_stride)
 {
     const int q = blockIdx.y;
     const uint4 *tab = tables + (int64_t)q * M;
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool active = c < chunks;
     // inactive lanes of the last wave read chunk 0 (in bounds) and drop the result
-    uint4 o = scan_chunk<ORDER, SIGNED>(codes, active ? c : 0, P, tab);
-    if (active) out[(int64_t)q * out_stride + c] = o;
+    uint32_t mn;
+    uint4 o = scan_chunk<ORDER, SIGNED>(codes, active ? c : 0, P, tab, mn);
+    if (active) {
+        out[(int64_t)q * out_stride + c] = o;
+        if (mins) mins[(int64_t)q * min_stride + c] = (uint8_t)mn;
+    }
 }
 
 void tk_launch_scan_flat(const uint4 *codes, int64_t chunks, int M, const uint4 *tables,
-                         int64_t nq, uint4 *out, int64_t out_stride, int signd, int order,
-                         hipStream_t s)
+                         int64_t nq, uint4 *out, int64_t out_stride, uint8_t *mins,
+                         int64_t min_stride, int signd, int order, hipStream_t s)
 {
     if (chunks == 0 || nq == 0) return;
     dim3 grid((unsigned)((chunks + 255) / 256), (unsigned)nq);
     int P = M / 2;
 #define TK_LAUNCH(O, S_)                                                                      \
     hipLaunchKernelGGL((scan_flat_kernel<O, S_>), grid, dim3(256), 0, s, codes, chunks, P,    \
-                       tables, M, out, out_stride)
+                       tables, M, out, out_stride, mins, min_stride)
     if (order == TK_ORDER_AVX) {
         if (signd) TK_LAUNCH(TK_ORDER_AVX, true); else TK_LAUNCH(TK_ORDER_AVX, false);
     } else {
@@ -198,7 +225,7 @@ template <int ORDER, bool SIGNED>
 __global__ __launch_bounds__(256) void scan_probes_kernel(
     const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
     const int *__restrict__ slot_prefix, const int64_t *__restrict__ slot_chunk0, int S,
-    uint4 *__restrict__ dist, int64_t cap)
+    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride)
 {
     const int q = blockIdx.y;
     const int *prefix = slot_prefix + (int64_t)q * (S + 1);
@@ -216,21 +243,25 @@ __global__ __launch_bounds__(256) void scan_probes_kernel(
     }
     const int64_t c = slot_chunk0[(int64_t)q * S + lo] + (ff - prefix[lo]);
     const uint4 *tab = tables + (int64_t)q * M;
-    uint4 o = scan_chunk<ORDER, SIGNED>(codes, c, P, tab);
-    if (active) dist[(int64_t)q * cap + f] = o;
+    uint32_t mn;
+    uint4 o = scan_chunk<ORDER, SIGNED>(codes, c, P, tab, mn);
+    if (active) {
+        dist[(int64_t)q * cap + f] = o;
+        if (mins) mins[(int64_t)q * min_stride + f] = (uint8_t)mn;
+    }
 }
 
 void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
                            const int *slot_prefix, const int64_t *slot_chunk0, int S,
-                           int max_flat_chunks, uint4 *dist, int64_t cap, int signd,
-                           int order, hipStream_t s)
+                           int max_flat_chunks, uint4 *dist, int64_t cap, uint8_t *mins,
+                           int64_t min_stride, int signd, int order, hipStream_t s)
 {
     if (nq == 0 || max_flat_chunks == 0 || S == 0) return;
     dim3 grid((unsigned)((max_flat_chunks + 255) / 256), (unsigned)nq);
     int P = M / 2;
 #define TK_LAUNCH(O, S_)                                                                      \
     hipLaunchKernelGGL((scan_probes_kernel<O, S_>), grid, dim3(256), 0, s, codes, P, tables,  \
-                       M, slot_prefix, slot_chunk0, S, dist, cap)
+                       M, slot_prefix, slot_chunk0, S, dist, cap, mins, min_stride)
     if (order == TK_ORDER_AVX) {
         if (signd) TK_LAUNCH(TK_ORDER_AVX, true); else TK_LAUNCH(TK_ORDER_AVX, false);
     } else {

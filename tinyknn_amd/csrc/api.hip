@@ -136,7 +136,7 @@ extern "C" int tk_estimate_pq_batch(const uint64_t *data, int64_t chunks, int M,
     TRY(S.out.ensure((size_t)nq * chunks * 16));
     HIPCHECK(hipMemcpyAsync(S.tables.p, tables, (size_t)nq * M * 16, hipMemcpyHostToDevice, st));
     tk_launch_scan_flat(S.tiled.as<uint4>(), chunks, M, S.tables.as<uint4>(), nq,
-                        S.out.as<uint4>(), chunks, signd, order, st);
+                        S.out.as<uint4>(), chunks, nullptr, 0, signd, order, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(out, S.out.p, (size_t)nq * chunks * 16, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
@@ -186,7 +186,7 @@ extern "C" int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t 
     HIPCHECK(hipMemcpyAsync(S.slots_i.p, si, sizeof si, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.slots_l.p, sl, sizeof sl, hipMemcpyHostToDevice, st));
     tk_launch_scan_flat(S.tiled.as<uint4>(), chunks, M, S.tables.as<uint4>(), 1, S.out.as<uint4>(),
-                        chunks, signd, order, st);
+                        chunks, nullptr, 0, signd, order, st);
     tk_launch_heap_replay(S.out.as<uint4>(), chunks, 1, S.slots_i.as<int>(),
                           S.slots_i.as<int>() + 2, S.slots_l.as<int64_t>(), 1,
                           S.labels.as<int64_t>(), S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R,
@@ -335,7 +335,7 @@ struct tk_index {
     // workspace
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, cslots_i, cslots_l, q, qpq, out, stage,
-        repeat_flag;
+        repeat_flag, cmins, mins;
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
     std::vector<hipEvent_t> evs;   // 8 per set
@@ -359,7 +359,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->shift, &ix->scale, &ix->cdist, &ix->cheap_idx, &ix->cheap_val,
                       &ix->probes, &ix->slot_prefix, &ix->slot_chunk0, &ix->slot_n, &ix->slot_loff,
                       &ix->dist, &ix->heap_idx, &ix->heap_val, &ix->cslots_i, &ix->cslots_l, &ix->q,
-                      &ix->qpq, &ix->out, &ix->stage, &ix->repeat_flag};
+                      &ix->qpq, &ix->out, &ix->stage, &ix->repeat_flag, &ix->cmins, &ix->mins};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
@@ -486,7 +486,9 @@ extern "C" int tk_index_set_data(tk_index *ix, const float *data, int64_t N, int
 
 struct Plan {
     int kc, rescore, R, S;
-    int64_t cap;  // uint4 per query in the distance buffer
+    int64_t cap;       // uint4 per query in the distance buffer
+    int64_t cap_min;   // bytes per query in the block-minimum buffer (multiple of 16)
+    int64_t ccap_min;  // same for the coarse stage
 };
 
 static int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &p)
@@ -503,6 +505,8 @@ static int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &
     p.cap = (int64_t)kc * ix->max_list_chunks;
     if (p.cap < 1) p.cap = 1;
     ARGCHECK(p.cap < (1ll << 31), "probed chunk range overflows int32");
+    p.cap_min = (p.cap + 15) / 16 * 16;
+    p.ccap_min = (ix->center_chunks + 15) / 16 * 16;
     return TK_OK;
 }
 
@@ -525,6 +529,8 @@ static int reserve(tk_index *ix, int64_t nq, int k, const Plan &p)
     TRY(ix->heap_val.ensure((size_t)nq * p.R * 4));
     TRY(ix->out.ensure((size_t)nq * k * 8));
     TRY(ix->repeat_flag.ensure((size_t)nq));
+    TRY(ix->mins.ensure((size_t)nq * p.cap_min));
+    TRY(ix->cmins.ensure((size_t)nq * p.ccap_min));
     return TK_OK;
 }
 
@@ -568,7 +574,8 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
     MARK();
     // 2. coarse stage = dtable.top(centers)                 ivf.py:131, fast_pq.py:284-312
     tk_launch_scan_flat(ix->center_codes.as<uint4>(), ix->center_chunks, M, ix->tables.as<uint4>(),
-                        nq, ix->cdist.as<uint4>(), ix->center_chunks, 1, ix->order, st);
+                        nq, ix->cdist.as<uint4>(), ix->center_chunks, ix->cmins.as<uint8_t>(),
+                        p.ccap_min, 1, ix->order, st);
     MARK();
     // positions of one list against a fresh heap are distinct labels: lane-per-query
     const bool fast_c = ix->heap_mode != 1 && ix->center_chunks * 16 <= 0xffffff;
@@ -584,7 +591,8 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
                                         ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
                                         ix->cslots_l.as<int64_t>(), 1, nullptr,
                                         ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
-                                        p.rescore, 1, 1, nullptr, st))
+                                        p.rescore, 1, 1, nullptr, ix->cmins.as<uint8_t>(),
+                                        p.ccap_min, st))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
     } else {
         tk_launch_heap_fill(ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
@@ -607,7 +615,8 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
     tk_launch_scan_probes(ix->codes.as<uint4>(), M, ix->tables.as<uint4>(), nq,
                           ix->slot_prefix.as<int>(), ix->slot_chunk0.as<int64_t>(), p.S,
-                          (int)p.cap, ix->dist.as<uint4>(), p.cap, 1, ix->order, st);
+                          (int)p.cap, ix->dist.as<uint4>(), p.cap, ix->mins.as<uint8_t>(), p.cap_min,
+                          1, ix->order, st);
     MARK();
     const bool fast = ix->heap_mode != 1 && ix->ids_unique && p.cap * 16 <= 0xffffff;
     const bool lanes = fast && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
@@ -622,7 +631,8 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
                                         ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
                                         ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
                                         ix->heap_val.as<int32_t>(), p.R, 1, 0,
-                                        ix->repeat_flag.as<unsigned char>(), st))
+                                        ix->repeat_flag.as<unsigned char>(),
+                                        ix->mins.as<uint8_t>(), p.cap_min, st))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
         // queries whose probe list wrapped (-1 from an unfilled coarse heap) may scan a
         // list twice; they take the wave kernel with the duplicate-label scan

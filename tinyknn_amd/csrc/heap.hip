@@ -23,6 +23,8 @@
 //     block, and the remaining votes are re-filtered;
 //   * the heap (int64 id, int32 value) lives in LDS; the duplicate-label scan is a
 //     64-lane compare + ballot, the sift-down runs wave-uniformly.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 // Heap state shared by the lanes of a wave lives in LDS and is accessed through
@@ -264,6 +266,9 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 //     global load; inside a segment lanes are decoupled: each walks to its next
 //     block with a byte below its bound, then all lanes with a pending candidate
 //     perform one insert together; a bound is refreshed when its block is done;
+//   * the scan kernel also wrote each block's minimum (1 byte per block): a lane
+//     tests 16 minima at once and touches only blocks that can contain a hit;
+//   * the top three heap levels (nodes 0..6) are kept in registers;
 //   * labels are resolved from the flat positions once, at the end.
 template <bool SIGNED>
 __device__ __forceinline__ int entry_val(uint32_t e)
@@ -290,7 +295,8 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
-    const unsigned char *__restrict__ skip, int nbuf)
+    const unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
+    int64_t cap_min)
 {
     // LDS: H[R+2][64] heap columns (+2 sentinel rows) | ST[nbuf][16][64] staged blocks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -307,11 +313,17 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
     const uint4 *drow = dist + qc * cap;
 
     const uint32_t fresh = (SIGNED ? 0x7f000000u : 0xff000000u) | 0x00ffffffu;
+    const uint32_t lowest = SIGNED ? 0x80000000u : 0u;    // a value no entry is below
     for (int j = 0; j < R; j++) H[j * 64 + lane] = fresh;
-    H[R * 64 + lane] = H[(R + 1) * 64 + lane] = SIGNED ? 0x80000000u : 0u;  // never > anything
+    H[R * 64 + lane] = H[(R + 1) * 64 + lane] = lowest;   // sentinel rows: never taken
+    // the top three levels (nodes 0..6) live in registers; nodes >= R are sentinels
+    uint32_t h0 = fresh, h1 = R > 1 ? fresh : lowest, h2 = R > 2 ? fresh : lowest,
+             h3 = R > 3 ? fresh : lowest, h4 = R > 4 ? fresh : lowest,
+             h5 = R > 5 ? fresh : lowest, h6 = R > 6 ? fresh : lowest;
     uint32_t bound = SIGNED ? 0x7fu : 0xffu;
 
     const int total = (valid && S > 0) ? prefix[S] : 0;   // flat chunks of this lane's query
+    const uint4 *mrow = (const uint4 *)(mins + qc * cap_min);   // per-block minima, 16 per uint4
     int nseg = (total + 15) >> 4;
     int max_nseg = nseg;
     for (int o = 32; o > 0; o >>= 1) {
@@ -337,20 +349,33 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
         }
     };
 
-    if (max_nseg > 0) stage(0, 0);
+    uint4 mins_next = make_uint4(0, 0, 0, 0);
+    if (max_nseg > 0) {
+        stage(0, 0);
+        if (total > 0) mins_next = mrow[0];
+    }
     for (int g = 0; g < max_nseg; g++) {
         const int buf = nbuf > 1 ? (g & 1) : 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // segment g has landed
-        if (nbuf > 1 && g + 1 < max_nseg) stage(g + 1, buf ^ 1);
-        int k = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // segment g (and its minima) landed
+        const uint4 mins_cur = mins_next;
+        if (nbuf > 1 && g + 1 < max_nseg) {
+            stage(g + 1, buf ^ 1);
+            if (16 * (g + 1) < total) mins_next = mrow[g + 1];
+        }
         int kmax = total - 16 * g;
         kmax = kmax < 0 ? 0 : (kmax > 16 ? 16 : kmax);
+        // blocks whose minimum is below the bound at segment start: a superset of the
+        // blocks the reference enters (the bound only decreases)
+        uint32_t hit = mask_lt16<SIGNED>(mins_cur, bound);
+        hit &= kmax >= 16 ? 0xffffu : ((1u << kmax) - 1u);
         uint32_t bits = 0;
         uint4 dd = make_uint4(0, 0, 0, 0);
         int cur = 0;
         for (;;) {
             // next block of this segment with a byte below the live bound
-            while (bits == 0 && k < kmax) {
+            while (bits == 0 && hit) {
+                const int k = __builtin_ctz(hit);
+                hit &= hit - 1;
                 dd = ST[(buf * 16 + k) * 64 + lane];
                 cur = 16 * g + k;
                 while (cur >= s_end) {   // next probed list (empty lists are stepped over)
@@ -362,7 +387,6 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
                 bits = mask_lt16<SIGNED>(dd, bound);          // cmp_mask, _fast_pq_256.pyx:81-90
                 const int rows = n - 16 * (cur - s_begin);    // `pos < n`, :111
                 if (rows < 16) bits &= rows > 0 ? ((1u << rows) - 1u) : 0u;
-                k++;
             }
             if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
             if (bits) {   // one insert per lane with a pending candidate
@@ -372,33 +396,68 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
                 const uint32_t by = (w >> (8 * (r & 3))) & 0xffu;
                 const uint32_t entry = (by << 24) | (uint32_t)(16 * cur + r);
                 const int v = entry_val<SIGNED>(entry);
-                // insert, _fast_pq.pyx:291-307, branch-free per level: H[R] and H[R+1]
-                // hold a value no entry exceeds, so children beyond the heap (clamped
-                // to R) are never taken; el/er are 256 B apart (one ds_read2st64).
-                int j = 0;
-                bool go = true;
-                do {
-                    const int l = 2 * j + 1;
-                    const int lc = l < R ? l : R;
-                    const uint32_t el = H[lc * 64 + lane];
-                    const uint32_t er = H[(lc + 1) * 64 + lane];
-                    const int vl = entry_val<SIGNED>(el), vr = entry_val<SIGNED>(er);
-                    const bool cl = vl > v;                 // vals[l] > nxt_val
-                    const int nv = cl ? vl : v;
-                    uint32_t ne = cl ? el : entry;
-                    int nxt = cl ? l : j;
-                    const bool cr = vr > nv;                // vals[r] > nxt_val
-                    ne = cr ? er : ne;
-                    nxt = cr ? l + 1 : nxt;
-                    H[j * 64 + lane] = ne;                  // entry itself when nxt == j
-                    go = nxt != j;
-                    j = nxt;
-                } while (go);
-                if (bits == 0) bound = H[lane] >> 24;     // refresh after the block, :123
+                // insert, _fast_pq.pyx:291-307.  Levels 0-2 in registers, the rest in
+                // LDS, branch-free per level: rows R and R+1 hold a value no entry
+                // exceeds, so children beyond the heap (clamped to R) are never taken.
+                {   // node 0, children 1 and 2
+                    const int v1 = entry_val<SIGNED>(h1), v2 = entry_val<SIGNED>(h2);
+                    const bool c1 = v1 > v;
+                    const int nv = c1 ? v1 : v;
+                    const bool c2 = v2 > nv;
+                    h0 = c2 ? h2 : (c1 ? h1 : entry);
+                    if (c1 | c2) {   // node 1 or 2, children (3,4) or (5,6)
+                        const uint32_t a = c2 ? h5 : h3, b = c2 ? h6 : h4;
+                        const int va = entry_val<SIGNED>(a), vb = entry_val<SIGNED>(b);
+                        const bool ca = va > v;
+                        const int nv1 = ca ? va : v;
+                        const bool cb = vb > nv1;
+                        const uint32_t ne1 = cb ? b : (ca ? a : entry);
+                        if (c2) h2 = ne1; else h1 = ne1;
+                        if (ca | cb) {   // node 3..6, children in LDS
+                            int j = (c2 ? 5 : 3) + (cb ? 1 : 0);
+                            bool first = true, go = true;
+                            do {
+                                const int l = 2 * j + 1;
+                                const int lc = l < R ? l : R;
+                                const uint32_t el = H[lc * 64 + lane];
+                                const uint32_t er = H[(lc + 1) * 64 + lane];
+                                const int vl = entry_val<SIGNED>(el), vr = entry_val<SIGNED>(er);
+                                const bool cl = vl > v;                 // vals[l] > nxt_val
+                                const int nvv = cl ? vl : v;
+                                uint32_t ne = cl ? el : entry;
+                                int nxt = cl ? l : j;
+                                const bool cr = vr > nvv;               // vals[r] > nxt_val
+                                ne = cr ? er : ne;
+                                nxt = cr ? l + 1 : nxt;
+                                if (first) {
+                                    h3 = j == 3 ? ne : h3; h4 = j == 4 ? ne : h4;
+                                    h5 = j == 5 ? ne : h5; h6 = j == 6 ? ne : h6;
+                                    first = false;
+                                } else {
+                                    H[j * 64 + lane] = ne;              // entry itself when nxt == j
+                                }
+                                go = nxt != j;
+                                j = nxt;
+                            } while (go);
+                        }
+                    }
+                }
+                if (bits == 0) bound = h0 >> 24;          // refresh after the block, :123
             }
         }
-        if (nbuf == 1 && g + 1 < max_nseg) stage(g + 1, 0);
+        if (nbuf == 1 && g + 1 < max_nseg) {
+            stage(g + 1, 0);
+            if (16 * (g + 1) < total) mins_next = mrow[g + 1];
+        }
     }
+    // registers back to their heap rows
+    if (R > 0) H[0 * 64 + lane] = h0;
+    if (R > 1) H[1 * 64 + lane] = h1;
+    if (R > 2) H[2 * 64 + lane] = h2;
+    if (R > 3) H[3 * 64 + lane] = h3;
+    if (R > 4) H[4 * 64 + lane] = h4;
+    if (R > 5) H[5 * 64 + lane] = h5;
+    if (R > 6) H[6 * 64 + lane] = h6;
     if (!valid) return;
     // ---- resolve flat positions to labels
     const int64_t *loffs = slot_label_off + qs * S;
@@ -557,7 +616,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, const unsigned char *skip,
-                                hipStream_t s)
+                                const uint8_t *mins, int64_t cap_min, hipStream_t s)
 {
     if (nq == 0 || R == 0) return 0;
     // heap columns + 16 staged blocks per lane, double-buffered when it fits
@@ -565,6 +624,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     size_t lds = (size_t)(R + 2) * 256 + (size_t)nbuf * 16384;
     static bool attr_set = false;
     if (!attr_set) {
+
         hipError_t e1 = hipFuncSetAttribute((const void *)heap_replay_lanes_kernel<true>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipError_t e2 = hipFuncSetAttribute((const void *)heap_replay_lanes_kernel<false>,
@@ -576,11 +636,11 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     if (signd)
         hipLaunchKernelGGL(heap_replay_lanes_kernel<true>, grid, dim3(64), lds, s, dist, cap, nq,
                            slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
-                           slots_uniform, skip, nbuf);
+                           slots_uniform, skip, nbuf, mins, cap_min);
     else
         hipLaunchKernelGGL(heap_replay_lanes_kernel<false>, grid, dim3(64), lds, s, dist, cap, nq,
                            slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
-                           slots_uniform, skip, nbuf);
+                           slots_uniform, skip, nbuf, mins, cap_min);
     return 0;
 }
 

@@ -26,17 +26,18 @@ void tk_launch_retile(const uint4 *src_ref, uint4 *dst_tiled, int64_t chunks, in
 // Flat scan: every chunk of one code array against nq tables.
 // tables: (nq, M) uint4 (16 table bytes per block); out: (nq, out_stride) uint4,
 // 16 int8/uint8 distances per chunk.
+// mins (optional): (nq, min_stride) bytes, the minimum of each chunk's 16 distances.
 void tk_launch_scan_flat(const uint4 *codes, int64_t chunks, int M, const uint4 *tables,
-                         int64_t nq, uint4 *out, int64_t out_stride, int signd, int order,
-                         hipStream_t s);
+                         int64_t nq, uint4 *out, int64_t out_stride, uint8_t *mins,
+                         int64_t min_stride, int signd, int order, hipStream_t s);
 
 // Probed-list scan: query q scans the lists slot 0..S-1 named by
 // slot_chunk0[q][s] (first global chunk) and slot_prefix[q][s..s+1] (flat chunk
 // range inside the query's distance row).  dist: (nq, cap) uint4.
 void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
                            const int *slot_prefix, const int64_t *slot_chunk0, int S,
-                           int max_flat_chunks, uint4 *dist, int64_t cap, int signd,
-                           int order, hipStream_t s);
+                           int max_flat_chunks, uint4 *dist, int64_t cap, uint8_t *mins,
+                           int64_t min_stride, int signd, int order, hipStream_t s);
 
 // Exact replay of the reference's sequential heap over precomputed distances.
 // One wave per query.  slot_n: true rows per slot; slot_label_off: offset into
@@ -54,13 +55,14 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 // (checked by the caller): heaps start fresh (-1 / 127|255), no label can repeat
 // among a query's lists (so `insert`'s duplicate test cannot fire), R*256 B of LDS
 // <= 160 KiB, cap*16 < 2^24 codes per query.  Writes (nq, R) heaps.  Returns 0.
-// skip (nq bytes or NULL): queries to leave untouched.
+// skip (nq bytes or NULL): queries to leave untouched.  mins: (nq, cap_min) per-block
+// minima written by the scan kernels, cap_min a multiple of 16.
 #define TK_LANES_MAX_R 574
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, const unsigned char *skip,
-                                hipStream_t s);
+                                const uint8_t *mins, int64_t cap_min, hipStream_t s);
 
 // Wave-per-query replay on packed entries; same preconditions and outputs as the
 // lane-per-query kernel (R*4 B of LDS).
