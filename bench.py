@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--cache-dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
+    ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -183,6 +184,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     dev.reserve(args.nq, args.k, args.n_probes)
     dev.set_heap_mode(args.heap_mode)
+    dev.set_scan_mode(args.scan_mode)
 
     def step():
         dev.query_batch_dev(q_dev.data_ptr(), qp_dev.data_ptr(), False, args.nq, args.k,
@@ -263,7 +265,7 @@ def main():
                    "recall_queries": rs, "parallelism": f"replica x{world} (queries sharded)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "scan_probes_kernel<AVX,signed>",
+                     "kernel": "scan_units_kernel<AVX,signed>" if args.scan_mode != 1 else "scan_probes_kernel<AVX,signed>",
                      "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
                      "launches_timed": n_prof},
         "stage_ms": stages,

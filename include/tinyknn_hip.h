@@ -151,6 +151,12 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
  * and for the parity tests. */
 int tk_index_set_heap_mode(tk_index *ix, int mode);
 
+/* Probed-list scan strategy.  0 = automatic: list-major (each chunk scored for
+ * four queries per pass, pairs grouped by list on the device) when a batch has at
+ * least 8 (query, probe) pairs per list, else query-major (one query per wave).
+ * 1 = always query-major, 2 = always list-major.  Identical outputs. */
+int tk_index_set_scan_mode(tk_index *ix, int mode);
+
 /* Stage timing.  With profiling on, every (sub-)batch records HIP events on its
  * stream around the stages (no synchronisation in the query call).
  * tk_index_last_profile synchronises that stream and returns the mean

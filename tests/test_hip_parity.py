@@ -307,6 +307,10 @@ def test_ivf_query_golden(tk, tag):
         # batch path, from the reference's own normalised queries
         qp = ivf._prepare(np.array(g["qn"], copy=True)) if False else None
         dev = ivf.device_index()
+        dev.set_scan_mode(2)
+        out2 = dev.query_batch(g["qn"], g["qpq"], k, n_probes)
+        np.testing.assert_array_equal(out2, g[f"ids_p{n_probes}"])
+        dev.set_scan_mode(0)
         out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
         np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
         np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])
@@ -340,8 +344,10 @@ def test_ivf_vs_oracle_larger(tk, oracle):
                             [ivf.pq_transformed_points[i].size for i in range(L)],
                             [ivf.ids[i] for i in range(L)], ivf.data)
     qn, qp = ivf._prepare(qs.copy())
-    for n_probes, heap_mode in ((1, 0), (5, 0), (10, 0), (10, 1), (10, 2), (20, 0), (50, 0), (50, 1), (50, 2)):
+    for n_probes, heap_mode, scan_mode in ((1, 0, 2), (5, 0, 1), (10, 0, 2), (10, 1, 1), (10, 2, 2), (20, 0, 0),
+                                           (50, 0, 2), (50, 1, 1), (50, 2, 0)):
         ivf.device_index().set_heap_mode(heap_mode)   # lane-per-query / wave-per-query replay
+        ivf.device_index().set_scan_mode(scan_mode)   # query-major / list-major scan
         out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)
         for qi in range(nq):
             ids, odbg = ox.query(qn[qi], 10, n_probes=n_probes, debug=True)
@@ -379,6 +385,7 @@ def test_ivf_saturating_and_duplicates(tk, oracle, build_probes):
     for n_probes in (3, 8, 20):
         for heap_mode in (0, 1, 2):
             ivf.device_index().set_heap_mode(heap_mode)
+            ivf.device_index().set_scan_mode(1 + heap_mode % 2)
             out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)
             for qi in range(nq):
                 ids, odbg = ox.query(qn[qi], 10, n_probes=n_probes, debug=True)

@@ -269,3 +269,278 @@ void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64
     }
 #undef TK_LAUNCH
 }
+
+// ===========================================================================
+// List-major scan ("units"): the throughput form for large batches.
+//
+// In a batch most inverted lists are probed by many queries (10 000 queries x 10
+// probes over 1087 lists: ~92 queries per list).  Here a lane still owns one
+// 16-row chunk, but scores it for FOUR queries per pass: the code dword is loaded
+// once and the six selector words derived from it (the VALU work that does not
+// depend on the query) are shared, so the cost per query drops from 21 to
+// 12 + 11/4 ops per dword, and the code bytes are fetched once per four queries.
+//   * work unit = (list l, group of 4 (query, probe-slot) pairs of l, chunk c);
+//     units are numbered list by list, so the 64 lanes of a wave hold 64
+//     consecutive units: no lane idles at list or query boundaries except at the
+//     very end of the grid;
+//   * the tables are no longer wave-uniform (a wave can straddle groups), so each
+//     lane reads its queries' 16-byte table rows with ordinary vector loads; lanes
+//     of one group hit the same address and the rows stay in L1 (832 B per query);
+//   * selectors produce the value<<8 pairs directly: with rows (B0,B2) / (B1,B3) of
+//     a code dword paired in one accumulator, one shift aligns both "bit 3" flags
+//     with byte 1 and byte 3 of a selector, so perm(lo half), perm(hi half) and two
+//     selecting perms give the two widened pairs (one perm fewer per query than the
+//     lookup-then-widen form of the query-major kernel).
+// Exactly the arithmetic of scan_chunk (same saturating chain per row).
+
+template <bool SIGNED>
+__device__ __forceinline__ void lut4x(uint32_t sel3, uint32_t kA, uint32_t kB, const uint4 t,
+                                      uint32_t &acc02, uint32_t &acc13)
+{
+    uint32_t lo = __builtin_amdgcn_perm(t.y, t.x, sel3);
+    uint32_t hi = __builtin_amdgcn_perm(t.w, t.z, sel3);
+    uint32_t wA = __builtin_amdgcn_perm(hi, lo, kA);   // [T[B2],0,T[B0],0]
+    uint32_t wB = __builtin_amdgcn_perm(hi, lo, kB);   // [T[B3],0,T[B1],0]
+    acc02 = sat_add2<SIGNED>(acc02, wA);
+    acc13 = sat_add2<SIGNED>(acc13, wB);
+}
+
+struct Sel6 {
+    uint32_t s_lo, kA_lo, kB_lo, s_hi, kA_hi, kB_hi;
+};
+
+__device__ __forceinline__ Sel6 make_sel(uint32_t v, uint32_t cA, uint32_t cB)
+{
+    Sel6 r;
+    r.s_lo = v & 0x07070707u;
+    r.kA_lo = and_or(v << 7, 0x04000400u, cA);
+    r.kB_lo = and_or(v >> 1, 0x04000400u, cB);
+    r.s_hi = (v >> 4) & 0x07070707u;
+    r.kA_hi = and_or(v << 3, 0x04000400u, cA);
+    r.kB_hi = and_or(v >> 5, 0x04000400u, cB);
+    return r;
+}
+
+template <bool SIGNED>
+__device__ __forceinline__ void finish_chunk(uint32_t (&a0)[8], uint4 &o, uint32_t &mn)
+{
+    uint32_t m = pk_min2<SIGNED>(pk_min2<SIGNED>(pk_min2<SIGNED>(a0[0], a0[1]),
+                                                 pk_min2<SIGNED>(a0[2], a0[3])),
+                                 pk_min2<SIGNED>(pk_min2<SIGNED>(a0[4], a0[5]),
+                                                 pk_min2<SIGNED>(a0[6], a0[7])));
+    m = pk_min2<SIGNED>(m, m >> 16);
+    mn = (m >> 8) & 0xffu;
+    // a0[2j] = rows (4j, 4j+2), a0[2j+1] = rows (4j+1, 4j+3)
+    o.x = __builtin_amdgcn_perm(a0[1], a0[0], 0x07030501u);
+    o.y = __builtin_amdgcn_perm(a0[3], a0[2], 0x07030501u);
+    o.z = __builtin_amdgcn_perm(a0[5], a0[4], 0x07030501u);
+    o.w = __builtin_amdgcn_perm(a0[7], a0[6], 0x07030501u);
+}
+
+#define TK_UNIT_Q 4
+
+template <int ORDER, bool SIGNED>
+__global__ __launch_bounds__(256) void scan_units_kernel(
+    const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
+    const int64_t *__restrict__ list_chunk_off, int n_lists,
+    const int *__restrict__ unit_prefix,   // (n_lists+1) units before each list
+    const int *__restrict__ pair_off,      // (n_lists+1) first record of each list (x4 padded)
+    const int *__restrict__ pair_q,        // query of a record, -1 = padding
+    const int *__restrict__ pair_f0,       // first flat chunk of that (query, slot) row range
+    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride)
+{
+    const int U = unit_prefix[n_lists];
+    const int stride = gridDim.x * 256;
+    const uint32_t cA = 0x020c000cu, cB = 0x030c010cu;
+    for (int u0 = blockIdx.x * 256 + (threadIdx.x & ~63); u0 < U; u0 += stride) {
+        const int u = u0 + (threadIdx.x & 63);
+        const bool active = u < U;
+        const int uu = active ? u : U - 1;
+        int lo = 0, hi = n_lists;   // unit_prefix[lo] <= uu < unit_prefix[hi]
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (unit_prefix[mid] <= uu) lo = mid; else hi = mid;
+        }
+        const int l = lo;
+        const int64_t c0 = list_chunk_off[l];
+        const int C = (int)(list_chunk_off[l + 1] - c0);
+        const int local = uu - unit_prefix[l];
+        const int qg = local / C, c = local - qg * C;
+        const int rec = pair_off[l] + TK_UNIT_Q * qg;
+        int q[TK_UNIT_Q], f0[TK_UNIT_Q];
+        const uint4 *tab[TK_UNIT_Q];
+#pragma unroll
+        for (int i = 0; i < TK_UNIT_Q; i++) {
+            q[i] = pair_q[rec + i];
+            f0[i] = pair_f0[rec + i];
+            tab[i] = tables + (int64_t)(q[i] < 0 ? 0 : q[i]) * M;
+        }
+        const int64_t gc = c0 + c;
+        const uint4 *src = codes + ((gc >> 3) * (int64_t)P) * 8 + (gc & 7);
+        uint32_t a0[TK_UNIT_Q][8], a1[TK_UNIT_Q][8];
+#pragma unroll
+        for (int i = 0; i < TK_UNIT_Q; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) a0[i][j] = a1[i][j] = 0;
+
+        const int steps = (ORDER == TK_ORDER_AVX) ? (P >> 1) : P;
+        for (int st = 0; st < steps; st++) {
+            // AVX: pairs 2*st (accumulator set 0) and 2*st+1 (set 1); SSE: pair st (set 0)
+            const int p0 = (ORDER == TK_ORDER_AVX) ? 2 * st : st;
+            const uint4 x0 = src[p0 * 8];
+            uint4 x1 = make_uint4(0, 0, 0, 0);
+            if (ORDER == TK_ORDER_AVX) x1 = src[(p0 + 1) * 8];
+            {   // pair p0 -> accumulator set 0.  Dword-outer / query-inner keeps the six
+                // selector words of one dword live instead of those of all eight.
+                uint4 tl[TK_UNIT_Q], th[TK_UNIT_Q];
+#pragma unroll
+                for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tab[i][2 * p0]; th[i] = tab[i][2 * p0 + 1]; }
+                const uint32_t xs0[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const Sel6 s = make_sel(xs0[j], cA, cB);
+#pragma unroll
+                    for (int i = 0; i < TK_UNIT_Q; i++) {
+                        lut4x<SIGNED>(s.s_lo, s.kA_lo, s.kB_lo, tl[i], a0[i][2 * j], a0[i][2 * j + 1]);
+                        lut4x<SIGNED>(s.s_hi, s.kA_hi, s.kB_hi, th[i], a0[i][2 * j], a0[i][2 * j + 1]);
+                    }
+                }
+            }
+            if (ORDER == TK_ORDER_AVX) {   // pair p0+1 -> accumulator set 1
+                uint4 tl[TK_UNIT_Q], th[TK_UNIT_Q];
+#pragma unroll
+                for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tab[i][2 * p0 + 2]; th[i] = tab[i][2 * p0 + 3]; }
+                const uint32_t xs1[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const Sel6 s = make_sel(xs1[j], cA, cB);
+#pragma unroll
+                    for (int i = 0; i < TK_UNIT_Q; i++) {
+                        lut4x<SIGNED>(s.s_lo, s.kA_lo, s.kB_lo, tl[i], a1[i][2 * j], a1[i][2 * j + 1]);
+                        lut4x<SIGNED>(s.s_hi, s.kA_hi, s.kB_hi, th[i], a1[i][2 * j], a1[i][2 * j + 1]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TK_UNIT_Q; i++) {
+            if (ORDER == TK_ORDER_AVX) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    a0[i][j] = sat_add2<SIGNED>(a0[i][j], a1[i][j] & 0xff00ff00u);
+            }
+            uint4 o;
+            uint32_t mn;
+            finish_chunk<SIGNED>(a0[i], o, mn);
+            if (active && q[i] >= 0) {
+                dist[(int64_t)q[i] * cap + f0[i] + c] = o;
+                if (mins) mins[(int64_t)q[i] * min_stride + f0[i] + c] = (uint8_t)mn;
+            }
+        }
+    }
+}
+
+// ---- pair lists: (query, slot) pairs grouped by the list they probe ------------
+__global__ void pairs_count_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
+                                   int64_t n_lists, int *__restrict__ count)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * S) return;
+    int64_t cl = probes[i];
+    if (cl < 0) cl += n_lists;
+    atomicAdd(&count[cl], 1);
+}
+
+// one workgroup: exclusive scans over the lists
+__global__ __launch_bounds__(1024) void pairs_scan_kernel(const int *__restrict__ count,
+                                                          const int64_t *__restrict__ list_chunk_off,
+                                                          int n_lists, int *__restrict__ pair_off,
+                                                          int *__restrict__ unit_prefix,
+                                                          int *__restrict__ cursor)
+{
+    __shared__ int s_rec[1024], s_unit[1024];
+    __shared__ int carry_rec, carry_unit;
+    if (threadIdx.x == 0) carry_rec = carry_unit = 0;
+    __syncthreads();
+    for (int base = 0; base < n_lists; base += 1024) {
+        const int l = base + threadIdx.x;
+        int rec = 0, unit = 0;
+        if (l < n_lists) {
+            const int groups = (count[l] + TK_UNIT_Q - 1) / TK_UNIT_Q;
+            rec = groups * TK_UNIT_Q;
+            unit = groups * (int)(list_chunk_off[l + 1] - list_chunk_off[l]);
+        }
+        s_rec[threadIdx.x] = rec;
+        s_unit[threadIdx.x] = unit;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+            int r = threadIdx.x >= o ? s_rec[threadIdx.x - o] : 0;
+            int un = threadIdx.x >= o ? s_unit[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_rec[threadIdx.x] += r;
+            s_unit[threadIdx.x] += un;
+            __syncthreads();
+        }
+        if (l < n_lists) {
+            pair_off[l] = carry_rec + s_rec[threadIdx.x] - rec;
+            unit_prefix[l] = carry_unit + s_unit[threadIdx.x] - unit;
+            cursor[l] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            carry_rec += s_rec[1023];
+            carry_unit += s_unit[1023];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pair_off[n_lists] = carry_rec;
+        unit_prefix[n_lists] = carry_unit;
+    }
+}
+
+__global__ void pairs_fill_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
+                                  int64_t n_lists, const int *__restrict__ slot_prefix,
+                                  const int *__restrict__ pair_off, int *__restrict__ cursor,
+                                  int *__restrict__ pair_q, int *__restrict__ pair_f0)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * S) return;
+    const int64_t qi = i / S;
+    const int s = (int)(i - qi * S);
+    int64_t cl = probes[i];
+    if (cl < 0) cl += n_lists;
+    const int pos = atomicAdd(&cursor[cl], 1);
+    pair_q[pair_off[cl] + pos] = (int)qi;
+    pair_f0[pair_off[cl] + pos] = slot_prefix[qi * (S + 1) + s];
+}
+
+void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
+                          const int64_t *probes, int S, int64_t n_lists,
+                          const int64_t *list_chunk_off, const int *slot_prefix, int *count,
+                          int *pair_off, int *unit_prefix, int *cursor, int *pair_q, int *pair_f0,
+                          int64_t max_records, uint4 *dist, int64_t cap, uint8_t *mins,
+                          int64_t min_stride, int signd, int order, int n_blocks, hipStream_t s)
+{
+    if (nq == 0 || S == 0) return;
+    const int64_t np = nq * S;
+    (void)hipMemsetAsync(count, 0, (size_t)n_lists * sizeof(int), s);
+    (void)hipMemsetAsync(pair_q, 0xff, (size_t)max_records * sizeof(int), s);   // -1 = padding record
+    hipLaunchKernelGGL(pairs_count_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
+                       probes, S, nq, n_lists, count);
+    hipLaunchKernelGGL(pairs_scan_kernel, dim3(1), dim3(1024), 0, s, count, list_chunk_off,
+                       (int)n_lists, pair_off, unit_prefix, cursor);
+    hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
+                       probes, S, nq, n_lists, slot_prefix, pair_off, cursor, pair_q, pair_f0);
+    const int P = M / 2;
+#define TK_LAUNCH(O, S_)                                                                     \
+    hipLaunchKernelGGL((scan_units_kernel<O, S_>), dim3(n_blocks), dim3(256), 0, s, codes, P, \
+                       tables, M, list_chunk_off, (int)n_lists, unit_prefix, pair_off, pair_q, \
+                       pair_f0, dist, cap, mins, min_stride)
+    if (order == TK_ORDER_AVX) {
+        if (signd) TK_LAUNCH(TK_ORDER_AVX, true); else TK_LAUNCH(TK_ORDER_AVX, false);
+    } else {
+        if (signd) TK_LAUNCH(TK_ORDER_SSE, true); else TK_LAUNCH(TK_ORDER_SSE, false);
+    }
+#undef TK_LAUNCH
+}

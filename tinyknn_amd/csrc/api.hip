@@ -335,7 +335,8 @@ struct tk_index {
     // workspace
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, cslots_i, cslots_l, q, qpq, out, stage,
-        repeat_flag, cmins, mins;
+        repeat_flag, cmins, mins, u_count, u_cursor, u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0;
+    int scan_mode = 0;         // 0 auto, 1 query-major kernel, 2 list-major (units) kernel
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
     std::vector<hipEvent_t> evs;   // 8 per set
@@ -359,7 +360,8 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->shift, &ix->scale, &ix->cdist, &ix->cheap_idx, &ix->cheap_val,
                       &ix->probes, &ix->slot_prefix, &ix->slot_chunk0, &ix->slot_n, &ix->slot_loff,
                       &ix->dist, &ix->heap_idx, &ix->heap_val, &ix->cslots_i, &ix->cslots_l, &ix->q,
-                      &ix->qpq, &ix->out, &ix->stage, &ix->repeat_flag, &ix->cmins, &ix->mins};
+                      &ix->qpq, &ix->out, &ix->stage, &ix->repeat_flag, &ix->cmins, &ix->mins, &ix->u_count, &ix->u_cursor,
+                      &ix->u_pair_off, &ix->u_unit_prefix, &ix->u_pair_q, &ix->u_pair_f0};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
@@ -531,6 +533,13 @@ static int reserve(tk_index *ix, int64_t nq, int k, const Plan &p)
     TRY(ix->repeat_flag.ensure((size_t)nq));
     TRY(ix->mins.ensure((size_t)nq * p.cap_min));
     TRY(ix->cmins.ensure((size_t)nq * p.ccap_min));
+    const size_t L = (size_t)ix->n_lists;
+    TRY(ix->u_count.ensure(L * 4));
+    TRY(ix->u_cursor.ensure(L * 4));
+    TRY(ix->u_pair_off.ensure((L + 1) * 4));
+    TRY(ix->u_unit_prefix.ensure((L + 1) * 4));
+    TRY(ix->u_pair_q.ensure(((size_t)nq * p.S + 4 * L) * 4));
+    TRY(ix->u_pair_f0.ensure(((size_t)nq * p.S + 4 * L) * 4));
     return TK_OK;
 }
 
@@ -613,10 +622,25 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
                          ix->slot_loff.as<int64_t>(), ix->repeat_flag.as<unsigned char>(), st);
     MARK();
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
-    tk_launch_scan_probes(ix->codes.as<uint4>(), M, ix->tables.as<uint4>(), nq,
-                          ix->slot_prefix.as<int>(), ix->slot_chunk0.as<int64_t>(), p.S,
-                          (int)p.cap, ix->dist.as<uint4>(), p.cap, ix->mins.as<uint8_t>(), p.cap_min,
-                          1, ix->order, st);
+    // list-major (4 queries per pass over a chunk) when lists are shared by enough
+    // queries and the unit count fits int32; otherwise one query per wave
+    const bool units = ix->scan_mode == 2 ||
+                       (ix->scan_mode == 0 && nq * p.S >= 8 * ix->n_lists &&
+                        (double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9);
+    if (units)
+        tk_launch_scan_units(ix->codes.as<uint4>(), M, ix->tables.as<uint4>(), nq,
+                             ix->probes.as<int64_t>(), p.S, ix->n_lists,
+                             ix->list_chunk_off.as<int64_t>(), ix->slot_prefix.as<int>(),
+                             ix->u_count.as<int>(), ix->u_pair_off.as<int>(),
+                             ix->u_unit_prefix.as<int>(), ix->u_cursor.as<int>(),
+                             ix->u_pair_q.as<int>(), ix->u_pair_f0.as<int>(),
+                             nq * p.S + 4 * ix->n_lists, ix->dist.as<uint4>(), p.cap,
+                             ix->mins.as<uint8_t>(), p.cap_min, 1, ix->order, 1536, st);
+    else
+        tk_launch_scan_probes(ix->codes.as<uint4>(), M, ix->tables.as<uint4>(), nq,
+                              ix->slot_prefix.as<int>(), ix->slot_chunk0.as<int64_t>(), p.S,
+                              (int)p.cap, ix->dist.as<uint4>(), p.cap, ix->mins.as<uint8_t>(),
+                              p.cap_min, 1, ix->order, st);
     MARK();
     const bool fast = ix->heap_mode != 1 && ix->ids_unique && p.cap * 16 <= 0xffffff;
     const bool lanes = fast && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
@@ -717,6 +741,14 @@ extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
     ARGCHECK(ix, "null index");
     ARGCHECK(mode >= 0 && mode <= 2, "mode");
     ix->heap_mode = mode;
+    return TK_OK;
+}
+
+extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
+{
+    ARGCHECK(ix, "null index");
+    ARGCHECK(mode >= 0 && mode <= 2, "mode");
+    ix->scan_mode = mode;
     return TK_OK;
 }
 

@@ -116,6 +116,10 @@ class DeviceIndex:
         """0: automatic (lane-per-query), 1: general wave kernel, 2: packed wave kernel."""
         _lib.check(_lib.lib().tk_index_set_heap_mode(self._h, int(mode)))
 
+    def set_scan_mode(self, mode):
+        """0: automatic, 1: query-major scan, 2: list-major scan (see tinyknn_hip.h)."""
+        _lib.check(_lib.lib().tk_index_set_scan_mode(self._h, int(mode)))
+
     def set_profiling(self, on):
         _lib.check(_lib.lib().tk_index_set_profiling(self._h, int(on)))
 
