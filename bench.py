@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
+    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (tk_index_set_pipeline)")
     args = ap.parse_args()
 
     import torch
@@ -182,6 +183,7 @@ def main():
     qp_dev = torch.from_numpy(np.ascontiguousarray(qp, dtype=np.float32)).to(device)
     out_dev = torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)
     stream = torch.cuda.current_stream().cuda_stream
+    dev.set_pipeline(args.pipeline)
     dev.reserve(args.nq, args.k, args.n_probes)
     dev.set_heap_mode(args.heap_mode)
     dev.set_scan_mode(args.scan_mode)
@@ -192,6 +194,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    dev.join(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -200,11 +203,20 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    dev.join(stream)            # the caller's stream waits for every batch in flight
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     stages, scan_bytes, n_prof = dev.last_profile()
+    # the same kernels with ONE batch in flight (no co-running batches), for reference
+    dev.set_pipeline(1)
+    dev.reserve(args.nq, args.k, args.n_probes)
+    dev.set_profiling(True)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    iso_stages, iso_bytes, _ = dev.last_profile()
     dev.set_profiling(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -262,13 +274,18 @@ def main():
                                f"build_probes=1 FastPQ dpb=2 M={M}",
                    "queries_per_step_per_gpu": args.nq, "k": args.k, "n_probes": args.n_probes,
                    "pass_1": (args.n_probes + 1) * args.k + 1, "recall10@10": recall,
-                   "recall_queries": rs, "parallelism": f"replica x{world} (queries sharded)"},
+                   "recall_queries": rs, "parallelism": f"replica x{world} (queries sharded)",
+                   "batches_in_flight": args.pipeline},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "scan_units_kernel<AVX,signed>" if args.scan_mode != 1 else "scan_probes_kernel<AVX,signed>",
                      "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
                      "launches_timed": n_prof},
         "stage_ms": stages,
+        "isolated": {"note": "same batch with one batch in flight (5 steps after the timed region)",
+                     "stage_ms": iso_stages, "ms_per_step": sum(iso_stages.values()),
+                     "scan_kernel_GBps": iso_bytes / (iso_stages["scan"] * 1e-3) / 1e9,
+                     "scan_kernel_frac_of_hbm_peak": iso_bytes / (iso_stages["scan"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
     }

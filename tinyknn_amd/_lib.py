@@ -57,6 +57,8 @@ SIGNATURES = {
                                        C.c_int, C.c_int, _i64p, _i64p, _i64p, _i32p]),
     "tk_index_query_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tk_index_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+    "tk_index_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tk_index_set_heap_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_set_scan_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -339,8 +339,10 @@ __device__ __forceinline__ void finish_chunk(uint32_t (&a0)[8], uint4 &o, uint32
 
 #define TK_UNIT_Q 4
 
-template <int ORDER, bool SIGNED>
-__global__ __launch_bounds__(256) void scan_units_kernel(
+// COARSE only tags the instantiation used for the coded centres so that profilers
+// list the two launches of a batch separately.
+template <int ORDER, bool SIGNED, int MINW, bool COARSE>
+__global__ __launch_bounds__(256, MINW) void scan_units_kernel(
     const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
     const int64_t *__restrict__ list_chunk_off, int n_lists,
     const int *__restrict__ unit_prefix,   // (n_lists+1) units before each list
@@ -367,13 +369,13 @@ __global__ __launch_bounds__(256) void scan_units_kernel(
         const int local = uu - unit_prefix[l];
         const int qg = local / C, c = local - qg * C;
         const int rec = pair_off[l] + TK_UNIT_Q * qg;
-        int q[TK_UNIT_Q], f0[TK_UNIT_Q];
-        const uint4 *tab[TK_UNIT_Q];
+        // table row offsets (in uint4) of the four queries; q and f0 are re-read at the
+        // end instead of being held across the loop (register pressure)
+        int tq[TK_UNIT_Q];
 #pragma unroll
         for (int i = 0; i < TK_UNIT_Q; i++) {
-            q[i] = pair_q[rec + i];
-            f0[i] = pair_f0[rec + i];
-            tab[i] = tables + (int64_t)(q[i] < 0 ? 0 : q[i]) * M;
+            const int qi = pair_q[rec + i];
+            tq[i] = (qi < 0 ? 0 : qi) * M;
         }
         const int64_t gc = c0 + c;
         const uint4 *src = codes + ((gc >> 3) * (int64_t)P) * 8 + (gc & 7);
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void scan_units_kernel(
                 // selector words of one dword live instead of those of all eight.
                 uint4 tl[TK_UNIT_Q], th[TK_UNIT_Q];
 #pragma unroll
-                for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tab[i][2 * p0]; th[i] = tab[i][2 * p0 + 1]; }
+                for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tables[tq[i] + 2 * p0]; th[i] = tables[tq[i] + 2 * p0 + 1]; }
                 const uint32_t xs0[4] = {x0.x, x0.y, x0.z, x0.w};
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void scan_units_kernel(
             if (ORDER == TK_ORDER_AVX) {   // pair p0+1 -> accumulator set 1
                 uint4 tl[TK_UNIT_Q], th[TK_UNIT_Q];
 #pragma unroll
-                for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tab[i][2 * p0 + 2]; th[i] = tab[i][2 * p0 + 3]; }
+                for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tables[tq[i] + 2 * p0 + 2]; th[i] = tables[tq[i] + 2 * p0 + 3]; }
                 const uint32_t xs1[4] = {x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -432,9 +434,11 @@ __global__ __launch_bounds__(256) void scan_units_kernel(
             uint4 o;
             uint32_t mn;
             finish_chunk<SIGNED>(a0[i], o, mn);
-            if (active && q[i] >= 0) {
-                dist[(int64_t)q[i] * cap + f0[i] + c] = o;
-                if (mins) mins[(int64_t)q[i] * min_stride + f0[i] + c] = (uint8_t)mn;
+            const int qi = pair_q[rec + i];
+            if (active && qi >= 0) {
+                const int f0 = pair_f0[rec + i];
+                dist[(int64_t)qi * cap + f0 + c] = o;
+                if (mins) mins[(int64_t)qi * min_stride + f0 + c] = (uint8_t)mn;
             }
         }
     }
@@ -515,12 +519,10 @@ __global__ void pairs_fill_kernel(const int64_t *__restrict__ probes, int S, int
     pair_f0[pair_off[cl] + pos] = slot_prefix[qi * (S + 1) + s];
 }
 
-void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
-                          const int64_t *probes, int S, int64_t n_lists,
+void tk_launch_unit_pairs(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
                           const int64_t *list_chunk_off, const int *slot_prefix, int *count,
                           int *pair_off, int *unit_prefix, int *cursor, int *pair_q, int *pair_f0,
-                          int64_t max_records, uint4 *dist, int64_t cap, uint8_t *mins,
-                          int64_t min_stride, int signd, int order, int n_blocks, hipStream_t s)
+                          int64_t max_records, hipStream_t s)
 {
     if (nq == 0 || S == 0) return;
     const int64_t np = nq * S;
@@ -532,15 +534,61 @@ void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_
                        (int)n_lists, pair_off, unit_prefix, cursor);
     hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
                        probes, S, nq, n_lists, slot_prefix, pair_off, cursor, pair_q, pair_f0);
+}
+
+// Descriptors for "every query scans the one list" (the coarse stage): records are
+// the queries themselves, padded to a multiple of 4.
+__global__ void pairs_identity_kernel(int64_t nq, int chunks, int *__restrict__ pair_off,
+                                      int *__restrict__ unit_prefix, int *__restrict__ pair_q,
+                                      int *__restrict__ pair_f0)
+{
+    const int64_t nrec = (nq + TK_UNIT_Q - 1) / TK_UNIT_Q * TK_UNIT_Q;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrec) {
+        pair_q[i] = i < nq ? (int)i : -1;
+        pair_f0[i] = 0;
+    }
+    if (i == 0) {
+        pair_off[0] = 0;
+        pair_off[1] = (int)nrec;
+        unit_prefix[0] = 0;
+        unit_prefix[1] = (int)(nrec / TK_UNIT_Q) * chunks;
+    }
+}
+
+void tk_launch_identity_pairs(int64_t nq, int chunks, int *pair_off, int *unit_prefix, int *pair_q,
+                              int *pair_f0, hipStream_t s)
+{
+    if (nq == 0) return;
+    const int64_t nrec = (nq + TK_UNIT_Q - 1) / TK_UNIT_Q * TK_UNIT_Q;
+    hipLaunchKernelGGL(pairs_identity_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s,
+                       nq, chunks, pair_off, unit_prefix, pair_q, pair_f0);
+}
+
+void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq, int S,
+                          int64_t n_lists, const int64_t *list_chunk_off, const int *pair_off,
+                          const int *unit_prefix, const int *pair_q, const int *pair_f0,
+                          uint4 *dist, int64_t cap, uint8_t *mins, int64_t min_stride, int signd,
+                          int order, int n_blocks, hipStream_t s)
+{
+    if (nq == 0 || S == 0) return;
     const int P = M / 2;
-#define TK_LAUNCH(O, S_)                                                                     \
-    hipLaunchKernelGGL((scan_units_kernel<O, S_>), dim3(n_blocks), dim3(256), 0, s, codes, P, \
-                       tables, M, list_chunk_off, (int)n_lists, unit_prefix, pair_off, pair_q, \
-                       pair_f0, dist, cap, mins, min_stride)
+    const bool coarse = n_lists == 1 && S == 1;
+#define TK_LAUNCH2(O, S_, W, C_)                                                                \
+    hipLaunchKernelGGL((scan_units_kernel<O, S_, W, C_>), dim3(n_blocks), dim3(256), 0, s, codes, \
+                       P, tables, M, list_chunk_off, (int)n_lists, unit_prefix, pair_off,         \
+                       pair_q, pair_f0, dist, cap, mins, min_stride)
+#define TK_LAUNCH(O, S_, W)                                            \
+    do {                                                               \
+        if (coarse) TK_LAUNCH2(O, S_, W, true);                        \
+        else TK_LAUNCH2(O, S_, W, false);                              \
+    } while (0)
     if (order == TK_ORDER_AVX) {
-        if (signd) TK_LAUNCH(TK_ORDER_AVX, true); else TK_LAUNCH(TK_ORDER_AVX, false);
+        // 3 waves/SIMD: 138 VGPRs; forcing 4 (128 VGPRs) spills in the loop and is slower
+        if (signd) TK_LAUNCH(TK_ORDER_AVX, true, 3); else TK_LAUNCH(TK_ORDER_AVX, false, 3);
     } else {
-        if (signd) TK_LAUNCH(TK_ORDER_SSE, true); else TK_LAUNCH(TK_ORDER_SSE, false);
+        if (signd) TK_LAUNCH(TK_ORDER_SSE, true, 3); else TK_LAUNCH(TK_ORDER_SSE, false, 3);
     }
 #undef TK_LAUNCH
+#undef TK_LAUNCH2
 }

@@ -255,7 +255,8 @@ extern "C" int tk_build_tables(const float *centers, int dq, int dpb, int f_orde
     ARGCHECK(nq >= 0, "nq");
     const int M = dq / dpb;
     const size_t esz = q_is_f64 ? 8 : 4;
-    ARGCHECK((size_t)16 * M * esz <= 60 * 1024, "too many blocks for the LDS table");
+    ARGCHECK(((size_t)16 * M + 576) * esz + 544 <= 64 * 1024 && 16 * M <= 8192,
+             "too many blocks for the LDS table");
     if (nq == 0) return TK_OK;
     Scratch &S = scratch();
     std::lock_guard<std::mutex> lk(S.mu);
@@ -313,6 +314,28 @@ extern "C" int64_t tk_knn_brute1(const float *x, const float *Y, int64_t n, int 
 
 // ---------------------------------------------------------------------------
 // device-resident index
+// buffers of ONE batch in flight
+struct Work {
+    DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
+        slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
+        u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
+        c_pair_f0;
+    hipStream_t stream = nullptr;   // only used when the pipeline depth is > 1
+    hipEvent_t done = nullptr;
+    void release()
+    {
+        DevBuf *b[] = {&tables, &shift, &scale, &cdist, &cheap_idx, &cheap_val, &probes,
+                       &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
+                       &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
+                       &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0};
+        for (DevBuf *x : b) x->release();
+        if (stream) (void)hipStreamDestroy(stream);
+        if (done) (void)hipEventDestroy(done);
+        stream = nullptr;
+        done = nullptr;
+    }
+};
+
 struct tk_index {
     // FastPQ
     DevBuf pq_centers;
@@ -332,37 +355,43 @@ struct tk_index {
     // vectors
     DevBuf data;
     int64_t N = 0;
-    // workspace
-    DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
-        slot_n, slot_loff, dist, heap_idx, heap_val, cslots_i, cslots_l, q, qpq, out, stage,
-        repeat_flag, cmins, mins, u_count, u_cursor, u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0;
+    // index-static descriptors of the coarse stage, staging buffers of the host API
+    DevBuf cslots_i, cslots_l, c_chunk_off, q, qpq, stage;
     int scan_mode = 0;         // 0 auto, 1 query-major kernel, 2 list-major (units) kernel
+    // per-batch workspaces: `depth` batches may be in flight (tk_index_set_pipeline),
+    // each on its own internal stream
+    std::vector<Work> works;
+    int depth = 1;
+    uint64_t calls = 0;
+    hipEvent_t ev_in = nullptr;    // caller stream -> worker stream hand-off
+    hipEvent_t ev_scan = nullptr;  // end of the most recent list scan (pipelined mode)
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
     std::vector<hipEvent_t> evs;   // 8 per set
+    std::vector<hipStream_t> ev_streams;
     size_t ev_used = 0;            // sets recorded since the last read
-    hipStream_t ev_stream = 0;
-    int last_S = 0, last_R = 0;
+    int last_S = 0, last_R = 0, last_work = 0;
     int64_t last_nq = 0;
 };
 
 extern "C" tk_index *tk_index_create(void)
 {
     if (require_gpu() != TK_OK) return nullptr;
-    return new tk_index();
+    tk_index *ix = new tk_index();
+    ix->works.resize(1);
+    return ix;
 }
 
 extern "C" void tk_index_destroy(tk_index *ix)
 {
     if (!ix) return;
     DevBuf *bufs[] = {&ix->pq_centers, &ix->active_centers, &ix->center_codes, &ix->list_chunk_off,
-                      &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->data, &ix->tables,
-                      &ix->shift, &ix->scale, &ix->cdist, &ix->cheap_idx, &ix->cheap_val,
-                      &ix->probes, &ix->slot_prefix, &ix->slot_chunk0, &ix->slot_n, &ix->slot_loff,
-                      &ix->dist, &ix->heap_idx, &ix->heap_val, &ix->cslots_i, &ix->cslots_l, &ix->q,
-                      &ix->qpq, &ix->out, &ix->stage, &ix->repeat_flag, &ix->cmins, &ix->mins, &ix->u_count, &ix->u_cursor,
-                      &ix->u_pair_off, &ix->u_unit_prefix, &ix->u_pair_q, &ix->u_pair_f0};
+                      &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->data, &ix->cslots_i,
+                      &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage};
     for (DevBuf *b : bufs) b->release();
+    for (Work &w : ix->works) w.release();
+    if (ix->ev_in) (void)hipEventDestroy(ix->ev_in);
+    if (ix->ev_scan) (void)hipEventDestroy(ix->ev_scan);
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -373,6 +402,7 @@ extern "C" int tk_index_set_pq(tk_index *ix, const float *centers, int dq, int d
     ARGCHECK(ix, "null index");
     ARGCHECK(dpb >= 1 && dpb <= 32 && dq % dpb == 0, "dq/dpb");
     ARGCHECK((dq / dpb) % 2 == 0, "number of blocks must be even");
+    ARGCHECK(dq / dpb <= 512, "at most 512 blocks");
     ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
     TRY(ix->pq_centers.ensure((size_t)16 * dq * 4));
     HIPCHECK(hipMemcpy(ix->pq_centers.p, centers, (size_t)16 * dq * 4, hipMemcpyHostToDevice));
@@ -408,6 +438,9 @@ extern "C" int tk_index_set_centers(tk_index *ix, const float *active_centers, i
                        hipMemcpyHostToDevice));
     TRY(upload_tiled(ix->center_codes, ix->stage, center_codes, center_chunks, ix->M));
     ix->n_lists = n_lists; ix->d = d; ix->center_chunks = center_chunks;
+    int64_t cco[2] = {0, center_chunks};
+    TRY(ix->c_chunk_off.ensure(sizeof cco));
+    HIPCHECK(hipMemcpy(ix->c_chunk_off.p, cco, sizeof cco, hipMemcpyHostToDevice));
     int ci[3] = {0, (int)center_chunks, (int)n_lists};
     int64_t cl[1] = {-1};
     TRY(ix->cslots_i.ensure(sizeof ci));
@@ -512,34 +545,38 @@ static int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &
     return TK_OK;
 }
 
-static int reserve(tk_index *ix, int64_t nq, int k, const Plan &p)
+static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
 {
     const int M = ix->M;
-    TRY(ix->tables.ensure((size_t)nq * M * 16));
-    TRY(ix->shift.ensure((size_t)nq * 8));
-    TRY(ix->scale.ensure((size_t)nq * 8));
-    TRY(ix->cdist.ensure((size_t)nq * ix->center_chunks * 16));
-    TRY(ix->cheap_idx.ensure((size_t)nq * p.rescore * 8));
-    TRY(ix->cheap_val.ensure((size_t)nq * p.rescore * 4));
-    TRY(ix->probes.ensure((size_t)nq * p.kc * 8));
-    TRY(ix->slot_prefix.ensure((size_t)nq * (p.S + 1) * 4));
-    TRY(ix->slot_chunk0.ensure((size_t)nq * p.S * 8));
-    TRY(ix->slot_n.ensure((size_t)nq * p.S * 4));
-    TRY(ix->slot_loff.ensure((size_t)nq * p.S * 8));
-    TRY(ix->dist.ensure((size_t)nq * p.cap * 16));
-    TRY(ix->heap_idx.ensure((size_t)nq * p.R * 8));
-    TRY(ix->heap_val.ensure((size_t)nq * p.R * 4));
-    TRY(ix->out.ensure((size_t)nq * k * 8));
-    TRY(ix->repeat_flag.ensure((size_t)nq));
-    TRY(ix->mins.ensure((size_t)nq * p.cap_min));
-    TRY(ix->cmins.ensure((size_t)nq * p.ccap_min));
+    TRY(w.tables.ensure((size_t)nq * M * 16));
+    TRY(w.shift.ensure((size_t)nq * 8));
+    TRY(w.scale.ensure((size_t)nq * 8));
+    TRY(w.cdist.ensure((size_t)nq * ix->center_chunks * 16));
+    TRY(w.cheap_idx.ensure((size_t)nq * p.rescore * 8));
+    TRY(w.cheap_val.ensure((size_t)nq * p.rescore * 4));
+    TRY(w.probes.ensure((size_t)nq * p.kc * 8));
+    TRY(w.slot_prefix.ensure((size_t)nq * (p.S + 1) * 4));
+    TRY(w.slot_chunk0.ensure((size_t)nq * p.S * 8));
+    TRY(w.slot_n.ensure((size_t)nq * p.S * 4));
+    TRY(w.slot_loff.ensure((size_t)nq * p.S * 8));
+    TRY(w.dist.ensure((size_t)nq * p.cap * 16));
+    TRY(w.heap_idx.ensure((size_t)nq * p.R * 8));
+    TRY(w.heap_val.ensure((size_t)nq * p.R * 4));
+    (void)k;
+    TRY(w.repeat_flag.ensure((size_t)nq));
+    TRY(w.mins.ensure((size_t)nq * p.cap_min));
+    TRY(w.cmins.ensure((size_t)nq * p.ccap_min));
     const size_t L = (size_t)ix->n_lists;
-    TRY(ix->u_count.ensure(L * 4));
-    TRY(ix->u_cursor.ensure(L * 4));
-    TRY(ix->u_pair_off.ensure((L + 1) * 4));
-    TRY(ix->u_unit_prefix.ensure((L + 1) * 4));
-    TRY(ix->u_pair_q.ensure(((size_t)nq * p.S + 4 * L) * 4));
-    TRY(ix->u_pair_f0.ensure(((size_t)nq * p.S + 4 * L) * 4));
+    TRY(w.u_count.ensure(L * 4));
+    TRY(w.u_cursor.ensure(L * 4));
+    TRY(w.u_pair_off.ensure((L + 1) * 4));
+    TRY(w.u_unit_prefix.ensure((L + 1) * 4));
+    TRY(w.u_pair_q.ensure(((size_t)nq * p.S + 4 * L) * 4));
+    TRY(w.u_pair_f0.ensure(((size_t)nq * p.S + 4 * L) * 4));
+    TRY(w.c_pair_off.ensure(8));
+    TRY(w.c_unit_prefix.ensure(8));
+    TRY(w.c_pair_q.ensure(((size_t)nq + 4) * 4));
+    TRY(w.c_pair_f0.ensure(((size_t)nq + 4) * 4));
     return TK_OK;
 }
 
@@ -549,11 +586,12 @@ extern "C" int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, i
 {
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
-    return reserve(ix, nq < MAX_SUB ? nq : MAX_SUB, k, p);
+    for (Work &w : ix->works) TRY(reserve(ix, w, nq < MAX_SUB ? nq : MAX_SUB, k, p));
+    return TK_OK;
 }
 
 // one sub-batch, everything on device
-static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int qpq_f64, int64_t nq,
+static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_dev, int qpq_f64, int64_t nq,
                      int k, const Plan &p, int64_t *out_dev, hipStream_t st)
 {
     const int M = ix->M;
@@ -566,9 +604,11 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
             ix->evs.push_back(e);
         }
         ev = &ix->evs[ix->ev_used * 8];
+        if (ix->ev_streams.size() <= ix->ev_used) ix->ev_streams.resize(ix->ev_used + 1);
+        ix->ev_streams[ix->ev_used] = st;
         ix->ev_used++;
-        ix->ev_stream = st;
         ix->last_S = p.S; ix->last_R = p.R; ix->last_nq = nq;
+        ix->last_work = (int)(&w - &ix->works[0]);
     }
     int evi = 0;
 #define MARK()                                                 \
@@ -578,104 +618,130 @@ static int run_batch(tk_index *ix, const float *q_dev, const void *qpq_dev, int 
     MARK();
     // 1. distance tables                                   fast_pq.py:186-222
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
-                           qpq_f64, nq, ix->sqrt_nb, 0.0, 1, ix->tables.as<uint8_t>(), ix->shift.p,
-                           ix->scale.as<double>(), st);
+                           qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>(), w.shift.p,
+                           w.scale.as<double>(), st);
     MARK();
     // 2. coarse stage = dtable.top(centers)                 ivf.py:131, fast_pq.py:284-312
-    tk_launch_scan_flat(ix->center_codes.as<uint4>(), ix->center_chunks, M, ix->tables.as<uint4>(),
-                        nq, ix->cdist.as<uint4>(), ix->center_chunks, ix->cmins.as<uint8_t>(),
-                        p.ccap_min, 1, ix->order, st);
+    const bool cunits = ix->scan_mode != 1 && nq >= 16 &&
+                        (double)nq / 4 * ix->center_chunks < 2.0e9;
+    if (cunits) {
+        // every query scans the one list of coded centres: list-major, no idle lanes
+        tk_launch_identity_pairs(nq, (int)ix->center_chunks, w.c_pair_off.as<int>(),
+                                 w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
+                                 w.c_pair_f0.as<int>(), st);
+        tk_launch_scan_units(ix->center_codes.as<uint4>(), M, w.tables.as<uint4>(), nq, 1, 1,
+                             ix->c_chunk_off.as<int64_t>(), w.c_pair_off.as<int>(),
+                             w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
+                             w.c_pair_f0.as<int>(), w.cdist.as<uint4>(), ix->center_chunks,
+                             w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, 3072, st);
+    } else {
+        tk_launch_scan_flat(ix->center_codes.as<uint4>(), ix->center_chunks, M,
+                            w.tables.as<uint4>(), nq, w.cdist.as<uint4>(), ix->center_chunks,
+                            w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, st);
+    }
     MARK();
     // positions of one list against a fresh heap are distinct labels: lane-per-query
     const bool fast_c = ix->heap_mode != 1 && ix->center_chunks * 16 <= 0xffffff;
     const bool lanes_c = fast_c && ix->heap_mode == 0 && p.rescore <= TK_LANES_MAX_R;
     if (fast_c && !lanes_c) {
-        tk_launch_heap_replay_packed(ix->cdist.as<uint4>(), ix->center_chunks, nq,
+        tk_launch_heap_replay_packed(w.cdist.as<uint4>(), ix->center_chunks, nq,
                                      ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
                                      ix->cslots_l.as<int64_t>(), 1, nullptr,
-                                     ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
+                                     w.cheap_idx.as<int64_t>(), w.cheap_val.as<int32_t>(),
                                      p.rescore, 1, 1, nullptr, st);
     } else if (lanes_c) {
-        if (tk_launch_heap_replay_lanes(ix->cdist.as<uint4>(), ix->center_chunks, nq,
+        if (tk_launch_heap_replay_lanes(w.cdist.as<uint4>(), ix->center_chunks, nq,
                                         ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
                                         ix->cslots_l.as<int64_t>(), 1, nullptr,
-                                        ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
-                                        p.rescore, 1, 1, nullptr, ix->cmins.as<uint8_t>(),
+                                        w.cheap_idx.as<int64_t>(), w.cheap_val.as<int32_t>(),
+                                        p.rescore, 1, 1, nullptr, w.cmins.as<uint8_t>(),
                                         p.ccap_min, st))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
     } else {
-        tk_launch_heap_fill(ix->cheap_idx.as<int64_t>(), ix->cheap_val.as<int32_t>(),
+        tk_launch_heap_fill(w.cheap_idx.as<int64_t>(), w.cheap_val.as<int32_t>(),
                             nq * p.rescore, 127, st);
-        tk_launch_heap_replay(ix->cdist.as<uint4>(), ix->center_chunks, nq,
+        tk_launch_heap_replay(w.cdist.as<uint4>(), ix->center_chunks, nq,
                               ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
-                              ix->cslots_l.as<int64_t>(), 1, nullptr, ix->cheap_idx.as<int64_t>(),
-                              ix->cheap_val.as<int32_t>(), p.rescore, 1, 1, nullptr, st);
+                              ix->cslots_l.as<int64_t>(), 1, nullptr, w.cheap_idx.as<int64_t>(),
+                              w.cheap_val.as<int32_t>(), p.rescore, 1, 1, nullptr, st);
     }
     MARK();
     tk_launch_rescore(q_dev, ix->d, ix->active_centers.as<float>(), ix->n_lists,
-                      ix->cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0,
-                      ix->probes.as<int64_t>(), nullptr, st);
-    tk_launch_make_slots(ix->probes.as<int64_t>(), nullptr, p.S, nq, ix->n_lists,
+                      w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0,
+                      w.probes.as<int64_t>(), nullptr, st);
+    tk_launch_make_slots(w.probes.as<int64_t>(), nullptr, p.S, nq, ix->n_lists,
                          ix->list_chunk_off.as<int64_t>(), ix->list_n.as<int64_t>(),
-                         ix->ids_off.as<int64_t>(), ix->slot_prefix.as<int>(),
-                         ix->slot_chunk0.as<int64_t>(), ix->slot_n.as<int>(),
-                         ix->slot_loff.as<int64_t>(), ix->repeat_flag.as<unsigned char>(), st);
-    MARK();
-    // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
-    // list-major (4 queries per pass over a chunk) when lists are shared by enough
+                         ix->ids_off.as<int64_t>(), w.slot_prefix.as<int>(),
+                         w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
+                         w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(), st);
+    // list-major scan (4 queries per pass over a chunk) when lists are shared by enough
     // queries and the unit count fits int32; otherwise one query per wave
     const bool units = ix->scan_mode == 2 ||
                        (ix->scan_mode == 0 && nq * p.S >= 8 * ix->n_lists &&
                         (double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9);
     if (units)
-        tk_launch_scan_units(ix->codes.as<uint4>(), M, ix->tables.as<uint4>(), nq,
-                             ix->probes.as<int64_t>(), p.S, ix->n_lists,
-                             ix->list_chunk_off.as<int64_t>(), ix->slot_prefix.as<int>(),
-                             ix->u_count.as<int>(), ix->u_pair_off.as<int>(),
-                             ix->u_unit_prefix.as<int>(), ix->u_cursor.as<int>(),
-                             ix->u_pair_q.as<int>(), ix->u_pair_f0.as<int>(),
-                             nq * p.S + 4 * ix->n_lists, ix->dist.as<uint4>(), p.cap,
-                             ix->mins.as<uint8_t>(), p.cap_min, 1, ix->order, 1536, st);
+        tk_launch_unit_pairs(nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
+                             ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
+                             w.u_count.as<int>(), w.u_pair_off.as<int>(),
+                             w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
+                             w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
+                             nq * p.S + 4 * ix->n_lists, st);
+    if (ix->depth > 1 && ix->ev_scan)
+        // batches in flight take turns on the VALU-bound scan: two overlapping scans
+        // would only stretch each other; the heap replays are what overlaps
+        HIPCHECK(hipStreamWaitEvent(st, ix->ev_scan, 0));
+    MARK();
+    // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
+    if (units)
+        tk_launch_scan_units(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
+                             ix->list_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
+                             w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(),
+                             w.u_pair_f0.as<int>(), w.dist.as<uint4>(), p.cap,
+                             w.mins.as<uint8_t>(), p.cap_min, 1, ix->order, 3072, st);
     else
-        tk_launch_scan_probes(ix->codes.as<uint4>(), M, ix->tables.as<uint4>(), nq,
-                              ix->slot_prefix.as<int>(), ix->slot_chunk0.as<int64_t>(), p.S,
-                              (int)p.cap, ix->dist.as<uint4>(), p.cap, ix->mins.as<uint8_t>(),
+        tk_launch_scan_probes(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), nq,
+                              w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), p.S,
+                              (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(),
                               p.cap_min, 1, ix->order, st);
     MARK();
+    if (ix->depth > 1) {
+        if (!ix->ev_scan) HIPCHECK(hipEventCreateWithFlags(&ix->ev_scan, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(ix->ev_scan, st));
+    }
     const bool fast = ix->heap_mode != 1 && ix->ids_unique && p.cap * 16 <= 0xffffff;
     const bool lanes = fast && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
     if (fast) {
         if (!lanes)
-            tk_launch_heap_replay_packed(ix->dist.as<uint4>(), p.cap, nq,
-                                         ix->slot_prefix.as<int>(), ix->slot_n.as<int>(),
-                                         ix->slot_loff.as<int64_t>(), p.S, ix->ids.as<int64_t>(),
-                                         ix->heap_idx.as<int64_t>(), ix->heap_val.as<int32_t>(),
-                                         p.R, 1, 0, ix->repeat_flag.as<unsigned char>(), st);
-        else if (tk_launch_heap_replay_lanes(ix->dist.as<uint4>(), p.cap, nq, ix->slot_prefix.as<int>(),
-                                        ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
-                                        ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
-                                        ix->heap_val.as<int32_t>(), p.R, 1, 0,
-                                        ix->repeat_flag.as<unsigned char>(),
-                                        ix->mins.as<uint8_t>(), p.cap_min, st))
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq,
+                                         w.slot_prefix.as<int>(), w.slot_n.as<int>(),
+                                         w.slot_loff.as<int64_t>(), p.S, ix->ids.as<int64_t>(),
+                                         w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
+                                         p.R, 1, 0, w.repeat_flag.as<unsigned char>(), st);
+        else if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
+                                        w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
+                                        ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                        w.heap_val.as<int32_t>(), p.R, 1, 0,
+                                        w.repeat_flag.as<unsigned char>(),
+                                        w.mins.as<uint8_t>(), p.cap_min, st))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
         // queries whose probe list wrapped (-1 from an unfilled coarse heap) may scan a
         // list twice; they take the wave kernel with the duplicate-label scan
-        tk_launch_heap_replay(ix->dist.as<uint4>(), p.cap, nq, ix->slot_prefix.as<int>(),
-                              ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
-                              ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
-                              ix->heap_val.as<int32_t>(), p.R, 1, 0,
-                              ix->repeat_flag.as<unsigned char>(), st);
+        tk_launch_heap_replay(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
+                              w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
+                              ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                              w.heap_val.as<int32_t>(), p.R, 1, 0,
+                              w.repeat_flag.as<unsigned char>(), st);
     } else {
-        tk_launch_heap_fill(ix->heap_idx.as<int64_t>(), ix->heap_val.as<int32_t>(), nq * p.R, 127,
+        tk_launch_heap_fill(w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), nq * p.R, 127,
                             st);
-        tk_launch_heap_replay(ix->dist.as<uint4>(), p.cap, nq, ix->slot_prefix.as<int>(),
-                              ix->slot_n.as<int>(), ix->slot_loff.as<int64_t>(), p.S,
-                              ix->ids.as<int64_t>(), ix->heap_idx.as<int64_t>(),
-                              ix->heap_val.as<int32_t>(), p.R, 1, 0, nullptr, st);
+        tk_launch_heap_replay(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
+                              w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
+                              ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                              w.heap_val.as<int32_t>(), p.R, 1, 0, nullptr, st);
     }
     MARK();
     // 4. strip sentinels, exact rescoring                   ivf.py:154-163
-    tk_launch_rescore(q_dev, ix->d, ix->data.as<float>(), ix->N, ix->heap_idx.as<int64_t>(), p.R,
+    tk_launch_rescore(q_dev, ix->d, ix->data.as<float>(), ix->N, w.heap_idx.as<int64_t>(), p.R,
                       nq, k, 1, out_dev, nullptr, st);
     MARK();
 #undef MARK
@@ -690,14 +756,52 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     ARGCHECK(nq >= 0, "nq");
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
     const size_t esz = q_pq_is_f64 ? 8 : 4;
     for (int64_t o = 0; o < nq; o += MAX_SUB) {
         int64_t sub = nq - o < MAX_SUB ? nq - o : MAX_SUB;
-        TRY(reserve(ix, sub, k, p));
-        TRY(run_batch(ix, q_dev + o * ix->d, (const char *)q_pq_dev + (size_t)o * ix->dq * esz,
+        Work &w = ix->works[ix->calls % (uint64_t)ix->depth];
+        ix->calls++;
+        hipStream_t st = caller;
+        if (ix->depth > 1) {
+            // the batch runs on the worker's own stream, after whatever the caller has
+            // enqueued so far (its inputs); tk_index_join re-joins the caller's stream
+            if (!w.stream) HIPCHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+            if (!w.done) HIPCHECK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+            if (!ix->ev_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_in, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(ix->ev_in, caller));
+            HIPCHECK(hipStreamWaitEvent(w.stream, ix->ev_in, 0));
+            st = w.stream;
+        }
+        TRY(reserve(ix, w, sub, k, p));
+        TRY(run_batch(ix, w, q_dev + o * ix->d, (const char *)q_pq_dev + (size_t)o * ix->dq * esz,
                       q_pq_is_f64, sub, k, p, out_ids_dev + o * k, st));
+        if (ix->depth > 1) HIPCHECK(hipEventRecord(w.done, st));
     }
+    return TK_OK;
+}
+
+extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
+{
+    ARGCHECK(ix, "null index");
+    ARGCHECK(depth >= 1 && depth <= 8, "depth must be in 1..8");
+    HIPCHECK(hipDeviceSynchronize());
+    while ((int)ix->works.size() > depth) {
+        ix->works.back().release();
+        ix->works.pop_back();
+    }
+    ix->works.resize((size_t)depth);
+    ix->depth = depth;
+    ix->calls = 0;
+    return TK_OK;
+}
+
+extern "C" int tk_index_join(tk_index *ix, void *stream)
+{
+    ARGCHECK(ix, "null index");
+    if (ix->depth > 1)
+        for (Work &w : ix->works)
+            if (w.done && w.stream) HIPCHECK(hipStreamWaitEvent((hipStream_t)stream, w.done, 0));
     return TK_OK;
 }
 
@@ -721,15 +825,16 @@ extern "C" int tk_index_query_batch(tk_index *ix, const float *q, const void *q_
     HIPCHECK(hipMemcpy(ix->qpq.p, q_pq, (size_t)nq * ix->dq * esz, hipMemcpyHostToDevice));
     int r = tk_index_query_batch_dev(ix, ix->q.as<float>(), ix->qpq.p, q_pq_is_f64, nq, k, n_probes,
                                      pass_1, outbuf.as<int64_t>(), nullptr);
+    const Work &lw = ix->works[(ix->calls + ix->depth - 1) % (uint64_t)ix->depth];   // last used
     if (r == TK_OK) {
         hipError_t e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMemcpy(out_ids, outbuf.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost);
         if (e == hipSuccess && out_probes)
-            e = hipMemcpy(out_probes, ix->probes.p, (size_t)nq * p.kc * 8, hipMemcpyDeviceToHost);
+            e = hipMemcpy(out_probes, lw.probes.p, (size_t)nq * p.kc * 8, hipMemcpyDeviceToHost);
         if (e == hipSuccess && out_heap_idx)
-            e = hipMemcpy(out_heap_idx, ix->heap_idx.p, (size_t)nq * p.R * 8, hipMemcpyDeviceToHost);
+            e = hipMemcpy(out_heap_idx, lw.heap_idx.p, (size_t)nq * p.R * 8, hipMemcpyDeviceToHost);
         if (e == hipSuccess && out_heap_val)
-            e = hipMemcpy(out_heap_val, ix->heap_val.p, (size_t)nq * p.R * 4, hipMemcpyDeviceToHost);
+            e = hipMemcpy(out_heap_val, lw.heap_val.p, (size_t)nq * p.R * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) r = fail(TK_ERR_HIP, hipGetErrorString(e));
     }
     outbuf.release();
@@ -767,7 +872,7 @@ extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_byte
     *scan_bytes = 0;
     *batches = (int)ix->ev_used;
     if (ix->ev_used == 0) return TK_OK;
-    HIPCHECK(hipStreamSynchronize(ix->ev_stream));
+    for (size_t b = 0; b < ix->ev_used; b++) HIPCHECK(hipStreamSynchronize(ix->ev_streams[b]));
     for (size_t b = 0; b < ix->ev_used; b++)
         for (int i = 0; i < 7; i++) {
             float ms = 0;
@@ -778,7 +883,8 @@ extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_byte
     // per query  sum over probed lists ceil(n/16)*M*8  +  16*M (table)  +  12*R (heap)
     const int S = ix->last_S;
     std::vector<int> pre((size_t)ix->last_nq * (S + 1));
-    HIPCHECK(hipMemcpy(pre.data(), ix->slot_prefix.p, pre.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(pre.data(), ix->works[ix->last_work].slot_prefix.p, pre.size() * 4,
+                       hipMemcpyDeviceToHost));
     double bytes = 0;
     for (int64_t i = 0; i < ix->last_nq; i++)
         bytes += (double)pre[(size_t)i * (S + 1) + S] * ix->M * 8 + 16.0 * ix->M + 12.0 * ix->last_R;

@@ -39,17 +39,24 @@ void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64
                            int max_flat_chunks, uint4 *dist, int64_t cap, uint8_t *mins,
                            int64_t min_stride, int signd, int order, hipStream_t s);
 
-// List-major form of the probed-list scan for large batches: groups the (query,
-// slot) pairs by list (count / scan / fill kernels) and scores each chunk for four
-// queries per pass.  Same outputs as tk_launch_scan_probes.  Work arrays: count,
-// cursor (n_lists), pair_off, unit_prefix (n_lists+1), pair_q, pair_f0
-// (max_records >= nq*S + 3*n_lists).
-void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
-                          const int64_t *probes, int S, int64_t n_lists,
+// List-major form of the probed-list scan for large batches.  tk_launch_unit_pairs
+// groups the (query, slot) pairs by list (count / scan / fill kernels);
+// tk_launch_scan_units scores each chunk for four queries per pass.  Same outputs
+// as tk_launch_scan_probes.  Work arrays: count, cursor (n_lists), pair_off,
+// unit_prefix (n_lists+1), pair_q, pair_f0 (max_records >= nq*S + 4*n_lists).
+void tk_launch_unit_pairs(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
                           const int64_t *list_chunk_off, const int *slot_prefix, int *count,
                           int *pair_off, int *unit_prefix, int *cursor, int *pair_q, int *pair_f0,
-                          int64_t max_records, uint4 *dist, int64_t cap, uint8_t *mins,
-                          int64_t min_stride, int signd, int order, int n_blocks, hipStream_t s);
+                          int64_t max_records, hipStream_t s);
+// descriptors for one list scanned by every query (pair_off/unit_prefix: 2 ints,
+// pair_q/pair_f0: nq rounded up to a multiple of 4)
+void tk_launch_identity_pairs(int64_t nq, int chunks, int *pair_off, int *unit_prefix, int *pair_q,
+                              int *pair_f0, hipStream_t s);
+void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq, int S,
+                          int64_t n_lists, const int64_t *list_chunk_off, const int *pair_off,
+                          const int *unit_prefix, const int *pair_q, const int *pair_f0,
+                          uint4 *dist, int64_t cap, uint8_t *mins, int64_t min_stride, int signd,
+                          int order, int n_blocks, hipStream_t s);
 
 // Exact replay of the reference's sequential heap over precomputed distances.
 // One wave per query.  slot_n: true rows per slot; slot_label_off: offset into

@@ -15,9 +15,9 @@
 //   dists -= shift
 //   scale = 128 / (f64(max) * sqrt_n_blocks)           always float64
 //   table = uint8(int(rint(f64(dists) * scale)))       half-even, wrap-around
-// One 64-lane workgroup per query; the 16*M distances sit in LDS.  The pairwise
-// tree is evaluated by lane 0 in numpy's exact order (16*M <= a few thousand adds;
-// the whole batch is microseconds and the scan kernels dominate).
+// One wave per query (four per workgroup); the 16*M distances sit in LDS.  The
+// pairwise mean is evaluated in numpy's exact order with the 8 accumulators of
+// every <=128-element leaf spread over the lanes; only the leaf combine is serial.
 #include "kernels.h"
 
 template <typename T>
@@ -56,51 +56,53 @@ __device__ __forceinline__ T einsum_selfdot(const T *a, int n)
     return acc[0] + acc[1 % L];
 }
 
-// numpy pairwise sum of a[0..n) (contiguous), exact order.
-template <typename T>
-__device__ T pairwise_leaf(const T *a, int n)
+// Leaves of numpy's pairwise recursion over n elements, in order: n > 128 splits at
+// n2 = n/2 - (n/2)%8 into [0,n2) and [n2,n).  Returns the leaf count (<= 64 for
+// n <= 8192).
+__device__ int pairwise_leaves(int n, int *leaf_off, int *leaf_n)
 {
-    if (n < 8) {
-        T res = 0;
-        for (int i = 0; i < n; i++) res += a[i];
-        return res;
+    int st_off[32], st_n[32];
+    int sp = 0, nl = 0;
+    st_off[0] = 0; st_n[0] = n; sp = 1;
+    while (sp > 0) {
+        sp--;
+        const int off = st_off[sp], m = st_n[sp];
+        if (m <= 128) {
+            leaf_off[nl] = off;
+            leaf_n[nl] = m;
+            nl++;
+        } else {
+            int n2 = m / 2;
+            n2 -= n2 % 8;
+            st_off[sp] = off + n2; st_n[sp] = m - n2; sp++;   // right, popped after
+            st_off[sp] = off; st_n[sp] = n2; sp++;            // left, popped first
+        }
     }
-    T r[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = a[j];
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) r[j] += a[i + j];
-    }
-    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res += a[i];
-    return res;
+    return nl;
 }
 
+// Combine the leaf sums in numpy's tree order (post-order: left + right).
 template <typename T>
-__device__ T pairwise_sum(const T *a, int n)
+__device__ T pairwise_combine(int n, const T *leaf_sum)
 {
-    // explicit post-order walk of numpy's recursion: n > 128 splits at
-    // n2 = n/2 - (n/2)%8 into [0,n2) and [n2,n)
-    int st_off[40], st_n[40], st_vis[40];
+    int st_n[40], st_vis[40];
     T vals[40];
-    int sp = 0, vp = 0;
-    st_off[0] = 0; st_n[0] = n; st_vis[0] = 0; sp = 1;
+    int sp = 0, vp = 0, next_leaf = 0;
+    st_n[0] = n; st_vis[0] = 0; sp = 1;
     while (sp > 0) {
-        int off = st_off[sp - 1], m = st_n[sp - 1];
+        const int m = st_n[sp - 1];
         if (m <= 128) {
-            vals[vp++] = pairwise_leaf(a + off, m);
+            vals[vp++] = leaf_sum[next_leaf++];
             sp--;
         } else if (!st_vis[sp - 1]) {
             st_vis[sp - 1] = 1;
             int n2 = m / 2;
             n2 -= n2 % 8;
-            st_off[sp] = off + n2; st_n[sp] = m - n2; st_vis[sp] = 0; sp++;
-            st_off[sp] = off; st_n[sp] = n2; st_vis[sp] = 0; sp++;
+            st_n[sp] = m - n2; st_vis[sp] = 0; sp++;
+            st_n[sp] = n2; st_vis[sp] = 0; sp++;
         } else {
-            T r = vals[--vp];
-            T l = vals[--vp];
+            const T r = vals[--vp];
+            const T l = vals[--vp];
             vals[vp++] = l + r;
             sp--;
         }
@@ -108,19 +110,30 @@ __device__ T pairwise_sum(const T *a, int n)
     return vals[0];
 }
 
+// One wave per query, blockDim.x / 64 queries per workgroup.  Per-wave LDS:
+//   dists[16M] T | acc[64][8] T | leaf_sum[64] T | leaf_off[64], leaf_n[64] int | misc
 template <typename T, bool SIGNED>
-__global__ __launch_bounds__(64) void build_tables_kernel(
+__global__ __launch_bounds__(256) void build_tables_kernel(
     const float *__restrict__ centers, int dq, int dpb, int f_order, const T *__restrict__ qs,
     double aux0, double aux1, uint8_t *__restrict__ tables, T *__restrict__ shift_out,
-    double *__restrict__ scale_out)
+    double *__restrict__ scale_out, int64_t nq, int wave_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *dists = (T *)smem;  // 16*M, numpy memory order
-    __shared__ T sh_shift;
-    const int lane = threadIdx.x;
-    const int64_t qi = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int waves = blockDim.x >> 6;
     const int M = dq / dpb;
     const int cnt = 16 * M;
+    unsigned char *base = smem + (size_t)wave * wave_lds;
+    T *dists = (T *)base;                 // numpy memory order
+    T *acc = dists + cnt;                 // [leaf][8]
+    T *leaf_sum = acc + 64 * 8;
+    int *leaf_off = (int *)(leaf_sum + 64);
+    int *leaf_n = leaf_off + 64;
+    T *sh_shift = (T *)(leaf_n + 64);
+    int *sh_nleaf = (int *)(sh_shift + 1);
+    const int64_t qraw = (int64_t)blockIdx.x * waves + wave;
+    const bool valid = qraw < nq;
+    const int64_t qi = valid ? qraw : nq - 1;   // surplus waves recompute the last query
     const T *q = qs + qi * dq;
     constexpr int MAXDPB = 32;
     T diff[MAXDPB];
@@ -129,13 +142,9 @@ __global__ __launch_bounds__(64) void build_tables_kernel(
         const int i = e / M, m = e - i * M;
         T v;
         if (SIGNED) {
-            if (dpb <= MAXDPB) {
-                for (int k = 0; k < dpb; k++)
-                    diff[k] = (T)centers[(int64_t)i * dq + m * dpb + k] - q[m * dpb + k];
-                v = einsum_selfdot<T>(diff, dpb);
-            } else {
-                v = 0;  // rejected on the host
-            }
+            for (int k = 0; k < dpb; k++)
+                diff[k] = (T)centers[(int64_t)i * dq + m * dpb + k] - q[m * dpb + k];
+            v = einsum_selfdot<T>(diff, dpb);
         } else {
             // np.square(centers - q).reshape(16, nb, dpb).sum(-1): sequential adds
             v = 0;
@@ -147,20 +156,53 @@ __global__ __launch_bounds__(64) void build_tables_kernel(
         }
         dists[f_order ? (m * 16 + i) : e] = v;
     }
+    if (lane == 0) *sh_nleaf = SIGNED ? pairwise_leaves(cnt, leaf_off, leaf_n) : 0;
     __syncthreads();
-    if (lane == 0) {
-        T sh;
-        if (SIGNED) {
-            T mean = pairwise_sum<T>(dists, cnt) / (T)cnt;   // _mean
-            sh = mean * (T)0.6931471806;                       // fast_pq.py:214
-        } else {
-            sh = dists[0];
-            for (int e = 1; e < cnt; e++) sh = dists[e] < sh ? dists[e] : sh;  // np.min
+    T shift;
+    if (SIGNED) {
+        // numpy's pairwise mean, the 8 accumulators of every <=128-element leaf in
+        // parallel (lane = leaf*8 + accumulator), then the exact combine tree
+        const int nleaf = *sh_nleaf;
+        for (int t = lane; t < nleaf * 8; t += 64) {
+            const int L = t >> 3, j = t & 7;
+            const int off = leaf_off[L], n = leaf_n[L];
+            T r = 0;
+            if (n >= 8) {
+                r = dists[off + j];
+                for (int i = 8; i < n - (n % 8); i += 8) r += dists[off + i + j];
+            }
+            acc[L * 8 + j] = r;
         }
-        sh_shift = sh;
+        __syncthreads();
+        for (int L = lane; L < nleaf; L += 64) {
+            const int off = leaf_off[L], n = leaf_n[L];
+            T res;
+            if (n < 8) {
+                res = 0;
+                for (int i = 0; i < n; i++) res += dists[off + i];
+            } else {
+                const T *r = acc + L * 8;
+                res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (int i = n - (n % 8); i < n; i++) res += dists[off + i];
+            }
+            leaf_sum[L] = res;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            T mean = pairwise_combine<T>(cnt, leaf_sum) / (T)cnt;   // _mean
+            *sh_shift = mean * (T)0.6931471806;                     // fast_pq.py:214
+        }
+        __syncthreads();
+        shift = *sh_shift;
+    } else {
+        T mn = INFINITY;
+        for (int e = lane; e < cnt; e += 64) mn = dists[e] < mn ? dists[e] : mn;   // np.min
+        for (int o = 32; o > 0; o >>= 1) {
+            T other = __shfl_xor(mn, o, 64);
+            mn = other < mn ? other : mn;
+        }
+        shift = mn;
     }
-    __syncthreads();
-    const T shift = sh_shift;
     T mx = -INFINITY;
     for (int e = lane; e < cnt; e += 64) {
         T v = dists[e] - shift;  // fast_pq.py:215 / :247
@@ -177,6 +219,7 @@ __global__ __launch_bounds__(64) void build_tables_kernel(
     else
         scale = 255.0 / (((double)mx * aux0) * aux1);  // :248
     __syncthreads();
+    if (!valid) return;
     for (int e = lane; e < cnt; e += 64) {
         const int i = e / M, m = e - i * M;
         double v = rint((double)dists[f_order ? (m * 16 + i) : e] * scale);
@@ -194,25 +237,32 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
 {
     if (nq == 0) return;
     const int M = dq / dpb;
-    size_t lds = (size_t)16 * M * (q_is_f64 ? 8 : 4);
-    dim3 grid((unsigned)nq), block(64);
+    const size_t esz = q_is_f64 ? 8 : 4;
+    // per-wave LDS: dists + 64x8 accumulators + 64 leaf sums + 2x64 ints + shift, nleaf
+    int wave_lds = (int)(((size_t)16 * M + 64 * 8 + 64) * esz + 128 * 4 + 32);
+    wave_lds = (wave_lds + 15) & ~15;
+    int waves = 64 * 1024 / wave_lds;
+    waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
+    size_t lds = (size_t)waves * wave_lds;
+    dim3 grid((unsigned)((nq + waves - 1) / waves)), block(64 * waves);
+    const int pdpb = dpb;
     if (q_is_f64) {
         if (signd)
             hipLaunchKernelGGL((build_tables_kernel<double, true>), grid, block, lds, s, centers, dq,
-                               dpb, f_order, (const double *)q, aux0, aux1, tables,
-                               (double *)shift, scale);
+                               pdpb, f_order, (const double *)q, aux0, aux1, tables,
+                               (double *)shift, scale, nq, wave_lds);
         else
             hipLaunchKernelGGL((build_tables_kernel<double, false>), grid, block, lds, s, centers,
-                               dq, dpb, f_order, (const double *)q, aux0, aux1, tables,
-                               (double *)shift, scale);
+                               dq, pdpb, f_order, (const double *)q, aux0, aux1, tables,
+                               (double *)shift, scale, nq, wave_lds);
     } else {
         if (signd)
             hipLaunchKernelGGL((build_tables_kernel<float, true>), grid, block, lds, s, centers, dq,
-                               dpb, f_order, (const float *)q, aux0, aux1, tables, (float *)shift,
-                               scale);
+                               pdpb, f_order, (const float *)q, aux0, aux1, tables, (float *)shift,
+                               scale, nq, wave_lds);
         else
             hipLaunchKernelGGL((build_tables_kernel<float, false>), grid, block, lds, s, centers,
-                               dq, dpb, f_order, (const float *)q, aux0, aux1, tables,
-                               (float *)shift, scale);
+                               dq, pdpb, f_order, (const float *)q, aux0, aux1, tables,
+                               (float *)shift, scale, nq, wave_lds);
     }
 }

@@ -112,6 +112,13 @@ class DeviceIndex:
     def reserve(self, nq, k, n_probes, pass_1=None):
         _lib.check(_lib.lib().tk_index_reserve(self._h, nq, int(k), int(n_probes), int(pass_1 or 0)))
 
+    def set_pipeline(self, depth):
+        """Number of batches in flight for query_batch_dev (see tinyknn_hip.h)."""
+        _lib.check(_lib.lib().tk_index_set_pipeline(self._h, int(depth)))
+
+    def join(self, stream=0):
+        _lib.check(_lib.lib().tk_index_join(self._h, stream))
+
     def set_heap_mode(self, mode):
         """0: automatic (lane-per-query), 1: general wave kernel, 2: packed wave kernel."""
         _lib.check(_lib.lib().tk_index_set_heap_mode(self._h, int(mode)))
