@@ -395,3 +395,111 @@ def test_ivf_saturating_and_duplicates(tk, oracle, build_probes):
                 np.testing.assert_array_equal(dbg["heap_val"][qi], odbg["heap_val"], err_msg=f"q{qi}")
                 np.testing.assert_array_equal(out[qi][out[qi] != -1] if len(ids) < 10 else out[qi], ids)
     print("queries with a -1 probe:", saw_sentinel)
+
+
+def test_config_c1_flat_scan(tk, oracle):
+    """BASELINE configs[0] (examples/example.py): N=16000 d=128 random, FastPQ(2)
+    => rotated to 64 dims, M=32, float64 table math.  Per query: distance_table +
+    estimate_distances, and the two-pass top(); all against the oracle."""
+    from tinyknn_amd import FastPQ
+    np.random.seed(10)
+    n, d = 16000, 128
+    X = np.random.randn(n, d).astype(np.float32)
+    qs = np.random.randn(40, d).astype(np.float32)
+    pq = FastPQ(dims_per_block=2, use_kmeans=True)
+    pq.fit(X[:4000])
+    data = pq.transform(X)
+    assert pq.R is not None and pq.centers.shape == (16, 64) and data.packed.shape == (1000, 32)
+    for signed in (True, False):
+        for q in qs[:20]:
+            dt = pq.distance_table(q) if signed else pq.udistance_table(q)
+            qp = np.concatenate([q, np.zeros(0, np.float32)]) @ pq.R.T
+            table, shift, scale = oracle.distance_table(pq.centers, 2, qp, pq.sqrt_n_blocks, signed)
+            np.testing.assert_array_equal(dt.tables, oracle.transform_tables(table))
+            assert dt.mean == shift and dt.scale == scale and dt.mean.dtype == np.float64
+            est = dt.estimate_distances(data)
+            exp = np.zeros(2 * len(data.packed), dtype=np.uint64)
+            oracle.estimate_pq(data.packed, dt.tables, exp, signed, oracle.ORDER_AVX)
+            np.testing.assert_array_equal(est, exp.view(np.int8 if signed else np.uint8)[:n])
+    for q in qs:
+        dt = pq.distance_table(q)
+        got = dt.top(data, X, k=10)
+        # oracle restatement of fast_pq.py:284-312
+        idx = np.zeros(30, np.int64); val = np.zeros(30, np.int32)
+        oracle.init_heap(idx, val, True)
+        oracle.query_pq(data.packed, n, dt.tables, idx, val, True, None, oracle.ORDER_AVX)
+        exp = idx[oracle.knn_brute1(q, X[idx], 10)]
+        np.testing.assert_array_equal(got, exp)
+
+
+def test_config_c3_euclidean_rotated_ivf(tk, oracle):
+    """BASELINE configs[2] shape (SIFT-like: euclidean, d=128 rotated to 64 dims,
+    M=32), 40k points, n_probes sweep; probes, heap arrays and ids vs the oracle."""
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(10)
+    n, d, nq = 40000, 128, 200
+    X = np.clip(np.abs(np.random.randn(n, d)) * 40, 0, 218).round().astype(np.float32)
+    qs = np.clip(np.abs(np.random.randn(nq, d)) * 40, 0, 218).round().astype(np.float32)
+    ivf = IVF("euclidean", 200, FastPQ(2))
+    ivf.fit(X[:10000]).build(X, n_probes=1)
+    assert ivf.pq.R is not None and ivf.pq.centers.shape == (16, 64)
+    ox = _oracle_index(oracle, ivf)
+    qn, qp = ivf._prepare(qs.copy())
+    assert qp.dtype == np.float64
+    for n_probes in (1, 5, 20):
+        out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)
+        for qi in range(nq):
+            ids, odbg = ox.query(qn[qi], 10, n_probes=n_probes, debug=True)
+            np.testing.assert_array_equal(dbg["probes"][qi], odbg["probes"], err_msg=f"q{qi}")
+            np.testing.assert_array_equal(dbg["heap_idx"][qi], odbg["heap_idx"], err_msg=f"q{qi}")
+            np.testing.assert_array_equal(dbg["heap_val"][qi], odbg["heap_val"], err_msg=f"q{qi}")
+            np.testing.assert_array_equal(out[qi][out[qi] != -1] if len(ids) < 10 else out[qi], ids)
+        # the public single-query API on the raw query
+        for qi in (0, 7, 99):
+            np.testing.assert_array_equal(ivf.query(qs[qi].copy(), 10, n_probes=n_probes), out[qi][out[qi] != -1])
+
+
+def test_pipelined_batches_and_join(tk, oracle):
+    """tk_index_set_pipeline: several batches in flight give the same ids as one."""
+    import ctypes as C
+    from tinyknn_amd import IVF, FastPQ, _lib
+    np.random.seed(5)
+    n, d, nq = 20000, 100, 300
+    X = np.random.randn(n, d).astype(np.float32)
+    ivf = IVF("angular", 100, FastPQ(2))
+    ivf.fit(X[:5000]).build(X, n_probes=1)
+    dev = ivf.device_index()
+    batches = []
+    for b in range(5):
+        qs = np.random.randn(nq, d).astype(np.float32)
+        batches.append(ivf._prepare(qs))
+    ref = [dev.query_batch(qn, qp, 10, 8) for qn, qp in batches]
+    L = _lib.lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+    dev.set_pipeline(3)
+    try:
+        bufs = []
+        for qn, qp in batches:
+            qn = np.ascontiguousarray(qn, np.float32); qp = np.ascontiguousarray(qp, np.float32)
+            dq_, dp_, do_ = dmalloc(qn.nbytes), dmalloc(qp.nbytes), dmalloc(nq * 10 * 8)
+            assert hip.hipMemcpy(dq_, qn.ctypes.data, qn.nbytes, 1) == 0
+            assert hip.hipMemcpy(dp_, qp.ctypes.data, qp.nbytes, 1) == 0
+            bufs.append((dq_, dp_, do_))
+        for dq_, dp_, do_ in bufs:          # 5 batches over 3 workspaces, no sync in between
+            dev.query_batch_dev(dq_, dp_, False, nq, 10, 8, do_)
+        dev.join(0)
+        assert hip.hipDeviceSynchronize() == 0
+        for (dq_, dp_, do_), exp in zip(bufs, ref):
+            out = np.zeros((nq, 10), np.int64)
+            assert hip.hipMemcpy(out.ctypes.data, do_, out.nbytes, 2) == 0
+            np.testing.assert_array_equal(out, exp)
+            for p in (dq_, dp_, do_):
+                hip.hipFree(p)
+    finally:
+        dev.set_pipeline(1)
