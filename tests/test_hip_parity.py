@@ -503,3 +503,54 @@ def test_pipelined_batches_and_join(tk, oracle):
                 hip.hipFree(p)
     finally:
         dev.set_pipeline(1)
+
+
+def test_hipgraph_captured_batch(tk):
+    """BASELINE configs[3]: the whole batch pipeline captured as ONE hipGraph and
+    replayed (fixed-shape launches, no host sync, no allocation after reserve)."""
+    import ctypes as C
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(6)
+    n, d, nq = 20000, 100, 500
+    X = np.random.randn(n, d).astype(np.float32)
+    ivf = IVF("angular", 100, FastPQ(2))
+    ivf.fit(X[:5000]).build(X, n_probes=1)
+    dev = ivf.device_index()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+    hip.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    hip.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    stream = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+    for n_probes in (1, 5, 10, 20):
+        qs = [ivf._prepare(np.random.randn(nq, d).astype(np.float32)) for _ in range(3)]
+        ref = [dev.query_batch(qn, qp, 10, n_probes) for qn, qp in qs]   # also warms + reserves
+        dq_, dp_, do_ = dmalloc(nq * d * 4), dmalloc(nq * 104 * 4), dmalloc(nq * 10 * 8)
+        dev.reserve(nq, 10, n_probes)
+        assert hip.hipStreamBeginCapture(stream, 0) == 0          # hipStreamCaptureModeGlobal
+        dev.query_batch_dev(dq_, dp_, False, nq, 10, n_probes, do_, stream=stream)
+        graph = C.c_void_p()
+        assert hip.hipStreamEndCapture(stream, C.byref(graph)) == 0
+        gexec = C.c_void_p()
+        assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
+        for (qn, qp), exp in zip(qs, ref):
+            qn = np.ascontiguousarray(qn, np.float32); qp = np.ascontiguousarray(qp, np.float32)
+            assert hip.hipMemcpyAsync(dq_, qn.ctypes.data, qn.nbytes, 1, stream) == 0
+            assert hip.hipMemcpyAsync(dp_, qp.ctypes.data, qp.nbytes, 1, stream) == 0
+            assert hip.hipGraphLaunch(gexec, stream) == 0
+            assert hip.hipStreamSynchronize(stream) == 0
+            out = np.zeros((nq, 10), np.int64)
+            assert hip.hipMemcpy(out.ctypes.data, do_, out.nbytes, 2) == 0
+            np.testing.assert_array_equal(out, exp, err_msg=f"n_probes {n_probes}")
+        hip.hipGraphExecDestroy(gexec); hip.hipGraphDestroy(graph)
+        for p in (dq_, dp_, do_):
+            hip.hipFree(p)
