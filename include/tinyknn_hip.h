@@ -93,6 +93,24 @@ int tk_build_tables(const float *centers, int dq, int dpb, int f_order, const vo
 int64_t tk_knn_brute1(const float *x, const float *Y, int64_t n, int d, int64_t k,
                       int64_t *out_pos);
 
+/* ---- device-resident code array ---------------------------------------------
+ * A TransformedData (fast_pq.py:30,184) kept in HBM so that repeated
+ * estimate_distances / top calls on the same data (examples/example.py:60-66 runs
+ * 1000 of them) do not re-send the codes over PCIe. */
+typedef struct tk_codes tk_codes;
+tk_codes *tk_codes_upload(const uint64_t *data, int64_t chunks, int M);
+void tk_codes_free(tk_codes *c);
+/* estimate_pq_* against the resident array: nq tables (nq, 2M) -> out (nq, 2*chunks) */
+int tk_codes_estimate(tk_codes *c, const uint64_t *tables, int64_t nq, uint64_t *out, int signd,
+                      int order);
+/* same with device-resident tables (nq, M, 16) uint8 / out (nq, chunks*16) bytes, enqueued
+ * on `stream`; four queries share each pass over the codes when nq >= 4 */
+int tk_codes_estimate_dev(tk_codes *c, const void *tables_dev, int64_t nq, void *out_dev,
+                          int signd, int order, void *stream);
+/* query_pq_* against the resident array (indices / vals / labels are host buffers) */
+int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, int64_t *indices,
+                   int32_t *vals, int R, int signd, const int64_t *labels, int order);
+
 /* ---- device-resident IVF index --------------------------------------------
  * Holds what the reference's IVF object holds after fit+build (ivf.py:14-17,
  * 77-102) in HBM, re-tiled for coalesced scans, and answers batches of queries

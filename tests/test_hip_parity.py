@@ -421,6 +421,21 @@ def test_config_c1_flat_scan(tk, oracle):
             exp = np.zeros(2 * len(data.packed), dtype=np.uint64)
             oracle.estimate_pq(data.packed, dt.tables, exp, signed, oracle.ORDER_AVX)
             np.testing.assert_array_equal(est, exp.view(np.int8 if signed else np.uint8)[:n])
+    # the batched form (one launch for all queries, codes resident in HBM)
+    from tinyknn_amd.fast_pq import estimate_batch
+    from tinyknn_amd import _fast_pq
+    assert _fast_pq.device_codes(data.packed)          # resident after the calls above
+    for signed in (True, False):
+        allq = estimate_batch(pq, data, qs, signed)
+        for i in (0, 3, 39):
+            dt = pq.distance_table(qs[i]) if signed else pq.udistance_table(qs[i])
+            np.testing.assert_array_equal(allq[i], dt.estimate_distances(data))
+    _fast_pq.cache_device_codes = False               # and the uncached host-buffer path
+    try:
+        dt = pq.distance_table(qs[0])
+        np.testing.assert_array_equal(dt.estimate_distances(data), estimate_batch(pq, data, qs[:1])[0])
+    finally:
+        _fast_pq.cache_device_codes = True
     for q in qs:
         dt = pq.distance_table(q)
         got = dt.top(data, X, k=10)

@@ -21,6 +21,57 @@ def _buf(a, dtype, ndim, name):
     return a
 
 
+# Code arrays that are scanned repeatedly (FastPQ.transform output: one array,
+# thousands of queries, examples/example.py:60-66) are kept in HBM between calls,
+# keyed by the identity of the numpy array and released when it is garbage
+# collected.  The device copy is NOT refreshed if the caller mutates the array in
+# place afterwards; set cache_device_codes = False (or call forget_device_codes)
+# for that usage.
+cache_device_codes = True
+_CACHE_MIN_BYTES = 16 * 1024
+_codes_cache = {}
+
+
+def forget_device_codes(data=None):
+    """Drop the HBM copy of one packed array (or of all of them)."""
+    keys = list(_codes_cache) if data is None else [id(data)]
+    for k in keys:
+        ent = _codes_cache.pop(k, None)
+        if ent is not None:
+            _lib.lib().tk_codes_free(ent[1])
+
+
+def device_codes(data):
+    """HBM-resident handle (tk_codes*) of a packed code array, or None."""
+    if not cache_device_codes or data.nbytes < _CACHE_MIN_BYTES:
+        return None
+    key = id(data)
+    sig = (data.ctypes.data, data.shape)
+    ent = _codes_cache.get(key)
+    if ent is not None and ent[0]() is data and ent[2] == sig:
+        return ent[1]
+    if ent is not None:
+        forget_device_codes(data)
+    h = _lib.lib().tk_codes_upload(_lib.ptr(data, _lib._u64p), data.shape[0], data.shape[1])
+    if not h:
+        _lib.check(-2)
+    import weakref
+
+    def _gone(_ref, key=key, h=h):
+        ent = _codes_cache.get(key)
+        if ent is not None and ent[1] == h:
+            del _codes_cache[key]
+            try:
+                _lib.lib().tk_codes_free(h)
+            except Exception:
+                pass
+
+    _codes_cache[key] = (weakref.ref(data, _gone), h, sig)
+    if len(_codes_cache) > 512:          # bound the number of resident arrays
+        forget_device_codes(next(iter(_codes_cache.values()))[0]())
+    return h
+
+
 def _estimate(data, tables, out, signd, order):
     data = _buf(data, np.uint64, 2, "data")
     tables = _buf(tables, np.uint64, 1, "tables")
@@ -29,6 +80,11 @@ def _estimate(data, tables, out, signd, order):
     assert tables.shape[0] >= 2 * M and out.shape[0] >= 2 * chunks
     if not out.flags.writeable:
         raise ValueError("buffer source array is read-only")
+    h = device_codes(data)
+    if h:
+        _lib.check(_lib.lib().tk_codes_estimate(h, _lib.ptr(tables, _lib._u64p), 1,
+                                                _lib.ptr(out, _lib._u64p), int(bool(signd)), order))
+        return
     _lib.check(_lib.lib().tk_estimate_pq(
         _lib.ptr(data, _lib._u64p), chunks, M, _lib.ptr(tables, _lib._u64p),
         _lib.ptr(out, _lib._u64p), int(bool(signd)), order))
@@ -45,6 +101,12 @@ def _query(data, n, tables, indices, vals, signd, labels, order):
     if labels is not None:
         labels = _buf(labels, np.int64, 1, "labels")
         lab = _lib.ptr(labels, _lib._i64p)
+    h = device_codes(data)
+    if h:
+        _lib.check(_lib.lib().tk_codes_query(
+            h, int(n), _lib.ptr(tables, _lib._u64p), _lib.ptr(indices, _lib._i64p),
+            _lib.ptr(vals, _lib._i32p), len(indices), int(bool(signd)), lab, order))
+        return
     _lib.check(_lib.lib().tk_query_pq(
         _lib.ptr(data, _lib._u64p), chunks, M, int(n), _lib.ptr(tables, _lib._u64p),
         _lib.ptr(indices, _lib._i64p), _lib.ptr(vals, _lib._i32p), len(indices),

@@ -313,6 +313,154 @@ extern "C" int64_t tk_knn_brute1(const float *x, const float *Y, int64_t n, int 
 }
 
 // ---------------------------------------------------------------------------
+// device-resident code array (a TransformedData kept in HBM)
+struct tk_codes {
+    DevBuf tiled;
+    int64_t chunks = 0;
+    int M = 0;
+    // scratch of the calls on this array
+    DevBuf tables, out, hidx, hval, labels, slots_i, slots_l, pair_off, unit_prefix, pair_q,
+        pair_f0, chunk_off;
+};
+
+extern "C" tk_codes *tk_codes_upload(const uint64_t *data, int64_t chunks, int M)
+{
+    if (require_gpu() != TK_OK) return nullptr;
+    if (chunks < 0 || M < 2 || M % 2) {
+        fail(TK_ERR_ARG, "bad argument: chunks / M");
+        return nullptr;
+    }
+    tk_codes *c = new tk_codes();
+    DevBuf stage;
+    const int P = M / 2;
+    bool ok = c->tiled.ensure((size_t)tk_tiled_uint4s(chunks, P) * 16 + 16) == TK_OK;
+    if (ok && chunks > 0) {
+        ok = stage.ensure((size_t)chunks * M * 8) == TK_OK &&
+             hipMemcpy(stage.p, data, (size_t)chunks * M * 8, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) {
+            tk_launch_retile(stage.as<uint4>(), c->tiled.as<uint4>(), chunks, P, 0);
+            ok = hipDeviceSynchronize() == hipSuccess;
+        }
+    }
+    stage.release();
+    if (!ok) {
+        fail(TK_ERR_HIP, "tk_codes_upload: device allocation or copy failed");
+        c->tiled.release();
+        delete c;
+        return nullptr;
+    }
+    c->chunks = chunks;
+    c->M = M;
+    return c;
+}
+
+extern "C" void tk_codes_free(tk_codes *c)
+{
+    if (!c) return;
+    DevBuf *b[] = {&c->tiled, &c->tables, &c->out, &c->hidx, &c->hval, &c->labels, &c->slots_i,
+                   &c->slots_l, &c->pair_off, &c->unit_prefix, &c->pair_q, &c->pair_f0,
+                   &c->chunk_off};
+    for (DevBuf *x : b) x->release();
+    delete c;
+}
+
+// nq tables against the resident array; tables/out are DEVICE pointers.  out:
+// (nq, chunks) uint4.  Four queries per pass (list-major kernel) when nq >= 4.
+extern "C" int tk_codes_estimate_dev(tk_codes *c, const void *tables_dev, int64_t nq,
+                                     void *out_dev, int signd, int order, void *stream)
+{
+    ARGCHECK(c, "null codes handle");
+    ARGCHECK(nq >= 0 && nq <= 65535, "0 <= nq <= 65535");
+    ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
+    if (nq == 0 || c->chunks == 0) return TK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool units = nq >= 4 && (double)nq / 4 * c->chunks < 2.0e9;
+    if (units) {
+        TRY(c->pair_off.ensure(8));
+        TRY(c->unit_prefix.ensure(8));
+        TRY(c->pair_q.ensure(((size_t)nq + 4) * 4));
+        TRY(c->pair_f0.ensure(((size_t)nq + 4) * 4));
+        if (!c->chunk_off.p) {
+            int64_t cco[2] = {0, c->chunks};
+            TRY(c->chunk_off.ensure(sizeof cco));
+            HIPCHECK(hipMemcpy(c->chunk_off.p, cco, sizeof cco, hipMemcpyHostToDevice));
+        }
+        tk_launch_identity_pairs(nq, (int)c->chunks, c->pair_off.as<int>(),
+                                 c->unit_prefix.as<int>(), c->pair_q.as<int>(),
+                                 c->pair_f0.as<int>(), st);
+        tk_launch_scan_units(c->tiled.as<uint4>(), c->M, (const uint4 *)tables_dev, nq, 1, 1,
+                             c->chunk_off.as<int64_t>(), c->pair_off.as<int>(),
+                             c->unit_prefix.as<int>(), c->pair_q.as<int>(), c->pair_f0.as<int>(),
+                             (uint4 *)out_dev, c->chunks, nullptr, 0, signd, order, 3072, st);
+    } else {
+        tk_launch_scan_flat(c->tiled.as<uint4>(), c->chunks, c->M, (const uint4 *)tables_dev, nq,
+                            (uint4 *)out_dev, c->chunks, nullptr, 0, signd, order, st);
+    }
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+// estimate_pq on the resident array, host tables/out (what estimate_distances needs)
+extern "C" int tk_codes_estimate(tk_codes *c, const uint64_t *tables, int64_t nq, uint64_t *out,
+                                 int signd, int order)
+{
+    ARGCHECK(c, "null codes handle");
+    ARGCHECK(nq >= 0 && nq <= 65535, "0 <= nq <= 65535");
+    if (nq == 0 || c->chunks == 0) return TK_OK;
+    TRY(c->tables.ensure((size_t)nq * c->M * 16));
+    TRY(c->out.ensure((size_t)nq * c->chunks * 16));
+    HIPCHECK(hipMemcpyAsync(c->tables.p, tables, (size_t)nq * c->M * 16, hipMemcpyHostToDevice, 0));
+    TRY(tk_codes_estimate_dev(c, c->tables.p, nq, c->out.p, signd, order, nullptr));
+    HIPCHECK(hipMemcpyAsync(out, c->out.p, (size_t)nq * c->chunks * 16, hipMemcpyDeviceToHost, 0));
+    HIPCHECK(hipStreamSynchronize(0));
+    return TK_OK;
+}
+
+// query_pq on the resident array (host heap in/out, optional host labels)
+extern "C" int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, int64_t *indices,
+                              int32_t *vals, int R, int signd, const int64_t *labels, int order)
+{
+    ARGCHECK(c, "null codes handle");
+    ARGCHECK(R >= 1 && (size_t)R * 12 <= 15 * 1024, "1 <= R <= 1280");
+    ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
+    ARGCHECK(c->chunks < (1ll << 31) / 16, "list too long");
+    const int64_t chunks = c->chunks;
+    if (chunks == 0) return TK_OK;
+    hipStream_t st = 0;
+    TRY(c->tables.ensure((size_t)c->M * 16));
+    TRY(c->out.ensure((size_t)chunks * 16));
+    TRY(c->hidx.ensure((size_t)R * 8));
+    TRY(c->hval.ensure((size_t)R * 4));
+    TRY(c->slots_i.ensure(3 * sizeof(int)));
+    TRY(c->slots_l.ensure(sizeof(int64_t)));
+    int64_t nlab = n < 16 * chunks ? n : 16 * chunks;
+    if (nlab < 0) nlab = 0;
+    if (labels && nlab > 0) {
+        TRY(c->labels.ensure((size_t)nlab * 8));
+        HIPCHECK(hipMemcpyAsync(c->labels.p, labels, (size_t)nlab * 8, hipMemcpyHostToDevice, st));
+    }
+    HIPCHECK(hipMemcpyAsync(c->tables.p, tables, (size_t)c->M * 16, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(c->hidx.p, indices, (size_t)R * 8, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(c->hval.p, vals, (size_t)R * 4, hipMemcpyHostToDevice, st));
+    int64_t nclamp = n > (int64_t)0x7fffffff ? 0x7fffffff : (n < 0 ? 0 : n);
+    int si[3] = {0, (int)chunks, (int)nclamp};
+    int64_t sl[1] = {labels ? 0 : -1};
+    HIPCHECK(hipMemcpyAsync(c->slots_i.p, si, sizeof si, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(c->slots_l.p, sl, sizeof sl, hipMemcpyHostToDevice, st));
+    tk_launch_scan_flat(c->tiled.as<uint4>(), chunks, c->M, c->tables.as<uint4>(), 1,
+                        c->out.as<uint4>(), chunks, nullptr, 0, signd, order, st);
+    tk_launch_heap_replay(c->out.as<uint4>(), chunks, 1, c->slots_i.as<int>(),
+                          c->slots_i.as<int>() + 2, c->slots_l.as<int64_t>(), 1,
+                          c->labels.as<int64_t>(), c->hidx.as<int64_t>(), c->hval.as<int32_t>(), R,
+                          signd, 1, nullptr, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(indices, c->hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(vals, c->hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return TK_OK;
+}
+
+// ---------------------------------------------------------------------------
 // device-resident index
 // buffers of ONE batch in flight
 struct Work {

@@ -176,6 +176,30 @@ def build_tables(pq, q_pq, signed=True):
     return tables.reshape(nq, M * 16).view(np.uint64), shift, scale
 
 
+def estimate_batch(pq, transformed_data, qs, signed=True):
+    """estimate_distances for many queries in one call: tables for all rows of `qs`
+    (tables.hip), then one pass of the list-major scan kernel over the resident
+    codes, four queries per pass.  Returns (nq, n) int8 / uint8 — row i equals
+    pq.distance_table(qs[i]).estimate_distances(transformed_data)."""
+    from ._fast_pq import device_codes, _buf
+    true_n, packed = transformed_data
+    packed = _buf(packed, np.uint64, 2, "data")
+    qp = np.stack([pq._pq_query(np.asarray(q)) for q in qs])
+    tables, _, _ = build_tables(pq, qp, signed)
+    order = _lib.ORDER_AVX if avx else _lib.ORDER_SSE
+    nq = len(qs)
+    out = np.zeros((nq, 2 * len(packed)), dtype=np.uint64)
+    h = device_codes(packed)
+    if h:
+        _lib.check(_lib.lib().tk_codes_estimate(h, _lib.ptr(tables, _lib._u64p), nq,
+                                                _lib.ptr(out, _lib._u64p), int(bool(signed)), order))
+    else:
+        _lib.check(_lib.lib().tk_estimate_pq_batch(
+            _lib.ptr(packed, _lib._u64p), packed.shape[0], packed.shape[1],
+            _lib.ptr(tables, _lib._u64p), nq, _lib.ptr(out, _lib._u64p), int(bool(signed)), order))
+    return out.view(np.int8 if signed else np.uint8)[:, :true_n]
+
+
 class _FastDistanceTable:
     """reference: fast_pq.py:255-312"""
 
