@@ -87,11 +87,12 @@ int tk_build_tables(const float *centers, int dq, int dpb, int f_order, const vo
                     uint8_t *tables, void *shift, double *scale);
 
 /* knn_brute1(x, Y, k)  utils.py:89-92 (+ bottom_k :22-25): squared distances of
- * the n rows of Y (n, d) float32 to x (d,), positions of the k smallest in
- * ascending order (ties: lower position first).  k >= n returns arange(n).
+ * the n rows of Y (n, d) to x (d,), each float32 or float64 (flags; float64
+ * arithmetic if either is, as numpy promotes `Y - x`), positions of the k smallest
+ * in ascending order (ties: lower position first).  k >= n returns arange(n).
  * out_pos: int64 (min(k, n),).  Returns the count written, or <0. */
-int64_t tk_knn_brute1(const float *x, const float *Y, int64_t n, int d, int64_t k,
-                      int64_t *out_pos);
+int64_t tk_knn_brute1(const void *x, int x_is_f64, const void *Y, int y_is_f64, int64_t n, int d,
+                      int64_t k, int64_t *out_pos);
 
 /* ---- device-resident code array ---------------------------------------------
  * A TransformedData (fast_pq.py:30,184) kept in HBM so that repeated
@@ -133,8 +134,9 @@ int tk_index_set_centers(tk_index *ix, const float *active_centers, int64_t n_li
  * ids (sum size,) labels. */
 int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const uint64_t *codes,
                        const int64_t *ids);
-/* IVF.data: the (normalised) float32 vectors used for rescoring  ivf.py:77-79 */
-int tk_index_set_data(tk_index *ix, const float *data, int64_t N, int d);
+/* IVF.data: the (normalised) vectors used for rescoring, float32 or float64 as the
+ * caller's X was (ivf.py:77-79 keeps X's dtype)  */
+int tk_index_set_data(tk_index *ix, const void *data, int data_is_f64, int64_t N, int d);
 
 /* Largest batch the workspace is currently sized for grows on demand; this call
  * pre-sizes it (so that tk_index_query_batch_dev never allocates, e.g. under

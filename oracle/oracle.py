@@ -41,7 +41,7 @@ class _Index(C.Structure):
         ("center_codes", C.c_void_p), ("center_chunks", C.c_int64),
         ("active_centers", C.c_void_p), ("list_chunk_off", C.c_void_p),
         ("list_n", C.c_void_p), ("codes", C.c_void_p), ("ids_off", C.c_void_p),
-        ("ids", C.c_void_p), ("data", C.c_void_p), ("N", C.c_int64),
+        ("ids", C.c_void_p), ("data", C.c_void_p), ("N", C.c_int64), ("data_is_f64", C.c_int),
     ]
 
 
@@ -174,21 +174,26 @@ def distance_table(centers, dpb, q_pq, sqrt_n_blocks, signed=True):
 
 # ---- rescoring ------------------------------------------------------------
 
+def _fx(a):
+    a = np.asarray(a)
+    return np.ascontiguousarray(a, dtype=np.float32 if a.dtype == np.float32 else np.float64)
+
+
 def sqdist_gather(x, Y, idx):
-    x = np.ascontiguousarray(x, dtype=np.float32)
-    Y = np.ascontiguousarray(Y, dtype=np.float32)
+    x, Y = _fx(x), _fx(Y)
     idx = np.ascontiguousarray(idx, dtype=np.int64)
-    out = np.zeros(len(idx), dtype=np.float32)
-    lib().tko_sqdist_gather_f32(_p(x, C.c_float), _p(Y, C.c_float), C.c_int64(Y.shape[0]),
-                                Y.shape[1], _p(idx, C.c_int64), C.c_int64(len(idx)),
-                                _p(out, C.c_float))
+    out = np.zeros(len(idx), dtype=np.float64)
+    lib().tko_sqdist_gather(C.c_void_p(x.ctypes.data), int(x.dtype == np.float64),
+                            C.c_void_p(Y.ctypes.data), int(Y.dtype == np.float64),
+                            C.c_int64(Y.shape[0]), Y.shape[1], _p(idx, C.c_int64),
+                            C.c_int64(len(idx)), _p(out, C.c_double))
     return out
 
 
 def bottom_k(dists, k):
-    dists = np.ascontiguousarray(dists, dtype=np.float32)
+    dists = np.ascontiguousarray(dists, dtype=np.float64)
     out = np.zeros(max(len(dists), 1), dtype=np.int64)
-    n = lib().tko_bottom_k(_p(dists, C.c_float), C.c_int64(len(dists)), C.c_int64(k),
+    n = lib().tko_bottom_k(_p(dists, C.c_double), C.c_int64(len(dists)), C.c_int64(k),
                            _p(out, C.c_int64))
     return out[:n]
 
@@ -231,7 +236,7 @@ class OracleIndex:
                     if self.n_lists else np.zeros(1, np.int64))
         if len(self.ids) == 0:
             self.ids = np.zeros(1, np.int64)
-        self.data = np.ascontiguousarray(data, dtype=np.float32)
+        self.data = _fx(data)
         self.d = self.data.shape[1]
         s = _Index()
         s.d, s.dq, s.dpb, s.M, s.order = self.d, self.dq, self.dpb, self.M, order
@@ -249,6 +254,7 @@ class OracleIndex:
         s.ids = self.ids.ctypes.data
         s.data = self.data.ctypes.data
         s.N = self.data.shape[0]
+        s.data_is_f64 = int(self.data.dtype == np.float64)
         self._s = s
 
     def pq_query(self, qn):

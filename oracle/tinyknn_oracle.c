@@ -552,18 +552,34 @@ int tko_udistance_table_f64(const float *centers, int dq, int dpb, const double 
 /* Exact rescoring (utils.py:22-25, 89-92)                             */
 /* ------------------------------------------------------------------ */
 
-/* knn_brute1's distances: diff = Y[idx] - x (f32), einsum("ij,ij->i").
- * A negative index addresses from the end, as numpy fancy indexing does
- * (fast_pq.py:311 can see -1 sentinels). */
-void tko_sqdist_gather_f32(const float *x, const float *Y, i64 nY, int d,
-                           const i64 *idx, i64 n, float *out)
+/* knn_brute1's distances: diff = Y[idx] - x, einsum("ij,ij->i") — float32 when both
+ * operands are float32, float64 otherwise (numpy's promotion).  Results are stored
+ * as double (exact for the float32 case).  A negative index addresses from the end,
+ * as numpy fancy indexing does (fast_pq.py:311 can see -1 sentinels). */
+void tko_sqdist_gather(const void *x, int x_is_f64, const void *Y, int y_is_f64, i64 nY, int d,
+                       const i64 *idx, i64 n, double *out)
 {
-    float *diff = (float *)malloc(sizeof(float) * (size_t)d);
+    if (!x_is_f64 && !y_is_f64) {
+        const float *xf = (const float *)x, *Yf = (const float *)Y;
+        float *diff = (float *)malloc(sizeof(float) * (size_t)d);
+        for (i64 i = 0; i < n; i++) {
+            i64 r = idx[i] < 0 ? idx[i] + nY : idx[i];
+            const float *y = Yf + r * (i64)d;
+            for (int j = 0; j < d; j++) diff[j] = y[j] - xf[j];
+            out[i] = (double)einsum_dot_f32(diff, diff, d);
+        }
+        free(diff);
+        return;
+    }
+    double *diff = (double *)malloc(sizeof(double) * (size_t)d);
     for (i64 i = 0; i < n; i++) {
         i64 r = idx[i] < 0 ? idx[i] + nY : idx[i];
-        const float *y = Y + r * (i64)d;
-        for (int j = 0; j < d; j++) diff[j] = y[j] - x[j];
-        out[i] = einsum_dot_f32(diff, diff, d);
+        for (int j = 0; j < d; j++) {
+            double yv = y_is_f64 ? ((const double *)Y)[r * (i64)d + j] : (double)((const float *)Y)[r * (i64)d + j];
+            double xv = x_is_f64 ? ((const double *)x)[j] : (double)((const float *)x)[j];
+            diff[j] = yv - xv;
+        }
+        out[i] = einsum_dot_f64(diff, diff, d);
     }
     free(diff);
 }
@@ -573,7 +589,7 @@ void tko_sqdist_gather_f32(const float *x, const float *Y, i64 nY, int d,
  * fixture host (numpy 2.2.6, AVX-512 argselect) the first k come back ascending
  * for the sizes this path produces, so ascending (ties: lower position first) is
  * the canonical order here.  Returns the number of positions written. */
-i64 tko_bottom_k(const float *dists, i64 n, i64 k, i64 *out)
+i64 tko_bottom_k(const double *dists, i64 n, i64 k, i64 *out)
 {
     if (k >= n) {
         for (i64 i = 0; i < n; i++) out[i] = i;
@@ -616,8 +632,9 @@ typedef struct {
     const uint64_t *codes;        /* all lists, reference chunk layout  */
     const i64 *ids_off;           /* (n_lists+1,)                       */
     const i64 *ids;               /* labels, list-major                 */
-    const float *data;            /* (N, d) rescoring vectors           */
+    const void *data;             /* (N, d) rescoring vectors           */
     i64 N;
+    int data_is_f64;              /* dtype of `data` (ivf.py:77 keeps X's) */
 } tko_index;
 
 /* One query.  `q` is the float32 query AFTER the caller applied the metric's
@@ -659,9 +676,9 @@ i64 tko_ivf_query(const tko_index *ix, const float *q, const void *q_pq, int k,
         for (i64 i = 0; i < rescore; i++) probes[i] = cidx[i];
         n_top = rescore;
     } else {
-        float *cd = (float *)malloc(sizeof(float) * (size_t)rescore);
+        double *cd = (double *)malloc(sizeof(double) * (size_t)rescore);
         i64 *best = (i64 *)malloc(sizeof(i64) * (size_t)rescore);
-        tko_sqdist_gather_f32(q, ix->active_centers, nC, ix->d, cidx, rescore, cd);
+        tko_sqdist_gather(q, 0, ix->active_centers, 0, nC, ix->d, cidx, rescore, cd);
         n_top = tko_bottom_k(cd, rescore, kc, best);        /* :311-312 */
         for (i64 i = 0; i < n_top; i++) probes[i] = cidx[best[i]];
         free(cd);
@@ -694,9 +711,9 @@ i64 tko_ivf_query(const tko_index *ix, const float *q, const void *q_pq, int k,
         for (i64 i = 0; i < nc; i++) out_ids[i] = hidx[i];
         n_out = nc;
     } else {
-        float *fd = (float *)malloc(sizeof(float) * (size_t)nc);
+        double *fd = (double *)malloc(sizeof(double) * (size_t)nc);
         i64 *best = (i64 *)malloc(sizeof(i64) * (size_t)nc);
-        tko_sqdist_gather_f32(q, ix->data, ix->N, ix->d, hidx, nc, fd);
+        tko_sqdist_gather(q, 0, ix->data, ix->data_is_f64, ix->N, ix->d, hidx, nc, fd);
         n_out = tko_bottom_k(fd, nc, k, best);
         for (i64 i = 0; i < n_out; i++) out_ids[i] = hidx[best[i]];
         free(fd);

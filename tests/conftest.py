@@ -30,7 +30,7 @@ def split_lists(g):
     return codes, ids
 
 
-G6_TAGS = ["eu20", "an20", "an100", "an100b2", "eu128"]
+G6_TAGS = ["eu20", "an20", "an100", "an100b2", "eu128", "eu20f64"]
 
 
 @pytest.fixture(scope="session")

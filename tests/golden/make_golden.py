@@ -71,6 +71,7 @@ def save(name, **arrays):
 
 
 def main():
+    only = set(sys.argv[2:]) if len(sys.argv) > 2 and sys.argv[1] == "--only-ivf" else None
     warnings.filterwarnings("ignore")
     tk = import_reference()
     from tinyknn import _transform as rt
@@ -79,6 +80,8 @@ def main():
     from tinyknn.utils import knn_brute1, pad1
     assert tk.avx is True
 
+    if only:
+        return make_ivf(tk, only, query_pq_avx, knn_brute1)
     # ---- G1/G2: layout (mirrors tests/test_transform.py:71-101) -------------
     np.random.seed(10)
     out = {}
@@ -218,6 +221,10 @@ def main():
     out["meta"] = np.array(meta, dtype=np.int64)
     save("g5_tables.npz", **out)
 
+    make_ivf(tk, None, query_pq_avx, knn_brute1)
+
+
+def make_ivf(tk, only, query_pq_avx, knn_brute1):
     # ---- G6: IVF end to end ---------------------------------------------------
     for tag, (n, d, metric, ncl, bprobes, nq, dtype) in {
         "eu20": (2000, 20, "euclidean", 44, 2, 24, np.float32),
@@ -225,7 +232,10 @@ def main():
         "an100": (2000, 100, "angular", 44, 1, 24, np.float32),
         "an100b2": (1000, 100, "angular", 31, 2, 16, np.float32),
         "eu128": (1200, 128, "euclidean", 34, 1, 16, np.float32),
+        "eu20f64": (1500, 20, "euclidean", 38, 1, 16, np.float64),   # float64 X: float64 rescoring
     }.items():
+        if only and tag not in only:
+            continue
         np.random.seed(10)
         # clustered data so that int8 sums use both rails
         cent = np.random.randn(30, d)

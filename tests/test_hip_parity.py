@@ -273,6 +273,19 @@ def test_knn_brute1_vs_oracle(tk, oracle, n, d, k):
         np.testing.assert_array_equal(knn_brute1(x, Y, k), oracle.knn_brute1(x, Y, k))
 
 
+@pytest.mark.parametrize("xd,yd", [(np.float32, np.float64), (np.float64, np.float32),
+                                    (np.float64, np.float64)])
+def test_knn_brute1_float64_vs_oracle(tk, oracle, xd, yd):
+    """numpy promotes `Y - x`: any float64 operand makes the rescoring float64."""
+    from tinyknn_amd.utils import knn_brute1
+    rng = np.random.default_rng(11)
+    for n, d, k in [(30, 100, 10), (111, 100, 10), (211, 128, 10), (50, 20, 10), (40, 7, 5)]:
+        for t in range(6):
+            Y = rng.standard_normal((n, d)).astype(yd)
+            x = rng.standard_normal(d).astype(xd)
+            np.testing.assert_array_equal(knn_brute1(x, Y, k), oracle.knn_brute1(x, Y, k))
+
+
 # ---- G6 --------------------------------------------------------------------
 
 class _State:

@@ -45,7 +45,8 @@ SIGNATURES = {
     "tk_heap_insert_is": (C.c_int, [_i64p, _i32p, C.c_int, C.c_int64, C.c_int32]),
     "tk_build_tables": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64,
                                   C.c_double, C.c_double, C.c_int, _u8p, C.c_void_p, _f64p]),
-    "tk_knn_brute1": (C.c_int64, [_f32p, _f32p, C.c_int64, C.c_int, C.c_int64, _i64p]),
+    "tk_knn_brute1": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                  C.c_int64, _i64p]),
     "tk_codes_upload": (C.c_void_p, [_u64p, C.c_int64, C.c_int]),
     "tk_codes_free": (None, [C.c_void_p]),
     "tk_codes_estimate": (C.c_int, [C.c_void_p, _u64p, C.c_int64, _u64p, C.c_int, C.c_int]),
@@ -58,7 +59,7 @@ SIGNATURES = {
     "tk_index_set_pq": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
     "tk_index_set_centers": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _u64p, C.c_int64]),
     "tk_index_set_lists": (C.c_int, [C.c_void_p, _i64p, _u64p, _i64p]),
-    "tk_index_set_data": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int]),
+    "tk_index_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]),
     "tk_index_reserve": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "tk_index_query_batch": (C.c_int, [C.c_void_p, _f32p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                        C.c_int, C.c_int, _i64p, _i64p, _i64p, _i32p]),

@@ -278,9 +278,10 @@ extern "C" int tk_build_tables(const float *centers, int dq, int dpb, int f_orde
     return TK_OK;
 }
 
-extern "C" int64_t tk_knn_brute1(const float *x, const float *Y, int64_t n, int d, int64_t k,
-                                 int64_t *out_pos)
+extern "C" int64_t tk_knn_brute1(const void *x, int x_is_f64, const void *Y, int y_is_f64,
+                                 int64_t n, int d, int64_t k, int64_t *out_pos)
 {
+    const size_t xsz = x_is_f64 ? 8 : 4, ysz = y_is_f64 ? 8 : 4;
     int r = require_gpu();
     if (r != TK_OK) return r;
     if (n < 0 || d < 1 || k < 0) return fail(TK_ERR_ARG, "bad argument: sizes");
@@ -297,13 +298,13 @@ extern "C" int64_t tk_knn_brute1(const float *x, const float *Y, int64_t n, int 
         hipError_t e_ = (x);                                                       \
         if (e_ != hipSuccess) return fail(TK_ERR_HIP, hipGetErrorString(e_));      \
     } while (0)
-    if ((r = S.q.ensure((size_t)d * 4)) || (r = S.rows.ensure((size_t)n * d * 4)) ||
+    if ((r = S.q.ensure((size_t)d * xsz)) || (r = S.rows.ensure((size_t)n * d * ysz)) ||
         (r = S.cand.ensure((size_t)n * 8)) || (r = S.pos.ensure((size_t)kk * 8)))
         return r;
-    HC(hipMemcpyAsync(S.q.p, x, (size_t)d * 4, hipMemcpyHostToDevice, st));
-    HC(hipMemcpyAsync(S.rows.p, Y, (size_t)n * d * 4, hipMemcpyHostToDevice, st));
+    HC(hipMemcpyAsync(S.q.p, x, (size_t)d * xsz, hipMemcpyHostToDevice, st));
+    HC(hipMemcpyAsync(S.rows.p, Y, (size_t)n * d * ysz, hipMemcpyHostToDevice, st));
     HC(hipMemcpyAsync(S.cand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-    tk_launch_rescore(S.q.as<float>(), d, S.rows.as<float>(), n, S.cand.as<int64_t>(), (int)n, 1,
+    tk_launch_rescore(S.q.p, x_is_f64, d, S.rows.p, y_is_f64, n, S.cand.as<int64_t>(), (int)n, 1,
                       (int)kk, 0, S.pos.as<int64_t>(), nullptr, st);
     HC(hipGetLastError());
     HC(hipMemcpyAsync(out_pos, S.pos.p, (size_t)kk * 8, hipMemcpyDeviceToHost, st));
@@ -503,6 +504,7 @@ struct tk_index {
     // vectors
     DevBuf data;
     int64_t N = 0;
+    int data_is_f64 = 0;
     // index-static descriptors of the coarse stage, staging buffers of the host API
     DevBuf cslots_i, cslots_l, c_chunk_off, q, qpq, stage;
     int scan_mode = 0;         // 0 auto, 1 query-major kernel, 2 list-major (units) kernel
@@ -655,14 +657,17 @@ extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const
     return TK_OK;
 }
 
-extern "C" int tk_index_set_data(tk_index *ix, const float *data, int64_t N, int d)
+extern "C" int tk_index_set_data(tk_index *ix, const void *data, int data_is_f64, int64_t N,
+                                 int d)
 {
     ARGCHECK(ix && ix->have_centers, "set_centers first");
     ARGCHECK(d == ix->d, "data dimension differs from the centres'");
     ARGCHECK(N >= 1, "N");
-    TRY(ix->data.ensure((size_t)N * d * 4));
-    HIPCHECK(hipMemcpy(ix->data.p, data, (size_t)N * d * 4, hipMemcpyHostToDevice));
+    const size_t esz = data_is_f64 ? 8 : 4;
+    TRY(ix->data.ensure((size_t)N * d * esz));
+    HIPCHECK(hipMemcpy(ix->data.p, data, (size_t)N * d * esz, hipMemcpyHostToDevice));
     ix->N = N;
+    ix->data_is_f64 = data_is_f64;
     ix->have_data = true;
     return TK_OK;
 }
@@ -683,7 +688,7 @@ static int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &
     int64_t rescore = 2 * kc + 10 < ix->n_lists ? 2 * kc + 10 : ix->n_lists;   // :293-294
     int64_t R = pass_1 > 0 ? pass_1 : (int64_t)(n_probes + 1) * k + 1;         // ivf.py:135-136
     ARGCHECK(R * 12 <= 15 * 1024 && rescore * 12 <= 15 * 1024, "heap larger than 15 KiB of LDS (R <= 1280)");
-    ARGCHECK(R * 12 + (int64_t)ix->d * 4 <= 64 * 1024, "rescoring tile larger than 64 KiB of LDS");
+    ARGCHECK(R * 16 + (int64_t)ix->d * 8 + 16 <= 64 * 1024, "rescoring tile larger than 64 KiB of LDS");
     p.kc = (int)kc; p.rescore = (int)rescore; p.R = (int)R; p.S = (int)kc;
     p.cap = (int64_t)kc * ix->max_list_chunks;
     if (p.cap < 1) p.cap = 1;
@@ -814,7 +819,7 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                               w.cheap_val.as<int32_t>(), p.rescore, 1, 1, nullptr, st);
     }
     MARK();
-    tk_launch_rescore(q_dev, ix->d, ix->active_centers.as<float>(), ix->n_lists,
+    tk_launch_rescore(q_dev, 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
                       w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0,
                       w.probes.as<int64_t>(), nullptr, st);
     tk_launch_make_slots(w.probes.as<int64_t>(), nullptr, p.S, nq, ix->n_lists,
@@ -889,8 +894,8 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
     }
     MARK();
     // 4. strip sentinels, exact rescoring                   ivf.py:154-163
-    tk_launch_rescore(q_dev, ix->d, ix->data.as<float>(), ix->N, w.heap_idx.as<int64_t>(), p.R,
-                      nq, k, 1, out_dev, nullptr, st);
+    tk_launch_rescore(q_dev, 0, ix->d, ix->data.p, ix->data_is_f64, ix->N,
+                      w.heap_idx.as<int64_t>(), p.R, nq, k, 1, out_dev, nullptr, st);
     MARK();
 #undef MARK
     HIPCHECK(hipGetLastError());

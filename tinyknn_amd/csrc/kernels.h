@@ -108,8 +108,9 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
 // (fast_pq.py:311).  If the candidate count <= k the ids are returned in heap
 // order (ivf.py:158-159 / fast_pq.py:307-308).  out: (nq, k) padded with -1;
 // out_count (nq,) optional.
-void tk_launch_rescore(const float *q, int d, const float *rows, int64_t n_rows,
-                       const int64_t *cand, int R, int64_t nq, int k, int strip,
+// q / rows: float32 or float64 (flags); float64 arithmetic if either is float64.
+void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
+                       int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
                        int64_t *out, int *out_count, hipStream_t s);
 
 // probes (nq, kc) list ids -> per-slot scan descriptors

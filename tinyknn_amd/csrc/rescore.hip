@@ -5,44 +5,54 @@
 // (ivf.py:154-163, final stage), and turns the coarse result into the per-slot
 // scan descriptors of the list scan.
 //
-// Distances are float32 and restate numpy's einsum("ij,ij->i") rounding (SSE3
-// baseline: 4 lanes, un-fused multiply-add, 16-element groups folded 3,2,1,0,
-// zero-filled tail vector, (l0+l1)+(l2+l3)); built with -ffp-contract=off.  One
-// lane owns one candidate row and carries the 4 lane-accumulators, reading its
-// row with 16-byte loads.  The k best are returned in ascending distance (ties:
+// Distances restate numpy's einsum("ij,ij->i") rounding (SSE3 baseline: 16-byte
+// vectors = 4 float32 or 2 float64 lanes, un-fused multiply-add, 4-vector groups
+// folded 3,2,1,0, zero-filled tail vector, pairwise horizontal add); float32 when
+// both the vectors and the query are float32, float64 otherwise (numpy's
+// promotion of `Y - x`); built with -ffp-contract=off.  One lane owns one
+// candidate row and carries the lane-accumulators.  The k best are returned in ascending distance (ties:
 // lower candidate position first) — the order numpy's argpartition yields on the
 // fixture host for these sizes; a rank-by-counting pass in LDS does the ordering.
 #include "kernels.h"
 
-__device__ __forceinline__ float sqdist_row(const float *__restrict__ y, const float *xs, int d)
+// squared distance of row y to the query xs in numpy's einsum order, computed in T
+// (float when both operands are float32, else double as numpy promotes): L = 16 /
+// sizeof(T) lane-accumulators, groups of 4 vectors folded 3,2,1,0, zero tail.
+template <typename T, typename TY>
+__device__ __forceinline__ T sqdist_row(const TY *__restrict__ y, const T *xs, int d)
 {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int L = 16 / (int)sizeof(T);
+    T acc[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) acc[l] = 0;
     int i = 0;
-    for (; d - i >= 16; i += 16) {
-        float df[16];
+    for (; d - i >= 4 * L; i += 4 * L) {
+        T df[4 * L];
 #pragma unroll
-        for (int t = 0; t < 16; t++) df[t] = y[i + t] - xs[i + t];
+        for (int t = 0; t < 4 * L; t++) df[t] = (T)y[i + t] - xs[i + t];
 #pragma unroll
-        for (int l = 0; l < 4; l++) {
-            float ab3 = df[12 + l] * df[12 + l] + acc[l];
-            float ab2 = df[8 + l] * df[8 + l] + ab3;
-            float ab1 = df[4 + l] * df[4 + l] + ab2;
+        for (int l = 0; l < L; l++) {
+            T ab3 = df[3 * L + l] * df[3 * L + l] + acc[l];
+            T ab2 = df[2 * L + l] * df[2 * L + l] + ab3;
+            T ab1 = df[L + l] * df[L + l] + ab2;
             acc[l] = df[l] * df[l] + ab1;
         }
     }
-    for (; i < d; i += 4) {
+    for (; i < d; i += L) {
 #pragma unroll
-        for (int l = 0; l < 4; l++) {
-            float df = (i + l < d) ? (y[i + l] - xs[i + l]) : 0.f;
+        for (int l = 0; l < L; l++) {
+            T df = (i + l < d) ? ((T)y[i + l] - xs[i + l]) : (T)0;
             acc[l] = df * df + acc[l];
         }
     }
-    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (L == 4) return (acc[0] + acc[1]) + (acc[2 % L] + acc[3 % L]);
+    return acc[0] + acc[1 % L];
 }
 
-// LDS: x[d] | cand[R] (int64) | dist[R] (float)
-__global__ __launch_bounds__(128) void rescore_kernel(const float *__restrict__ q, int d,
-                                                      const float *__restrict__ rows,
+// LDS: cand[R] (int64) | dist[R] (T) | x[d] (T)
+template <typename T, typename TY, typename TX>
+__global__ __launch_bounds__(128) void rescore_kernel(const TX *__restrict__ q, int d,
+                                                      const TY *__restrict__ rows,
                                                       int64_t n_rows,
                                                       const int64_t *__restrict__ cand, int R,
                                                       int k, int strip, int64_t *__restrict__ out,
@@ -50,14 +60,14 @@ __global__ __launch_bounds__(128) void rescore_kernel(const float *__restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int64_t *cs = (int64_t *)smem;
-    float *ds = (float *)(smem + (size_t)R * 8);
-    float *xs = ds + R;
+    T *ds = (T *)(smem + (size_t)R * 8);
+    T *xs = ds + R;
     __shared__ int s_count;
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.x;
     const int64_t *c = cand + qi * R;
 
-    for (int t = tid; t < d; t += blockDim.x) xs[t] = q[qi * d + t];
+    for (int t = tid; t < d; t += blockDim.x) xs[t] = (T)q[qi * d + t];
     // ordered compaction of the candidate ids (ivf.py:154-155 drops -1)
     if (tid < 64) {
         int base = 0;
@@ -83,14 +93,14 @@ __global__ __launch_bounds__(128) void rescore_kernel(const float *__restrict__ 
     for (int t = tid; t < nc; t += blockDim.x) {
         int64_t id = cs[t];
         if (id < 0) id += n_rows;  // numpy fancy indexing with a negative index
-        ds[t] = sqdist_row(rows + id * (int64_t)d, xs, d);
+        ds[t] = sqdist_row<T, TY>(rows + id * (int64_t)d, xs, d);
     }
     __syncthreads();
     for (int t = tid; t < nc; t += blockDim.x) {
-        const float dv = ds[t];
+        const T dv = ds[t];
         int rank = 0;
         for (int u = 0; u < nc; u++) {
-            const float du = ds[u];
+            const T du = ds[u];
             rank += (du < dv) || (du == dv && u < t);
         }
         if (rank < k) o[rank] = cs[t];
@@ -98,14 +108,30 @@ __global__ __launch_bounds__(128) void rescore_kernel(const float *__restrict__ 
     if (tid == 0 && out_count) out_count[qi] = k;
 }
 
-void tk_launch_rescore(const float *q, int d, const float *rows, int64_t n_rows,
-                       const int64_t *cand, int R, int64_t nq, int k, int strip, int64_t *out,
-                       int *out_count, hipStream_t s)
+void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
+                       int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
+                       int64_t *out, int *out_count, hipStream_t s)
 {
     if (nq == 0 || k == 0) return;
-    size_t lds = (size_t)R * 12 + (size_t)d * 4;
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(128), lds, s, q, d, rows, n_rows,
-                       cand, R, k, strip, out, out_count);
+    const bool dbl = q_is_f64 || rows_is_f64;   // numpy promotes `Y - x` to float64
+    size_t lds = (size_t)R * 8 + ((size_t)R + d) * (dbl ? 8 : 4) + 16;
+    dim3 grid((unsigned)nq), block(128);
+    if (!dbl)
+        hipLaunchKernelGGL((rescore_kernel<float, float, float>), grid, block, lds, s,
+                           (const float *)q, d, (const float *)rows, n_rows, cand, R, k, strip, out,
+                           out_count);
+    else if (rows_is_f64 && q_is_f64)
+        hipLaunchKernelGGL((rescore_kernel<double, double, double>), grid, block, lds, s,
+                           (const double *)q, d, (const double *)rows, n_rows, cand, R, k, strip,
+                           out, out_count);
+    else if (rows_is_f64)
+        hipLaunchKernelGGL((rescore_kernel<double, double, float>), grid, block, lds, s,
+                           (const float *)q, d, (const double *)rows, n_rows, cand, R, k, strip, out,
+                           out_count);
+    else
+        hipLaunchKernelGGL((rescore_kernel<double, float, double>), grid, block, lds, s,
+                           (const double *)q, d, (const float *)rows, n_rows, cand, R, k, strip, out,
+                           out_count);
 }
 
 // ---------------------------------------------------------------------------

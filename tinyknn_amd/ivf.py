@@ -55,11 +55,11 @@ class DeviceIndex:
         allids = (np.ascontiguousarray(np.concatenate(ids)) if ids else np.zeros(1, np.int64))
         _lib.check(L.tk_index_set_lists(self._h, _lib.ptr(sizes, _lib._i64p),
                                         _lib.ptr(codes, _lib._u64p), _lib.ptr(allids, _lib._i64p)))
-        if ivf.data.dtype != np.float32:
-            raise TypeError("tinyknn_amd rescoring runs in float32 on the GPU; build the index "
-                            f"from float32 vectors (got {ivf.data.dtype})")
-        data = np.ascontiguousarray(ivf.data)
-        _lib.check(L.tk_index_set_data(self._h, _lib.ptr(data, _lib._f32p), data.shape[0],
+        # IVF.data keeps the dtype of the X passed to build (ivf.py:77); float64 vectors
+        # are rescored in float64 like numpy would
+        is64 = ivf.data.dtype != np.float32
+        data = np.ascontiguousarray(ivf.data, dtype=np.float64 if is64 else np.float32)
+        _lib.check(L.tk_index_set_data(self._h, data.ctypes.data, int(is64), data.shape[0],
                                        data.shape[1]))
         self.code_bytes = int(codes.nbytes)
 

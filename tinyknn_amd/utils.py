@@ -86,20 +86,19 @@ def knn_brute(X, Y, k, metric="euclidean", chunk=100):
 
 def knn_brute1(x, Y, k):
     """Positions of the k rows of Y closest to x, ascending (GPU: rescore.hip).
-    reference: utils.py:89-92.  float32 only on the device path."""
+    reference: utils.py:89-92.  float32 arithmetic when both are float32, float64
+    otherwise, as numpy promotes `Y - x`."""
     x = np.asarray(x)
     Y = np.asarray(Y)
-    if x.dtype != np.float32 or Y.dtype != np.float32:
-        raise TypeError("tinyknn_amd rescoring runs in float32 on the GPU; got "
-                        f"{x.dtype} / {Y.dtype}")
-    Y = np.ascontiguousarray(Y)
-    x = np.ascontiguousarray(x)
+    x = np.ascontiguousarray(x, dtype=np.float32 if x.dtype == np.float32 else np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float32 if Y.dtype == np.float32 else np.float64)
     n, d = Y.shape
     assert x.shape == (d,)
     kk = min(int(k), n)
     out = np.zeros(max(kk, 1), dtype=np.int64)
     got = _lib.check(_lib.lib().tk_knn_brute1(
-        _lib.ptr(x, _lib._f32p), _lib.ptr(Y, _lib._f32p), n, d, int(k), _lib.ptr(out, _lib._i64p)))
+        x.ctypes.data, int(x.dtype == np.float64), Y.ctypes.data, int(Y.dtype == np.float64),
+        n, d, int(k), _lib.ptr(out, _lib._i64p)))
     return out[:got]
 
 
