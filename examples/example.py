@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Flat 4-bit PQ scan demo on the GPU — the protocol of the reference's
+examples/example.py (BASELINE configs[0]: N=16000, d=128, 1000 queries,
+dims_per_block=2), once per query through the drop-in API and once batched.
+
+    python examples/example.py --input random-16000-128 --k 1000
+"""
+import argparse
+import os
+import re
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tinyknn_amd import FastPQ, knn_brute, utils            # noqa: E402
+from tinyknn_amd.fast_pq import estimate_batch             # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--input", default="random-16000-128", help=".npy file or random-n-d")
+ap.add_argument("--k", type=int, default=1000, help="number of queries")
+ap.add_argument("--dpb", type=int, default=2)
+ap.add_argument("--unsigned", action="store_true")
+args = ap.parse_args()
+
+m = re.match(r"random-(\d+)-(\d+)", args.input)
+np.random.seed(10)
+if m:
+    n, d = map(int, m.groups())
+    X = np.random.randn(n, d).astype(np.float32)
+    qs = np.random.randn(args.k, d).astype(np.float32)
+else:
+    data = np.load(args.input).astype(np.float32)
+    np.random.shuffle(data)
+    qs, X = data[:args.k], data[args.k:]
+    n, d = X.shape
+signed = not args.unsigned
+print(f"{n=}, {d=}, queries={len(qs)}, dims_per_block={args.dpb}")
+
+with utils.timer(True, "Computing true neighbours"):
+    trus = knn_brute(qs, X, k=1)[:, 0]
+with utils.timer(True, "Fitting PQ"):
+    pq = FastPQ(dims_per_block=args.dpb).fit(X[:10**5])
+with utils.timer(True, "Transforming data"):
+    data = pq.transform(X)
+
+# one query at a time, as the reference does (fast_pq.py:186-282 per call)
+t_table = t_scan = 0.0
+sat_up = sat_down = total = 0
+places = []
+for q, tru in zip(qs, trus):
+    t0 = time.time()
+    dtable = pq.distance_table(q) if signed else pq.udistance_table(q)
+    t1 = time.time()
+    est8 = dtable.estimate_distances(data)
+    t2 = time.time()
+    t_table += t1 - t0
+    t_scan += t2 - t1
+    sat_up += int(np.sum(est8 == (127 if signed else 255)))
+    sat_down += int(np.sum(est8 == -128)) if signed else 0
+    total += est8.size
+    places.append(int(np.sum(est8 < est8[tru])))
+print()
+print("Median place of true nearest neighbor:", np.median(places))
+for quant in (0.5, 0.75, 0.9, 0.99):
+    print(f"{quant:.2%} quantile:", np.quantile(places, quant))
+print("Queries/second:", len(qs) / (t_table + t_scan))
+print()
+print("Total time spent on preprocess:", t_table)
+print("Total time spent on search:", t_scan)
+print(f"Saturation degree: up: {sat_up}/{total}, down: {sat_down}/{total}")
+
+# the same work as one batch: tables for all queries, one list-major scan launch
+t0 = time.time()
+allest = estimate_batch(pq, data, qs, signed)
+tb = time.time() - t0
+assert np.array_equal(allest[-1], est8)
+print()
+print("Batched (one launch for all queries):")
+print("Queries/second:", len(qs) / tb)

@@ -117,7 +117,7 @@ def test_query_pq_vs_oracle_random(tk, oracle, seed):
     for trial in range(12):
         M = int(rng.choice([4, 8, 32, 52]))
         n = int(rng.choice([1, 15, 16, 17, 100, 1000, 5000, 70000]))
-        R = int(rng.choice([1, 2, 3, 21, 30, 111, 511, 1000]))
+        R = int(rng.choice([1, 2, 3, 21, 30, 111, 511, 1000, 1400, 5000]))
         signed = bool(rng.integers(0, 2))
         npad = n + (-n) % 16
         codes = rng.integers(0, 16, size=(npad, M)).astype(np.uint8)

@@ -158,7 +158,7 @@ extern "C" int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t 
     ARGCHECK(M >= 2 && M % 2 == 0, "M must be even");
     ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
     ARGCHECK(chunks < (1ll << 31) / 16, "list too long");
-    ARGCHECK((size_t)R * 12 <= 15 * 1024, "heap larger than 15 KiB of LDS (R <= 1280)");
+    ARGCHECK((size_t)R * 12 + 16 <= 64 * 1024, "heap larger than 64 KiB of LDS (R <= 5460)");
     if (chunks == 0) return TK_OK;
     Scratch &S = scratch();
     std::lock_guard<std::mutex> lk(S.mu);
@@ -220,7 +220,7 @@ static int heap_insert_host(int64_t *indices, int32_t *vals, int R, int64_t i, i
 {
     TRY(require_gpu());
     ARGCHECK(R >= 1, "R");
-    ARGCHECK((size_t)R * 12 <= 15 * 1024, "heap larger than 15 KiB of LDS (R <= 1280)");
+    ARGCHECK((size_t)R * 12 + 16 <= 64 * 1024, "heap larger than 64 KiB of LDS (R <= 5460)");
     Scratch &S = scratch();
     std::lock_guard<std::mutex> lk(S.mu);
     hipStream_t st = 0;
@@ -422,7 +422,7 @@ extern "C" int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, in
                               int32_t *vals, int R, int signd, const int64_t *labels, int order)
 {
     ARGCHECK(c, "null codes handle");
-    ARGCHECK(R >= 1 && (size_t)R * 12 <= 15 * 1024, "1 <= R <= 1280");
+    ARGCHECK(R >= 1 && (size_t)R * 12 + 16 <= 64 * 1024, "1 <= R <= 5460");
     ARGCHECK(order == TK_ORDER_SSE || order == TK_ORDER_AVX, "order");
     ARGCHECK(c->chunks < (1ll << 31) / 16, "list too long");
     const int64_t chunks = c->chunks;
@@ -687,8 +687,10 @@ static int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &
     int64_t kc = n_probes < ix->n_lists ? n_probes : ix->n_lists;              // fast_pq.py:291
     int64_t rescore = 2 * kc + 10 < ix->n_lists ? 2 * kc + 10 : ix->n_lists;   // :293-294
     int64_t R = pass_1 > 0 ? pass_1 : (int64_t)(n_probes + 1) * k + 1;         // ivf.py:135-136
-    ARGCHECK(R * 12 <= 15 * 1024 && rescore * 12 <= 15 * 1024, "heap larger than 15 KiB of LDS (R <= 1280)");
-    ARGCHECK(R * 16 + (int64_t)ix->d * 8 + 16 <= 64 * 1024, "rescoring tile larger than 64 KiB of LDS");
+    ARGCHECK(R * 12 + 16 <= 64 * 1024 && rescore * 12 + 16 <= 64 * 1024,
+             "heap larger than 64 KiB of LDS (pass_1 <= 5460)");
+    ARGCHECK(R * (ix->data_is_f64 ? 16 : 12) + (int64_t)ix->d * (ix->data_is_f64 ? 8 : 4) + 16 <= 64 * 1024,
+             "rescoring tile larger than 64 KiB of LDS");
     p.kc = (int)kc; p.rescore = (int)rescore; p.R = (int)R; p.S = (int)kc;
     p.cap = (int64_t)kc * ix->max_list_chunks;
     if (p.cap < 1) p.cap = 1;

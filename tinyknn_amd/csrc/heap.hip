@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_kernel(
     lds_vi64 *hidx = LDS_PTR(lds_vi64, smem + wave * wstride);
     lds_vi32 *hval = LDS_PTR(lds_vi32, smem + wave * wstride + (size_t)R * 8);
     const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * TK_HEAP_WAVES + wave;
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (q >= nq) return;   // wave-uniform; the kernel uses no workgroup barrier
 
     if (only_flagged) {
@@ -235,8 +235,11 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
                            hipStream_t s)
 {
     if (nq == 0 || R == 0) return;
-    size_t lds = (((size_t)R * 12 + 15) & ~(size_t)15) * TK_HEAP_WAVES;
-    dim3 grid((unsigned)((nq + TK_HEAP_WAVES - 1) / TK_HEAP_WAVES)), block(64 * TK_HEAP_WAVES);
+    const size_t wstride = ((size_t)R * 12 + 15) & ~(size_t)15;
+    int waves = (int)(64 * 1024 / wstride);   // large heaps: fewer query-waves per workgroup
+    waves = waves < 1 ? 1 : (waves > TK_HEAP_WAVES ? TK_HEAP_WAVES : waves);
+    size_t lds = wstride * waves;
+    dim3 grid((unsigned)((nq + waves - 1) / waves)), block(64 * waves);
     if (signd)
         hipLaunchKernelGGL(heap_replay_kernel<true>, grid, block, lds, s, dist, cap, slot_prefix,
                            slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform,
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
     const int wave = threadIdx.x >> 6;
     lds_vu32 *H = LDS_PTR(lds_vu32, smem + (size_t)wave * R * 4);  // [R] per wave
     const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * TK_HEAP_WAVES + wave;
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (q >= nq) return;   // wave-uniform; no workgroup barrier below
     if (skip && skip[q]) return;
     const int64_t qs = slots_uniform ? 0 : q;
@@ -600,8 +603,10 @@ void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, co
                                   hipStream_t s)
 {
     if (nq == 0 || R == 0) return;
-    size_t lds = (size_t)R * 4 * TK_HEAP_WAVES;
-    dim3 grid((unsigned)((nq + TK_HEAP_WAVES - 1) / TK_HEAP_WAVES)), block(64 * TK_HEAP_WAVES);
+    int waves = (int)(64 * 1024 / ((size_t)R * 4));
+    waves = waves < 1 ? 1 : (waves > TK_HEAP_WAVES ? TK_HEAP_WAVES : waves);
+    size_t lds = (size_t)R * 4 * waves;
+    dim3 grid((unsigned)((nq + waves - 1) / waves)), block(64 * waves);
     if (signd)
         hipLaunchKernelGGL(heap_replay_packed_kernel<true>, grid, block, lds, s, dist, cap,
                            slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
