@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--recall-sample", type=int, default=1000)
     ap.add_argument("--cache-dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (tk_index_set_pipeline)")
@@ -159,13 +160,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_id = local_rank % torch.cuda.device_count()     # (== local_rank on a real node)
+    torch.cuda.set_device(dev_id)
+    device = torch.device("cuda", dev_id)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from tinyknn_amd import _lib
-    _lib.check(_lib.lib().tk_set_device(local_rank))
+    _lib.check(_lib.lib().tk_set_device(dev_id))
 
     # -- index: rank 0 builds (or loads) first so that the cache exists for the others
     if world > 1 and rank != 0:
@@ -218,7 +223,8 @@ def main():
     torch.cuda.synchronize()
     iso_stages, iso_bytes, _ = dev.last_profile()
     dev.set_profiling(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64,
+                     device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
