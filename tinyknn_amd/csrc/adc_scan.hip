@@ -445,22 +445,14 @@ __global__ __launch_bounds__(256, MINW) void scan_units_kernel(
 }
 
 // ---- pair lists: (query, slot) pairs grouped by the list they probe ------------
-__global__ void pairs_count_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
-                                   int64_t n_lists, int *__restrict__ count)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * S) return;
-    int64_t cl = probes[i];
-    if (cl < 0) cl += n_lists;
-    atomicAdd(&count[cl], 1);
-}
-
+// (the per-list pair counts come from make_slots_kernel)
 // one workgroup: exclusive scans over the lists
-__global__ __launch_bounds__(1024) void pairs_scan_kernel(const int *__restrict__ count,
+__global__ __launch_bounds__(1024) void pairs_scan_kernel(int *__restrict__ count,
                                                           const int64_t *__restrict__ list_chunk_off,
                                                           int n_lists, int *__restrict__ pair_off,
                                                           int *__restrict__ unit_prefix,
-                                                          int *__restrict__ cursor)
+                                                          int *__restrict__ cursor,
+                                                          int *__restrict__ pair_q)
 {
     __shared__ int s_rec[1024], s_unit[1024];
     __shared__ int carry_rec, carry_unit;
@@ -468,9 +460,11 @@ __global__ __launch_bounds__(1024) void pairs_scan_kernel(const int *__restrict_
     __syncthreads();
     for (int base = 0; base < n_lists; base += 1024) {
         const int l = base + threadIdx.x;
-        int rec = 0, unit = 0;
+        int rec = 0, unit = 0, cnt = 0;
         if (l < n_lists) {
-            const int groups = (count[l] + TK_UNIT_Q - 1) / TK_UNIT_Q;
+            cnt = count[l];
+            count[l] = 0;   // zero again for the next batch
+            const int groups = (cnt + TK_UNIT_Q - 1) / TK_UNIT_Q;
             rec = groups * TK_UNIT_Q;
             unit = groups * (int)(list_chunk_off[l + 1] - list_chunk_off[l]);
         }
@@ -486,9 +480,11 @@ __global__ __launch_bounds__(1024) void pairs_scan_kernel(const int *__restrict_
             __syncthreads();
         }
         if (l < n_lists) {
-            pair_off[l] = carry_rec + s_rec[threadIdx.x] - rec;
+            const int off = carry_rec + s_rec[threadIdx.x] - rec;
+            pair_off[l] = off;
             unit_prefix[l] = carry_unit + s_unit[threadIdx.x] - unit;
             cursor[l] = 0;
+            for (int t = cnt; t < rec; t++) pair_q[off + t] = -1;   // padding records
         }
         __syncthreads();
         if (threadIdx.x == 1023) {
@@ -526,12 +522,9 @@ void tk_launch_unit_pairs(int64_t nq, const int64_t *probes, int S, int64_t n_li
 {
     if (nq == 0 || S == 0) return;
     const int64_t np = nq * S;
-    (void)hipMemsetAsync(count, 0, (size_t)n_lists * sizeof(int), s);
-    (void)hipMemsetAsync(pair_q, 0xff, (size_t)max_records * sizeof(int), s);   // -1 = padding record
-    hipLaunchKernelGGL(pairs_count_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
-                       probes, S, nq, n_lists, count);
+    (void)max_records;
     hipLaunchKernelGGL(pairs_scan_kernel, dim3(1), dim3(1024), 0, s, count, list_chunk_off,
-                       (int)n_lists, pair_off, unit_prefix, cursor);
+                       (int)n_lists, pair_off, unit_prefix, cursor, pair_q);
     hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
                        probes, S, nq, n_lists, slot_prefix, pair_off, cursor, pair_q, pair_f0);
 }

@@ -255,7 +255,7 @@ extern "C" int tk_build_tables(const float *centers, int dq, int dpb, int f_orde
     ARGCHECK(nq >= 0, "nq");
     const int M = dq / dpb;
     const size_t esz = q_is_f64 ? 8 : 4;
-    ARGCHECK(((size_t)16 * M + 576) * esz + 544 <= 64 * 1024 && 16 * M <= 8192,
+    ARGCHECK(((size_t)16 * M + 640) * esz <= 64 * 1024 && 16 * M <= 8192,
              "too many blocks for the LDS table");
     if (nq == 0) return TK_OK;
     Scratch &S = scratch();
@@ -722,7 +722,13 @@ static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
     TRY(w.mins.ensure((size_t)nq * p.cap_min));
     TRY(w.cmins.ensure((size_t)nq * p.ccap_min));
     const size_t L = (size_t)ix->n_lists;
-    TRY(w.u_count.ensure(L * 4));
+    {
+        const void *before = w.u_count.p;
+        TRY(w.u_count.ensure(L * 4));
+        // the per-list pair counters are zero between batches (the scan kernel re-zeroes
+        // them after reading); a fresh buffer must start that way
+        if (w.u_count.p != before) HIPCHECK(hipMemset(w.u_count.p, 0, w.u_count.cap));
+    }
     TRY(w.u_cursor.ensure(L * 4));
     TRY(w.u_pair_off.ensure((L + 1) * 4));
     TRY(w.u_unit_prefix.ensure((L + 1) * 4));
@@ -821,6 +827,11 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                               w.cheap_val.as<int32_t>(), p.rescore, 1, 1, nullptr, st);
     }
     MARK();
+    // list-major scan (4 queries per pass over a chunk) when lists are shared by enough
+    // queries and the unit count fits int32; otherwise one query per wave
+    const bool units = ix->scan_mode == 2 ||
+                       (ix->scan_mode == 0 && nq * p.S >= 8 * ix->n_lists &&
+                        (double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9);
     tk_launch_rescore(q_dev, 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
                       w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0,
                       w.probes.as<int64_t>(), nullptr, st);
@@ -828,12 +839,8 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                          ix->list_chunk_off.as<int64_t>(), ix->list_n.as<int64_t>(),
                          ix->ids_off.as<int64_t>(), w.slot_prefix.as<int>(),
                          w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
-                         w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(), st);
-    // list-major scan (4 queries per pass over a chunk) when lists are shared by enough
-    // queries and the unit count fits int32; otherwise one query per wave
-    const bool units = ix->scan_mode == 2 ||
-                       (ix->scan_mode == 0 && nq * p.S >= 8 * ix->n_lists &&
-                        (double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9);
+                         w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(),
+                         units ? w.u_count.as<int>() : nullptr, st);
     if (units)
         tk_launch_unit_pairs(nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
                              ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),

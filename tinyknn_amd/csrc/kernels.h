@@ -40,7 +40,8 @@ void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64
                            int64_t min_stride, int signd, int order, hipStream_t s);
 
 // List-major form of the probed-list scan for large batches.  tk_launch_unit_pairs
-// groups the (query, slot) pairs by list (count / scan / fill kernels);
+// groups the (query, slot) pairs by list (scan + fill kernels; `count` comes from
+// tk_launch_make_slots and is left zeroed again);
 // tk_launch_scan_units scores each chunk for four queries per pass.  Same outputs
 // as tk_launch_scan_probes.  Work arrays: count, cursor (n_lists), pair_off,
 // unit_prefix (n_lists+1), pair_q, pair_f0 (max_records >= nq*S + 4*n_lists).
@@ -113,9 +114,10 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
                        int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
                        int64_t *out, int *out_count, hipStream_t s);
 
-// probes (nq, kc) list ids -> per-slot scan descriptors
+// probes (nq, kc) list ids -> per-slot scan descriptors; pair_count (n_lists, zeroed, or
+// NULL) receives the number of (query, slot) pairs per list
 void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
                           int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
-                          hipStream_t s);
+                          int *pair_count, hipStream_t s);

@@ -56,67 +56,87 @@ __device__ __forceinline__ T einsum_selfdot(const T *a, int n)
     return acc[0] + acc[1 % L];
 }
 
-// Leaves of numpy's pairwise recursion over n elements, in order: n > 128 splits at
-// n2 = n/2 - (n/2)%8 into [0,n2) and [n2,n).  Returns the leaf count (<= 64 for
-// n <= 8192).
-__device__ int pairwise_leaves(int n, int *leaf_off, int *leaf_n)
+// numpy's pairwise recursion over n elements (n > 128 splits at n2 = n/2 - (n/2)%8
+// into [0,n2) and [n2,n)) depends only on n, so the host lays it out once per
+// launch and passes it by value: the <=64 leaves in order, and the internal nodes
+// as (dst, left, right) adds grouped by tree level so that a level runs in parallel.
+struct PwProgram {
+    unsigned short leaf_off[64], leaf_n[64];
+    unsigned char op_dst[64], op_a[64], op_b[64];
+    unsigned char level_start[10];   // ops of level v are [level_start[v-1], level_start[v])
+    int nleaf, nlevels, root;
+};
+
+static int pw_build(PwProgram &P, int off, int n, int &next_internal, int *level_of,
+                    unsigned char (*ops)[3], int *op_level, int &nops)
 {
-    int st_off[32], st_n[32];
-    int sp = 0, nl = 0;
-    st_off[0] = 0; st_n[0] = n; sp = 1;
-    while (sp > 0) {
-        sp--;
-        const int off = st_off[sp], m = st_n[sp];
-        if (m <= 128) {
-            leaf_off[nl] = off;
-            leaf_n[nl] = m;
-            nl++;
-        } else {
-            int n2 = m / 2;
-            n2 -= n2 % 8;
-            st_off[sp] = off + n2; st_n[sp] = m - n2; sp++;   // right, popped after
-            st_off[sp] = off; st_n[sp] = n2; sp++;            // left, popped first
-        }
+    if (n <= 128) {
+        int id = P.nleaf++;
+        P.leaf_off[id] = (unsigned short)off;
+        P.leaf_n[id] = (unsigned short)n;
+        level_of[id] = 0;
+        return id;
     }
-    return nl;
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    int l = pw_build(P, off, n2, next_internal, level_of, ops, op_level, nops);
+    int r = pw_build(P, off + n2, n - n2, next_internal, level_of, ops, op_level, nops);
+    int id = next_internal++;
+    level_of[id] = 1 + (level_of[l] > level_of[r] ? level_of[l] : level_of[r]);
+    ops[nops][0] = (unsigned char)id;
+    ops[nops][1] = (unsigned char)l;
+    ops[nops][2] = (unsigned char)r;
+    op_level[nops] = level_of[id];
+    nops++;
+    return id;
 }
 
-// Combine the leaf sums in numpy's tree order (post-order: left + right).
-template <typename T>
-__device__ T pairwise_combine(int n, const T *leaf_sum)
+static PwProgram pw_program(int n)
 {
-    int st_n[40], st_vis[40];
-    T vals[40];
-    int sp = 0, vp = 0, next_leaf = 0;
-    st_n[0] = n; st_vis[0] = 0; sp = 1;
-    while (sp > 0) {
-        const int m = st_n[sp - 1];
-        if (m <= 128) {
-            vals[vp++] = leaf_sum[next_leaf++];
+    PwProgram P = {};
+    int level_of[128];
+    unsigned char ops[64][3];
+    int op_level[64];
+    int nops = 0;
+    // leaves get ids 0..nleaf-1 in order, so count them first
+    int nleaf = 0;
+    {
+        int st[64][2], sp = 0;
+        st[sp][0] = 0; st[sp][1] = n; sp++;
+        while (sp) {
             sp--;
-        } else if (!st_vis[sp - 1]) {
-            st_vis[sp - 1] = 1;
-            int n2 = m / 2;
-            n2 -= n2 % 8;
-            st_n[sp] = m - n2; st_vis[sp] = 0; sp++;
-            st_n[sp] = n2; st_vis[sp] = 0; sp++;
-        } else {
-            const T r = vals[--vp];
-            const T l = vals[--vp];
-            vals[vp++] = l + r;
-            sp--;
+            int m = st[sp][1];
+            if (m <= 128) { nleaf++; continue; }
+            int n2 = m / 2; n2 -= n2 % 8;
+            st[sp][0] = 0; st[sp][1] = m - n2; sp++;
+            st[sp][0] = 0; st[sp][1] = n2; sp++;
         }
     }
-    return vals[0];
+    int next_internal = nleaf;
+    P.root = pw_build(P, 0, n, next_internal, level_of, ops, op_level, nops);
+    int maxl = 0;
+    for (int i = 0; i < nops; i++) maxl = op_level[i] > maxl ? op_level[i] : maxl;
+    P.nlevels = maxl;
+    int k = 0;
+    for (int lv = 1; lv <= maxl; lv++) {
+        for (int i = 0; i < nops; i++)
+            if (op_level[i] == lv) {
+                P.op_dst[k] = ops[i][0]; P.op_a[k] = ops[i][1]; P.op_b[k] = ops[i][2];
+                k++;
+            }
+        P.level_start[lv] = (unsigned char)k;
+    }
+    P.level_start[0] = 0;
+    return P;
 }
 
 // One wave per query, blockDim.x / 64 queries per workgroup.  Per-wave LDS:
-//   dists[16M] T | acc[64][8] T | leaf_sum[64] T | leaf_off[64], leaf_n[64] int | misc
+//   dists[16M] T | acc[64][8] T | node_val[128] T (leaf sums, then inner nodes)
 template <typename T, bool SIGNED>
 __global__ __launch_bounds__(256) void build_tables_kernel(
     const float *__restrict__ centers, int dq, int dpb, int f_order, const T *__restrict__ qs,
     double aux0, double aux1, uint8_t *__restrict__ tables, T *__restrict__ shift_out,
-    double *__restrict__ scale_out, int64_t nq, int wave_lds)
+    double *__restrict__ scale_out, int64_t nq, int wave_lds, const PwProgram pw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -126,11 +146,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
     unsigned char *base = smem + (size_t)wave * wave_lds;
     T *dists = (T *)base;                 // numpy memory order
     T *acc = dists + cnt;                 // [leaf][8]
-    T *leaf_sum = acc + 64 * 8;
-    int *leaf_off = (int *)(leaf_sum + 64);
-    int *leaf_n = leaf_off + 64;
-    T *sh_shift = (T *)(leaf_n + 64);
-    int *sh_nleaf = (int *)(sh_shift + 1);
+    T *node_val = acc + 64 * 8;
     const int64_t qraw = (int64_t)blockIdx.x * waves + wave;
     const bool valid = qraw < nq;
     const int64_t qi = valid ? qraw : nq - 1;   // surplus waves recompute the last query
@@ -156,16 +172,16 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
         }
         dists[f_order ? (m * 16 + i) : e] = v;
     }
-    if (lane == 0) *sh_nleaf = SIGNED ? pairwise_leaves(cnt, leaf_off, leaf_n) : 0;
     __syncthreads();
     T shift;
     if (SIGNED) {
         // numpy's pairwise mean, the 8 accumulators of every <=128-element leaf in
-        // parallel (lane = leaf*8 + accumulator), then the exact combine tree
-        const int nleaf = *sh_nleaf;
+        // parallel (lane = leaf*8 + accumulator), then the exact combine tree level
+        // by level
+        const int nleaf = pw.nleaf;
         for (int t = lane; t < nleaf * 8; t += 64) {
             const int L = t >> 3, j = t & 7;
-            const int off = leaf_off[L], n = leaf_n[L];
+            const int off = pw.leaf_off[L], n = pw.leaf_n[L];
             T r = 0;
             if (n >= 8) {
                 r = dists[off + j];
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
         }
         __syncthreads();
         for (int L = lane; L < nleaf; L += 64) {
-            const int off = leaf_off[L], n = leaf_n[L];
+            const int off = pw.leaf_off[L], n = pw.leaf_n[L];
             T res;
             if (n < 8) {
                 res = 0;
@@ -185,15 +201,17 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
                 res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
                 for (int i = n - (n % 8); i < n; i++) res += dists[off + i];
             }
-            leaf_sum[L] = res;
+            node_val[L] = res;
         }
         __syncthreads();
-        if (lane == 0) {
-            T mean = pairwise_combine<T>(cnt, leaf_sum) / (T)cnt;   // _mean
-            *sh_shift = mean * (T)0.6931471806;                     // fast_pq.py:214
+        for (int lv = 1; lv <= pw.nlevels; lv++) {
+            const int t = pw.level_start[lv - 1] + lane;
+            if (t < pw.level_start[lv])
+                node_val[pw.op_dst[t]] = node_val[pw.op_a[t]] + node_val[pw.op_b[t]];
+            __syncthreads();
         }
-        __syncthreads();
-        shift = *sh_shift;
+        const T mean = node_val[pw.root] / (T)cnt;   // _mean
+        shift = mean * (T)0.6931471806;              // fast_pq.py:214
     } else {
         T mn = INFINITY;
         for (int e = lane; e < cnt; e += 64) mn = dists[e] < mn ? dists[e] : mn;   // np.min
@@ -238,8 +256,9 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
     if (nq == 0) return;
     const int M = dq / dpb;
     const size_t esz = q_is_f64 ? 8 : 4;
-    // per-wave LDS: dists + 64x8 accumulators + 64 leaf sums + 2x64 ints + shift, nleaf
-    int wave_lds = (int)(((size_t)16 * M + 64 * 8 + 64) * esz + 128 * 4 + 32);
+    // per-wave LDS: dists + 64x8 accumulators + 128 tree nodes
+    const PwProgram pw = pw_program(16 * M);
+    int wave_lds = (int)(((size_t)16 * M + 64 * 8 + 128) * esz);
     wave_lds = (wave_lds + 15) & ~15;
     int waves = 64 * 1024 / wave_lds;
     waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
@@ -250,19 +269,19 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
         if (signd)
             hipLaunchKernelGGL((build_tables_kernel<double, true>), grid, block, lds, s, centers, dq,
                                pdpb, f_order, (const double *)q, aux0, aux1, tables,
-                               (double *)shift, scale, nq, wave_lds);
+                               (double *)shift, scale, nq, wave_lds, pw);
         else
             hipLaunchKernelGGL((build_tables_kernel<double, false>), grid, block, lds, s, centers,
                                dq, pdpb, f_order, (const double *)q, aux0, aux1, tables,
-                               (double *)shift, scale, nq, wave_lds);
+                               (double *)shift, scale, nq, wave_lds, pw);
     } else {
         if (signd)
             hipLaunchKernelGGL((build_tables_kernel<float, true>), grid, block, lds, s, centers, dq,
                                pdpb, f_order, (const float *)q, aux0, aux1, tables, (float *)shift,
-                               scale, nq, wave_lds);
+                               scale, nq, wave_lds, pw);
         else
             hipLaunchKernelGGL((build_tables_kernel<float, false>), grid, block, lds, s, centers,
                                dq, pdpb, f_order, (const float *)q, aux0, aux1, tables,
-                               (float *)shift, scale, nq, wave_lds);
+                               (float *)shift, scale, nq, wave_lds, pw);
     }
 }
