@@ -79,7 +79,7 @@ def build_index(args, device):
     driver runs N = 1, 2, 4, 8 back to back on one box."""
     from tinyknn_amd import IVF, FastPQ
     from tinyknn_amd.fast_pq import TransformedData
-    tag = f"n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}"
+    tag = f"n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}_b{args.build_probes}"
     cache = os.path.join(args.cache_dir, f"tinyknn_bench_{tag}.npz")
     X, cent = synth(args.n, 0, args.d, args.seed)
     ivf = IVF("angular", args.n_clusters, FastPQ(2))
@@ -106,7 +106,7 @@ def build_index(args, device):
     ivf.all_centers = C / np.linalg.norm(C, axis=1, keepdims=True)       # ivf.py:38-45
     ivf.pq.fit(sample[:min(len(sample), 30000)])
     log(f"[bench] fit done in {time.time() - t0:.1f}s")
-    ivf.build(X, n_probes=1)
+    ivf.build(X, n_probes=args.build_probes)
     log(f"[bench] build done in {time.time() - t0:.1f}s")
     L = len(ivf.active_centers)
     try:
@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--cache-dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--build-probes", type=int, default=1, help="lists per point (ivf.py:53)")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (tk_index_set_pipeline)")
@@ -277,7 +278,7 @@ def main():
         "dtype": "int8 (saturating PQ sums) + f32 (tables, rescoring)", "data": "synthetic",
         "config": {"workload": "glove-100-angular stand-in: 300 Gaussian clusters sigma 0.7, "
                                f"N={args.n} d={args.d} IVF n_clusters={args.n_clusters} "
-                               f"build_probes=1 FastPQ dpb=2 M={M}",
+                               f"build_probes={args.build_probes} FastPQ dpb=2 M={M}",
                    "queries_per_step_per_gpu": args.nq, "k": args.k, "n_probes": args.n_probes,
                    "pass_1": (args.n_probes + 1) * args.k + 1, "recall10@10": recall,
                    "recall_queries": rs, "parallelism": f"replica x{world} (queries sharded)",

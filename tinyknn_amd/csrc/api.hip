@@ -809,7 +809,7 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                                      ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
                                      ix->cslots_l.as<int64_t>(), 1, nullptr,
                                      w.cheap_idx.as<int64_t>(), w.cheap_val.as<int32_t>(),
-                                     p.rescore, 1, 1, nullptr, st);
+                                     p.rescore, 1, 1, nullptr, 0, 0, st);
     } else if (lanes_c) {
         if (tk_launch_heap_replay_lanes(w.cdist.as<uint4>(), ix->center_chunks, nq,
                                         ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
@@ -870,32 +870,38 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
         if (!ix->ev_scan) HIPCHECK(hipEventCreateWithFlags(&ix->ev_scan, hipEventDisableTiming));
         HIPCHECK(hipEventRecord(ix->ev_scan, st));
     }
-    const bool fast = ix->heap_mode != 1 && ix->ids_unique && p.cap * 16 <= 0xffffff;
-    const bool lanes = fast && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
-    if (fast) {
+    // heaps start fresh here, so packed entries apply.  Distinct labels: one query per
+    // lane (or per wave for big heaps), and the few queries whose probe list wrapped a -1
+    // (a list may then be scanned twice) re-run with the duplicate test.  Repeating labels
+    // (build n_probes >= 2): the packed wave kernel with the duplicate test for everybody.
+    const bool packed_ok = ix->heap_mode != 1 && p.cap * 16 <= 0xffffff;
+    if (packed_ok && ix->ids_unique) {
+        const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
         if (!lanes)
-            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq,
-                                         w.slot_prefix.as<int>(), w.slot_n.as<int>(),
-                                         w.slot_loff.as<int64_t>(), p.S, ix->ids.as<int64_t>(),
-                                         w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
-                                         p.R, 1, 0, w.repeat_flag.as<unsigned char>(), st);
-        else if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
-                                        w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
-                                        ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                        w.heap_val.as<int32_t>(), p.R, 1, 0,
-                                        w.repeat_flag.as<unsigned char>(),
-                                        w.mins.as<uint8_t>(), p.cap_min, st))
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
+                                         w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
+                                         ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0,
+                                         w.repeat_flag.as<unsigned char>(), 0, 0, st);
+        else if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq,
+                                             w.slot_prefix.as<int>(), w.slot_n.as<int>(),
+                                             w.slot_loff.as<int64_t>(), p.S, ix->ids.as<int64_t>(),
+                                             w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
+                                             p.R, 1, 0, w.repeat_flag.as<unsigned char>(),
+                                             w.mins.as<uint8_t>(), p.cap_min, st))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
-        // queries whose probe list wrapped (-1 from an unfilled coarse heap) may scan a
-        // list twice; they take the wave kernel with the duplicate-label scan
-        tk_launch_heap_replay(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
-                              w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
-                              ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                              w.heap_val.as<int32_t>(), p.R, 1, 0,
-                              w.repeat_flag.as<unsigned char>(), st);
+        tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
+                                     w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
+                                     ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                     w.heap_val.as<int32_t>(), p.R, 1, 0,
+                                     w.repeat_flag.as<unsigned char>(), 1, 1, st);
+    } else if (packed_ok) {
+        tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
+                                     w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
+                                     ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                     w.heap_val.as<int32_t>(), p.R, 1, 0, nullptr, 0, 1, st);
     } else {
-        tk_launch_heap_fill(w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), nq * p.R, 127,
-                            st);
+        tk_launch_heap_fill(w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), nq * p.R, 127, st);
         tk_launch_heap_replay(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
                               w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
                               ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),

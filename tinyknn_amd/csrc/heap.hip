@@ -493,27 +493,37 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
 // dwords of LDS (children l, l+1 are adjacent dwords).  Far fewer instructions per
 // insert than heap_replay_kernel (no label array, no duplicate scan, one LDS word
 // per node), which is what bounds that kernel at 10^4 concurrent queries.
-template <bool SIGNED>
+// DEDUPE: labels may repeat among a query's lists (IVF.build(n_probes >= 2), or a
+// wrapped probe id).  The low 24 bits of an entry are then a SLOT number instead of
+// a position; lab[slot] holds the int64 label, `insert` first runs the reference's
+// duplicate test over lab[] with all 64 lanes, and a new entry takes over the slot
+// of the root it evicts.  `flags`/`run_if`: process query q iff flags[q] == run_if.
+template <bool SIGNED, bool DEDUPE>
 __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
     const uint4 *__restrict__ dist, int64_t cap, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
-    const unsigned char *__restrict__ skip, int64_t nq)
+    const unsigned char *__restrict__ flags, int run_if, int64_t nq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6;
-    lds_vu32 *H = LDS_PTR(lds_vu32, smem + (size_t)wave * R * 4);  // [R] per wave
+    const size_t wstride = DEDUPE ? (((size_t)R * 12 + 15) & ~(size_t)15) : (size_t)R * 4;
+    lds_vi64 *lab = LDS_PTR(lds_vi64, smem + wave * wstride);                       // [R] (DEDUPE)
+    lds_vu32 *H = LDS_PTR(lds_vu32, smem + wave * wstride + (DEDUPE ? (size_t)R * 8 : 0));  // [R]
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (q >= nq) return;   // wave-uniform; no workgroup barrier below
-    if (skip && skip[q]) return;
+    if (flags && (int)flags[q] != run_if) return;
     const int64_t qs = slots_uniform ? 0 : q;
     const int *prefix = slot_prefix + qs * (S + 1);
     const uint4 *drow = dist + q * cap;
 
-    const uint32_t fresh = (SIGNED ? 0x7f000000u : 0xff000000u) | 0x00ffffffu;
-    for (int t = lane; t < R; t += 64) H[t] = fresh;
+    const uint32_t fresh_val = SIGNED ? 0x7f000000u : 0xff000000u;
+    for (int t = lane; t < R; t += 64) {
+        H[t] = fresh_val | (DEDUPE ? (uint32_t)t : 0x00ffffffu);
+        if (DEDUPE) lab[t] = -1;
+    }
     uint32_t bound = SIGNED ? 0x7fu : 0xffu;
     const uint4 never = SIGNED ? make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu)
                                : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
@@ -521,6 +531,8 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
         const int c0 = prefix[s];
         const int nchunks = prefix[s + 1] - c0;
         const int n = slot_n[qs * S + s];
+        const int64_t loff = slot_label_off[qs * S + s];
+        const int64_t *labp = loff < 0 ? nullptr : labels + loff;
         for (int base = 0; base < nchunks; base += 64) {
             const int b = base + lane;
             const bool have = b < nchunks;
@@ -528,9 +540,30 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
             if (have) dd = drow[c0 + b];
             bool vote = have && any_lt16<SIGNED>(dd, bound);
             uint64_t mask = __builtin_amdgcn_ballot_w64(vote);
+            // DEDUPE: the 16 labels of a voted block are fetched by lanes 0..15 with one
+            // vector load, one block ahead of the block being replayed
+            auto load_labels = [&](int jb) -> int64_t {
+                const int64_t inl = 16 * (int64_t)(base + jb) + lane;
+                if (lane >= 16 || inl >= n) return -2;   // never a label
+                return labp ? labp[inl] : inl;
+            };
+            int j_pref = -1;
+            int64_t lab_pref = -2;
+            if (DEDUPE && mask) {
+                j_pref = __builtin_ctzll(mask);
+                lab_pref = load_labels(j_pref);
+            }
             while (mask) {
                 const int j = __builtin_ctzll(mask);
                 mask &= mask - 1;
+                int64_t lab_cur = -2;
+                if (DEDUPE) {
+                    lab_cur = (j == j_pref) ? lab_pref : load_labels(j);
+                    if (mask) {
+                        j_pref = __builtin_ctzll(mask);
+                        lab_pref = load_labels(j_pref);
+                    }
+                }
                 const uint32_t d0 = __builtin_amdgcn_readlane(dd.x, j);
                 const uint32_t d1 = __builtin_amdgcn_readlane(dd.y, j);
                 const uint32_t d2 = __builtin_amdgcn_readlane(dd.z, j);
@@ -547,7 +580,19 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
                     const int r = __builtin_ctz(bits);
                     bits &= bits - 1;
                     const uint32_t byr = __builtin_amdgcn_readlane(by, r);
-                    const uint32_t entry = (byr << 24) | (pos0 + (uint32_t)r);
+                    uint32_t low = pos0 + (uint32_t)r;
+                    if (DEDUPE) {
+                        const uint32_t llo = __builtin_amdgcn_readlane((uint32_t)lab_cur, r);
+                        const uint32_t lhi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)lab_cur >> 32), r);
+                        const int64_t label = (int64_t)(((uint64_t)lhi << 32) | llo);
+                        bool dup = false;   // `if i == indices[j]: return`, _fast_pq.pyx:284-287
+                        for (int t = lane; t < R; t += 64) dup |= (lab[t] == label);
+                        if (__builtin_amdgcn_ballot_w64(dup)) continue;
+                        // the new entry inherits the slot of the root it replaces
+                        low = __builtin_amdgcn_readfirstlane(H[0]) & 0x00ffffffu;
+                        if (lane == 0) lab[low] = label;
+                    }
+                    const uint32_t entry = (byr << 24) | low;
                     const int v = entry_val<SIGNED>(entry);
                     int jn = 0;
                     for (;;) {  // insert, _fast_pq.pyx:291-307
@@ -574,13 +619,15 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
             }
         }
     }
-    // resolve flat positions to labels
+    // heap arrays out
     const int64_t *loffs = slot_label_off + qs * S;
     for (int t = lane; t < R; t += 64) {
         const uint32_t e = H[t];
         const uint32_t pos = e & 0x00ffffffu;
         int64_t label = -1;
-        if (pos != 0x00ffffffu) {
+        if (DEDUPE) {
+            label = lab[pos];
+        } else if (pos != 0x00ffffffu) {   // resolve the flat position
             const int f = (int)(pos >> 4);
             int lo = 0, hi = S;
             while (hi - lo > 1) {
@@ -599,22 +646,22 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
 void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                   const int *slot_n, const int64_t *slot_label_off, int S,
                                   const int64_t *labels, int64_t *heap_idx, int32_t *heap_val,
-                                  int R, int signd, int slots_uniform, const unsigned char *skip,
-                                  hipStream_t s)
+                                  int R, int signd, int slots_uniform, const unsigned char *flags,
+                                  int run_if, int dedupe, hipStream_t s)
 {
     if (nq == 0 || R == 0) return;
-    int waves = (int)(64 * 1024 / ((size_t)R * 4));
+    const size_t wstride = dedupe ? (((size_t)R * 12 + 15) & ~(size_t)15) : (size_t)R * 4;
+    int waves = (int)(64 * 1024 / wstride);
     waves = waves < 1 ? 1 : (waves > TK_HEAP_WAVES ? TK_HEAP_WAVES : waves);
-    size_t lds = (size_t)R * 4 * waves;
+    size_t lds = wstride * waves;
     dim3 grid((unsigned)((nq + waves - 1) / waves)), block(64 * waves);
-    if (signd)
-        hipLaunchKernelGGL(heap_replay_packed_kernel<true>, grid, block, lds, s, dist, cap,
-                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
-                           slots_uniform, skip, nq);
-    else
-        hipLaunchKernelGGL(heap_replay_packed_kernel<false>, grid, block, lds, s, dist, cap,
-                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
-                           slots_uniform, skip, nq);
+#define TK_LAUNCH(S_, D_)                                                                        \
+    hipLaunchKernelGGL((heap_replay_packed_kernel<S_, D_>), grid, block, lds, s, dist, cap,      \
+                       slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,    \
+                       slots_uniform, flags, run_if, nq)
+    if (signd) { if (dedupe) TK_LAUNCH(true, true); else TK_LAUNCH(true, false); }
+    else { if (dedupe) TK_LAUNCH(false, true); else TK_LAUNCH(false, false); }
+#undef TK_LAUNCH
 }
 
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,

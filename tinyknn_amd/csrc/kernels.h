@@ -84,13 +84,15 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 int signd, int slots_uniform, const unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, hipStream_t s);
 
-// Wave-per-query replay on packed entries; same preconditions and outputs as the
-// lane-per-query kernel (R*4 B of LDS).
+// Wave-per-query replay on packed 32-bit entries from FRESH heaps (R*4 B of LDS, or
+// R*12 with `dedupe`: int64 labels per slot + the reference's duplicate-label test,
+// for labels that can repeat).  flags/run_if: only queries with flags[q] == run_if
+// (flags may be NULL).  cap*16 < 2^24 (no dedupe) / R < 2^24.
 void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                   const int *slot_n, const int64_t *slot_label_off, int S,
                                   const int64_t *labels, int64_t *heap_idx, int32_t *heap_val,
-                                  int R, int signd, int slots_uniform, const unsigned char *skip,
-                                  hipStream_t s);
+                                  int R, int signd, int slots_uniform, const unsigned char *flags,
+                                  int run_if, int dedupe, hipStream_t s);
 
 void tk_launch_heap_fill(int64_t *heap_idx, int32_t *heap_val, int64_t count, int32_t v,
                          hipStream_t s);
