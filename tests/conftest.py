@@ -33,6 +33,20 @@ def split_lists(g):
 G6_TAGS = ["eu20", "an20", "an100", "an100b2", "eu128", "eu20f64"]
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """Build the HIP library (hipcc cross-compiles for gfx950 without a GPU) and the
+    oracle if they are missing or older than their sources."""
+    import subprocess
+    csrc = os.path.join(ROOT, "tinyknn_amd", "csrc")
+    so = os.path.join(ROOT, "tinyknn_amd", "libtinyknn_hip.so")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(ROOT, "include", "tinyknn_hip.h"))
+    if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
+        subprocess.check_call(["make", "-s", "-j4", "-C", csrc])
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O

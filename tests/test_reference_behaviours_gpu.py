@@ -1,0 +1,139 @@
+"""The behaviours the reference's own test-suite pins for this path
+(/root/reference/tests/test_ivf.py, test_multiprobe.py, test_pq.py::test_recall,
+test_heap.py), re-expressed against the GPU implementation through the drop-in
+Python API (fit / build are host code, every query runs the HIP kernels)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tk():
+    import tinyknn_amd
+    from tinyknn_amd import _lib
+    assert _lib.device_count() >= 1
+    return tinyknn_amd
+
+
+@pytest.mark.filterwarnings("ignore:Number of distinct clusters")
+def test_small_n(tk):
+    # tests/test_ivf.py:7-31 — 1..4 points, one cluster, with and without an outlier
+    np.random.seed(1)
+    d = 10
+    for metric in ["euclidean", "angular"]:
+        for n in range(1, 5):
+            for far in (False, True):
+                if far and n < 2:
+                    continue
+                X = np.random.randn(n, d).astype(np.float32)
+                if far:
+                    X[0, :] = 10**5
+                q = np.random.randn(d).astype(np.float32)
+                ivf = tk.IVF(metric, 1, tk.FastPQ(2))
+                ivf.fit(X).build(X, n_probes=1)
+                res = ivf.query(q, n)
+                assert res.dtype == np.int64 and all(0 <= i < n for i in res)
+
+
+def _recall(tk, n, d, nq, at, metric, n_probes, build_probes=2):
+    X = np.random.randn(n, d).astype(np.float32)
+    qs = np.random.randn(nq, d).astype(np.float32)
+    trus = tk.knn_brute(qs, X, k=at, metric=metric) if at < n else np.broadcast_to(np.arange(n), (nq, n))
+    ivf = tk.IVF(metric, int(n**0.5), tk.FastPQ(2))
+    ivf.fit(X).build(X, n_probes=build_probes)
+    got = 0
+    for q, tru in zip(qs, trus):
+        got += len(set(ivf.query(q, k=at, n_probes=n_probes)) & set(tru))
+    return got / nq / at
+
+
+@pytest.mark.filterwarnings("ignore:Number of distinct clusters")
+def test_recall_thresholds(tk):
+    # tests/test_ivf.py:34-47,67-69
+    np.random.seed(10)
+    for metric, thr in (("euclidean", (0.1, 0.2, 0.35, 0.5)), ("angular", (0.09, 0.18, 0.27, 0.36))):
+        for n_probes, t in zip((1, 2, 4, 8), thr):
+            assert _recall(tk, 100, 20, 10, 10, metric, n_probes) > t
+    np.random.seed(10)
+    assert _recall(tk, 15, 10, 30, 10, "euclidean", 1) > 0.05
+
+
+@pytest.mark.parametrize("metric", ["angular", "euclidean"])
+def test_multiprobe_monotone_and_good(tk, metric):
+    # tests/test_multiprobe.py:32-67 — duplicates across lists (build_probes > 1)
+    np.random.seed(10)
+    n, d, nq, at = 1000, 10, 30, 10
+    X = np.random.randn(n, d).astype(np.float32)
+    qs = np.random.randn(nq, d).astype(np.float32)
+    trus = tk.knn_brute(qs, X, k=at, metric=metric)
+
+    def rec(bp, qp):
+        ivf = tk.IVF(metric, int(n**0.5), tk.FastPQ(2))
+        ivf.fit(X).build(X, n_probes=bp)
+        ids = ivf.query_batch(qs, at, n_probes=qp)
+        for row in ids:                                  # no id is returned twice
+            r = row[row >= 0]
+            assert len(set(r)) == len(r)
+        return np.mean([len(set(g) & set(t)) / at for g, t in zip(ids, trus)])
+
+    table = [[rec(bp, qp) for qp in range(1, 5)] for bp in range(1, 5)]
+    for i in range(1, 4):
+        for j in range(4):
+            assert table[i][j] >= table[i - 1][j] - 0.1
+            assert table[j][i] >= table[j][i - 1] - 0.1
+    assert rec(4, 10) >= 0.9
+    assert rec(10, 4) >= 0.9
+
+
+@pytest.mark.parametrize("i,method,signed,use_kmeans",
+                         [(i, m, s, u) for i in (1, 3) for m in ("argpartition", "top")
+                          for s in (True, False) for u in (True, False)])
+def test_pq_recall(tk, i, method, signed, use_kmeans):
+    # tests/test_pq.py:56-82
+    np.random.seed(10 + i)
+    n = np.random.randint(16 * i, 16 * (i + 1))
+    d, k = 8 * i, 100
+    X = np.random.randn(n, d).astype(np.float32)
+    qs = np.random.randn(k, d).astype(np.float32)
+    trus = tk.knn_brute(qs, X, k=1)[:, 0]
+    pq = tk.FastPQ(dims_per_block=2, use_kmeans=use_kmeans)
+    data = pq.fit_transform(X)
+    hit = 0
+    for q, tru in zip(qs, trus):
+        dt = pq.distance_table(q) if signed else pq.udistance_table(q)
+        if method == "argpartition":
+            top10 = dt.estimate_distances(data).argpartition(10)[:10]
+        else:
+            top10 = dt.top(data, X, 10)
+        hit += tru in top10
+    assert hit / k > 0.8
+
+
+def test_heap_invariant_and_heapq(tk):
+    # tests/test_heap.py:52-94
+    import heapq
+    from tinyknn_amd._fast_pq import init_heap, insert
+    np.random.seed(13)
+    for vs in ([0, 1, 2, 3, 4], [4, 3, 2, 1, 0], [2, 2, 0, 1, 2, 0, 1]):
+        n = len(vs)
+        idx = np.empty(n, np.int64); val = np.empty(n, np.int32)
+        init_heap(idx, val, True)
+        for i, v in enumerate(vs):
+            if v < val[0]:
+                insert(idx, val, i, v)
+            assert v in val and i in idx
+            for j in range(1, n):
+                assert val[j] <= val[(j - 1) // 2]
+    idx = np.empty(10, np.int64); val = np.empty(10, np.int32)
+    init_heap(idx, val, True)
+    py = [(-127, -1)] * 10
+    for t in range(120):
+        top = -py[0][0]
+        assert top == val[0]
+        v = np.random.randint(10000 // (t + 1))
+        if v < val[0]:
+            insert(idx, val, t, v)
+        if v < top:
+            heapq.heappop(py); heapq.heappush(py, (-v, t))
+        assert set(val) == {-vi for vi, _ in py}
