@@ -495,7 +495,8 @@ struct tk_index {
     int64_t n_lists = 0, center_chunks = 0;
     int d = 0;
     // lists
-    DevBuf list_chunk_off, list_n, ids_off, ids, codes;
+    DevBuf list_chunk_off, list_n, ids_off, ids, codes, ids32;
+    bool have_ids32 = false;   // every label fits int32: the lane kernel can run the duplicate test
     int64_t total_chunks = 0, total_ids = 0;
     int max_list_chunks = 0;
     bool ids_unique = false;   // no label occurs twice => the lane-per-query replay is exact
@@ -536,7 +537,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
 {
     if (!ix) return;
     DevBuf *bufs[] = {&ix->pq_centers, &ix->active_centers, &ix->center_codes, &ix->list_chunk_off,
-                      &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->data, &ix->cslots_i,
+                      &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->ids32, &ix->data, &ix->cslots_i,
                       &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
@@ -650,6 +651,18 @@ extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const
     HIPCHECK(hipMemcpy(ix->list_n.p, list_sizes, (size_t)L * 8, hipMemcpyHostToDevice));
     if (ioff[L] > 0)
         HIPCHECK(hipMemcpy(ix->ids.p, ids, (size_t)ioff[L] * 8, hipMemcpyHostToDevice));
+    {   // int32 copy of the labels for the lane kernel's duplicate test
+        bool fits = true;
+        for (int64_t i = 0; i < ioff[L] && fits; i++) fits = ids[i] >= 0 && ids[i] < 0x7fffffff;
+        ix->have_ids32 = false;
+        if (fits && ioff[L] > 0 && !ix->ids_unique) {
+            std::vector<int32_t> tmp((size_t)ioff[L]);
+            for (int64_t i = 0; i < ioff[L]; i++) tmp[(size_t)i] = (int32_t)ids[i];
+            TRY(ix->ids32.ensure(tmp.size() * 4));
+            HIPCHECK(hipMemcpy(ix->ids32.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+            ix->have_ids32 = true;
+        }
+    }
     ix->total_chunks = coff[L];
     ix->total_ids = ioff[L];
     ix->max_list_chunks = (int)maxc;
@@ -816,7 +829,7 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                                         ix->cslots_l.as<int64_t>(), 1, nullptr,
                                         w.cheap_idx.as<int64_t>(), w.cheap_val.as<int32_t>(),
                                         p.rescore, 1, 1, nullptr, w.cmins.as<uint8_t>(),
-                                        p.ccap_min, st))
+                                        p.ccap_min, nullptr, st))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
     } else {
         tk_launch_heap_fill(w.cheap_idx.as<int64_t>(), w.cheap_val.as<int32_t>(),
@@ -888,13 +901,21 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                                              w.slot_loff.as<int64_t>(), p.S, ix->ids.as<int64_t>(),
                                              w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
                                              p.R, 1, 0, w.repeat_flag.as<unsigned char>(),
-                                             w.mins.as<uint8_t>(), p.cap_min, st))
+                                             w.mins.as<uint8_t>(), p.cap_min, nullptr, st))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
                                      w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
                                      ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                      w.heap_val.as<int32_t>(), p.R, 1, 0,
                                      w.repeat_flag.as<unsigned char>(), 1, 1, st);
+    } else if (packed_ok && ix->have_ids32 && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R_DEDUPE) {
+        // repeating labels that fit int32: one query per lane with the duplicate test
+        if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
+                                        w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
+                                        ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                        w.heap_val.as<int32_t>(), p.R, 1, 0, nullptr,
+                                        w.mins.as<uint8_t>(), p.cap_min, ix->ids32.as<int32_t>(), st))
+            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
     } else if (packed_ok) {
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
                                      w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,

@@ -292,19 +292,30 @@ __device__ __forceinline__ uint32_t mask_lt16(const uint4 v, uint32_t bound8)
     return m;
 }
 
-template <bool SIGNED>
+// DEDUPE (labels may repeat, IVF.build(n_probes >= 2)): the low 24 bits of an entry are
+// a SLOT, LAB[slot][lane] holds the slot's 32-bit label, `insert` first scans LAB for
+// the candidate's label (the reference's duplicate test, _fast_pq.pyx:284-287) and a
+// new entry inherits the slot of the root it evicts.  labels32 = the ids as int32.
+template <bool SIGNED, bool DEDUPE>
 __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
     const unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
-    int64_t cap_min)
+    int64_t cap_min, const int32_t *__restrict__ labels32)
 {
-    // LDS: H[R+2][64] heap columns (+2 sentinel rows) | ST[nbuf][16][64] staged blocks
+    // LDS: H[R+2][64] heap columns (+2 sentinel rows) | DEDUPE: LAB[ceil(R/4)][64][4]
+    //      labels by slot, CNT[256][64] label-hash counters | ST[nbuf][16][64] staged blocks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *H = (uint32_t *)smem;
-    uint4 *ST = (uint4 *)(smem + (size_t)(R + 2) * 256);
+    const int R4 = (R + 3) >> 2;
+    uint32_t *LAB = (uint32_t *)(smem + (size_t)(R + 2) * 256);
+    uint32_t *CNT = (uint32_t *)(smem + (size_t)(R + 2) * 256 + (size_t)R4 * 1024);  // 4 x uint8 per dword
+    uint4 *ST = (uint4 *)(smem + (size_t)(R + 2) * 256 +
+                          (DEDUPE ? (size_t)R4 * 1024 + 256 * 64 : 0));
+#define TK_LAB(slot) LAB[(((slot) >> 2) * 64 + lane) * 4 + ((slot) & 3)]
+#define TK_HASH(label) (((uint32_t)(label) * 0x9E3779B1u) >> 24)
     const int lane = threadIdx.x;
     const int64_t q = (int64_t)blockIdx.x * 64 + lane;
     // `skip`: queries whose probe list may repeat a list (left to the wave kernel)
@@ -315,14 +326,22 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
     const int *sn = slot_n + qs * S;
     const uint4 *drow = dist + qc * cap;
 
-    const uint32_t fresh = (SIGNED ? 0x7f000000u : 0xff000000u) | 0x00ffffffu;
+    const uint32_t fresh_val = SIGNED ? 0x7f000000u : 0xff000000u;
+    const uint32_t fresh = fresh_val | 0x00ffffffu;
     const uint32_t lowest = SIGNED ? 0x80000000u : 0u;    // a value no entry is below
-    for (int j = 0; j < R; j++) H[j * 64 + lane] = fresh;
+    for (int j = 0; j < R; j++)
+        H[j * 64 + lane] = DEDUPE ? (fresh_val | (uint32_t)j) : fresh;   // node j owns slot j
+    if (DEDUPE) {
+        for (int g = 0; g < R4; g++)                                     // every label -1
+            ((uint4 *)LAB)[g * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int b = 0; b < 64; b++) CNT[b * 64 + lane] = 0;
+    }
     H[R * 64 + lane] = H[(R + 1) * 64 + lane] = lowest;   // sentinel rows: never taken
     // the top three levels (nodes 0..6) live in registers; nodes >= R are sentinels
-    uint32_t h0 = fresh, h1 = R > 1 ? fresh : lowest, h2 = R > 2 ? fresh : lowest,
-             h3 = R > 3 ? fresh : lowest, h4 = R > 4 ? fresh : lowest,
-             h5 = R > 5 ? fresh : lowest, h6 = R > 6 ? fresh : lowest;
+#define TK_FRESH(j) (R > (j) ? (DEDUPE ? (fresh_val | (uint32_t)(j)) : fresh) : lowest)
+    uint32_t h0 = TK_FRESH(0), h1 = TK_FRESH(1), h2 = TK_FRESH(2), h3 = TK_FRESH(3),
+             h4 = TK_FRESH(4), h5 = TK_FRESH(5), h6 = TK_FRESH(6);
+#undef TK_FRESH
     uint32_t bound = SIGNED ? 0x7fu : 0xffu;
 
     const int total = (valid && S > 0) ? prefix[S] : 0;   // flat chunks of this lane's query
@@ -337,7 +356,12 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
 
     // slot cursor (monotonic): flat chunks [s_begin, s_end) belong to slot s with n rows
     int s = 0, s_begin = 0, s_end = 0, n = 0;
-    if (total > 0) { s_end = prefix[1]; n = sn[0]; }
+    int64_t s_loff = 0;   // DEDUPE: label offset of the current slot
+    if (total > 0) {
+        s_end = prefix[1];
+        n = sn[0];
+        if (DEDUPE) s_loff = slot_label_off[qs * S];
+    }
 
     // stage segment g (16 blocks per lane, each lane from its own row) by LDS-DMA:
     // one global_load_lds_dwordx4 per block row k writes ST[buf][k][0..63]
@@ -374,6 +398,8 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
         uint32_t bits = 0;
         uint4 dd = make_uint4(0, 0, 0, 0);
         int cur = 0;
+        uint32_t lab_next = 0;        // DEDUPE: label of the lowest pending row, fetched ahead
+        int64_t lab_base = 0;         //         first label of the current block
         for (;;) {
             // next block of this segment with a byte below the live bound
             while (bits == 0 && hit) {
@@ -386,10 +412,15 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
                     s_begin = s_end;
                     s_end = prefix[s + 1];
                     n = sn[s];
+                    if (DEDUPE) s_loff = slot_label_off[qs * S + s];
                 }
                 bits = mask_lt16<SIGNED>(dd, bound);          // cmp_mask, _fast_pq_256.pyx:81-90
                 const int rows = n - 16 * (cur - s_begin);    // `pos < n`, :111
                 if (rows < 16) bits &= rows > 0 ? ((1u << rows) - 1u) : 0u;
+                if (DEDUPE && bits) {
+                    lab_base = s_loff + 16 * (int64_t)(cur - s_begin);
+                    lab_next = (uint32_t)labels32[lab_base + __builtin_ctz(bits)];
+                }
             }
             if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
             if (bits) {   // one insert per lane with a pending candidate
@@ -397,8 +428,40 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
                 bits &= bits - 1;
                 const uint32_t w = r < 4 ? dd.x : r < 8 ? dd.y : r < 12 ? dd.z : dd.w;
                 const uint32_t by = (w >> (8 * (r & 3))) & 0xffu;
-                const uint32_t entry = (by << 24) | (uint32_t)(16 * cur + r);
+                uint32_t low = (uint32_t)(16 * cur + r);
+                bool dup = false;
+                if (DEDUPE) {
+                    const uint32_t label = lab_next;
+                    if (bits) lab_next = (uint32_t)labels32[lab_base + __builtin_ctz(bits)];
+                    // `if i == indices[j]: return` over every slot, _fast_pq.pyx:284-287.  A
+                    // counter per label hash tells most candidates apart without the scan
+                    // (a heap never holds more than R <= 232 labels: no uint8 overflow).
+                    const uint32_t hb = TK_HASH(label);
+                    low = h0 & 0x00ffffffu;            // the evicted root's slot
+                    const uint32_t cw = CNT[(hb >> 2) * 64 + lane];
+                    const uint32_t gone = TK_LAB(low); // label leaving with the root
+                    if ((cw >> (8 * (hb & 3))) & 0xffu) {
+#pragma unroll 4
+                        for (int g = 0; g < R4; g++) {
+                            const uint4 lv = ((const uint4 *)LAB)[g * 64 + lane];
+                            dup |= (lv.x == label) | (lv.y == label) | (lv.z == label) | (lv.w == label);
+                        }
+                    }
+                    if (!dup) {
+                        // lane-private counters, 4 per dword: ds_add_u32 without return
+                        if (gone != 0xffffffffu) {
+                            const uint32_t hg = TK_HASH(gone);
+                            __hip_atomic_fetch_add(&CNT[(hg >> 2) * 64 + lane], 0u - (1u << (8 * (hg & 3))),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                        __hip_atomic_fetch_add(&CNT[(hb >> 2) * 64 + lane], 1u << (8 * (hb & 3)),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        TK_LAB(low) = label;
+                    }
+                }
+                const uint32_t entry = (by << 24) | low;
                 const int v = entry_val<SIGNED>(entry);
+                if (!dup)
                 // insert, _fast_pq.pyx:291-307.  Levels 0-2 in registers, the rest in
                 // LDS, branch-free per level: rows R and R+1 hold a value no entry
                 // exceeds, so children beyond the heap (clamped to R) are never taken.
@@ -462,13 +525,15 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
     if (R > 5) H[5 * 64 + lane] = h5;
     if (R > 6) H[6 * 64 + lane] = h6;
     if (!valid) return;
-    // ---- resolve flat positions to labels
+    // ---- resolve flat positions (or slots) to labels
     const int64_t *loffs = slot_label_off + qs * S;
     for (int j = 0; j < R; j++) {
         const uint32_t e = H[j * 64 + lane];
         const uint32_t pos = e & 0x00ffffffu;
         int64_t label = -1;
-        if (pos != 0x00ffffffu) {
+        if (DEDUPE) {
+            label = (int64_t)(int32_t)TK_LAB(pos);
+        } else if (pos != 0x00ffffffu) {
             const int f = (int)(pos >> 4);
             int lo = 0, hi = S;  // prefix[lo] <= f < prefix[hi]
             while (hi - lo > 1) {
@@ -664,35 +729,43 @@ void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, co
 #undef TK_LAUNCH
 }
 
+#undef TK_LAB
+#undef TK_HASH
+
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, const unsigned char *skip,
-                                const uint8_t *mins, int64_t cap_min, hipStream_t s)
+                                const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
+                                hipStream_t s)
 {
     if (nq == 0 || R == 0) return 0;
-    // heap columns + 16 staged blocks per lane, double-buffered when it fits
-    int nbuf = ((size_t)(R + 2) * 256 + 2 * 16384 <= 160 * 1024) ? 2 : 1;
-    size_t lds = (size_t)(R + 2) * 256 + (size_t)nbuf * 16384;
+    const int dedupe = labels32 != nullptr;
+    // heap columns (+ label slots) + 16 staged blocks per lane, double-buffered when it fits
+    const size_t fixed = (size_t)(R + 2) * 256 +
+                         (dedupe ? (size_t)((R + 3) / 4) * 1024 + 256 * 64 : 0);
+    int nbuf = (fixed + 2 * 16384 <= 160 * 1024) ? 2 : 1;
+    size_t lds = fixed + (size_t)nbuf * 16384;
     static bool attr_set = false;
     if (!attr_set) {
-
-        hipError_t e1 = hipFuncSetAttribute((const void *)heap_replay_lanes_kernel<true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipError_t e2 = hipFuncSetAttribute((const void *)heap_replay_lanes_kernel<false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e1 != hipSuccess || e2 != hipSuccess) return -1;
+        const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false>,
+                             (const void *)heap_replay_lanes_kernel<false, false>,
+                             (const void *)heap_replay_lanes_kernel<true, true>,
+                             (const void *)heap_replay_lanes_kernel<false, true>};
+        for (const void *f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess)
+                return -1;
         attr_set = true;
     }
     dim3 grid((unsigned)((nq + 63) / 64));
-    if (signd)
-        hipLaunchKernelGGL(heap_replay_lanes_kernel<true>, grid, dim3(64), lds, s, dist, cap, nq,
-                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
-                           slots_uniform, skip, nbuf, mins, cap_min);
-    else
-        hipLaunchKernelGGL(heap_replay_lanes_kernel<false>, grid, dim3(64), lds, s, dist, cap, nq,
-                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,
-                           slots_uniform, skip, nbuf, mins, cap_min);
+#define TK_LAUNCH(S_, D_)                                                                       \
+    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_>), grid, dim3(64), lds, s, dist, cap, nq, \
+                       slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
+                       slots_uniform, skip, nbuf, mins, cap_min, labels32)
+    if (signd) { if (dedupe) TK_LAUNCH(true, true); else TK_LAUNCH(true, false); }
+    else { if (dedupe) TK_LAUNCH(false, true); else TK_LAUNCH(false, false); }
+#undef TK_LAUNCH
     return 0;
 }
 

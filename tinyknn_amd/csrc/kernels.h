@@ -78,11 +78,15 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 // skip (nq bytes or NULL): queries to leave untouched.  mins: (nq, cap_min) per-block
 // minima written by the scan kernels, cap_min a multiple of 16.
 #define TK_LANES_MAX_R 574
+// with labels32 (labels may repeat: duplicate test on 32-bit label slots + uint8
+// label-hash counters) the LDS budget is (2R+2)*256 + 16 KiB + 16 KiB and R <= 255
+#define TK_LANES_MAX_R_DEDUPE 232
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, const unsigned char *skip,
-                                const uint8_t *mins, int64_t cap_min, hipStream_t s);
+                                const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
+                                hipStream_t s);
 
 // Wave-per-query replay on packed 32-bit entries from FRESH heaps (R*4 B of LDS, or
 // R*12 with `dedupe`: int64 labels per slot + the reference's duplicate-label test,
