@@ -35,20 +35,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def synth(n, nq, d, seed, n_centres=300, sigma=0.7):
+def synth(n, nq, d, seed, n_centres=300, sigma=0.7, kind="glove-like"):
     rng = np.random.RandomState(seed)
     cent = rng.randn(n_centres, d)
     X = np.empty((n, d), dtype=np.float32)
     step = 200000
     for i in range(0, n, step):
         m = min(step, n - i)
-        X[i:i + m] = cent[rng.randint(n_centres, size=m)] + sigma * rng.randn(m, d)
+        if kind == "sift-like":      # SURVEY §8d C3 stand-in
+            X[i:i + m] = np.clip(np.abs(rng.randn(m, d)) * 40, 0, 218).round()
+        else:
+            X[i:i + m] = cent[rng.randint(n_centres, size=m)] + sigma * rng.randn(m, d)
     return X, cent
 
 
-def synth_queries(cent, nq, seed, sigma=0.7):
+def synth_queries(cent, nq, seed, sigma=0.7, kind="glove-like"):
     rng = np.random.RandomState(seed)
     d = cent.shape[1]
+    if kind == "sift-like":
+        return np.clip(np.abs(rng.randn(nq, d)) * 40, 0, 218).round().astype(np.float32)
     return (cent[rng.randint(len(cent), size=nq)] + sigma * rng.randn(nq, d)).astype(np.float32)
 
 
@@ -79,14 +84,16 @@ def build_index(args, device):
     driver runs N = 1, 2, 4, 8 back to back on one box."""
     from tinyknn_amd import IVF, FastPQ
     from tinyknn_amd.fast_pq import TransformedData
-    tag = f"n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}_b{args.build_probes}"
+    tag = f"n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}_b{args.build_probes}_{args.metric}_{args.data}"
     cache = os.path.join(args.cache_dir, f"tinyknn_bench_{tag}.npz")
-    X, cent = synth(args.n, 0, args.d, args.seed)
-    ivf = IVF("angular", args.n_clusters, FastPQ(2))
+    X, cent = synth(args.n, 0, args.d, args.seed, kind=args.data)
+    ang = args.metric == "angular"
+    ivf = IVF(args.metric, args.n_clusters, FastPQ(2))
     if os.path.exists(cache):
         z = np.load(cache)
         ivf.pq.centers = z["pq_centers"]
         ivf.pq.sqrt_n_blocks = float(z["sqrt_n_blocks"])
+        ivf.pq.R = z["R"] if "R" in z else None
         ivf.active_centers = z["active_centers"]
         ivf.pq_transformed_centers = TransformedData(int(z["center_size"]), z["center_codes"])
         sizes = z["list_sizes"]
@@ -95,22 +102,24 @@ def build_index(args, device):
         ivf.pq_transformed_points = [TransformedData(int(sizes[i]), z["list_codes"][coff[i]:coff[i + 1]])
                                      for i in range(len(sizes))]
         ivf.ids = [z["ids"][ioff[i]:ioff[i + 1]] for i in range(len(sizes))]
-        ivf.data = X / np.linalg.norm(X, axis=1, keepdims=True)
+        ivf.data = X / np.linalg.norm(X, axis=1, keepdims=True) if ang else X
         log(f"[bench] index loaded from {cache}")
         return ivf, cent
     t0 = time.time()
     rng = np.random.RandomState(args.seed + 1)
     sample = X[rng.choice(len(X), min(len(X), args.fit_sample), replace=False)]
-    sample = sample / np.linalg.norm(sample, axis=1, keepdims=True)
+    if ang:
+        sample = sample / np.linalg.norm(sample, axis=1, keepdims=True)
     C = quick_kmeans(sample, args.n_clusters, 8, args.seed, device)
-    ivf.all_centers = C / np.linalg.norm(C, axis=1, keepdims=True)       # ivf.py:38-45
+    ivf.all_centers = C / np.linalg.norm(C, axis=1, keepdims=True) if ang else C   # ivf.py:36-45
     ivf.pq.fit(sample[:min(len(sample), 30000)])
     log(f"[bench] fit done in {time.time() - t0:.1f}s")
     ivf.build(X, n_probes=args.build_probes)
     log(f"[bench] build done in {time.time() - t0:.1f}s")
     L = len(ivf.active_centers)
     try:
-        np.savez(cache, pq_centers=ivf.pq.centers, sqrt_n_blocks=ivf.pq.sqrt_n_blocks,
+        extra = {} if ivf.pq.R is None else {"R": ivf.pq.R}
+        np.savez(cache, pq_centers=ivf.pq.centers, sqrt_n_blocks=ivf.pq.sqrt_n_blocks, **extra,
                  active_centers=ivf.active_centers, center_size=ivf.pq_transformed_centers.size,
                  center_codes=ivf.pq_transformed_centers.packed,
                  list_sizes=np.array([ivf.pq_transformed_points[i].size for i in range(L)], np.int64),
@@ -150,6 +159,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--build-probes", type=int, default=1, help="lists per point (ivf.py:53)")
+    ap.add_argument("--metric", choices=["angular", "euclidean"], default="angular")
+    ap.add_argument("--data", choices=["glove-like", "sift-like"], default="glove-like",
+                    help="synthetic stand-in: Gaussian clusters, or |N(0,1)|*40 clipped to [0,218]")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (tk_index_set_pipeline)")
@@ -157,6 +169,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    ang = args.metric == "angular"
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -183,10 +196,11 @@ def main():
     M = ivf.pq.centers.shape[1] // 2
 
     # -- this rank's batch, normalised on the host exactly like ivf.py:125-127
-    qs = synth_queries(cent, args.nq, args.seed + 100 + rank)
+    qs = synth_queries(cent, args.nq, args.seed + 100 + rank, kind=args.data)
     qn, qp = ivf._prepare(qs.copy())
+    qp_is_f64 = qp.dtype != np.float32      # rotated PQ: float64 table-build queries
     q_dev = torch.from_numpy(qn).to(device)
-    qp_dev = torch.from_numpy(np.ascontiguousarray(qp, dtype=np.float32)).to(device)
+    qp_dev = torch.from_numpy(np.ascontiguousarray(qp)).to(device)
     out_dev = torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)
     stream = torch.cuda.current_stream().cuda_stream
     dev.set_pipeline(args.pipeline)
@@ -195,7 +209,7 @@ def main():
     dev.set_scan_mode(args.scan_mode)
 
     def step():
-        dev.query_batch_dev(q_dev.data_ptr(), qp_dev.data_ptr(), False, args.nq, args.k,
+        dev.query_batch_dev(q_dev.data_ptr(), qp_dev.data_ptr(), qp_is_f64, args.nq, args.k,
                             args.n_probes, out_dev.data_ptr(), stream=stream)
 
     for _ in range(args.warmup):
@@ -251,6 +265,8 @@ def main():
     rs = min(args.recall_sample, args.nq)
     data_t = torch.from_numpy(ivf.data).to(device)
     sims = q_dev[:rs] @ data_t.T
+    if not ang:   # squared euclidean: smallest |x|^2 - 2 q.x
+        sims = 2 * sims - (data_t * data_t).sum(1)[None]
     truth = sims.topk(args.k, dim=1).indices.cpu().numpy()
     recall = float(np.mean([len(set(truth[i]) & set(got[i])) / args.k for i in range(rs)]))
     del data_t, sims
@@ -271,12 +287,17 @@ def main():
         parity = {"queries_checked": cs, "identical_rows": int((want == got[:cs]).all(axis=1).sum())}
 
     line = {
-        "metric": "queries/sec at Recall10@10 on GloVe-100 angular (synthetic stand-in), IVF+4-bit PQ",
+        "metric": "queries/sec at Recall10@10 on GloVe-100 angular (synthetic stand-in), IVF+4-bit PQ"
+                  if (args.data, args.metric, args.d) == ("glove-like", "angular", 100) else
+                  f"queries/sec at Recall10@10, {args.data} {args.metric} d={args.d} (synthetic), IVF+4-bit PQ",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8 (saturating PQ sums) + f32 (tables, rescoring)", "data": "synthetic",
-        "config": {"workload": "glove-100-angular stand-in: 300 Gaussian clusters sigma 0.7, "
+        "config": {"workload": (f"{args.data} {args.metric} stand-in "
+                                "(glove-like: 300 Gaussian clusters sigma 0.7; sift-like: |N(0,1)|*40 clipped): "
+                                if (args.data, args.metric) != ("glove-like", "angular") else
+                                "glove-100-angular stand-in: 300 Gaussian clusters sigma 0.7, ") +
                                f"N={args.n} d={args.d} IVF n_clusters={args.n_clusters} "
                                f"build_probes={args.build_probes} FastPQ dpb=2 M={M}",
                    "queries_per_step_per_gpu": args.nq, "k": args.k, "n_probes": args.n_probes,
