@@ -9,7 +9,20 @@
 // start, inserts EVERY passing lane without re-checking, and refreshes the bound
 // once per block.  `insert` drops a label that is already present anywhere and
 // otherwise replaces the root and sifts down (left child unless the right one is
-// strictly greater).  This file replays exactly that, one wavefront per query:
+// strictly greater).  This file replays exactly that from the int8 distances the scan
+// kernels wrote.  Three kernels, all bit-exact (tests compare heap arrays, layout
+// included, with the compiled reference):
+//
+//   heap_replay_lanes_kernel   one query per LANE (64 per wave), packed 32-bit entries
+//                              in LDS columns, LDS-DMA staged distance blocks, block
+//                              minima, top heap levels in registers; fresh heaps only;
+//                              with DEDUPE also labels that can repeat.  The batch path.
+//   heap_replay_packed_kernel  one query per WAVE on the same packed entries (heaps too
+//                              big for the lane kernel's LDS budget).
+//   heap_replay_kernel         the general form below: int64 labels, arbitrary incoming
+//                              heaps (tk_query_pq continues whatever the caller passes).
+//
+// The general kernel, one wavefront per query:
 //
 //   * the int8 distances were produced by adc_scan.hip (16 per chunk);
 //   * a step covers 64 blocks (1024 codes): lane b holds block b's 16 bytes and
