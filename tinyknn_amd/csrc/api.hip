@@ -756,11 +756,21 @@ static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
 
 static const int64_t MAX_SUB = 32768;  // gridDim.y limit of the scan kernels is 65535
 
+// Queries per sub-batch: the distance buffer is nq * cap * 17 bytes (16 int8 + 1 minimum
+// per chunk, cap = n_probes * longest list); keep it under ~4 GiB per workspace.
+static int64_t sub_batch(const Plan &p)
+{
+    int64_t s = (int64_t)(4.0e9 / ((double)p.cap * 17.0));
+    s = s < 64 ? 64 : s;
+    return s < MAX_SUB ? s : MAX_SUB;
+}
+
 extern "C" int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, int pass_1)
 {
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
-    for (Work &w : ix->works) TRY(reserve(ix, w, nq < MAX_SUB ? nq : MAX_SUB, k, p));
+    const int64_t ms = sub_batch(p);
+    for (Work &w : ix->works) TRY(reserve(ix, w, nq < ms ? nq : ms, k, p));
     return TK_OK;
 }
 
@@ -947,8 +957,9 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
     ARGCHECK(nq >= 0, "nq");
     hipStream_t caller = (hipStream_t)stream;
     const size_t esz = q_pq_is_f64 ? 8 : 4;
-    for (int64_t o = 0; o < nq; o += MAX_SUB) {
-        int64_t sub = nq - o < MAX_SUB ? nq - o : MAX_SUB;
+    const int64_t ms = sub_batch(p);
+    for (int64_t o = 0; o < nq; o += ms) {
+        int64_t sub = nq - o < ms ? nq - o : ms;
         Work &w = ix->works[ix->calls % (uint64_t)ix->depth];
         ix->calls++;
         hipStream_t st = caller;
@@ -1003,8 +1014,8 @@ extern "C" int tk_index_query_batch(tk_index *ix, const float *q, const void *q_
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     ARGCHECK(nq >= 0, "nq");
     if (nq == 0) return TK_OK;
-    ARGCHECK(!(out_probes || out_heap_idx || out_heap_val) || nq <= MAX_SUB,
-             "debug outputs need nq <= 32768");
+    ARGCHECK(!(out_probes || out_heap_idx || out_heap_val) || nq <= sub_batch(p),
+             "debug outputs need the batch to fit one sub-batch");
     const size_t esz = q_pq_is_f64 ? 8 : 4;
     TRY(ix->q.ensure((size_t)nq * ix->d * 4));
     TRY(ix->qpq.ensure((size_t)nq * ix->dq * esz));
