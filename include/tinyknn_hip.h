@@ -199,6 +199,41 @@ int tk_index_set_scan_mode(tk_index *ix, int mode);
 int tk_index_set_profiling(tk_index *ix, int on);
 int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches);
 
+/* ---- list-sharded index over `world` ranks, one process per GPU --------
+ * The inverted lists (ivf.py:100-102) are partitioned by cluster id: owner[l] is the rank
+ * that stores list l's packed codes.  PQ, coarse centres, ids and the rescoring vectors are
+ * replicated (set_pq / set_centers / set_data as usual), so every rank derives the same
+ * probe order without communication.  tk_index_set_lists_shard replaces tk_index_set_lists:
+ * list_sizes and ids describe ALL lists, codes_owned only the lists with owner[l] == rank,
+ * concatenated in list order.
+ *
+ * The reference chains all probed lists of a query through ONE order-dependent heap
+ * (ivf.py:137-150), so partial top-k's do not merge; the exchange carries the int8 distance
+ * bytes to the query's home rank (query i lives on rank i / ceil(nq/world)), which replays
+ * the heap exactly as the unsharded index does.  One batch =
+ *   tk_index_shard_scan_dev    tables + coarse stage for all nq queries, then the owned
+ *                              (query, list) segments scored straight into `send_dev`:
+ *                              `world` regions of `capacity` uint4 (16 distances each),
+ *                              region h = my segments of rank h's queries, in (query,
+ *                              probe slot) order; *flag_dev |= 1 if a region overflowed
+ *                              (repeat the batch with a larger capacity);
+ *   all-to-all(send -> recv)   equal splits of capacity*16 bytes (RCCL, by the caller);
+ *   tk_index_shard_finish_dev  received segments -> distance rows of the home queries,
+ *                              heap replay, rescoring; out_ids_home_dev: int64
+ *                              (ceil(nq/world), k), rows past nq and missing ids = -1;
+ *   all-gather of the id rows  (by the caller).
+ * Both calls enqueue on `stream` and use workspace `slot` (< pipeline depth), so that
+ * several batches can be in flight on different streams.  nq <= 32768 per batch. */
+int tk_index_set_lists_shard(tk_index *ix, const int64_t *list_sizes, const int32_t *owner,
+                             int rank, int world, const uint64_t *codes_owned,
+                             const int64_t *ids);
+int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
+                            int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                            int64_t capacity, void *send_dev, int *flag_dev, void *stream);
+int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq, int k,
+                              int n_probes, int pass_1, int64_t capacity, const void *recv_dev,
+                              int64_t *out_ids_home_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

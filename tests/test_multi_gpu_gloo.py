@@ -53,6 +53,82 @@ def test_replica_group_two_ranks(nq):
         np.testing.assert_array_equal(ret[r], exp)
 
 
+def _shard_worker(rank, world, port, tag, nq, k, n_probes, tiny, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import golden
+        from test_oracle_golden import load_oracle_index
+        from shard_cpu_engine import OracleShardEngine
+        from oracle import oracle as O
+        from tinyknn_amd.multi_gpu import ListShardedIndex, shard_lists
+        g = golden(f"g6_ivf_{tag}.npz")
+        ox = load_oracle_index(O, g)
+
+        class HostSide:
+            def _prepare(self, qs):
+                return qs, ox.pq_query(qs)
+
+        owner = shard_lists(g["list_sizes"], world)
+        eng = OracleShardEngine(O, ox, owner, rank, world)
+        idx = ListShardedIndex(HostSide(), engine=eng, owner=owner, list_sizes=g["list_sizes"])
+        if tiny:
+            idx.capacity[(nq, n_probes)] = 3      # overflows: the batch must be repeated
+        out = idx.query_batch(g["qn"][:nq], k, n_probes)
+        ret[rank] = (out, idx.capacity[(nq, n_probes)])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nq,tiny", [(2, 24, False), (2, 7, True), (3, 24, False), (2, 1, False)])
+def test_list_sharded_index_gloo(world, nq, tiny):
+    """Lists sharded by cluster id over `world` gloo ranks: the all-to-all carries every
+    segment to the right place of the right home rank (checked byte for byte by the CPU
+    engine), overflow repeats the batch, ids equal the reference's on every rank."""
+    import torch.multiprocessing as mp
+    from conftest import golden
+    tag, k, n_probes = "an100", 10, 5
+    port = 31500 + (os.getpid() * 7 + nq + world) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, port, tag, nq, k, n_probes, tiny, ret), nprocs=world,
+             join=True)
+    g = golden(f"g6_ivf_{tag}.npz")
+    exp = g[f"ids_p{n_probes}"][:nq]
+    for r in range(world):
+        np.testing.assert_array_equal(ret[r][0], exp)
+        assert not tiny or ret[r][1] > 3
+
+
+def test_shard_lists_and_capacity():
+    from tinyknn_amd.multi_gpu import shard_capacity, shard_lists, shard_positions
+    rng = np.random.RandomState(3)
+    sizes = rng.randint(0, 4000, size=300)
+    chunks = (sizes + 15) // 16
+    for world in (1, 2, 8):
+        owner = shard_lists(sizes, world)
+        load = np.bincount(owner, weights=chunks, minlength=world)
+        assert load.max() - load.min() <= chunks.max()
+        np.testing.assert_array_equal(owner, shard_lists(sizes, world))    # deterministic
+        cap = shard_capacity(sizes, owner, world, 1000, 10)
+        assert 1 <= cap <= -(-1000 // world) * 10 * chunks.max()
+        # size-biased random probes fit the default capacity
+        probes = rng.choice(300, size=(1000, 10), p=chunks / chunks.sum())
+        src, pos = shard_positions(probes, chunks, owner, world, cap)
+        assert (pos >= 0).all()
+        # segments of one (source, home) stream tile its region without gaps or overlap
+        qh = -(-1000 // world)
+        for h in range(world):
+            for s in range(world):
+                m = src[h * qh:(h + 1) * qh] == s
+                st = pos[h * qh:(h + 1) * qh][m]
+                ln = chunks[probes[h * qh:(h + 1) * qh]][m]
+                np.testing.assert_array_equal(st, np.cumsum(ln) - ln)
+
+
 def test_shard_bounds():
     from tinyknn_amd.multi_gpu import shard_bounds
     for nq in (0, 1, 7, 8, 10000):

@@ -1,0 +1,153 @@
+"""List-sharded index on the MI355X.  A 1-GPU box cannot run W RCCL ranks,
+so the W ranks are (a) simulated in one process — W shard handles on the same device,
+the all-to-all done by hand on the region layout the C ABI documents — and (b) run as two
+gloo processes sharing the GPU (collectives staged through the host).  Either way the ids
+must equal the unsharded index's, the golden fixtures' and the oracle's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import G6_TAGS, golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, owner=None):
+    """-> (ids (nq, k), overflow flags (world,), capacity)"""
+    import torch
+    from tinyknn_amd.multi_gpu import _HipShardEngine, shard_capacity, shard_lists
+    L = ivf.active_centers.shape[0]
+    sizes = np.array([0 if isinstance(t, np.ndarray) else t.size
+                      for t in ivf.pq_transformed_points[:L]], dtype=np.int64)
+    if owner is None:
+        owner = shard_lists(sizes, world)
+    nq = len(qn)
+    if capacity is None:
+        capacity = shard_capacity(sizes, owner, world, nq, n_probes)
+    qh = -(-nq // world)
+    qn_t = torch.from_numpy(np.ascontiguousarray(qn, dtype=np.float32)).cuda()
+    qp_t = torch.from_numpy(np.ascontiguousarray(qp)).cuda()
+    engines = [_HipShardEngine(ivf, owner, r, world, 1) for r in range(world)]
+    sends = [torch.full((world, capacity * 16), 0xAB, dtype=torch.uint8, device="cuda")
+             for _ in range(world)]
+    flags = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(world)]
+    for r, e in enumerate(engines):
+        e.scan(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r])
+    homes = []
+    for h, e in enumerate(engines):
+        recv = torch.stack([sends[s][h] for s in range(world)]).contiguous()   # all-to-all
+        out = torch.zeros(qh * k, dtype=torch.int64, device="cuda")
+        e.finish(0, qn_t, k, n_probes, pass_1, capacity, recv, out)
+        homes.append(out.view(qh, k))
+    torch.cuda.synchronize()
+    ids = torch.cat(homes).cpu().numpy()
+    assert (ids[nq:] == -1).all()
+    for e in engines:
+        e.dev.close()
+    return ids[:nq], np.array([int(f.item()) for f in flags]), capacity
+
+
+@pytest.mark.parametrize("tag", G6_TAGS)
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_golden(tag, world):
+    from test_hip_parity import ivf_from_fixture
+    g = golden(f"g6_ivf_{tag}.npz")
+    ivf = ivf_from_fixture(None, g)
+    for n_probes in g["probes_list"]:
+        n_probes = int(n_probes)
+        ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes)
+        assert not flags.any()
+        np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+
+
+def test_sharded_overflow_is_flagged_and_harmless():
+    """A region that is too small raises the flag on the ranks involved and nothing is
+    written out of bounds; the exact capacity (largest stream) passes."""
+    from test_hip_parity import ivf_from_fixture
+    from tinyknn_amd.multi_gpu import shard_lists, shard_positions
+    g = golden("g6_ivf_an100.npz")
+    ivf = ivf_from_fixture(None, g)
+    world, n_probes = 2, 5
+    ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, capacity=4)
+    assert flags.any()
+    owner = shard_lists(g["list_sizes"], world)
+    chunks = (g["list_sizes"] + 15) // 16
+    probes = g[f"probes_p{n_probes}"].copy()
+    probes[probes < 0] += len(chunks)
+    src, pos = shard_positions(probes, chunks, owner, world, 10 ** 9)
+    exact = int((pos + chunks[probes]).max())
+    ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, capacity=exact)
+    assert not flags.any()
+    np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+    _, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, capacity=exact - 1)
+    assert flags.any()
+
+
+@pytest.mark.parametrize("build_probes,world", [(1, 4), (2, 3), (1, 8)])
+def test_sharded_vs_unsharded_larger(oracle, build_probes, world):
+    """60k x 100 angular index, 1003 queries (not a multiple of the world size): the sharded
+    pipeline returns the ids of the unsharded one (itself pinned to the oracle), for distinct
+    (lane replay) and repeating labels (duplicate test); a sample is checked against the
+    oracle directly."""
+    from tinyknn_amd import IVF, FastPQ
+    from test_hip_parity import _oracle_index
+    np.random.seed(10)
+    n, d, nq = 60000, 100, 1003
+    cent = np.random.randn(300, d)
+    X = (cent[np.random.randint(300, size=n)] + 0.7 * np.random.randn(n, d)).astype(np.float32)
+    qs = (cent[np.random.randint(300, size=nq)] + 0.7 * np.random.randn(nq, d)).astype(np.float32)
+    ivf = IVF("angular", 244, FastPQ(2))
+    ivf.fit(X[:20000]).build(X, n_probes=build_probes)
+    qn, qp = ivf._prepare(qs.copy())
+    ox = _oracle_index(oracle, ivf)
+    for n_probes in (1, 10, 30):
+        want = ivf.device_index().query_batch(qn, qp, 10, n_probes)
+        ids, flags, cap = simulate_world(ivf, world, qn, qp, 10, n_probes)
+        assert not flags.any(), f"default capacity {cap} overflowed"
+        np.testing.assert_array_equal(ids, want)
+        np.testing.assert_array_equal(ids[:60], ox.query_batch(qn[:60], 10, n_probes))
+
+
+def test_sharded_world1_public_class():
+    """ListShardedIndex without a process group: the all-to-all is a copy."""
+    from test_hip_parity import ivf_from_fixture
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+    g = golden("g6_ivf_eu128.npz")
+    ivf = ivf_from_fixture(None, g)
+    idx = ListShardedIndex(ivf)
+    np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=5), g["ids_p5"])
+    idx.capacity[(len(g["qs"]), 10)] = 2           # overflow -> repeated with more room
+    np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=10), g["ids_p10"])
+    assert idx.capacity[(len(g["qs"]), 10)] > 2
+
+
+def _gloo_gpu_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_hip_parity import ivf_from_fixture
+        from tinyknn_amd.multi_gpu import ListShardedIndex
+        g = golden("g6_ivf_an100b2.npz")
+        ivf = ivf_from_fixture(None, g)
+        idx = ListShardedIndex(ivf, depth=2)
+        ret[rank] = {p: idx.query_batch(g["qs"], 10, n_probes=p) for p in (1, 5, 10)}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_two_processes_one_gpu():
+    import torch.multiprocessing as mp
+    port = 33500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gloo_gpu_worker, args=(2, port, ret), nprocs=2, join=True)
+    g = golden("g6_ivf_an100b2.npz")
+    for r in range(2):
+        for p in (1, 5, 10):
+            np.testing.assert_array_equal(ret[r][p], g[f"ids_p{p}"])

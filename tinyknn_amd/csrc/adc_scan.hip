@@ -529,6 +529,13 @@ void tk_launch_unit_pairs(int64_t nq, const int64_t *probes, int S, int64_t n_li
                        probes, S, nq, n_lists, slot_prefix, pair_off, cursor, pair_q, pair_f0);
 }
 
+void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_lists, int *pair_off,
+                          int *unit_prefix, int *cursor, int *pair_q, hipStream_t s)
+{
+    hipLaunchKernelGGL(pairs_scan_kernel, dim3(1), dim3(1024), 0, s, count, list_chunk_off,
+                       (int)n_lists, pair_off, unit_prefix, cursor, pair_q);
+}
+
 // Descriptors for "every query scans the one list" (the coarse stage): records are
 // the queries themselves, padded to a multiple of 4.
 __global__ void pairs_identity_kernel(int64_t nq, int chunks, int *__restrict__ pair_off,

@@ -468,7 +468,7 @@ struct Work {
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
-        c_pair_f0;
+        c_pair_f0, spos, rpos;
     hipStream_t stream = nullptr;   // only used when the pipeline depth is > 1
     hipEvent_t done = nullptr;
     void release()
@@ -476,7 +476,8 @@ struct Work {
         DevBuf *b[] = {&tables, &shift, &scale, &cdist, &cheap_idx, &cheap_val, &probes,
                        &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
-                       &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0};
+                       &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
+                       &spos, &rpos};
         for (DevBuf *x : b) x->release();
         if (stream) (void)hipStreamDestroy(stream);
         if (done) (void)hipEventDestroy(done);
@@ -502,6 +503,12 @@ struct tk_index {
     bool ids_unique = false;   // no label occurs twice => the lane-per-query replay is exact
     int heap_mode = 0;         // 0 auto (lanes, else packed wave), 1 general wave, 2 packed wave
     bool have_pq = false, have_centers = false, have_lists = false, have_data = false;
+    // list-sharded index: this rank stores the codes of the lists it owns;
+    // list_chunk_off stays the GLOBAL layout (every rank derives the same distance rows),
+    // local_chunk_off addresses this rank's code storage (lists of other ranks: empty)
+    DevBuf owner, local_chunk_off;
+    int rank = 0, world = 1;
+    bool sharded = false;
     // vectors
     DevBuf data;
     int64_t N = 0;
@@ -538,7 +545,8 @@ extern "C" void tk_index_destroy(tk_index *ix)
     if (!ix) return;
     DevBuf *bufs[] = {&ix->pq_centers, &ix->active_centers, &ix->center_codes, &ix->list_chunk_off,
                       &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->ids32, &ix->data, &ix->cslots_i,
-                      &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage};
+                      &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage, &ix->owner,
+                      &ix->local_chunk_off};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
     if (ix->ev_in) (void)hipEventDestroy(ix->ev_in);
@@ -602,17 +610,21 @@ extern "C" int tk_index_set_centers(tk_index *ix, const float *active_centers, i
     return TK_OK;
 }
 
-extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const uint64_t *codes,
-                                  const int64_t *ids)
+// `owner` == NULL: the whole index; otherwise `codes` holds only the lists with
+// owner[l] == rank, concatenated in list order
+static int set_lists_impl(tk_index *ix, const int64_t *list_sizes, const uint64_t *codes,
+                          const int64_t *ids, const int32_t *owner, int rank, int world)
 {
     ARGCHECK(ix && ix->have_centers, "set_centers first");
     const int64_t L = ix->n_lists;
-    std::vector<int64_t> coff(L + 1, 0), ioff(L + 1, 0);
+    std::vector<int64_t> coff(L + 1, 0), ioff(L + 1, 0), loff(L + 1, 0);
     int64_t maxc = 0;
     for (int64_t i = 0; i < L; i++) {
         ARGCHECK(list_sizes[i] >= 0, "negative list size");
+        ARGCHECK(!owner || (owner[i] >= 0 && owner[i] < world), "owner out of range");
         int64_t c = (list_sizes[i] + 15) / 16;
         coff[i + 1] = coff[i] + c;
+        loff[i + 1] = loff[i] + ((!owner || owner[i] == rank) ? c : 0);
         ioff[i + 1] = ioff[i] + list_sizes[i];
         if (c > maxc) maxc = c;
     }
@@ -641,7 +653,17 @@ extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const
         }
         ix->ids_unique = uniq;
     }
-    TRY(upload_tiled(ix->codes, ix->stage, codes, coff[L], ix->M));
+    TRY(upload_tiled(ix->codes, ix->stage, codes, loff[L], ix->M));
+    ix->sharded = owner != nullptr;
+    ix->rank = owner ? rank : 0;
+    ix->world = owner ? world : 1;
+    if (owner) {
+        TRY(ix->owner.ensure((size_t)L * 4));
+        TRY(ix->local_chunk_off.ensure((size_t)(L + 1) * 8));
+        HIPCHECK(hipMemcpy(ix->owner.p, owner, (size_t)L * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(ix->local_chunk_off.p, loff.data(), (size_t)(L + 1) * 8,
+                           hipMemcpyHostToDevice));
+    }
     TRY(ix->list_chunk_off.ensure((size_t)(L + 1) * 8));
     TRY(ix->ids_off.ensure((size_t)(L + 1) * 8));
     TRY(ix->list_n.ensure((size_t)L * 8));
@@ -668,6 +690,21 @@ extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const
     ix->max_list_chunks = (int)maxc;
     ix->have_lists = true;
     return TK_OK;
+}
+
+extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const uint64_t *codes,
+                                  const int64_t *ids)
+{
+    return set_lists_impl(ix, list_sizes, codes, ids, nullptr, 0, 1);
+}
+
+extern "C" int tk_index_set_lists_shard(tk_index *ix, const int64_t *list_sizes,
+                                        const int32_t *owner, int rank, int world,
+                                        const uint64_t *codes_owned, const int64_t *ids)
+{
+    ARGCHECK(owner, "owner");
+    ARGCHECK(world >= 1 && rank >= 0 && rank < world, "rank/world");
+    return set_lists_impl(ix, list_sizes, codes_owned, ids, owner, rank, world);
 }
 
 extern "C" int tk_index_set_data(tk_index *ix, const void *data, int data_is_f64, int64_t N,
@@ -774,37 +811,57 @@ extern "C" int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, i
     return TK_OK;
 }
 
-// one sub-batch, everything on device
-static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_dev, int qpq_f64, int64_t nq,
-                     int k, const Plan &p, int64_t *out_dev, hipStream_t st)
+// stage timers of one batch (tk_index_set_profiling)
+struct Prof {
+    hipEvent_t *ev = nullptr;
+    int evi = 0;
+    int mark(hipStream_t st)
+    {
+        if (ev) HIPCHECK(hipEventRecord(ev[evi++], st));
+        return TK_OK;
+    }
+};
+
+static int prof_begin(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st, Prof &pf)
+{
+    if (ix->profiling == 0 || ix->ev_used >= 4096) return TK_OK;
+    while (ix->evs.size() < (ix->ev_used + 1) * 8) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreate(&e));
+        ix->evs.push_back(e);
+    }
+    pf.ev = &ix->evs[ix->ev_used * 8];
+    if (ix->ev_streams.size() <= ix->ev_used) ix->ev_streams.resize(ix->ev_used + 1);
+    ix->ev_streams[ix->ev_used] = st;
+    ix->ev_used++;
+    ix->last_S = p.S; ix->last_R = p.R; ix->last_nq = nq;
+    ix->last_work = (int)(&w - &ix->works[0]);
+    return TK_OK;
+}
+
+// list-major scan (4 queries per pass over a chunk) when lists are shared by enough
+// queries and the unit count fits int32; otherwise one query per wave
+static bool use_units(const tk_index *ix, int64_t nq, const Plan &p)
+{
+    return ix->scan_mode == 2 ||
+           (ix->scan_mode == 0 && nq * p.S >= 8 * ix->n_lists &&
+            (double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9);
+}
+
+// Stages 1-2 of a batch: tables, coarse stage, probe lists, per-slot descriptors.
+// `pair_count`: per-list (query, slot) pair counters for the list-major scan (or NULL);
+// with `owner` only the lists owned by `me` are counted (list-sharded index).
+static int stage_front(tk_index *ix, Work &w, const float *q_dev, const void *qpq_dev, int qpq_f64,
+                       int64_t nq, const Plan &p, int *pair_count, const int *owner, int me,
+                       hipStream_t st, Prof &pf)
 {
     const int M = ix->M;
-    const bool prof = ix->profiling != 0 && ix->ev_used < 4096;
-    hipEvent_t *ev = nullptr;
-    if (prof) {
-        while (ix->evs.size() < (ix->ev_used + 1) * 8) {
-            hipEvent_t e;
-            HIPCHECK(hipEventCreate(&e));
-            ix->evs.push_back(e);
-        }
-        ev = &ix->evs[ix->ev_used * 8];
-        if (ix->ev_streams.size() <= ix->ev_used) ix->ev_streams.resize(ix->ev_used + 1);
-        ix->ev_streams[ix->ev_used] = st;
-        ix->ev_used++;
-        ix->last_S = p.S; ix->last_R = p.R; ix->last_nq = nq;
-        ix->last_work = (int)(&w - &ix->works[0]);
-    }
-    int evi = 0;
-#define MARK()                                                 \
-    do {                                                       \
-        if (prof) HIPCHECK(hipEventRecord(ev[evi++], st));     \
-    } while (0)
-    MARK();
+    TRY(pf.mark(st));
     // 1. distance tables                                   fast_pq.py:186-222
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
                            qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>(), w.shift.p,
                            w.scale.as<double>(), st);
-    MARK();
+    TRY(pf.mark(st));
     // 2. coarse stage = dtable.top(centers)                 ivf.py:131, fast_pq.py:284-312
     const bool cunits = ix->scan_mode != 1 && nq >= 16 &&
                         (double)nq / 4 * ix->center_chunks < 2.0e9;
@@ -823,7 +880,7 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                             w.tables.as<uint4>(), nq, w.cdist.as<uint4>(), ix->center_chunks,
                             w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, st);
     }
-    MARK();
+    TRY(pf.mark(st));
     // positions of one list against a fresh heap are distinct labels: lane-per-query
     const bool fast_c = ix->heap_mode != 1 && ix->center_chunks * 16 <= 0xffffff;
     const bool lanes_c = fast_c && ix->heap_mode == 0 && p.rescore <= TK_LANES_MAX_R;
@@ -849,12 +906,7 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                               ix->cslots_l.as<int64_t>(), 1, nullptr, w.cheap_idx.as<int64_t>(),
                               w.cheap_val.as<int32_t>(), p.rescore, 1, 1, nullptr, st);
     }
-    MARK();
-    // list-major scan (4 queries per pass over a chunk) when lists are shared by enough
-    // queries and the unit count fits int32; otherwise one query per wave
-    const bool units = ix->scan_mode == 2 ||
-                       (ix->scan_mode == 0 && nq * p.S >= 8 * ix->n_lists &&
-                        (double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9);
+    TRY(pf.mark(st));
     tk_launch_rescore(q_dev, 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
                       w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0,
                       w.probes.as<int64_t>(), nullptr, st);
@@ -863,7 +915,77 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                          ix->ids_off.as<int64_t>(), w.slot_prefix.as<int>(),
                          w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
                          w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(),
-                         units ? w.u_count.as<int>() : nullptr, st);
+                         pair_count, owner, me, st);
+    return TK_OK;
+}
+
+// Stages 3b-4: the heap replay over the distance rows of queries [q0, q0 + nq) of the
+// batch's slot arrays (dist/mins/heaps: `nq` rows starting at row 0), then the exact
+// rescoring.  q_dev: row 0 = query q0.
+static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq, int k,
+                      const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf)
+{
+    const int *slot_prefix = w.slot_prefix.as<int>() + q0 * (p.S + 1);
+    const int *slot_n = w.slot_n.as<int>() + q0 * p.S;
+    const int64_t *slot_loff = w.slot_loff.as<int64_t>() + q0 * p.S;
+    const unsigned char *repeat_flag = w.repeat_flag.as<unsigned char>() + q0;
+    // heaps start fresh here, so packed entries apply.  Distinct labels: one query per
+    // lane (or per wave for big heaps), and the few queries whose probe list wrapped a -1
+    // (a list may then be scanned twice) re-run with the duplicate test.  Repeating labels
+    // (build n_probes >= 2): the packed wave kernel with the duplicate test for everybody.
+    const bool packed_ok = ix->heap_mode != 1 && p.cap * 16 <= 0xffffff;
+    if (packed_ok && ix->ids_unique) {
+        const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
+        if (!lanes)
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
+                                         slot_loff, p.S, ix->ids.as<int64_t>(),
+                                         w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), p.R,
+                                         1, 0, repeat_flag, 0, 0, st);
+        else if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
+                                             slot_loff, p.S, ix->ids.as<int64_t>(),
+                                             w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
+                                             p.R, 1, 0, repeat_flag, w.mins.as<uint8_t>(),
+                                             p.cap_min, nullptr, st))
+            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
+        tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                     p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                     w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
+    } else if (packed_ok && ix->have_ids32 && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R_DEDUPE) {
+        // repeating labels that fit int32: one query per lane with the duplicate test
+        if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
+                                        slot_loff, p.S, ix->ids.as<int64_t>(),
+                                        w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), p.R, 1,
+                                        0, nullptr, w.mins.as<uint8_t>(), p.cap_min,
+                                        ix->ids32.as<int32_t>(), st))
+            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
+    } else if (packed_ok) {
+        tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                     p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                     w.heap_val.as<int32_t>(), p.R, 1, 0, nullptr, 0, 1, st);
+    } else {
+        tk_launch_heap_fill(w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), nq * p.R, 127, st);
+        tk_launch_heap_replay(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff, p.S,
+                              ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                              w.heap_val.as<int32_t>(), p.R, 1, 0, nullptr, st);
+    }
+    TRY(pf.mark(st));
+    // 4. strip sentinels, exact rescoring                   ivf.py:154-163
+    tk_launch_rescore(q_dev, 0, ix->d, ix->data.p, ix->data_is_f64, ix->N,
+                      w.heap_idx.as<int64_t>(), p.R, nq, k, 1, out_dev, nullptr, st);
+    TRY(pf.mark(st));
+    return TK_OK;
+}
+
+// one sub-batch, everything on device
+static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_dev, int qpq_f64, int64_t nq,
+                     int k, const Plan &p, int64_t *out_dev, hipStream_t st)
+{
+    const int M = ix->M;
+    Prof pf;
+    TRY(prof_begin(ix, w, nq, p, st, pf));
+    const bool units = use_units(ix, nq, p);
+    TRY(stage_front(ix, w, q_dev, qpq_dev, qpq_f64, nq, p, units ? w.u_count.as<int>() : nullptr,
+                    nullptr, 0, st, pf));
     if (units)
         tk_launch_unit_pairs(nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
                              ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
@@ -875,7 +997,7 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
         // batches in flight take turns on the VALU-bound scan: two overlapping scans
         // would only stretch each other; the heap replays are what overlaps
         HIPCHECK(hipStreamWaitEvent(st, ix->ev_scan, 0));
-    MARK();
+    TRY(pf.mark(st));
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
     if (units)
         tk_launch_scan_units(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
@@ -888,62 +1010,12 @@ static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_
                               w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), p.S,
                               (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(),
                               p.cap_min, 1, ix->order, st);
-    MARK();
+    TRY(pf.mark(st));
     if (ix->depth > 1) {
         if (!ix->ev_scan) HIPCHECK(hipEventCreateWithFlags(&ix->ev_scan, hipEventDisableTiming));
         HIPCHECK(hipEventRecord(ix->ev_scan, st));
     }
-    // heaps start fresh here, so packed entries apply.  Distinct labels: one query per
-    // lane (or per wave for big heaps), and the few queries whose probe list wrapped a -1
-    // (a list may then be scanned twice) re-run with the duplicate test.  Repeating labels
-    // (build n_probes >= 2): the packed wave kernel with the duplicate test for everybody.
-    const bool packed_ok = ix->heap_mode != 1 && p.cap * 16 <= 0xffffff;
-    if (packed_ok && ix->ids_unique) {
-        const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
-        if (!lanes)
-            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
-                                         w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
-                                         ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                         w.heap_val.as<int32_t>(), p.R, 1, 0,
-                                         w.repeat_flag.as<unsigned char>(), 0, 0, st);
-        else if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq,
-                                             w.slot_prefix.as<int>(), w.slot_n.as<int>(),
-                                             w.slot_loff.as<int64_t>(), p.S, ix->ids.as<int64_t>(),
-                                             w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
-                                             p.R, 1, 0, w.repeat_flag.as<unsigned char>(),
-                                             w.mins.as<uint8_t>(), p.cap_min, nullptr, st))
-            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
-        tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
-                                     w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
-                                     ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                     w.heap_val.as<int32_t>(), p.R, 1, 0,
-                                     w.repeat_flag.as<unsigned char>(), 1, 1, st);
-    } else if (packed_ok && ix->have_ids32 && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R_DEDUPE) {
-        // repeating labels that fit int32: one query per lane with the duplicate test
-        if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
-                                        w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
-                                        ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                        w.heap_val.as<int32_t>(), p.R, 1, 0, nullptr,
-                                        w.mins.as<uint8_t>(), p.cap_min, ix->ids32.as<int32_t>(), st))
-            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
-    } else if (packed_ok) {
-        tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
-                                     w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
-                                     ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                     w.heap_val.as<int32_t>(), p.R, 1, 0, nullptr, 0, 1, st);
-    } else {
-        tk_launch_heap_fill(w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), nq * p.R, 127, st);
-        tk_launch_heap_replay(w.dist.as<uint4>(), p.cap, nq, w.slot_prefix.as<int>(),
-                              w.slot_n.as<int>(), w.slot_loff.as<int64_t>(), p.S,
-                              ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                              w.heap_val.as<int32_t>(), p.R, 1, 0, nullptr, st);
-    }
-    MARK();
-    // 4. strip sentinels, exact rescoring                   ivf.py:154-163
-    tk_launch_rescore(q_dev, 0, ix->d, ix->data.p, ix->data_is_f64, ix->N,
-                      w.heap_idx.as<int64_t>(), p.R, nq, k, 1, out_dev, nullptr, st);
-    MARK();
-#undef MARK
+    TRY(stage_back(ix, w, q_dev, 0, nq, k, p, out_dev, st, pf));
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
@@ -955,6 +1027,7 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     ARGCHECK(nq >= 0, "nq");
+    ARGCHECK(!ix->sharded, "list-sharded index: use tk_index_shard_scan_dev / _finish_dev");
     hipStream_t caller = (hipStream_t)stream;
     const size_t esz = q_pq_is_f64 ? 8 : 4;
     const int64_t ms = sub_batch(p);
@@ -978,6 +1051,126 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
                       q_pq_is_f64, sub, k, p, out_ids_dev + o * k, st));
         if (ix->depth > 1) HIPCHECK(hipEventRecord(w.done, st));
     }
+    return TK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// list-sharded batch = shard_scan -> all-to-all of the send buffer -> shard_finish
+static int reserve_shard(tk_index *ix, Work &w, int64_t nq, int64_t qh, const Plan &p)
+{
+    const int M = ix->M;
+    TRY(w.tables.ensure((size_t)nq * M * 16));
+    TRY(w.shift.ensure((size_t)nq * 8));
+    TRY(w.scale.ensure((size_t)nq * 8));
+    TRY(w.cdist.ensure((size_t)nq * ix->center_chunks * 16));
+    TRY(w.cheap_idx.ensure((size_t)nq * p.rescore * 8));
+    TRY(w.cheap_val.ensure((size_t)nq * p.rescore * 4));
+    TRY(w.probes.ensure((size_t)nq * p.kc * 8));
+    TRY(w.slot_prefix.ensure((size_t)nq * (p.S + 1) * 4));
+    TRY(w.slot_chunk0.ensure((size_t)nq * p.S * 8));
+    TRY(w.slot_n.ensure((size_t)nq * p.S * 4));
+    TRY(w.slot_loff.ensure((size_t)nq * p.S * 8));
+    TRY(w.repeat_flag.ensure((size_t)nq));
+    TRY(w.cmins.ensure((size_t)nq * p.ccap_min));
+    TRY(w.spos.ensure((size_t)nq * p.S * 4));
+    TRY(w.rpos.ensure((size_t)qh * p.S * 4));
+    // rows of the home queries only
+    TRY(w.dist.ensure((size_t)qh * p.cap * 16));
+    TRY(w.mins.ensure((size_t)qh * p.cap_min));
+    TRY(w.heap_idx.ensure((size_t)qh * p.R * 8));
+    TRY(w.heap_val.ensure((size_t)qh * p.R * 4));
+    const size_t L = (size_t)ix->n_lists;
+    {
+        const void *before = w.u_count.p;
+        TRY(w.u_count.ensure(L * 4));
+        if (w.u_count.p != before) HIPCHECK(hipMemset(w.u_count.p, 0, w.u_count.cap));
+    }
+    TRY(w.u_cursor.ensure(L * 4));
+    TRY(w.u_pair_off.ensure((L + 1) * 4));
+    TRY(w.u_unit_prefix.ensure((L + 1) * 4));
+    TRY(w.u_pair_q.ensure(((size_t)nq * p.S + 4 * L) * 4));
+    TRY(w.u_pair_f0.ensure(((size_t)nq * p.S + 4 * L) * 4));
+    TRY(w.c_pair_off.ensure(8));
+    TRY(w.c_unit_prefix.ensure(8));
+    TRY(w.c_pair_q.ensure(((size_t)nq + 4) * 4));
+    TRY(w.c_pair_f0.ensure(((size_t)nq + 4) * 4));
+    return TK_OK;
+}
+
+static int shard_args(tk_index *ix, int slot, int64_t nq, int64_t capacity, const Plan &p,
+                      int64_t &qh)
+{
+    ARGCHECK(ix->sharded, "not a list-sharded index (tk_index_set_lists_shard)");
+    ARGCHECK(slot >= 0 && slot < ix->depth, "slot must be < the pipeline depth");
+    ARGCHECK(nq >= 1 && nq <= MAX_SUB, "1 <= nq <= 32768 per sharded batch");
+    ARGCHECK(capacity >= 1 && capacity * ix->world < (1ll << 31), "capacity");
+    qh = (nq + ix->world - 1) / ix->world;
+    ARGCHECK((double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9,
+             "too many scan units for one batch");
+    ARGCHECK((double)qh * p.cap * 17.0 < 16.0e9, "distance rows of the home queries exceed 16 GB");
+    return TK_OK;
+}
+
+extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_dev,
+                                       const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
+                                       int n_probes, int pass_1, int64_t capacity, void *send_dev,
+                                       int *flag_dev, void *stream)
+{
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, capacity, p, qh));
+    ARGCHECK(send_dev && flag_dev, "send/flag buffers");
+    Work &w = ix->works[(size_t)slot];
+    hipStream_t st = (hipStream_t)stream;
+    TRY(reserve_shard(ix, w, nq, qh, p));
+    Prof pf;
+    const int *owner = ix->owner.as<int>();
+    TRY(stage_front(ix, w, q_dev, q_pq_dev, q_pq_is_f64, nq, p, w.u_count.as<int>(), owner,
+                    ix->rank, st, pf));
+    tk_launch_shard_positions(w.probes.as<int64_t>(), w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
+                              owner, ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
+                              w.rpos.as<int>(), flag_dev, st);
+    tk_launch_pairs_scan(w.u_count.as<int>(), ix->local_chunk_off.as<int64_t>(), ix->n_lists,
+                         w.u_pair_off.as<int>(), w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
+                         w.u_pair_q.as<int>(), st);
+    tk_launch_shard_pairs_fill(w.probes.as<int64_t>(), p.S, nq, ix->n_lists, owner, ix->rank,
+                               w.spos.as<int>(), w.u_pair_off.as<int>(), w.u_cursor.as<int>(),
+                               w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(), st);
+    // the owned segments are scored straight into the send buffer (row stride 0, the
+    // record's offset is the segment's position); the minima are rebuilt by the receiver
+    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
+                         ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
+                         w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
+                         (uint4 *)send_dev, 0, nullptr, 0, 1, ix->order, 3072, st);
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq,
+                                         int k, int n_probes, int pass_1, int64_t capacity,
+                                         const void *recv_dev, int64_t *out_ids_home_dev,
+                                         void *stream)
+{
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, capacity, p, qh));
+    ARGCHECK(recv_dev && out_ids_home_dev, "recv/out buffers");
+    Work &w = ix->works[(size_t)slot];
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t q0 = (int64_t)ix->rank * qh;
+    int64_t nqh = nq - q0;
+    nqh = nqh < 0 ? 0 : (nqh > qh ? qh : nqh);
+    HIPCHECK(hipMemsetAsync(out_ids_home_dev, 0xff, (size_t)qh * k * 8, st));   // -1 rows
+    if (nqh > 0) {
+        tk_launch_shard_unpack((const uint4 *)recv_dev, w.rpos.as<int>(),
+                               w.slot_prefix.as<int>() + q0 * (p.S + 1), p.S, nqh,
+                               w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(), p.cap_min, 1, st);
+        Prof pf;
+        TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf));
+    }
+    HIPCHECK(hipGetLastError());
     return TK_OK;
 }
 

@@ -121,9 +121,28 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
                        int64_t *out, int *out_count, hipStream_t s);
 
 // probes (nq, kc) list ids -> per-slot scan descriptors; pair_count (n_lists, zeroed, or
-// NULL) receives the number of (query, slot) pairs per list
+// NULL) receives the number of (query, slot) pairs per list — with `owner` (n_lists ranks,
+// list-sharded index) only for the lists owned by `me`
 void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
                           int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
-                          int *pair_count, hipStream_t s);
+                          int *pair_count, const int *owner, int me, hipStream_t s);
+
+// the exclusive scans of tk_launch_unit_pairs alone (the caller fills the records)
+void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_lists, int *pair_off,
+                          int *unit_prefix, int *cursor, int *pair_q, hipStream_t s);
+
+// ---- list-sharded index (shard.hip) ----
+// positions of the (query, slot) segments in the all-to-all buffers: W regions of C uint4;
+// home rank of query i = i / qh.  spos: (nq, S), rpos: (qh, S); *flag |= 1 on overflow.
+void tk_launch_shard_positions(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
+                               int64_t n_lists, const int *owner, int me, int W, int64_t qh,
+                               int64_t C, int *spos, int *rpos, int *flag, hipStream_t s);
+void tk_launch_shard_pairs_fill(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
+                                const int *owner, int me, const int *spos, const int *pair_off,
+                                int *cursor, int *pair_q, int *pair_f0, hipStream_t s);
+// slot_prefix: rows of the home queries; dist/mins: (nq_home, cap) / (nq_home, min_stride)
+void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_prefix, int S,
+                            int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,
+                            int64_t min_stride, int signd, hipStream_t s);

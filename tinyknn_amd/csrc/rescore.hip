@@ -145,7 +145,8 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
                                   int64_t *__restrict__ slot_chunk0, int *__restrict__ slot_n,
                                   int64_t *__restrict__ slot_label_off,
                                   unsigned char *__restrict__ repeat_flag,
-                                  int *__restrict__ pair_count)
+                                  int *__restrict__ pair_count, const int *__restrict__ owner,
+                                  int me)
 {
     int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
@@ -161,7 +162,8 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
         slot_chunk0[qi * S + s] = c0;
         slot_n[qi * S + s] = (int)list_n[cl];
         slot_label_off[qi * S + s] = ids_off[cl];
-        if (pair_count) atomicAdd(&pair_count[cl], 1);   // pairs per list, for the list-major scan
+        // pairs per list, for the list-major scan (sharded index: of the lists I own)
+        if (pair_count && (!owner || owner[cl] == me)) atomicAdd(&pair_count[cl], 1);
     }
     if (repeat_flag) repeat_flag[qi] = wrapped;
 }
@@ -170,11 +172,11 @@ void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
                           int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
-                          int *pair_count, hipStream_t s)
+                          int *pair_count, const int *owner, int me, hipStream_t s)
 {
     (void)probe_count;
     if (nq == 0) return;
     hipLaunchKernelGGL(make_slots_kernel, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, s,
                        probes, kc, nq, n_lists, list_chunk_off, list_n, ids_off, slot_prefix,
-                       slot_chunk0, slot_n, slot_label_off, repeat_flag, pair_count);
+                       slot_chunk0, slot_n, slot_label_off, repeat_flag, pair_count, owner, me);
 }

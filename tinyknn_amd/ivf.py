@@ -18,7 +18,9 @@ from .utils import group_data_by_indices, knn_brute, timer
 class DeviceIndex:
     """HBM-resident copy of a built IVF (C ABI: tk_index_*)."""
 
-    def __init__(self, ivf):
+    def __init__(self, ivf, owner=None, rank=0, world=1):
+        """owner (n_lists,) int32 + rank/world: list-sharded index — only the codes of the
+        lists with owner[l] == rank are uploaded (tinyknn_hip.h, tk_index_set_lists_shard)."""
         L = _lib.lib()
         pq = ivf.pq
         self._h = L.tk_index_create()
@@ -47,14 +49,26 @@ class DeviceIndex:
                 sizes.append(0)
                 continue
             sizes.append(td.size)
-            packed.append(np.ascontiguousarray(td.packed, dtype=np.uint64))
+            if owner is None or owner[i] == rank:
+                packed.append(np.ascontiguousarray(td.packed, dtype=np.uint64))
             ids.append(np.asarray(ivf.ids[i], dtype=np.int64)[:td.size])
         sizes = np.array(sizes, dtype=np.int64)
         codes = (np.ascontiguousarray(np.concatenate(packed)) if packed
                  else np.zeros((1, M), dtype=np.uint64))
         allids = (np.ascontiguousarray(np.concatenate(ids)) if ids else np.zeros(1, np.int64))
-        _lib.check(L.tk_index_set_lists(self._h, _lib.ptr(sizes, _lib._i64p),
-                                        _lib.ptr(codes, _lib._u64p), _lib.ptr(allids, _lib._i64p)))
+        self.list_sizes = sizes
+        self.rank, self.world = int(rank), int(world)
+        if owner is None:
+            _lib.check(L.tk_index_set_lists(self._h, _lib.ptr(sizes, _lib._i64p),
+                                            _lib.ptr(codes, _lib._u64p),
+                                            _lib.ptr(allids, _lib._i64p)))
+        else:
+            own = np.ascontiguousarray(owner, dtype=np.int32)
+            assert own.shape == (self.n_lists,)
+            _lib.check(L.tk_index_set_lists_shard(self._h, _lib.ptr(sizes, _lib._i64p),
+                                                  _lib.ptr(own, _lib._i32p), self.rank,
+                                                  self.world, _lib.ptr(codes, _lib._u64p),
+                                                  _lib.ptr(allids, _lib._i64p)))
         # IVF.data keeps the dtype of the X passed to build (ivf.py:77); float64 vectors
         # are rescored in float64 like numpy would
         is64 = ivf.data.dtype != np.float32
@@ -108,6 +122,20 @@ class DeviceIndex:
         _lib.check(_lib.lib().tk_index_query_batch_dev(
             self._h, qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
             int(pass_1 or 0), out_ptr, stream))
+
+    def shard_scan_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1, capacity,
+                       send_ptr, flag_ptr, stream=0):
+        """First half of a list-sharded batch (tk_index_shard_scan_dev)."""
+        _lib.check(_lib.lib().tk_index_shard_scan_dev(
+            self._h, int(slot), qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
+            int(pass_1 or 0), int(capacity), send_ptr, flag_ptr, stream))
+
+    def shard_finish_dev(self, slot, qn_ptr, nq, k, n_probes, pass_1, capacity, recv_ptr, out_ptr,
+                         stream=0):
+        """Second half, after the all-to-all (tk_index_shard_finish_dev)."""
+        _lib.check(_lib.lib().tk_index_shard_finish_dev(
+            self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0),
+            int(capacity), recv_ptr, out_ptr, stream))
 
     def reserve(self, nq, k, n_probes, pass_1=None):
         _lib.check(_lib.lib().tk_index_reserve(self._h, nq, int(k), int(n_probes), int(pass_1 or 0)))

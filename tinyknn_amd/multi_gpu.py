@@ -1,4 +1,10 @@
-"""Multi-GPU serving: one process per GPU, replicas of the index, queries sharded.
+"""Multi-GPU serving: one process per GPU.  Two modes.
+
+ReplicaGroup — replicas of the index, queries sharded (no data-path collective).
+ListShardedIndex — inverted lists sharded by cluster id, queries broadcast, one
+all-to-all of int8 distance bytes per batch + the all-gather of the ids (below).
+
+Replica mode:
 
 The path shards by QUERY: every rank holds the whole index in its own HBM (the
 GloVe-100 index is 0.5 GB, the 100M x 128 one 53 GB — both far below 288 GB) and
@@ -62,3 +68,224 @@ class ReplicaGroup:
             a, b = shard_bounds(nq, self.world, r)
             res[a:b] = o.cpu().numpy()[:b - a]
         return res
+
+
+# ---------------------------------------------------------------------------
+# list-sharded index (C ABI: tk_index_set_lists_shard,
+# tk_index_shard_scan_dev, tk_index_shard_finish_dev)
+
+def shard_lists(list_sizes, world):
+    """owner (n_lists,) int32: lists partitioned by cluster id, size-balanced (longest
+    list first onto the least-loaded rank; ties -> lowest list id / lowest rank), so that
+    every rank computes the same partition from the replicated list sizes."""
+    chunks = (np.asarray(list_sizes, dtype=np.int64) + 15) // 16
+    owner = np.zeros(len(chunks), dtype=np.int32)
+    load = np.zeros(world, dtype=np.int64)
+    for l in np.argsort(-chunks, kind="stable"):
+        r = int(np.argmin(load))
+        owner[l] = r
+        load[r] += chunks[l]
+    return owner
+
+
+def shard_capacity(list_sizes, owner, world, nq, n_probes, slack=1.5):
+    """uint4 (16 distances) per (source, home) region of the all-to-all buffers.
+    Expected stream length = queries per home x probes x size-biased mean list length x
+    the source's share of the codes, times `slack`; a batch that overflows raises the
+    device flag and is repeated with twice the capacity (exactness never depends on it)."""
+    chunks = (np.asarray(list_sizes, dtype=np.float64) + 15) // 16
+    tot = max(chunks.sum(), 1.0)
+    per_probe = (chunks * chunks).sum() / tot          # E[chunks | list hit with p ~ size]
+    share = max(np.bincount(owner, weights=chunks, minlength=world).max() / tot, 1.0 / world)
+    qh = -(-nq // world)
+    kc = min(n_probes, len(chunks))
+    worst = qh * kc * int(chunks.max() if len(chunks) else 1)
+    want = int(slack * qh * kc * per_probe * share) + 1024
+    return int(max(1, min(want, worst)))
+
+
+def shard_positions(probes, chunks, owner, world, capacity):
+    """Host restatement of shard_positions_kernel (shard.hip), used by tests and CPU
+    engines.  probes (nq, S) list ids (already wrapped to >= 0); chunks (n_lists,).
+    Returns (src, pos): owner rank and offset in uint4 units inside the (src -> home)
+    region of every (query, slot) segment, or pos = -1 where the region overflowed."""
+    nq, S = probes.shape
+    qh = -(-nq // world)
+    src = owner[probes]
+    n = chunks[probes].astype(np.int64)
+    pos = np.full((nq, S), -1, dtype=np.int64)
+    for h in range(world):
+        blk = slice(h * qh, min(nq, (h + 1) * qh))
+        for s_ in range(world):
+            m = src[blk] == s_
+            c = np.where(m, n[blk], 0).ravel()
+            start = np.cumsum(c) - c
+            ok = m.ravel() & (start + c <= capacity)
+            pv = pos[blk].ravel()
+            pv[ok] = start[ok]
+            pos[blk] = pv.reshape(pos[blk].shape)
+    return src, pos
+
+
+class _HipShardEngine:
+    """scan / finish on the MI355X (torch tensors carry the device buffers)."""
+
+    def __init__(self, ivf, owner, rank, world, depth):
+        from .ivf import DeviceIndex
+        self.dev = DeviceIndex(ivf, owner=owner, rank=rank, world=world)
+        self.dev.set_pipeline(depth)
+        self.device = "cuda"
+
+    def scan(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_scan_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
+                                qn.shape[0], k, n_probes, pass_1, capacity, send.data_ptr(),
+                                flag.data_ptr(), stream=st)
+
+    def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_finish_dev(slot, qn.data_ptr(), qn.shape[0], k, n_probes, pass_1, capacity,
+                                  recv.data_ptr(), out_home.data_ptr(), stream=st)
+
+
+class ListShardedIndex:
+    """One rank of an IVF index whose inverted lists are sharded by cluster id.
+
+    Every rank passes the same batch.  Per batch and rank: tables + coarse stage for all
+    queries (replicated, so the probe order needs no communication), scan of the owned
+    (query, list) segments straight into the send buffer, ONE all-to-all of int8 distance
+    bytes (query i is replayed on rank i // ceil(nq/world); 1/26-1/16 of the code bytes
+    scanned), exact heap replay + rescoring of the home queries, all-gather of the ids.
+    Results are identical to the unsharded index (and to the reference) by construction:
+    the home rank replays the same distance rows in the same order.
+
+    `engine`: object with scan/finish (default: the HIP engine); tests inject a CPU one.
+    """
+
+    def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.ivf, self.group = ivf, group
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.backend = dist.get_backend(group) if on else None
+        if list_sizes is None:
+            list_sizes = [0 if isinstance(t, np.ndarray) else t.size
+                          for t in ivf.pq_transformed_points[:ivf.active_centers.shape[0]]]
+        self.list_sizes = np.array(list_sizes, dtype=np.int64)
+        self.owner = shard_lists(self.list_sizes, self.world) if owner is None else owner
+        self.depth = depth
+        self.engine = engine if engine is not None else _HipShardEngine(
+            ivf, self.owner, self.rank, self.world, depth)
+        self.device = self.engine.device
+        self.capacity = {}          # (nq, n_probes) -> uint4 per region, grows on overflow
+        self._bufs = {}
+        self._calls = 0
+        self._streams = ([torch.cuda.Stream() for _ in range(depth)]
+                         if self.device == "cuda" and depth > 1 else None)
+        self._pending = []
+
+    # -- collectives (RCCL on device tensors; any other backend is staged through the host)
+    def _all_to_all(self, recv, send):
+        if self.world == 1:
+            recv.copy_(send)
+        elif self.backend == "nccl" or self.device == "cpu":
+            self.dist.all_to_all_single(recv, send, group=self.group)
+        else:
+            r, s_ = self.torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
+            self.dist.all_to_all_single(r, s_, group=self.group)
+            recv.copy_(r)
+
+    def _all_gather(self, out, inp):
+        if self.world == 1:
+            out.copy_(inp)
+        elif self.backend == "nccl" or self.device == "cpu":
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+        else:
+            o = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+
+    def _buffers(self, slot, nq, k, capacity):
+        key = (slot, nq, k, capacity)
+        if self._bufs.get(slot, (None,))[0] != key:
+            t, W = self.torch, self.world
+            qh = -(-nq // W)
+            mk = lambda n, dt: t.empty(n, dtype=dt, device=self.device)
+            self._bufs[slot] = (key, dict(
+                send=mk(W * capacity * 16, t.uint8), recv=mk(W * capacity * 16, t.uint8),
+                flag=mk(1, t.int32), home=mk(qh * k + 1, t.int64), all=mk(W * (qh * k + 1), t.int64)))
+        return self._bufs[slot][1]
+
+    def _enqueue(self, qn, qp, k, n_probes, pass_1, capacity):
+        """One batch on the current stream; returns the gathered (world, qh*k+1) tensor
+        (last column: the rank's overflow flag)."""
+        nq = qn.shape[0]
+        slot = self._calls % self.depth
+        self._calls += 1
+        b = self._buffers(slot, nq, k, capacity)
+        qh = -(-nq // self.world)
+        b["flag"].zero_()
+        self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"])
+        self._all_to_all(b["recv"], b["send"])
+        self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, b["recv"], b["home"][:qh * k])
+        b["home"][qh * k:] = b["flag"]
+        self._all_gather(b["all"], b["home"])
+        return b["all"].view(self.world, qh * k + 1)
+
+    def _capacity(self, nq, n_probes):
+        key = (nq, n_probes)
+        if key not in self.capacity:
+            self.capacity[key] = shard_capacity(self.list_sizes, self.owner, self.world, nq, n_probes)
+        return self.capacity[key]
+
+    def query_prepared(self, qn, qp, k, n_probes=1, pass_1=None):
+        """qn / qp: tensors on the engine's device (normalised queries, table-build queries).
+        Synchronous; repeats the batch with a larger capacity if a region overflowed."""
+        nq = qn.shape[0]
+        qh = -(-nq // self.world)
+        while True:
+            cap = self._capacity(nq, n_probes)
+            g = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
+            g = g.cpu().numpy()
+            if not g[:, -1].any():
+                return g[:, :-1].reshape(self.world * qh, k)[:nq]
+            worst = qh * min(n_probes, len(self.list_sizes)) * int((self.list_sizes.max() + 15) // 16)
+            assert cap < worst, "overflow at the worst-case capacity"
+            self.capacity[(nq, n_probes)] = min(2 * cap, worst)
+
+    def query_batch(self, qs, k, n_probes=1, pass_1=None):
+        """Every rank passes the same (nq, d) batch and receives all (nq, k) ids
+        (rows padded with -1 like IVF.query_batch)."""
+        t = self.torch
+        qs = np.array(qs, dtype=np.float32, order="C", copy=True)
+        out = np.empty((len(qs), k), dtype=np.int64)
+        for lo in range(0, len(qs), 32768):
+            qn, qp = self.ivf._prepare(qs[lo:lo + 32768])
+            out[lo:lo + len(qn)] = self.query_prepared(
+                t.from_numpy(np.ascontiguousarray(qn)).to(self.device),
+                t.from_numpy(np.ascontiguousarray(qp)).to(self.device), k, n_probes, pass_1)
+        return out
+
+    # -- batches in flight (bench): each on its own stream, checked at join()
+    def submit(self, qn, qp, k, n_probes=1, pass_1=None):
+        t = self.torch
+        cap = self._capacity(qn.shape[0], n_probes)
+        if self._streams is None:
+            g = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
+        else:
+            st = self._streams[self._calls % self.depth]
+            st.wait_stream(t.cuda.current_stream())
+            with t.cuda.stream(st):
+                g = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
+        return g
+
+    def join(self):
+        if self._streams is not None:
+            cur = self.torch.cuda.current_stream()
+            for st in self._streams:
+                cur.wait_stream(st)
