@@ -15,7 +15,11 @@ the reference's host code does (ivf.py:125-127), when the timed region starts.
 
 N > 1: replicas — every rank holds the whole index (0.5 GB of 288 GB) and owns its
 own batch of queries; no data-path collective; "weak".
-Prints ONE JSON line on rank 0.
+After that measurement a second, untimed-for-`value` leg runs the LIST-SHARDED index
+(lists partitioned by cluster id, one RCCL all-to-all of int8 distance bytes + the
+all-gather of the ids per batch) on one shared batch, checks its ids
+against the replica's and reports it under "list_sharded" (`--shard lists` forces it
+at N = 1, `--shard none` skips it).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -140,6 +144,54 @@ def oracle_index(ivf):
                          [ivf.ids[i] for i in range(L)], ivf.data)
 
 
+def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
+    """Strong-scaling leg: ONE batch of args.nq queries per step, shared by all ranks;
+    lists sharded by cluster id.  Returns a dict (rank 0 reports it)."""
+    import torch
+    import torch.distributed as dist
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+    qs = synth_queries(cent, args.nq, args.seed + 100, kind=args.data)     # rank 0's batch
+    qn, qp = ivf._prepare(qs.copy())
+    qn_t = torch.from_numpy(qn).to(device)
+    qp_t = torch.from_numpy(np.ascontiguousarray(qp)).to(device)
+    want = torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)
+    dev.query_batch_dev(qn_t.data_ptr(), qp_t.data_ptr(), qp.dtype != np.float32, args.nq, args.k,
+                        args.n_probes, want.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = want.cpu().numpy()
+    idx = ListShardedIndex(ivf, depth=args.pipeline)
+    got = idx.query_prepared(qn_t, qp_t, args.k, args.n_probes)     # also settles the capacity
+    same = int((got == want).all(axis=1).sum())
+    for _ in range(max(1, args.warmup)):
+        idx.submit(qn_t, qp_t, args.k, args.n_probes)
+    idx.join()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g = idx.submit(qn_t, qp_t, args.k, args.n_probes)
+    idx.join()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    cap = idx.capacity[(args.nq, args.n_probes)]
+    load = np.bincount(idx.owner, weights=(idx.list_sizes + 15) // 16, minlength=world)
+    return {"queries_per_s": args.nq * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+            "scaling": "strong (one shared batch of %d queries per step)" % args.nq,
+            "identical_rows_vs_replica": same, "rows": args.nq,
+            "overflow_in_timed_steps": bool(g.cpu().numpy()[:, -1].any()),
+            "exchange": {"all_to_all_bytes_per_rank_per_step": int(world * cap * 16),
+                         "region_capacity_uint4": int(cap),
+                         "all_gather_bytes_per_rank_per_step": int((-(-args.nq // world) * args.k + 1) * 8)},
+            "code_chunks_per_rank": [int(x) for x in load], "batches_in_flight": args.pipeline}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +217,10 @@ def main():
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (tk_index_set_pipeline)")
+    ap.add_argument("--shard", choices=["auto", "none", "lists"], default="auto",
+                    help="list-sharded leg after the replica measurement (auto: when N > 1)")
+    ap.add_argument("--shard-limit", type=float, default=240.0,
+                    help="seconds after which a stuck list-sharded leg is abandoned")
     args = ap.parse_args()
 
     import torch
@@ -247,7 +303,18 @@ def main():
     elapsed = float(t.item())
     got = out_dev.cpu().numpy()
 
+    do_shard = args.shard == "lists" or (args.shard == "auto" and world > 1)
     if rank != 0:
+        if do_shard:
+            import threading
+            wd = threading.Timer(args.shard_limit + 120.0, lambda: os._exit(0))
+            wd.daemon = True
+            wd.start()
+            try:
+                list_sharded_leg(args, ivf, cent, dev, device, world, rank)
+            except Exception as e:      # rank 0 reports; a stuck collective ends by the timer
+                log(f"[bench] rank {rank}: list-sharded leg failed: {e!r}")
+            wd.cancel()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -319,7 +386,28 @@ def main():
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
     }
-    print(json.dumps(line))
+    if do_shard:
+        # the replica line above is complete: a list-sharded leg that gets stuck (it is the
+        # one part that cannot be rehearsed on a 1-GPU box with RCCL) must not lose it
+        import threading
+
+        def bail():
+            line["list_sharded"] = {"error": f"abandoned after {args.shard_limit:.0f}s"}
+            print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        wd = threading.Timer(args.shard_limit, bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            line["list_sharded"] = list_sharded_leg(args, ivf, cent, dev, device, world, rank)
+        except Exception as e:
+            # the other ranks may be waiting in a collective: do not join them again
+            line["list_sharded"] = {"error": repr(e)}
+            print(json.dumps(line), flush=True)
+            os._exit(0)
+        wd.cancel()
+    print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
