@@ -162,13 +162,16 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
                              int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                              int64_t *out_ids_dev, void *stream);
 
-/* Batches in flight.  depth = 1 (default): tk_index_query_batch_dev enqueues the
- * whole pipeline on the caller's stream.  depth > 1: consecutive calls alternate
- * between `depth` workspaces, each batch running on an internal stream that first
- * waits for the work the caller has enqueued so far; the latency-bound heap replay
- * of one batch then overlaps the scan of the next.  The caller must not reuse its
- * input/output buffers of a call before tk_index_join(ix, stream), which makes
- * `stream` wait for every batch in flight. */
+/* Batches in flight.  depth = 1 (default): tk_index_query_batch_dev enqueues the whole
+ * pipeline on the caller's stream.  depth > 1: a call enqueues the FIRST half of its batch
+ * (tables, coarse stage, scan descriptors) on the caller's stream and the SECOND half of
+ * the previous call's batch (list scan, heap replay, rescoring) on one of `depth` internal
+ * streams; tk_index_join enqueues the last second half.  The latency-bound heap replays
+ * (157 waves per 10 000 queries) of up to `depth` batches then overlap the VALU-bound
+ * kernels of the others, which take turns in the order
+ *     scan(b-1) | tables(b+1), coarse scan(b+1) | scan(b) | ...
+ * The caller must not reuse the input/output buffers of a call before
+ * tk_index_join(ix, stream), which also makes `stream` wait for every batch in flight. */
 int tk_index_set_pipeline(tk_index *ix, int depth);
 int tk_index_join(tk_index *ix, void *stream);
 

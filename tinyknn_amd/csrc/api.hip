@@ -469,8 +469,8 @@ struct Work {
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
         c_pair_f0, spos, rpos;
-    hipStream_t stream = nullptr;   // only used when the pipeline depth is > 1
-    hipEvent_t done = nullptr;
+    hipEvent_t front_done = nullptr, done = nullptr;   // pipelined mode (depth > 1)
+    bool busy = false;                                 // `done` has been recorded
     void release()
     {
         DevBuf *b[] = {&tables, &shift, &scale, &cdist, &cheap_idx, &cheap_val, &probes,
@@ -479,12 +479,15 @@ struct Work {
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
                        &spos, &rpos};
         for (DevBuf *x : b) x->release();
-        if (stream) (void)hipStreamDestroy(stream);
+        if (front_done) (void)hipEventDestroy(front_done);
         if (done) (void)hipEventDestroy(done);
-        stream = nullptr;
-        done = nullptr;
+        front_done = done = nullptr;
+        busy = false;
     }
 };
+
+struct Pending;
+static int flush_pending(struct tk_index *ix);
 
 struct tk_index {
     // FastPQ
@@ -521,8 +524,9 @@ struct tk_index {
     std::vector<Work> works;
     int depth = 1;
     uint64_t calls = 0;
-    hipEvent_t ev_in = nullptr;    // caller stream -> worker stream hand-off
-    hipEvent_t ev_scan = nullptr;  // end of the most recent list scan (pipelined mode)
+    std::vector<hipStream_t> back_streams;   // `depth` of them (pipelined mode)
+    hipEvent_t ev_turn = nullptr;  // end of the most recent chip-filling kernel (pipelined mode)
+    struct Pending *pending = nullptr;   // second half of the previous call (pipelined mode)
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
     std::vector<hipEvent_t> evs;   // 8 per set
@@ -543,14 +547,16 @@ extern "C" tk_index *tk_index_create(void)
 extern "C" void tk_index_destroy(tk_index *ix)
 {
     if (!ix) return;
+    (void)flush_pending(ix);
+    (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&ix->pq_centers, &ix->active_centers, &ix->center_codes, &ix->list_chunk_off,
                       &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->ids32, &ix->data, &ix->cslots_i,
                       &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage, &ix->owner,
                       &ix->local_chunk_off};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
-    if (ix->ev_in) (void)hipEventDestroy(ix->ev_in);
-    if (ix->ev_scan) (void)hipEventDestroy(ix->ev_scan);
+    if (ix->ev_turn) (void)hipEventDestroy(ix->ev_turn);
+    for (hipStream_t st : ix->back_streams) (void)hipStreamDestroy(st);
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -806,6 +812,7 @@ extern "C" int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, i
 {
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
+    TRY(flush_pending(ix));
     const int64_t ms = sub_batch(p);
     for (Work &w : ix->works) TRY(reserve(ix, w, nq < ms ? nq : ms, k, p));
     return TK_OK;
@@ -813,11 +820,12 @@ extern "C" int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, i
 
 // stage timers of one batch (tk_index_set_profiling)
 struct Prof {
-    hipEvent_t *ev = nullptr;
+    const std::vector<hipEvent_t> *evs = nullptr;   // the index's event pool (it may grow)
+    size_t base = 0;
     int evi = 0;
     int mark(hipStream_t st)
     {
-        if (ev) HIPCHECK(hipEventRecord(ev[evi++], st));
+        if (evs) HIPCHECK(hipEventRecord((*evs)[base + (size_t)evi++], st));
         return TK_OK;
     }
 };
@@ -830,7 +838,8 @@ static int prof_begin(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStrea
         HIPCHECK(hipEventCreate(&e));
         ix->evs.push_back(e);
     }
-    pf.ev = &ix->evs[ix->ev_used * 8];
+    pf.evs = &ix->evs;
+    pf.base = ix->ev_used * 8;
     if (ix->ev_streams.size() <= ix->ev_used) ix->ev_streams.resize(ix->ev_used + 1);
     ix->ev_streams[ix->ev_used] = st;
     ix->ev_used++;
@@ -851,11 +860,28 @@ static bool use_units(const tk_index *ix, int64_t nq, const Plan &p)
 // Stages 1-2 of a batch: tables, coarse stage, probe lists, per-slot descriptors.
 // `pair_count`: per-list (query, slot) pair counters for the list-major scan (or NULL);
 // with `owner` only the lists owned by `me` are counted (list-sharded index).
+// Pipelined mode: the chip-filling, VALU-bound kernels of the batches in flight (table
+// build, coarse scan, list scan) take turns — two of them at once only stretch each other;
+// what overlaps them is the latency-bound heap replays (157 waves per 10 000 queries).
+static int turn_wait(tk_index *ix, hipStream_t st)
+{
+    if (ix->ev_turn) HIPCHECK(hipStreamWaitEvent(st, ix->ev_turn, 0));
+    return TK_OK;
+}
+
+static int turn_pass(tk_index *ix, hipStream_t st)
+{
+    if (!ix->ev_turn) HIPCHECK(hipEventCreateWithFlags(&ix->ev_turn, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(ix->ev_turn, st));
+    return TK_OK;
+}
+
 static int stage_front(tk_index *ix, Work &w, const float *q_dev, const void *qpq_dev, int qpq_f64,
                        int64_t nq, const Plan &p, int *pair_count, const int *owner, int me,
-                       hipStream_t st, Prof &pf)
+                       bool turns, hipStream_t st, Prof &pf)
 {
     const int M = ix->M;
+    if (turns) TRY(turn_wait(ix, st));
     TRY(pf.mark(st));
     // 1. distance tables                                   fast_pq.py:186-222
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
@@ -881,6 +907,7 @@ static int stage_front(tk_index *ix, Work &w, const float *q_dev, const void *qp
                             w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, st);
     }
     TRY(pf.mark(st));
+    if (turns) TRY(turn_pass(ix, st));
     // positions of one list against a fresh heap are distinct labels: lane-per-query
     const bool fast_c = ix->heap_mode != 1 && ix->center_chunks * 16 <= 0xffffff;
     const bool lanes_c = fast_c && ix->heap_mode == 0 && p.rescore <= TK_LANES_MAX_R;
@@ -976,48 +1003,92 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     return TK_OK;
 }
 
-// one sub-batch, everything on device
-static int run_batch(tk_index *ix, Work &w, const float *q_dev, const void *qpq_dev, int qpq_f64, int64_t nq,
-                     int k, const Plan &p, int64_t *out_dev, hipStream_t st)
-{
-    const int M = ix->M;
+// One sub-batch in two halves.  batch_front: tables, coarse stage, probe lists, scan
+// descriptors.  batch_back: list scan, heap replay, rescoring.
+//
+// depth == 1: back to back on the caller's stream.
+// depth  > 1: the first half runs on the caller's stream, the second half on one of `depth`
+// internal streams, and the second half of call b is enqueued AFTER the first half of call
+// b+1 (or by tk_index_join).  In enqueue order the chip-filling kernels then read
+//     ... scan(b-1) | tables(b+1) coarse-scan(b+1) | scan(b) | tables(b+2) ...
+// and take turns in exactly that order, so that scan(b) finds its coarse heap replay and
+// descriptors (latency-bound, ~0.25 ms) finished during scan(b-1) instead of holding the
+// turn for them, while the heap replays of b-1 and b-2 (0.7 ms of latency each) overlap.
+struct Pending {
+    Work *w;
+    const float *q_dev;
+    int64_t nq;
+    int k;
+    Plan p;
+    int64_t *out_dev;
+    bool units;
     Prof pf;
-    TRY(prof_begin(ix, w, nq, p, st, pf));
-    const bool units = use_units(ix, nq, p);
-    TRY(stage_front(ix, w, q_dev, qpq_dev, qpq_f64, nq, p, units ? w.u_count.as<int>() : nullptr,
-                    nullptr, 0, st, pf));
-    if (units)
-        tk_launch_unit_pairs(nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
+    hipStream_t front_st, back_st;
+};
+
+static int batch_front(tk_index *ix, Pending &b, const void *qpq_dev, int qpq_f64)
+{
+    Work &w = *b.w;
+    const Plan &p = b.p;
+    hipStream_t st = b.front_st;
+    TRY(prof_begin(ix, w, b.nq, p, b.back_st, b.pf));
+    b.units = use_units(ix, b.nq, p);
+    TRY(stage_front(ix, w, b.q_dev, qpq_dev, qpq_f64, b.nq, p,
+                    b.units ? w.u_count.as<int>() : nullptr, nullptr, 0, ix->depth > 1, st, b.pf));
+    if (b.units)
+        tk_launch_unit_pairs(b.nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
                              ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
                              w.u_count.as<int>(), w.u_pair_off.as<int>(),
                              w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
                              w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
-                             nq * p.S + 4 * ix->n_lists, st);
-    if (ix->depth > 1 && ix->ev_scan)
-        // batches in flight take turns on the VALU-bound scan: two overlapping scans
-        // would only stretch each other; the heap replays are what overlaps
-        HIPCHECK(hipStreamWaitEvent(st, ix->ev_scan, 0));
-    TRY(pf.mark(st));
+                             b.nq * p.S + 4 * ix->n_lists, st);
+    HIPCHECK(hipGetLastError());
+    if (ix->depth > 1) HIPCHECK(hipEventRecord(w.front_done, st));
+    return TK_OK;
+}
+
+static int batch_back(tk_index *ix, Pending &b)
+{
+    Work &w = *b.w;
+    const Plan &p = b.p;
+    const int M = ix->M;
+    hipStream_t st = b.back_st;
+    if (ix->depth > 1) {
+        HIPCHECK(hipStreamWaitEvent(st, w.front_done, 0));
+        TRY(turn_wait(ix, st));
+    }
+    TRY(b.pf.mark(st));
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
-    if (units)
-        tk_launch_scan_units(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
+    if (b.units)
+        tk_launch_scan_units(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), b.nq, p.S, ix->n_lists,
                              ix->list_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                              w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(),
                              w.u_pair_f0.as<int>(), w.dist.as<uint4>(), p.cap,
                              w.mins.as<uint8_t>(), p.cap_min, 1, ix->order, 3072, st);
     else
-        tk_launch_scan_probes(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), nq,
+        tk_launch_scan_probes(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), b.nq,
                               w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), p.S,
                               (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(),
                               p.cap_min, 1, ix->order, st);
-    TRY(pf.mark(st));
-    if (ix->depth > 1) {
-        if (!ix->ev_scan) HIPCHECK(hipEventCreateWithFlags(&ix->ev_scan, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(ix->ev_scan, st));
-    }
-    TRY(stage_back(ix, w, q_dev, 0, nq, k, p, out_dev, st, pf));
+    TRY(b.pf.mark(st));
+    if (ix->depth > 1) TRY(turn_pass(ix, st));
+    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf));
     HIPCHECK(hipGetLastError());
+    if (ix->depth > 1) {
+        HIPCHECK(hipEventRecord(w.done, st));
+        w.busy = true;
+    }
     return TK_OK;
+}
+
+static int flush_pending(tk_index *ix)
+{
+    if (!ix->pending) return TK_OK;
+    Pending *b = ix->pending;
+    ix->pending = nullptr;
+    int r = batch_back(ix, *b);
+    delete b;
+    return r;
 }
 
 extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_dev,
@@ -1033,23 +1104,37 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
     const int64_t ms = sub_batch(p);
     for (int64_t o = 0; o < nq; o += ms) {
         int64_t sub = nq - o < ms ? nq - o : ms;
-        Work &w = ix->works[ix->calls % (uint64_t)ix->depth];
-        ix->calls++;
-        hipStream_t st = caller;
+        Work &w = ix->works[ix->calls % ix->works.size()];
+        Pending b;
+        b.w = &w;
+        b.q_dev = q_dev + o * ix->d;
+        b.nq = sub;
+        b.k = k;
+        b.p = p;
+        b.out_dev = out_ids_dev + o * k;
+        b.units = false;
+        b.front_st = b.back_st = caller;
         if (ix->depth > 1) {
-            // the batch runs on the worker's own stream, after whatever the caller has
-            // enqueued so far (its inputs); tk_index_join re-joins the caller's stream
-            if (!w.stream) HIPCHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+            while ((int)ix->back_streams.size() < ix->depth) {
+                hipStream_t st;
+                HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                ix->back_streams.push_back(st);
+            }
+            b.back_st = ix->back_streams[ix->calls % (uint64_t)ix->depth];
+            if (!w.front_done) HIPCHECK(hipEventCreateWithFlags(&w.front_done, hipEventDisableTiming));
             if (!w.done) HIPCHECK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
-            if (!ix->ev_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_in, hipEventDisableTiming));
-            HIPCHECK(hipEventRecord(ix->ev_in, caller));
-            HIPCHECK(hipStreamWaitEvent(w.stream, ix->ev_in, 0));
-            st = w.stream;
+            // the workspace is free once the second half of its previous batch is through
+            if (w.busy) HIPCHECK(hipStreamWaitEvent(caller, w.done, 0));
         }
+        ix->calls++;
         TRY(reserve(ix, w, sub, k, p));
-        TRY(run_batch(ix, w, q_dev + o * ix->d, (const char *)q_pq_dev + (size_t)o * ix->dq * esz,
-                      q_pq_is_f64, sub, k, p, out_ids_dev + o * k, st));
-        if (ix->depth > 1) HIPCHECK(hipEventRecord(w.done, st));
+        TRY(batch_front(ix, b, (const char *)q_pq_dev + (size_t)o * ix->dq * esz, q_pq_is_f64));
+        if (ix->depth > 1) {
+            TRY(flush_pending(ix));              // second half of the previous call
+            ix->pending = new Pending(b);
+        } else {
+            TRY(batch_back(ix, b));
+        }
     }
     return TK_OK;
 }
@@ -1127,7 +1212,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     Prof pf;
     const int *owner = ix->owner.as<int>();
     TRY(stage_front(ix, w, q_dev, q_pq_dev, q_pq_is_f64, nq, p, w.u_count.as<int>(), owner,
-                    ix->rank, st, pf));
+                    ix->rank, false, st, pf));
     tk_launch_shard_positions(w.probes.as<int64_t>(), w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
                               owner, ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
                               w.rpos.as<int>(), flag_dev, st);
@@ -1178,12 +1263,16 @@ extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
 {
     ARGCHECK(ix, "null index");
     ARGCHECK(depth >= 1 && depth <= 8, "depth must be in 1..8");
+    TRY(flush_pending(ix));
     HIPCHECK(hipDeviceSynchronize());
-    while ((int)ix->works.size() > depth) {
+    // depth second halves in flight + the first half being built + the deferred one
+    const size_t n_works = depth > 1 ? (size_t)depth + 2 : 1;
+    while (ix->works.size() > n_works) {
         ix->works.back().release();
         ix->works.pop_back();
     }
-    ix->works.resize((size_t)depth);
+    ix->works.resize(n_works);
+    for (Work &w : ix->works) w.busy = false;
     ix->depth = depth;
     ix->calls = 0;
     return TK_OK;
@@ -1192,9 +1281,10 @@ extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
 extern "C" int tk_index_join(tk_index *ix, void *stream)
 {
     ARGCHECK(ix, "null index");
+    TRY(flush_pending(ix));
     if (ix->depth > 1)
         for (Work &w : ix->works)
-            if (w.done && w.stream) HIPCHECK(hipStreamWaitEvent((hipStream_t)stream, w.done, 0));
+            if (w.busy) HIPCHECK(hipStreamWaitEvent((hipStream_t)stream, w.done, 0));
     return TK_OK;
 }
 
@@ -1218,7 +1308,8 @@ extern "C" int tk_index_query_batch(tk_index *ix, const float *q, const void *q_
     HIPCHECK(hipMemcpy(ix->qpq.p, q_pq, (size_t)nq * ix->dq * esz, hipMemcpyHostToDevice));
     int r = tk_index_query_batch_dev(ix, ix->q.as<float>(), ix->qpq.p, q_pq_is_f64, nq, k, n_probes,
                                      pass_1, outbuf.as<int64_t>(), nullptr);
-    const Work &lw = ix->works[(ix->calls + ix->depth - 1) % (uint64_t)ix->depth];   // last used
+    if (r == TK_OK) r = flush_pending(ix);
+    const Work &lw = ix->works[(ix->calls + ix->works.size() - 1) % ix->works.size()];   // last used
     if (r == TK_OK) {
         hipError_t e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMemcpy(out_ids, outbuf.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost);
@@ -1238,6 +1329,7 @@ extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
 {
     ARGCHECK(ix, "null index");
     ARGCHECK(mode >= 0 && mode <= 2, "mode");
+    TRY(flush_pending(ix));
     ix->heap_mode = mode;
     return TK_OK;
 }
@@ -1246,6 +1338,7 @@ extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
 {
     ARGCHECK(ix, "null index");
     ARGCHECK(mode >= 0 && mode <= 2, "mode");
+    TRY(flush_pending(ix));
     ix->scan_mode = mode;
     return TK_OK;
 }
@@ -1263,6 +1356,7 @@ extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_byte
     ARGCHECK(ix, "null index");
     for (int i = 0; i < 7; i++) ms7[i] = 0;
     *scan_bytes = 0;
+    TRY(flush_pending(ix));
     *batches = (int)ix->ev_used;
     if (ix->ev_used == 0) return TK_OK;
     for (size_t b = 0; b < ix->ev_used; b++) HIPCHECK(hipStreamSynchronize(ix->ev_streams[b]));
