@@ -163,13 +163,14 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
                              int64_t *out_ids_dev, void *stream);
 
 /* Batches in flight.  depth = 1 (default): tk_index_query_batch_dev enqueues the whole
- * pipeline on the caller's stream.  depth > 1: a call enqueues the FIRST half of its batch
- * (tables, coarse stage, scan descriptors) on the caller's stream and the SECOND half of
- * the previous call's batch (list scan, heap replay, rescoring) on one of `depth` internal
- * streams; tk_index_join enqueues the last second half.  The latency-bound heap replays
- * (157 waves per 10 000 queries) of up to `depth` batches then overlap the VALU-bound
- * kernels of the others, which take turns in the order
- *     scan(b-1) | tables(b+1), coarse scan(b+1) | scan(b) | ...
+ * pipeline on the caller's stream.  depth > 1: the chip-filling, VALU-bound kernels (table
+ * build, coarse scan, list scan) of all batches run on the caller's stream, in order; the
+ * latency-bound kernels of a batch (heap replays: 157 waves per 10 000 queries; rescoring;
+ * descriptors) run on one of `depth` internal streams and overlap the other batches'
+ * scans.  A call enqueues the first half of its batch (tables, coarse stage, descriptors)
+ * and the SECOND half of the previous call's batch (list scan, heap replay, rescoring), so
+ * that the caller's stream reads  scan(b-1) | tables(b+1), coarse scan(b+1) | scan(b) | ...
+ * and never waits for a coarse heap replay; tk_index_join enqueues the last second half.
  * The caller must not reuse the input/output buffers of a call before
  * tk_index_join(ix, stream), which also makes `stream` wait for every batch in flight. */
 int tk_index_set_pipeline(tk_index *ix, int depth);

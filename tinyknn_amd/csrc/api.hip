@@ -469,7 +469,8 @@ struct Work {
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
         c_pair_f0, spos, rpos;
-    hipEvent_t front_done = nullptr, done = nullptr;   // pipelined mode (depth > 1)
+    // pipelined mode (depth > 1): hand-offs between the caller's stream and a latency stream
+    hipEvent_t coarse_scanned = nullptr, front_done = nullptr, scanned = nullptr, done = nullptr;
     bool busy = false;                                 // `done` has been recorded
     void release()
     {
@@ -479,9 +480,11 @@ struct Work {
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
                        &spos, &rpos};
         for (DevBuf *x : b) x->release();
-        if (front_done) (void)hipEventDestroy(front_done);
-        if (done) (void)hipEventDestroy(done);
-        front_done = done = nullptr;
+        hipEvent_t *evs[] = {&coarse_scanned, &front_done, &scanned, &done};
+        for (hipEvent_t *e : evs) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
         busy = false;
     }
 };
@@ -524,8 +527,7 @@ struct tk_index {
     std::vector<Work> works;
     int depth = 1;
     uint64_t calls = 0;
-    std::vector<hipStream_t> back_streams;   // `depth` of them (pipelined mode)
-    hipEvent_t ev_turn = nullptr;  // end of the most recent chip-filling kernel (pipelined mode)
+    std::vector<hipStream_t> lat_streams;    // `depth` of them (pipelined mode)
     struct Pending *pending = nullptr;   // second half of the previous call (pipelined mode)
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
@@ -555,8 +557,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->local_chunk_off};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
-    if (ix->ev_turn) (void)hipEventDestroy(ix->ev_turn);
-    for (hipStream_t st : ix->back_streams) (void)hipStreamDestroy(st);
+    for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -860,28 +861,13 @@ static bool use_units(const tk_index *ix, int64_t nq, const Plan &p)
 // Stages 1-2 of a batch: tables, coarse stage, probe lists, per-slot descriptors.
 // `pair_count`: per-list (query, slot) pair counters for the list-major scan (or NULL);
 // with `owner` only the lists owned by `me` are counted (list-sharded index).
-// Pipelined mode: the chip-filling, VALU-bound kernels of the batches in flight (table
-// build, coarse scan, list scan) take turns — two of them at once only stretch each other;
-// what overlaps them is the latency-bound heap replays (157 waves per 10 000 queries).
-static int turn_wait(tk_index *ix, hipStream_t st)
-{
-    if (ix->ev_turn) HIPCHECK(hipStreamWaitEvent(st, ix->ev_turn, 0));
-    return TK_OK;
-}
-
-static int turn_pass(tk_index *ix, hipStream_t st)
-{
-    if (!ix->ev_turn) HIPCHECK(hipEventCreateWithFlags(&ix->ev_turn, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(ix->ev_turn, st));
-    return TK_OK;
-}
-
 static int stage_front(tk_index *ix, Work &w, const float *q_dev, const void *qpq_dev, int qpq_f64,
                        int64_t nq, const Plan &p, int *pair_count, const int *owner, int me,
-                       bool turns, hipStream_t st, Prof &pf)
+                       hipStream_t st, hipStream_t sl, Prof &pf)
 {
+    // st: stream of the chip-filling kernels (table build, coarse scan); sl: stream of the
+    // latency-bound rest (== st unless the index is in pipelined mode)
     const int M = ix->M;
-    if (turns) TRY(turn_wait(ix, st));
     TRY(pf.mark(st));
     // 1. distance tables                                   fast_pq.py:186-222
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
@@ -907,7 +893,11 @@ static int stage_front(tk_index *ix, Work &w, const float *q_dev, const void *qp
                             w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, st);
     }
     TRY(pf.mark(st));
-    if (turns) TRY(turn_pass(ix, st));
+    if (sl != st) {
+        HIPCHECK(hipEventRecord(w.coarse_scanned, st));
+        HIPCHECK(hipStreamWaitEvent(sl, w.coarse_scanned, 0));
+        st = sl;
+    }
     // positions of one list against a fresh heap are distinct labels: lane-per-query
     const bool fast_c = ix->heap_mode != 1 && ix->center_chunks * 16 <= 0xffffff;
     const bool lanes_c = fast_c && ix->heap_mode == 0 && p.rescore <= TK_LANES_MAX_R;
@@ -1007,13 +997,16 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
 // descriptors.  batch_back: list scan, heap replay, rescoring.
 //
 // depth == 1: back to back on the caller's stream.
-// depth  > 1: the first half runs on the caller's stream, the second half on one of `depth`
-// internal streams, and the second half of call b is enqueued AFTER the first half of call
-// b+1 (or by tk_index_join).  In enqueue order the chip-filling kernels then read
+// depth  > 1: the chip-filling, VALU-bound kernels (table build, coarse scan, list scan) of
+// ALL batches run on the caller's stream, in order, back to back — two of them at once would
+// only stretch each other — and the latency-bound kernels of a batch (coarse heap replay,
+// probe rescoring, descriptors; heap replay over the lists, rescoring: 157 waves per 10 000
+// queries, 0.2 + 0.8 ms) on one of `depth` internal streams, handed over by events.  The
+// second half of call b is enqueued AFTER the first half of call b+1 (or by tk_index_join),
+// so that the caller's stream reads
 //     ... scan(b-1) | tables(b+1) coarse-scan(b+1) | scan(b) | tables(b+2) ...
-// and take turns in exactly that order, so that scan(b) finds its coarse heap replay and
-// descriptors (latency-bound, ~0.25 ms) finished during scan(b-1) instead of holding the
-// turn for them, while the heap replays of b-1 and b-2 (0.7 ms of latency each) overlap.
+// and scan(b) finds its descriptors finished during scan(b-1) instead of stalling the
+// stream for them, while the heap replays of the previous batches overlap all of it.
 struct Pending {
     Work *w;
     const float *q_dev;
@@ -1023,27 +1016,26 @@ struct Pending {
     int64_t *out_dev;
     bool units;
     Prof pf;
-    hipStream_t front_st, back_st;
+    hipStream_t st, sl;   // chip-filling kernels / latency-bound kernels
 };
 
 static int batch_front(tk_index *ix, Pending &b, const void *qpq_dev, int qpq_f64)
 {
     Work &w = *b.w;
     const Plan &p = b.p;
-    hipStream_t st = b.front_st;
-    TRY(prof_begin(ix, w, b.nq, p, b.back_st, b.pf));
+    TRY(prof_begin(ix, w, b.nq, p, b.sl, b.pf));
     b.units = use_units(ix, b.nq, p);
     TRY(stage_front(ix, w, b.q_dev, qpq_dev, qpq_f64, b.nq, p,
-                    b.units ? w.u_count.as<int>() : nullptr, nullptr, 0, ix->depth > 1, st, b.pf));
+                    b.units ? w.u_count.as<int>() : nullptr, nullptr, 0, b.st, b.sl, b.pf));
     if (b.units)
         tk_launch_unit_pairs(b.nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
                              ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
                              w.u_count.as<int>(), w.u_pair_off.as<int>(),
                              w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
                              w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
-                             b.nq * p.S + 4 * ix->n_lists, st);
+                             b.nq * p.S + 4 * ix->n_lists, b.sl);
     HIPCHECK(hipGetLastError());
-    if (ix->depth > 1) HIPCHECK(hipEventRecord(w.front_done, st));
+    if (b.sl != b.st) HIPCHECK(hipEventRecord(w.front_done, b.sl));
     return TK_OK;
 }
 
@@ -1052,11 +1044,8 @@ static int batch_back(tk_index *ix, Pending &b)
     Work &w = *b.w;
     const Plan &p = b.p;
     const int M = ix->M;
-    hipStream_t st = b.back_st;
-    if (ix->depth > 1) {
-        HIPCHECK(hipStreamWaitEvent(st, w.front_done, 0));
-        TRY(turn_wait(ix, st));
-    }
+    hipStream_t st = b.st;
+    if (b.sl != b.st) HIPCHECK(hipStreamWaitEvent(st, w.front_done, 0));
     TRY(b.pf.mark(st));
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
     if (b.units)
@@ -1071,11 +1060,14 @@ static int batch_back(tk_index *ix, Pending &b)
                               (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(),
                               p.cap_min, 1, ix->order, st);
     TRY(b.pf.mark(st));
-    if (ix->depth > 1) TRY(turn_pass(ix, st));
-    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf));
+    if (b.sl != b.st) {
+        HIPCHECK(hipEventRecord(w.scanned, st));
+        HIPCHECK(hipStreamWaitEvent(b.sl, w.scanned, 0));
+    }
+    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, b.sl, b.pf));
     HIPCHECK(hipGetLastError());
-    if (ix->depth > 1) {
-        HIPCHECK(hipEventRecord(w.done, st));
+    if (b.sl != b.st) {
+        HIPCHECK(hipEventRecord(w.done, b.sl));
         w.busy = true;
     }
     return TK_OK;
@@ -1113,16 +1105,17 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
         b.p = p;
         b.out_dev = out_ids_dev + o * k;
         b.units = false;
-        b.front_st = b.back_st = caller;
+        b.st = b.sl = caller;
         if (ix->depth > 1) {
-            while ((int)ix->back_streams.size() < ix->depth) {
+            while ((int)ix->lat_streams.size() < ix->depth) {
                 hipStream_t st;
                 HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-                ix->back_streams.push_back(st);
+                ix->lat_streams.push_back(st);
             }
-            b.back_st = ix->back_streams[ix->calls % (uint64_t)ix->depth];
-            if (!w.front_done) HIPCHECK(hipEventCreateWithFlags(&w.front_done, hipEventDisableTiming));
-            if (!w.done) HIPCHECK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+            b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
+            hipEvent_t *evs[] = {&w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
+            for (hipEvent_t *e : evs)
+                if (!*e) HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
             // the workspace is free once the second half of its previous batch is through
             if (w.busy) HIPCHECK(hipStreamWaitEvent(caller, w.done, 0));
         }
@@ -1212,7 +1205,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     Prof pf;
     const int *owner = ix->owner.as<int>();
     TRY(stage_front(ix, w, q_dev, q_pq_dev, q_pq_is_f64, nq, p, w.u_count.as<int>(), owner,
-                    ix->rank, false, st, pf));
+                    ix->rank, st, st, pf));
     tk_launch_shard_positions(w.probes.as<int64_t>(), w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
                               owner, ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
                               w.rpos.as<int>(), flag_dev, st);
