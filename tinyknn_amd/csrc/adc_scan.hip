@@ -338,6 +338,10 @@ __device__ __forceinline__ void finish_chunk(uint32_t (&a0)[8], uint4 &o, uint32
 }
 
 #define TK_UNIT_Q 4
+// work counters of the list-major scan: TK_TICKETS ints, 128 bytes apart, behind the
+// (n_lists+1)-entry unit_prefix table in the same allocation
+#define TK_TICKETS 8
+#define TK_TICKET_OFF(n_lists) ((((n_lists) + 1 + 31) / 32 + 1) * 32)
 
 // COARSE only tags the instantiation used for the coded centres so that profilers
 // list the two launches of a batch separately.
@@ -352,9 +356,47 @@ __global__ __launch_bounds__(256, MINW) void scan_units_kernel(
     uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride)
 {
     const int U = unit_prefix[n_lists];
-    const int stride = gridDim.x * 256;
     const uint32_t cA = 0x020c000cu, cB = 0x030c010cu;
-    for (int u0 = blockIdx.x * 256 + (threadIdx.x & ~63); u0 < U; u0 += stride) {
+    // Blocks of 64 consecutive units.  Every wave takes one block statically; the rest are
+    // drawn from TK_TICKETS work counters (behind the prefix table, a cache line each,
+    // zeroed by the kernel that wrote the table; a wave starts at its home counter and moves
+    // on when a range is used up).  With other batches' heap replays sharing some SIMDs a
+    // static split leaves the kernel waiting for its slowest waves.  One counter would not
+    // do: same-address atomics retire at ~60 M/s and this kernel wants 70 M blocks/s.
+    int *ticket = const_cast<int *>(unit_prefix) + TK_TICKET_OFF(n_lists);
+    const int NB = (U + 63) >> 6;
+    const int NW = gridDim.x * 4 < NB ? gridDim.x * 4 : NB;   // blocks handed out statically
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int dyn = NB - NW;
+    int tried = 0, tk = wid & (TK_TICKETS - 1);
+    // synchronous draw: the search through the other ranges once a wave's range is used up
+    auto draw = [&]() -> int {
+        while (tried < TK_TICKETS) {
+            const int lo = (int)((int64_t)dyn * tk / TK_TICKETS);
+            const int len = (int)((int64_t)dyn * (tk + 1) / TK_TICKETS) - lo;
+            int got = len;
+            if ((threadIdx.x & 63) == 0) {
+                int *t = ticket + tk * 32;
+                if (__atomic_load_n(t, __ATOMIC_RELAXED) < len) got = atomicAdd(t, 1);
+            }
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got < len) return NW + lo + got;
+            tried++;
+            tk = (tk + 1) & (TK_TICKETS - 1);
+        }
+        return NB;
+    };
+    int blk = wid < NW ? wid : NB;
+    while (blk < NB) {
+        // draw the block after this one now; the answer is looked at after this block's work
+        int nlo = 0, nlen = 0, ngot = 0;
+        const bool drawn = dyn > 0 && tried < TK_TICKETS;
+        if (drawn) {
+            nlo = (int)((int64_t)dyn * tk / TK_TICKETS);
+            nlen = (int)((int64_t)dyn * (tk + 1) / TK_TICKETS) - nlo;
+            if ((threadIdx.x & 63) == 0) ngot = atomicAdd(ticket + tk * 32, 1);
+        }
+        const int u0 = blk << 6;
         const int u = u0 + (threadIdx.x & 63);
         const bool active = u < U;
         const int uu = active ? u : U - 1;
@@ -441,6 +483,17 @@ __global__ __launch_bounds__(256, MINW) void scan_units_kernel(
                 if (mins) mins[(int64_t)qi * min_stride + f0 + c] = (uint8_t)mn;
             }
         }
+        // next block
+        blk = NB;
+        if (!drawn) break;
+        ngot = __builtin_amdgcn_readfirstlane(ngot);
+        if (ngot < nlen) {
+            blk = NW + nlo + ngot;
+            continue;
+        }
+        tried++;
+        tk = (tk + 1) & (TK_TICKETS - 1);
+        blk = draw();
     }
 }
 
@@ -497,6 +550,7 @@ __global__ __launch_bounds__(1024) void pairs_scan_kernel(int *__restrict__ coun
         pair_off[n_lists] = carry_rec;
         unit_prefix[n_lists] = carry_unit;
     }
+    if (threadIdx.x < TK_TICKETS) unit_prefix[TK_TICKET_OFF(n_lists) + threadIdx.x * 32] = 0;
 }
 
 __global__ void pairs_fill_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
@@ -553,6 +607,7 @@ __global__ void pairs_identity_kernel(int64_t nq, int chunks, int *__restrict__ 
         pair_off[1] = (int)nrec;
         unit_prefix[0] = 0;
         unit_prefix[1] = (int)(nrec / TK_UNIT_Q) * chunks;
+        for (int t = 0; t < TK_TICKETS; t++) unit_prefix[TK_TICKET_OFF(1) + t * 32] = 0;
     }
 }
 

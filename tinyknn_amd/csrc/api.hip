@@ -378,7 +378,7 @@ extern "C" int tk_codes_estimate_dev(tk_codes *c, const void *tables_dev, int64_
     const bool units = nq >= 4 && (double)nq / 4 * c->chunks < 2.0e9;
     if (units) {
         TRY(c->pair_off.ensure(8));
-        TRY(c->unit_prefix.ensure(8));
+        TRY(c->unit_prefix.ensure(tk_unit_prefix_ints(1) * 4));
         TRY(c->pair_q.ensure(((size_t)nq + 4) * 4));
         TRY(c->pair_f0.ensure(((size_t)nq + 4) * 4));
         if (!c->chunk_off.p) {
@@ -392,7 +392,7 @@ extern "C" int tk_codes_estimate_dev(tk_codes *c, const void *tables_dev, int64_
         tk_launch_scan_units(c->tiled.as<uint4>(), c->M, (const uint4 *)tables_dev, nq, 1, 1,
                              c->chunk_off.as<int64_t>(), c->pair_off.as<int>(),
                              c->unit_prefix.as<int>(), c->pair_q.as<int>(), c->pair_f0.as<int>(),
-                             (uint4 *)out_dev, c->chunks, nullptr, 0, signd, order, 3072, st);
+                             (uint4 *)out_dev, c->chunks, nullptr, 0, signd, order, 768, st);
     } else {
         tk_launch_scan_flat(c->tiled.as<uint4>(), c->chunks, c->M, (const uint4 *)tables_dev, nq,
                             (uint4 *)out_dev, c->chunks, nullptr, 0, signd, order, st);
@@ -788,11 +788,11 @@ static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
     }
     TRY(w.u_cursor.ensure(L * 4));
     TRY(w.u_pair_off.ensure((L + 1) * 4));
-    TRY(w.u_unit_prefix.ensure((L + 1) * 4));
+    TRY(w.u_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
     TRY(w.u_pair_q.ensure(((size_t)nq * p.S + 4 * L) * 4));
     TRY(w.u_pair_f0.ensure(((size_t)nq * p.S + 4 * L) * 4));
     TRY(w.c_pair_off.ensure(8));
-    TRY(w.c_unit_prefix.ensure(8));
+    TRY(w.c_unit_prefix.ensure(tk_unit_prefix_ints(1) * 4));
     TRY(w.c_pair_q.ensure(((size_t)nq + 4) * 4));
     TRY(w.c_pair_f0.ensure(((size_t)nq + 4) * 4));
     return TK_OK;
@@ -886,7 +886,7 @@ static int stage_front(tk_index *ix, Work &w, const float *q_dev, const void *qp
                              ix->c_chunk_off.as<int64_t>(), w.c_pair_off.as<int>(),
                              w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
                              w.c_pair_f0.as<int>(), w.cdist.as<uint4>(), ix->center_chunks,
-                             w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, 3072, st);
+                             w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, 768, st);
     } else {
         tk_launch_scan_flat(ix->center_codes.as<uint4>(), ix->center_chunks, M,
                             w.tables.as<uint4>(), nq, w.cdist.as<uint4>(), ix->center_chunks,
@@ -1053,7 +1053,7 @@ static int batch_back(tk_index *ix, Pending &b)
                              ix->list_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                              w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(),
                              w.u_pair_f0.as<int>(), w.dist.as<uint4>(), p.cap,
-                             w.mins.as<uint8_t>(), p.cap_min, 1, ix->order, 3072, st);
+                             w.mins.as<uint8_t>(), p.cap_min, 1, ix->order, 768, st);
     else
         tk_launch_scan_probes(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), b.nq,
                               w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), p.S,
@@ -1165,11 +1165,11 @@ static int reserve_shard(tk_index *ix, Work &w, int64_t nq, int64_t qh, const Pl
     }
     TRY(w.u_cursor.ensure(L * 4));
     TRY(w.u_pair_off.ensure((L + 1) * 4));
-    TRY(w.u_unit_prefix.ensure((L + 1) * 4));
+    TRY(w.u_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
     TRY(w.u_pair_q.ensure(((size_t)nq * p.S + 4 * L) * 4));
     TRY(w.u_pair_f0.ensure(((size_t)nq * p.S + 4 * L) * 4));
     TRY(w.c_pair_off.ensure(8));
-    TRY(w.c_unit_prefix.ensure(8));
+    TRY(w.c_unit_prefix.ensure(tk_unit_prefix_ints(1) * 4));
     TRY(w.c_pair_q.ensure(((size_t)nq + 4) * 4));
     TRY(w.c_pair_f0.ensure(((size_t)nq + 4) * 4));
     return TK_OK;
@@ -1220,7 +1220,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
                          ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                          w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
-                         (uint4 *)send_dev, 0, nullptr, 0, 1, ix->order, 3072, st);
+                         (uint4 *)send_dev, 0, nullptr, 0, 1, ix->order, 768, st);
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }

@@ -13,6 +13,13 @@
 // so that 8 consecutive chunks share one 128-byte line per pair and a wave whose
 // lanes own consecutive chunks reads whole lines.  The chunk count is padded to a
 // multiple of 8 with zero chunks.
+// ints in a unit_prefix array for n_lists lists: the prefix table, then (128-byte aligned)
+// the 8 work counters of tk_launch_scan_units, 128 bytes apart
+static inline size_t tk_unit_prefix_ints(int64_t n_lists)
+{
+    return (size_t)(((n_lists + 1 + 31) / 32 + 1) * 32 + 8 * 32);
+}
+
 static inline int64_t tk_tiled_uint4s(int64_t chunks, int P)
 {
     return ((chunks + 7) / 8) * 8 * (int64_t)P;
