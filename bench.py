@@ -296,6 +296,13 @@ def main():
     torch.cuda.synchronize()
     iso_stages, iso_bytes, _ = dev.last_profile()
     dev.set_profiling(False)
+    # the same batch through the HOST-pointer entry point (tk_index_query_batch: H2D of the
+    # queries, the pipeline, D2H of the ids, synchronous) — the PCIe-inclusive rate
+    dev.query_batch(qn, qp, args.k, args.n_probes)
+    th = time.perf_counter()
+    for _ in range(3):
+        host_ids = dev.query_batch(qn, qp, args.k, args.n_probes)
+    host_qps = 3 * args.nq / (time.perf_counter() - th)
     t = torch.tensor([elapsed], dtype=torch.float64,
                      device=device if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -383,6 +390,10 @@ def main():
                      "stage_ms": iso_stages, "ms_per_step": sum(iso_stages.values()),
                      "scan_kernel_GBps": iso_bytes / (iso_stages["scan"] * 1e-3) / 1e9,
                      "scan_kernel_frac_of_hbm_peak": iso_bytes / (iso_stages["scan"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        "host_boundary": {"queries_per_s": host_qps,
+                          "note": "tk_index_query_batch with host buffers: H2D queries + pipeline + D2H ids, "
+                                  "synchronous, one batch at a time (never `value`)",
+                          "identical_to_device_path": bool((host_ids == got).all())},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
     }
