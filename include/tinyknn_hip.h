@@ -112,6 +112,28 @@ int tk_codes_estimate_dev(tk_codes *c, const void *tables_dev, int64_t nq, void 
 int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, int64_t *indices,
                    int32_t *vals, int R, int signd, const int64_t *labels, int order);
 
+/* ---- offline build path: the step before the hot path -------------
+ * Both restate numpy's rounding (einsum order; OpenBLAS GEMM = FMA chain over k for the
+ * shapes involved; argpartition's dumb_select) and reproduce the compiled reference's codes
+ * and list memberships on the golden fixtures.
+ *
+ * tk_encode_pq: the per-block nearest-centroid search of FastPQ.transform
+ * (fast_pq.py:174-181: knn_brute(col, code, 1) for every block).  data: (n, dq) rows after
+ * the reference's padding (utils.py pad2) and, for a rotated PQ, after `data @ R.T` (a BLAS
+ * GEMM that stays on the host; then float64).  labels: (n, M) uint8, to be packed by
+ * transform_data (_transform.py:4-77). */
+int tk_encode_pq(const float *centers, int dq, int dpb, const void *data, int data_is_f64,
+                 int64_t n, uint8_t *labels);
+/* tk_assign_lists: knn_brute(X, Y, k, metric) of IVF.build (ivf.py:85, utils.py:66-86) for
+ * k <= 2 and d <= 384.  X: (n, d) float32 rows — whole 100-row chunks only (n % 100 rows at
+ * the end of a data set are a differently shaped GEMM in numpy: the caller keeps numpy for
+ * them); normalise != 0: X is divided by its row norms first (angular metric,
+ * utils.py:73-74; d <= 128).  Y: (L, d) centres AFTER the caller's numpy normalisation,
+ * float32 or float64, ynorm2 = np.einsum("ij,ij->i", Y, Y) in Y's dtype.
+ * nearest: (n, k) int64 in numpy's argpartition order. */
+int tk_assign_lists(const float *X, int64_t n, int d, int normalise, const void *Y, int y_is_f64,
+                    const void *ynorm2, int64_t L, int k, int64_t *nearest);
+
 /* ---- device-resident IVF index --------------------------------------------
  * Holds what the reference's IVF object holds after fit+build (ivf.py:14-17,
  * 77-102) in HBM, re-tiled for coalesced scans, and answers batches of queries

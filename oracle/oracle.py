@@ -296,3 +296,44 @@ class OracleIndex:
                                   C.c_int64(len(qn)), k, n_probes, int(pass_1 or 0),
                                   out.ctypes.data)
         return out
+
+
+# ---- offline build path -----------------------------------
+
+def encode_pq(centers, dpb, data_pq):
+    """labels (n, M) uint8 of FastPQ.transform's per-block knn_brute(col, code, 1)
+    (fast_pq.py:174-181); data_pq: padded (rotated) rows, float32 or float64."""
+    centers = np.ascontiguousarray(centers, dtype=np.float32)
+    is64 = data_pq.dtype != np.float32
+    data_pq = np.ascontiguousarray(data_pq, dtype=np.float64 if is64 else np.float32)
+    n, dq = data_pq.shape
+    assert centers.shape == (16, dq)
+    labels = np.empty((n, dq // dpb), dtype=np.uint8)
+    lib().tko_encode_pq(_p(centers, C.c_float), dq, int(dpb), C.c_void_p(data_pq.ctypes.data),
+                        int(is64), C.c_int64(n), _p(labels, C.c_uint8))
+    return labels
+
+
+def fastpq_transform(centers, dpb, R, data):
+    """FastPQ.transform (fast_pq.py:147-184) -> (true_n, packed)"""
+    true_n = data.shape[0]
+    pr, pc = (-data.shape[0]) % 16, (-data.shape[1]) % (4 * dpb)
+    padded = np.zeros((data.shape[0] + pr, data.shape[1] + pc), dtype=data.dtype)
+    padded[:data.shape[0], :data.shape[1]] = data
+    if R is not None:
+        padded = padded @ R.T          # BLAS GEMM: not restated, numpy as in the reference
+    return true_n, transform_data(encode_pq(centers, dpb, padded))
+
+
+def assign(X, Y, k, metric):
+    """knn_brute(X, Y, k, metric) (utils.py:66-86) for k <= 2; a trailing 1-row chunk
+    (len(X) % 100 == 1) is a GEMV in numpy and stays numpy."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    y64 = Y.dtype != np.float32
+    Y = np.ascontiguousarray(Y, dtype=np.float64 if y64 else np.float32)
+    out = np.empty((len(X), k), dtype=np.int64)
+    rc = lib().tko_assign(_p(X, C.c_float), C.c_int64(len(X)), X.shape[1],
+                          C.c_void_p(Y.ctypes.data), int(y64), C.c_int64(len(Y)), int(k),
+                          int(metric == "angular"), _p(out, C.c_int64))
+    assert rc == 0
+    return out

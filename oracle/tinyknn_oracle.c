@@ -740,3 +740,168 @@ void tko_ivf_query_batch(const tko_index *ix, const float *qs, const void *qs_pq
     }
     free(tmp);
 }
+
+/* ------------------------------------------------------------------ */
+/* Offline build path: the step BEFORE the hot path   */
+/* FastPQ.transform fast_pq.py:147-184, IVF.build ivf.py:85-102,       */
+/* knn_brute utils.py:66-86                                            */
+/* ------------------------------------------------------------------ */
+
+/* numpy's `A @ B.T` here is an OpenBLAS GEMM.  On the fixture host (OpenBLAS 0.3.29,
+ * AVX-512 kernels) every GEMM the build path issues — K = dims_per_block, K = d <= 128,
+ * float32 and float64, >= 32 rows — returns, for every output element, the FMA chain
+ * over k ascending starting from 0 (one accumulator per element, no K split)
+ * [measured against exact rational arithmetic and numpy, tests/test_build_path.py].  NOT
+ * restated, and kept in numpy by every caller: the rotation `data @ R.T` (fast_pq.py:168;
+ * its DGEMM order changes with the row count and the thread split), operands of a few rows
+ * (small-matrix kernels) and 1-row operands (GEMV).
+ * argpartition(part, k)[:, :k] for k <= 2 is restated as numpy's generic path (dumb_select:
+ * first occurrence of the minimum by strict `<`); with EXACT ties numpy's AVX-512 argselect
+ * network may pick another of the tied entries — unpinned by the reference, absent from its
+ * fixtures. */
+static inline float chain_f32(const float *a2, const float *b, int K)
+{
+    float acc = 0.0f;
+    for (int k = 0; k < K; k++) acc = fmaf(a2[k], b[k], acc);
+    return acc;
+}
+
+/* labels[i][b] = knn_brute(col_b, code_b, 1)[i]   fast_pq.py:174-181: per block the
+ * squared distance in the expanded form  (|x|^2 + |c|^2) - (2x).c   (utils.py:84; note
+ * `2 * Xchunk @ Y.T` parses as (2*Xchunk) @ Y.T), norms by einsum, the product by GEMM,
+ * argpartition(.., 1)[:, :1] = first occurrence of the minimum (numpy's dumb_select for
+ * kth < 3).  data: (n, dq) rows already padded (and rotated: then float64). */
+void tko_encode_pq(const float *centers, int dq, int dpb, const void *data, int is_f64, i64 n,
+                   uint8_t *labels)
+{
+    const int M = dq / dpb;
+    float yn[16];
+    float x2f[32];
+    double x2d[32], yd[32];
+    for (int b = 0; b < M; b++) {
+        for (int c = 0; c < 16; c++) {
+            const float *y = centers + (i64)c * dq + b * dpb;
+            yn[c] = einsum_dot_f32(y, y, dpb);
+        }
+        for (i64 i = 0; i < n; i++) {
+            int best = 0;
+            if (!is_f64) {
+                const float *x = (const float *)data + i * dq + b * dpb;
+                const float xn = einsum_dot_f32(x, x, dpb);
+                for (int k = 0; k < dpb; k++) x2f[k] = 2.0f * x[k];
+                float bestv = 0;
+                for (int c = 0; c < 16; c++) {
+                    const float p = chain_f32(x2f, centers + (i64)c * dq + b * dpb, dpb);
+                    const float part = (xn + yn[c]) - p;
+                    if (c == 0 || part < bestv) { bestv = part; best = c; }
+                }
+            } else {
+                const double *x = (const double *)data + i * dq + b * dpb;
+                const double xn = einsum_dot_f64(x, x, dpb);
+                for (int k = 0; k < dpb; k++) x2d[k] = 2.0 * x[k];
+                double bestv = 0;
+                for (int c = 0; c < 16; c++) {
+                    const float *y = centers + (i64)c * dq + b * dpb;
+                    for (int k = 0; k < dpb; k++) yd[k] = (double)y[k];
+                    double p = 0.0;
+                    for (int k = 0; k < dpb; k++) p = fma(x2d[k], yd[k], p);
+                    const double part = (xn + (double)yn[c]) - p;
+                    if (c == 0 || part < bestv) { bestv = part; best = c; }
+                }
+            }
+            labels[i * M + b] = (uint8_t)best;
+        }
+    }
+}
+
+/* np.linalg.norm(X, axis=1) for float32 rows: sqrt(add.reduce(x*x)) with numpy's
+ * pairwise summation (ivf.py:79, utils.py:74-75) */
+static float row_norm_f32(const float *x, int d, float *tmp)
+{
+    for (int k = 0; k < d; k++) tmp[k] = x[k] * x[k];
+    return sqrtf(pairwise_f32(tmp, d));
+}
+static double row_norm_f64(const double *x, int d, double *tmp)
+{
+    for (int k = 0; k < d; k++) tmp[k] = x[k] * x[k];
+    return sqrt(pairwise_f64(tmp, d));
+}
+
+/* np.argpartition(part, k, axis=1)[:, :k] for k <= 2 (kth < 3: numpy's dumb_select, a
+ * selection sort of the first kth+1 positions by strict `<`, swapping into place) */
+static void dumb_select_first(const double *v, i64 n, int k, i64 *out)
+{
+    /* position 0: first occurrence of the minimum */
+    i64 m0 = 0;
+    for (i64 j = 1; j < n; j++) if (v[j] < v[m0]) m0 = j;
+    out[0] = m0;
+    if (k < 2) return;
+    /* after swapping positions 0 and m0 the scan order of the rest is
+     * 1 .. m0-1, (original 0 at position m0), m0+1 .. n-1 */
+    i64 best = -1;
+    for (i64 pos = 1; pos < n; pos++) {
+        const i64 j = (pos == m0) ? 0 : pos;
+        if (best < 0 || v[j] < v[best]) best = j;
+    }
+    out[1] = best;
+}
+
+/* knn_brute(X, Y, k, metric) utils.py:66-86, k <= 2.  X: (n, d) float32 (IVF.data after
+ * ivf.py:77-79); Y: (L, d) all_centers, float32 or float64; angular: both are divided by
+ * their row norms first (utils.py:73-75).  out: (n, k).  Chunks of one row (n % 100 == 1)
+ * are a GEMV in numpy and not restated: the caller keeps numpy for that row. */
+int tko_assign(const float *X, i64 n, int d, const void *Y, int y_is_f64, i64 L, int k,
+               int angular, i64 *out)
+{
+    if (k < 1 || k > 2 || k > L || d > 4096) return -1;
+    float *Yf = NULL, *ynf = NULL, *xf = (float *)malloc(sizeof(float) * (size_t)d * 3);
+    double *Yd = NULL, *ynd = NULL, *xd = (double *)malloc(sizeof(double) * (size_t)d * 2);
+    double *part = (double *)malloc(sizeof(double) * (size_t)L);
+    float *tmpf = xf + d, *x2f = xf + 2 * d;
+    double *x2d = xd + d;
+    if (y_is_f64) {
+        Yd = (double *)malloc(sizeof(double) * (size_t)L * d);
+        ynd = (double *)malloc(sizeof(double) * (size_t)L);
+        double *tmpd = (double *)malloc(sizeof(double) * (size_t)d);
+        for (i64 j = 0; j < L; j++) {
+            const double *y = (const double *)Y + j * d;
+            double nr = angular ? row_norm_f64(y, d, tmpd) : 1.0;
+            for (int t = 0; t < d; t++) Yd[j * d + t] = angular ? y[t] / nr : y[t];
+            ynd[j] = einsum_dot_f64(Yd + j * d, Yd + j * d, d);
+        }
+        free(tmpd);
+    } else {
+        Yf = (float *)malloc(sizeof(float) * (size_t)L * d);
+        ynf = (float *)malloc(sizeof(float) * (size_t)L);
+        for (i64 j = 0; j < L; j++) {
+            const float *y = (const float *)Y + j * d;
+            float nr = angular ? row_norm_f32(y, d, tmpf) : 1.0f;
+            for (int t = 0; t < d; t++) Yf[j * d + t] = angular ? y[t] / nr : y[t];
+            ynf[j] = einsum_dot_f32(Yf + j * d, Yf + j * d, d);
+        }
+    }
+    for (i64 i = 0; i < n; i++) {
+        const float *x0 = X + i * d;
+        float nr = angular ? row_norm_f32(x0, d, tmpf) : 1.0f;
+        for (int t = 0; t < d; t++) xf[t] = angular ? x0[t] / nr : x0[t];
+        const float xn = einsum_dot_f32(xf, xf, d);
+        if (y_is_f64) {
+            /* float32 X against float64 Y: numpy promotes (2*X) to float64, DGEMM */
+            for (int t = 0; t < d; t++) x2d[t] = (double)(2.0f * xf[t]);
+            for (i64 j = 0; j < L; j++) {
+                double p = 0.0;
+                for (int t = 0; t < d; t++) p = fma(x2d[t], Yd[j * d + t], p);
+                part[j] = ((double)xn + ynd[j]) - p;
+            }
+        } else {
+            for (int t = 0; t < d; t++) x2f[t] = 2.0f * xf[t];
+            for (i64 j = 0; j < L; j++) {
+                const float p = chain_f32(x2f, Yf + j * d, d);
+                part[j] = (double)((xn + ynf[j]) - p);
+            }
+        }
+        dumb_select_first(part, L, k, out + i * k);
+    }
+    free(xf); free(xd); free(part); free(Yf); free(ynf); free(Yd); free(ynd);
+    return 0;
+}

@@ -47,6 +47,9 @@ SIGNATURES = {
                                   C.c_double, C.c_double, C.c_int, _u8p, C.c_void_p, _f64p]),
     "tk_knn_brute1": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                   C.c_int64, _i64p]),
+    "tk_encode_pq": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, _u8p]),
+    "tk_assign_lists": (C.c_int, [_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int64, C.c_int, _i64p]),
     "tk_codes_upload": (C.c_void_p, [_u64p, C.c_int64, C.c_int]),
     "tk_codes_free": (None, [C.c_void_p]),
     "tk_codes_estimate": (C.c_int, [C.c_void_p, _u64p, C.c_int64, _u64p, C.c_int, C.c_int]),

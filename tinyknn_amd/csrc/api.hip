@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <mutex>
 #include <stdlib.h>
+#include <string.h>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -459,6 +460,87 @@ extern "C" int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, in
     HIPCHECK(hipMemcpyAsync(vals, c->hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     return TK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// offline build path (build.hip): host buffers in, host buffers out, rows in slabs
+extern "C" int tk_encode_pq(const float *centers, int dq, int dpb, const void *data,
+                            int data_is_f64, int64_t n, uint8_t *labels)
+{
+    TRY(require_gpu());
+    ARGCHECK(centers && data && labels, "null buffer");
+    ARGCHECK(dpb >= 1 && dpb <= 32 && dq >= dpb && dq % dpb == 0, "dq/dpb");
+    ARGCHECK(n >= 0, "n");
+    const int M = dq / dpb;
+    ARGCHECK((size_t)(16 * dq + 16 * M) * 4 <= 64 * 1024, "codebook larger than 64 KiB of LDS");
+    const size_t esz = data_is_f64 ? 8 : 4;
+    const int64_t slab = 1 << 20;
+    DevBuf dc, dd, dl;
+    TRY(dc.ensure((size_t)16 * dq * 4));
+    HIPCHECK(hipMemcpy(dc.p, centers, (size_t)16 * dq * 4, hipMemcpyHostToDevice));
+    int rc = TK_OK;
+    for (int64_t o = 0; o < n && rc == TK_OK; o += slab) {
+        const int64_t m = n - o < slab ? n - o : slab;
+        if ((rc = dd.ensure((size_t)m * dq * esz)) != TK_OK) break;
+        if ((rc = dl.ensure((size_t)m * M)) != TK_OK) break;
+        hipError_t e = hipMemcpy(dd.p, (const char *)data + (size_t)o * dq * esz,
+                                 (size_t)m * dq * esz, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            tk_launch_encode_pq(dc.as<float>(), dq, dpb, dd.p, data_is_f64, m, dl.as<uint8_t>(), 0);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpy(labels + (size_t)o * M, dl.p, (size_t)m * M, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TK_ERR_HIP, hipGetErrorString(e));
+    }
+    dc.release(); dd.release(); dl.release();
+    return rc;
+}
+
+extern "C" int tk_assign_lists(const float *X, int64_t n, int d, int normalise, const void *Y,
+                               int y_is_f64, const void *ynorm2, int64_t L, int k,
+                               int64_t *nearest)
+{
+    TRY(require_gpu());
+    ARGCHECK(X && Y && ynorm2 && nearest, "null buffer");
+    ARGCHECK(n >= 0 && d >= 1 && L >= 1 && L < (1ll << 31), "sizes");
+    ARGCHECK(k >= 1 && k <= 2 && k <= L, "k must be 1 or 2 (numpy's dumb_select range)");
+    ARGCHECK(d <= 384, "d > 384: OpenBLAS splits K there and the FMA chain no longer holds");
+    ARGCHECK(!normalise || d <= 128, "row normalisation on the device needs d <= 128");
+    const size_t ysz = y_is_f64 ? 8 : 4;
+    // Y (L, d) -> Yt (d, L): a wave reads consecutive centres
+    std::vector<char> yt((size_t)L * d * ysz);
+    for (int64_t j = 0; j < L; j++)
+        for (int t = 0; t < d; t++)
+            memcpy(&yt[((size_t)t * L + j) * ysz], (const char *)Y + ((size_t)j * d + t) * ysz, ysz);
+    const int64_t slab = 1 << 20;
+    DevBuf dy, dn, dx, dxn, dout;
+    TRY(dy.ensure(yt.size()));
+    TRY(dn.ensure((size_t)L * ysz));
+    HIPCHECK(hipMemcpy(dy.p, yt.data(), yt.size(), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dn.p, ynorm2, (size_t)L * ysz, hipMemcpyHostToDevice));
+    int rc = TK_OK;
+    for (int64_t o = 0; o < n && rc == TK_OK; o += slab) {
+        const int64_t m = n - o < slab ? n - o : slab;
+        if ((rc = dx.ensure((size_t)m * d * 4)) != TK_OK) break;
+        if ((rc = dout.ensure((size_t)m * k * 8)) != TK_OK) break;
+        if (normalise && (rc = dxn.ensure((size_t)m * d * 4)) != TK_OK) break;
+        hipError_t e = hipMemcpy(dx.p, X + (size_t)o * d, (size_t)m * d * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const float *xs = dx.as<float>();
+            if (normalise) {
+                tk_launch_normalise_rows(dx.as<float>(), m, d, dxn.as<float>(), 0);
+                xs = dxn.as<float>();
+            }
+            tk_launch_assign(xs, m, d, dy.p, dn.p, y_is_f64, (int)L, k, dout.as<int64_t>(), 0);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpy(nearest + (size_t)o * k, dout.p, (size_t)m * k * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TK_ERR_HIP, hipGetErrorString(e));
+    }
+    dy.release(); dn.release(); dx.release(); dxn.release(); dout.release();
+    return rc;
 }
 
 // ---------------------------------------------------------------------------

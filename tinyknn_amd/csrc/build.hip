@@ -1,0 +1,255 @@
+// build.hip — the step BEFORE the hot path: PQ encoding
+// (FastPQ.transform, fast_pq.py:147-184) and the assignment of every point to its nearest
+// coarse centres (IVF.build, ivf.py:85; knn_brute, utils.py:66-86).  On the CPU both are a
+// Python loop over 100-row chunks — hours at 100M vectors.
+//
+// Both are chains of numpy operations whose rounding the kernels restate (-ffp-contract=off;
+// every FMA below is explicit):
+//   part = (|x|^2 + |y|^2) - (2x) @ y.T          utils.py:84 ("2 * X @ Y.T" = (2X) @ Y.T)
+//   |.|^2      np.einsum("ij,ij->i"): numpy's SSE3-baseline kernel (np_order.h)
+//   (2x)@y.T   OpenBLAS GEMM: for the shapes the path issues (100-row chunks, K <= 384) every
+//              output element is the FMA chain over k ascending from 0 [measured against
+//              exact rational arithmetic and numpy, tests/test_build_path.py]
+//   argpartition(part, k)[:, :k], k <= 2: numpy's dumb_select (kth < 3): a selection sort
+//              by strict "<" that swaps the winners into place
+// float32 rows against float32 centres run in float32; a float64 operand (rotated PQ,
+// float64 centres) promotes the rest to float64 exactly as numpy does.
+#include "kernels.h"
+#include "np_order.h"
+
+// ---------------------------------------------------------------------------
+// labels[row][b] = argmin_c part(row, b, c), first occurrence of the minimum
+template <typename T>
+struct Fma;
+template <>
+struct Fma<float> { static __device__ __forceinline__ float f(float a, float b, float c) { return __builtin_fmaf(a, b, c); } };
+template <>
+struct Fma<double> { static __device__ __forceinline__ double f(double a, double b, double c) { return __builtin_fma(a, b, c); } };
+
+#define TK_ENC_MAX_DPB 32
+
+template <typename T>
+__global__ __launch_bounds__(256) void encode_pq_kernel(const float *__restrict__ centers, int dq,
+                                                        int dpb, const T *__restrict__ data,
+                                                        int64_t n, uint8_t *__restrict__ labels)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *cen = (float *)smem;            // (16, dq)
+    float *yn = cen + 16 * dq;             // (M, 16): |code|^2 per block
+    const int M = dq / dpb;
+    for (int e = threadIdx.x; e < 16 * dq; e += 256) cen[e] = centers[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * M; e += 256) {
+        const int b = e >> 4, c = e & 15;
+        yn[e] = einsum_selfdot<float>(cen + c * dq + b * dpb, dpb);
+    }
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const T *x0 = data + row * dq;
+    for (int b = 0; b < M; b++) {
+        T x[TK_ENC_MAX_DPB], x2[TK_ENC_MAX_DPB];
+        for (int k = 0; k < dpb; k++) {
+            x[k] = x0[b * dpb + k];
+            x2[k] = (T)2 * x[k];
+        }
+        const T xn = einsum_selfdot<T>(x, dpb);
+        int best = 0;
+        T bestv = 0;
+        for (int c = 0; c < 16; c++) {
+            const float *y = cen + c * dq + b * dpb;
+            T p = 0;
+            for (int k = 0; k < dpb; k++) p = Fma<T>::f(x2[k], (T)y[k], p);
+            const T part = (xn + (T)yn[b * 16 + c]) - p;
+            if (c == 0 || part < bestv) {
+                bestv = part;
+                best = c;
+            }
+        }
+        labels[row * M + b] = (uint8_t)best;
+    }
+}
+
+int tk_launch_encode_pq(const float *centers, int dq, int dpb, const void *data, int is_f64,
+                        int64_t n, uint8_t *labels, hipStream_t s)
+{
+    if (n == 0) return 0;
+    const int M = dq / dpb;
+    const size_t lds = (size_t)(16 * dq + 16 * M) * 4;
+    if (lds > 64 * 1024 || dpb > TK_ENC_MAX_DPB) return -1;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (is_f64)
+        hipLaunchKernelGGL(encode_pq_kernel<double>, grid, dim3(256), lds, s, centers, dq, dpb,
+                           (const double *)data, n, labels);
+    else
+        hipLaunchKernelGGL(encode_pq_kernel<float>, grid, dim3(256), lds, s, centers, dq, dpb,
+                           (const float *)data, n, labels);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// X / np.linalg.norm(X, axis=1, keepdims=True) for float32 rows of d <= 128 elements:
+// sqrt(add.reduce(x*x)) with numpy's pairwise summation = one leaf of 8 accumulators.
+__global__ void normalise_rows_kernel(const float *__restrict__ X, int64_t n, int d,
+                                      float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *x = X + i * d;
+    float res;
+    if (d < 8) {
+        res = 0.0f;
+        for (int t = 0; t < d; t++) res += x[t] * x[t];
+    } else {
+        float r[8];
+        for (int j = 0; j < 8; j++) r[j] = x[j] * x[j];
+        int t = 8;
+        for (; t < d - (d % 8); t += 8)
+            for (int j = 0; j < 8; j++) r[j] += x[t + j] * x[t + j];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; t < d; t++) res += x[t] * x[t];
+    }
+    const float nr = __builtin_sqrtf(res);     // HIP's default: correctly rounded sqrt and divide
+    for (int t = 0; t < d; t++) out[i * d + t] = x[t] / nr;
+}
+
+// knn_brute for TK_AS_ROWS rows per workgroup: thread t scores centres t, t+256, ...; the
+// rows are wave-uniform (scalar loads feed the FMAs), Yt is (d, L) so that a wave reads
+// consecutive centres.  Every thread keeps its three best (value, index) per row, the
+// workgroup merges them, and dumb_select's answer follows from the three best overall.
+#define TK_AS_ROWS 8
+
+template <typename T>
+struct Cand {
+    T v;
+    int j;
+};
+
+template <typename T>
+__device__ __forceinline__ bool cand_lt(T v, int j, const Cand<T> &b)
+{
+    return b.j < 0 || v < b.v || (v == b.v && j < b.j);
+}
+
+template <typename T>
+__device__ __forceinline__ void cand_push(Cand<T> (&top)[3], T v, int j)
+{
+    if (cand_lt(v, j, top[0])) {
+        top[2] = top[1]; top[1] = top[0]; top[0] = {v, j};
+    } else if (cand_lt(v, j, top[1])) {
+        top[2] = top[1]; top[1] = {v, j};
+    } else if (cand_lt(v, j, top[2])) {
+        top[2] = {v, j};
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ X, int64_t n, int d,
+                                                     const T *__restrict__ Yt,
+                                                     const T *__restrict__ ynorm2, int L, int k,
+                                                     int64_t *__restrict__ nearest)
+{
+    __shared__ Cand<T> s_top[TK_AS_ROWS][4][3];   // the three best of each wave
+    __shared__ T s_v0[TK_AS_ROWS];
+    const int64_t r0 = (int64_t)blockIdx.x * TK_AS_ROWS;
+    const int nr = n - r0 < TK_AS_ROWS ? (int)(n - r0) : TK_AS_ROWS;
+    // |x|^2 in float32 (np.einsum on the float32 rows), promoted when added to float64 |y|^2
+    T xn[TK_AS_ROWS];
+    for (int r = 0; r < TK_AS_ROWS; r++) {
+        const float *x = X + (r0 + (r < nr ? r : 0)) * d;
+        xn[r] = (T)einsum_selfdot<float>(x, d);
+    }
+    Cand<T> top[TK_AS_ROWS][3];
+#pragma unroll
+    for (int r = 0; r < TK_AS_ROWS; r++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) top[r][t] = {(T)0, -1};
+    for (int j = threadIdx.x; j < L; j += 256) {
+        T p[TK_AS_ROWS];
+#pragma unroll
+        for (int r = 0; r < TK_AS_ROWS; r++) p[r] = 0;
+        for (int t = 0; t < d; t++) {
+            const T y = Yt[(int64_t)t * L + j];
+#pragma unroll
+            for (int r = 0; r < TK_AS_ROWS; r++) {
+                const float x2 = 2.0f * X[(r0 + (r < nr ? r : 0)) * d + t];   // wave-uniform
+                p[r] = Fma<T>::f((T)x2, y, p[r]);
+            }
+        }
+        const T yn = ynorm2[j];
+#pragma unroll
+        for (int r = 0; r < TK_AS_ROWS; r++) {
+            const T part = (xn[r] + yn) - p[r];
+            cand_push(top[r], part, j);
+            if (j == 0) s_v0[r] = part;
+        }
+    }
+    // the three best of the wave: butterfly over the lanes, each step merging the partner's
+    // three into mine (both lanes end up with the same list)
+#pragma unroll
+    for (int r = 0; r < TK_AS_ROWS; r++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            Cand<T> other[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                other[t].v = __shfl_xor(top[r][t].v, o, 64);
+                other[t].j = __shfl_xor(top[r][t].j, o, 64);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (other[t].j >= 0) cand_push(top[r], other[t].v, other[t].j);
+        }
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int t = 0; t < 3; t++) s_top[r][threadIdx.x >> 6][t] = top[r][t];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nr) {
+        const int r = threadIdx.x;
+        Cand<T> best[3] = {{(T)0, -1}, {(T)0, -1}, {(T)0, -1}};
+        for (int t = 0; t < 4; t++)
+            for (int u = 0; u < 3; u++) {
+                const Cand<T> c = s_top[r][t][u];
+                if (c.j >= 0) cand_push(best, c.v, c.j);
+            }
+        const int m0 = best[0].j;          // first occurrence of the minimum
+        nearest[(r0 + r) * k] = m0;
+        if (k == 2) {
+            // dumb_select, second pass: positions 0 and m0 were swapped, so the scan order
+            // is 1 .. m0-1, (element 0 at position m0), m0+1 .. L-1, strict "<"
+            int second;
+            if (m0 == 0) {
+                second = best[1].j;
+            } else {
+                int s = -1;
+                T sv = 0;
+                for (int u = 1; u < 3; u++)
+                    if (best[u].j > 0) { s = best[u].j; sv = best[u].v; break; }
+                const T v0 = s_v0[r];
+                if (s < 0 || v0 < sv || (v0 == sv && m0 < s)) second = 0;
+                else second = s;
+            }
+            nearest[(r0 + r) * k + 1] = second;
+        }
+    }
+}
+
+void tk_launch_normalise_rows(const float *X, int64_t n, int d, float *out, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(normalise_rows_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, X,
+                       n, d, out);
+}
+
+void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const void *ynorm2,
+                      int y_is_f64, int L, int k, int64_t *nearest, hipStream_t s)
+{
+    if (n == 0) return;
+    dim3 grid((unsigned)((n + TK_AS_ROWS - 1) / TK_AS_ROWS));
+    if (y_is_f64)
+        hipLaunchKernelGGL(assign_kernel<double>, grid, dim3(256), 0, s, X, n, d, (const double *)Yt,
+                           (const double *)ynorm2, L, k, nearest);
+    else
+        hipLaunchKernelGGL(assign_kernel<float>, grid, dim3(256), 0, s, X, n, d, (const float *)Yt,
+                           (const float *)ynorm2, L, k, nearest);
+}

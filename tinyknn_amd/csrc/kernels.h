@@ -153,3 +153,15 @@ void tk_launch_shard_pairs_fill(const int64_t *probes, int S, int64_t nq, int64_
 void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_prefix, int S,
                             int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,
                             int64_t min_stride, int signd, hipStream_t s);
+
+// ---- offline build path (build.hip) ----
+// labels (n, M) uint8 = FastPQ.transform's per-block nearest centroid; data: (n, dq) padded
+// (rotated) rows on the device.  Returns -1 when the codebook does not fit 64 KiB of LDS.
+int tk_launch_encode_pq(const float *centers, int dq, int dpb, const void *data, int is_f64,
+                        int64_t n, uint8_t *labels, hipStream_t s);
+// out = X / np.linalg.norm(X, axis=1, keepdims=True), float32 rows, d <= 128
+void tk_launch_normalise_rows(const float *X, int64_t n, int d, float *out, hipStream_t s);
+// knn_brute(X, Y, k <= 2, "euclidean"): Yt (d, L) = Y transposed, ynorm2 (L,) = einsum |y|^2,
+// float32 or float64 both; nearest (n, k)
+void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const void *ynorm2,
+                      int y_is_f64, int L, int k, int64_t *nearest, hipStream_t s);

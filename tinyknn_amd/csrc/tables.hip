@@ -19,42 +19,7 @@
 // pairwise mean is evaluated in numpy's exact order with the 8 accumulators of
 // every <=128-element leaf spread over the lanes; only the leaf combine is serial.
 #include "kernels.h"
-
-template <typename T>
-struct EinsumLanes;
-template <>
-struct EinsumLanes<float> { static constexpr int L = 4; };
-template <>
-struct EinsumLanes<double> { static constexpr int L = 2; };
-
-// sum_k a[k]*a[k] for k < n in numpy's einsum order (see header)
-template <typename T>
-__device__ __forceinline__ T einsum_selfdot(const T *a, int n)
-{
-    constexpr int L = EinsumLanes<T>::L;
-    T acc[L];
-#pragma unroll
-    for (int l = 0; l < L; l++) acc[l] = 0;
-    int i = 0;
-    for (; n - i >= 4 * L; i += 4 * L) {
-#pragma unroll
-        for (int l = 0; l < L; l++) {
-            T ab3 = a[i + 3 * L + l] * a[i + 3 * L + l] + acc[l];
-            T ab2 = a[i + 2 * L + l] * a[i + 2 * L + l] + ab3;
-            T ab1 = a[i + L + l] * a[i + L + l] + ab2;
-            acc[l] = a[i + l] * a[i + l] + ab1;
-        }
-    }
-    for (; i < n; i += L) {
-#pragma unroll
-        for (int l = 0; l < L; l++) {
-            T x = (i + l < n) ? a[i + l] : (T)0;
-            acc[l] = x * x + acc[l];
-        }
-    }
-    if (L == 4) return (acc[0] + acc[1]) + (acc[2 % L] + acc[3 % L]);
-    return acc[0] + acc[1 % L];
-}
+#include "np_order.h"
 
 // numpy's pairwise recursion over n elements (n > 128 splits at n2 = n/2 - (n/2)%8
 // into [0,n2) and [n2,n)) depends only on n, so the host lays it out once per

@@ -38,6 +38,11 @@ def _gauss_polar_code():
     return np.array(pts)
 
 
+# default of FastPQ.transform / IVF.build: False = host numpy as in the reference, True = the
+# nearest-centroid / nearest-centre searches on the GPU (build.hip; same codes and lists)
+device_build = False
+
+
 class FastPQ:
     """4-bit product quantizer: 16 centroids per block of `dims_per_block` dims.
     reference: fast_pq.py:33-252"""
@@ -103,9 +108,29 @@ class FastPQ:
                 out.append(base @ chol.T + np.mean(col, axis=0))
         return out
 
-    def transform(self, data, verbose=False):
+    def encode_labels(self, data, device=None):
+        """(n, M) uint8 nearest-centroid labels of rows that are already padded (and
+        rotated): the body of transform, fast_pq.py:171-182.  device: run the search on the
+        GPU (build.hip, same labels); None = the module default `device_build`."""
+        dpb = self.dims_per_block
+        n, d = data.shape
+        M = d // dpb
+        if device_build if device is None else device:
+            is64 = data.dtype != np.float32
+            data = np.ascontiguousarray(data, dtype=np.float64 if is64 else np.float32)
+            c32 = np.ascontiguousarray(self.centers, dtype=np.float32)
+            labels = np.empty((n, M), dtype=np.uint8)
+            _lib.check(_lib.lib().tk_encode_pq(_lib.ptr(c32, _lib._f32p), d, dpb, data.ctypes.data,
+                                               int(is64), n, _lib.ptr(labels, _lib._u8p)))
+            return labels
+        blocks = data.reshape(n, M, dpb).transpose(1, 0, 2)
+        books = self.centers.reshape(16, M, dpb).transpose(1, 0, 2)
+        return np.hstack([knn_brute(col, book, 1) for col, book in zip(blocks, books)]).astype(np.uint8)
+
+    def transform(self, data, verbose=False, device=None):
         """Encode rows to 4-bit codes in the Quick-ADC layout.
-        reference: fast_pq.py:147-184"""
+        reference: fast_pq.py:147-184.  device=True: the nearest-centroid search runs on
+        the GPU (padding and the rotation GEMM stay numpy, as in the reference)."""
         assert self.centers is not None, "PQ has not been fitted"
         if data.size == 0:
             return data
@@ -114,6 +139,8 @@ class FastPQ:
         data = pad2(data, 16, dpad * dpb)
         if self.R is not None:
             data = data @ self.R.T
+        if device_build if device is None else device:
+            return TransformedData(true_n, transform_data(self.encode_labels(data, True)))
         n, d = data.shape
         M = d // dpb
         blocks = data.reshape(n, M, dpb).transpose(1, 0, 2)

@@ -206,27 +206,111 @@ class IVF:
             self.pq.fit(X, verbose=verbose)
         return self
 
-    def build(self, X, n_probes=2, verbose=False):
+    def build(self, X, n_probes=2, verbose=False, device=None):
         """Assign every point to its n_probes nearest centres and encode the lists.
-        reference: ivf.py:53-104"""
+        reference: ivf.py:53-104.  device=True (default: fast_pq.device_build): the two
+        searches — nearest centres per point, nearest centroid per block — run on the GPU
+        (build.hip) and give the lists and codes numpy gives; everything else (normalisation,
+        the rotation GEMM, grouping, packing) is the same host code."""
         assert n_probes <= self.n_clusters, (
             f"Can't assign points to {n_probes} clusters, as index only has {self.n_clusters}")
+        from . import fast_pq as _fp
+        device = _fp.device_build if device is None else device
         self._dev = None
         self.data = data = X.copy()
         if self.metric == "angular":
             data /= np.linalg.norm(data, axis=1, keepdims=True)
         with timer(verbose, "Computing nearest clusters..."):
-            nearest = knn_brute(data, self.all_centers, k=n_probes, metric=self.metric)
+            if device:
+                nearest = self._nearest_on_device(data, n_probes)
+            else:
+                nearest = knn_brute(data, self.all_centers, k=n_probes, metric=self.metric)
         with timer(verbose, "PQ Transforming active centers..."):
             self.active_centers = np.ascontiguousarray(
                 self.all_centers[np.unique(nearest)], dtype=np.float32)
-            self.pq_transformed_centers = self.pq.transform(self.active_centers)
+            self.pq_transformed_centers = self.pq.transform(self.active_centers, device=device)
         with timer(verbose, "Transforming points..."):
             n_active = self.active_centers.shape[0]
-            groups, self.ids = group_data_by_indices(data, nearest, n_active)
-            for i in range(n_active):
-                self.pq_transformed_points[i] = self.pq.transform(groups[i])
+            if device:
+                self._encode_lists_on_device(data, nearest, n_active)
+            else:
+                groups, self.ids = group_data_by_indices(data, nearest, n_active)
+                for i in range(n_active):
+                    self.pq_transformed_points[i] = self.pq.transform(groups[i])
         return self
+
+    def _nearest_on_device(self, data, n_probes):
+        """knn_brute(data, all_centers, n_probes, metric) (utils.py:66-86): whole 100-row
+        chunks on the GPU, the last partial chunk — a differently shaped GEMM — in numpy."""
+        Y = np.asarray(self.all_centers)
+        exact_ok = (data.dtype == np.float32 and n_probes <= 2 and n_probes < len(Y)
+                    and data.shape[1] <= 384
+                    and (self.metric != "angular" or data.shape[1] <= 128))
+        if not exact_ok:
+            return knn_brute(data, Y, k=n_probes, metric=self.metric)
+        y64 = Y.dtype != np.float32
+        Y = np.ascontiguousarray(Y, dtype=np.float64 if y64 else np.float32)
+        if self.metric == "angular":
+            Y = Y / np.linalg.norm(Y, axis=1, keepdims=True)          # utils.py:75
+        ynorm2 = np.ascontiguousarray(np.einsum("ij,ij->i", Y, Y))    # utils.py:80
+        n = data.shape[0]
+        full = n - n % 100
+        out = np.zeros((n, n_probes), dtype=np.int64)
+        X = np.ascontiguousarray(data[:full])
+        _lib.check(_lib.lib().tk_assign_lists(
+            _lib.ptr(X, _lib._f32p), full, X.shape[1], int(self.metric == "angular"),
+            Y.ctypes.data, int(y64), ynorm2.ctypes.data, Y.shape[0], int(n_probes),
+            _lib.ptr(out, _lib._i64p)))
+        if full < n:
+            out[full:] = knn_brute(data[full:], self.all_centers, k=n_probes, metric=self.metric)
+        return out
+
+    def _encode_lists_on_device(self, data, nearest, n_active):
+        """ivf.py:98-102 with ONE pass over the points: a row's code does not depend on the
+        list it lands in, so all rows are encoded once (slabs of rows: pad, rotate on the
+        host as the reference does, nearest centroids on the GPU) and the per-list arrays
+        are gathered from the labels; the rows that pad a list to a multiple of 16 carry the
+        code of the zero vector, as pad2 + transform give them (fast_pq.py:165)."""
+        from ._transform import transform_data
+        from .fast_pq import TransformedData
+        pq = self.pq
+        dpb = pq.dims_per_block
+        n, d = data.shape
+        pad = (-d) % (dpad * dpb)
+        dq = pq.centers.shape[1]
+        M = dq // dpb
+        labels = np.empty((n, M), dtype=np.uint8)
+        slab = 1 << 20
+        for o in range(0, n, slab):
+            rows = data[o:o + slab]
+            if pad:
+                rows = np.concatenate([rows, np.zeros((len(rows), pad), rows.dtype)], axis=1)
+            if pq.R is not None:
+                rows = rows @ pq.R.T
+            labels[o:o + slab] = pq.encode_labels(rows, True)
+        zero = pq.encode_labels(np.zeros((16, dq), dtype=np.float64 if pq.R is not None else data.dtype),
+                                True)[0]
+        # grouping as group_data_by_indices does (utils.py:95-162), without copying the vectors
+        ids = [[] for _ in range(n_active)]
+        for j in range(nearest.shape[1]):
+            col = nearest[:, j]
+            order = np.argsort(col)
+            uniq, counts = np.unique(col[order], return_counts=True)
+            start = 0
+            for g, cnt in zip(uniq, counts):
+                ids[g].append(order[start:start + cnt])
+                start += cnt
+        self.ids = [np.hstack(i) if i else np.empty(0) for i in ids]
+        for i in range(n_active):
+            sel = self.ids[i].astype(np.int64)
+            if len(sel) == 0:
+                self.pq_transformed_points[i] = np.empty((0, d))     # fast_pq.py:162-163
+                continue
+            lab = labels[sel]
+            padrows = (-len(sel)) % 16
+            if padrows:
+                lab = np.concatenate([lab, np.repeat(zero[None], padrows, axis=0)])
+            self.pq_transformed_points[i] = TransformedData(len(sel), transform_data(lab))
 
     # ---- queries (GPU) -----------------------------------------------------
     def device_index(self):
