@@ -118,7 +118,7 @@ def build_index(args, device):
     ivf.all_centers = C / np.linalg.norm(C, axis=1, keepdims=True) if ang else C   # ivf.py:36-45
     ivf.pq.fit(sample[:min(len(sample), 30000)])
     log(f"[bench] fit done in {time.time() - t0:.1f}s")
-    ivf.build(X, n_probes=args.build_probes)
+    ivf.build(X, n_probes=args.build_probes, device=True)   # build.hip: same lists and codes as numpy
     log(f"[bench] build done in {time.time() - t0:.1f}s")
     L = len(ivf.active_centers)
     try:
