@@ -472,7 +472,9 @@ extern "C" int tk_encode_pq(const float *centers, int dq, int dpb, const void *d
     ARGCHECK(dpb >= 1 && dpb <= 32 && dq >= dpb && dq % dpb == 0, "dq/dpb");
     ARGCHECK(n >= 0, "n");
     const int M = dq / dpb;
-    ARGCHECK((size_t)(16 * dq + 16 * M) * 4 <= 64 * 1024, "codebook larger than 64 KiB of LDS");
+    ARGCHECK(32 % dpb == 0, "dims_per_block must divide 32 for the device encoder");
+    ARGCHECK((size_t)16 * M * (dpb + 1) * 4 + 4 * 64 * 33 * 8 + 4 * 64 * (size_t)M <= 160 * 1024,
+             "codebook larger than the LDS budget");
     const size_t esz = data_is_f64 ? 8 : 4;
     const int64_t slab = 1 << 20;
     DevBuf dc, dd, dl;
@@ -486,7 +488,8 @@ extern "C" int tk_encode_pq(const float *centers, int dq, int dpb, const void *d
         hipError_t e = hipMemcpy(dd.p, (const char *)data + (size_t)o * dq * esz,
                                  (size_t)m * dq * esz, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            tk_launch_encode_pq(dc.as<float>(), dq, dpb, dd.p, data_is_f64, m, dl.as<uint8_t>(), 0);
+            if (tk_launch_encode_pq(dc.as<float>(), dq, dpb, dd.p, data_is_f64, m, dl.as<uint8_t>(), 0))
+                rc = fail(TK_ERR_HIP, "encode_pq_kernel: LDS budget / attribute");
             e = hipGetLastError();
         }
         if (e == hipSuccess)

@@ -27,47 +27,78 @@ template <>
 struct Fma<double> { static __device__ __forceinline__ double f(double a, double b, double c) { return __builtin_fma(a, b, c); } };
 
 #define TK_ENC_MAX_DPB 32
+#define TK_ENC_STRIP 32    // elements per staged column strip (a multiple of every dims_per_block <= 32 that divides it)
 
-template <typename T>
+// DPB > 0: dims_per_block known at compile time (the row slice stays in registers);
+// DPB == 0: any dims_per_block <= 32.
+template <typename T, int DPB>
 __global__ __launch_bounds__(256) void encode_pq_kernel(const float *__restrict__ centers, int dq,
-                                                        int dpb, const T *__restrict__ data,
+                                                        int dpb_rt, const T *__restrict__ data,
                                                         int64_t n, uint8_t *__restrict__ labels)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *cen = (float *)smem;            // (16, dq)
-    float *yn = cen + 16 * dq;             // (M, 16): |code|^2 per block
+    const int dpb = DPB > 0 ? DPB : dpb_rt;
+    constexpr int CAP = DPB > 0 ? DPB : TK_ENC_MAX_DPB;
     const int M = dq / dpb;
-    for (int e = threadIdx.x; e < 16 * dq; e += 256) cen[e] = centers[e];
-    __syncthreads();
+    // per block b: 16 x (dpb centroid coordinates, |centroid|^2), so that one centroid is one
+    // contiguous LDS read
+    float *cb = (float *)smem;             // (M, 16, dpb + 1)
     for (int e = threadIdx.x; e < 16 * M; e += 256) {
         const int b = e >> 4, c = e & 15;
-        yn[e] = einsum_selfdot<float>(cen + c * dq + b * dpb, dpb);
+        float y[CAP];
+        for (int k = 0; k < dpb; k++) {
+            y[k] = centers[c * dq + b * dpb + k];
+            cb[e * (dpb + 1) + k] = y[k];
+        }
+        cb[e * (dpb + 1) + dpb] = einsum_selfdot<float>(y, dpb);
     }
     __syncthreads();
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= n) return;
-    const T *x0 = data + row * dq;
-    for (int b = 0; b < M; b++) {
-        T x[TK_ENC_MAX_DPB], x2[TK_ENC_MAX_DPB];
-        for (int k = 0; k < dpb; k++) {
-            x[k] = x0[b * dpb + k];
-            x2[k] = (T)2 * x[k];
+    // Rows are staged through LDS in column strips of TK_ENC_STRIP elements: the 64 rows of
+    // a wave are adjacent in memory, so the strip is read with coalesced loads (a lane
+    // walking its own row would touch 64 different lines per load and thrash L1), and the
+    // labels leave as one contiguous block per wave.
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T *tile = (T *)(cb + 16 * M * (dpb + 1)) + (size_t)wave * 64 * (TK_ENC_STRIP + 1);
+    uint8_t *lab = (uint8_t *)((T *)(cb + 16 * M * (dpb + 1)) + (size_t)4 * 64 * (TK_ENC_STRIP + 1)) +
+                   (size_t)wave * 64 * M;
+    const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    for (int s0 = 0; s0 < dq; s0 += TK_ENC_STRIP) {
+        const int w = dq - s0 < TK_ENC_STRIP ? dq - s0 : TK_ENC_STRIP;
+        __syncthreads();
+        for (int e = lane; e < 64 * w; e += 64) {
+            const int r = e / w, k = e - r * w;
+            tile[r * (TK_ENC_STRIP + 1) + k] = row0 + r < n ? data[(row0 + r) * dq + s0 + k] : (T)0;
         }
-        const T xn = einsum_selfdot<T>(x, dpb);
-        int best = 0;
-        T bestv = 0;
-        for (int c = 0; c < 16; c++) {
-            const float *y = cen + c * dq + b * dpb;
-            T p = 0;
-            for (int k = 0; k < dpb; k++) p = Fma<T>::f(x2[k], (T)y[k], p);
-            const T part = (xn + (T)yn[b * 16 + c]) - p;
-            if (c == 0 || part < bestv) {
-                bestv = part;
-                best = c;
+        __syncthreads();
+        for (int b = s0 / dpb; b < (s0 + w) / dpb; b++) {
+            T x[CAP], x2[CAP];
+#pragma unroll
+            for (int k = 0; k < dpb; k++) {
+                x[k] = tile[lane * (TK_ENC_STRIP + 1) + b * dpb - s0 + k];
+                x2[k] = (T)2 * x[k];
             }
+            const T xn = einsum_selfdot<T>(x, dpb);
+            int best = 0;
+            T bestv = 0;
+            const float *yb = cb + b * 16 * (dpb + 1);
+#pragma unroll 4
+            for (int c = 0; c < 16; c++) {
+                const float *y = yb + c * (dpb + 1);
+                T p = 0;
+#pragma unroll
+                for (int k = 0; k < dpb; k++) p = Fma<T>::f(x2[k], (T)y[k], p);
+                const T part = (xn + (T)y[dpb]) - p;
+                if (c == 0 || part < bestv) {
+                    bestv = part;
+                    best = c;
+                }
+            }
+            lab[lane * M + b] = (uint8_t)best;
         }
-        labels[row * M + b] = (uint8_t)best;
     }
+    __syncthreads();
+    const int64_t nrow = n - row0 < 64 ? n - row0 : 64;      // rows of this wave (may be <= 0)
+    for (int64_t e = lane; e < nrow * M; e += 64) labels[row0 * M + e] = lab[e];
 }
 
 int tk_launch_encode_pq(const float *centers, int dq, int dpb, const void *data, int is_f64,
@@ -75,15 +106,37 @@ int tk_launch_encode_pq(const float *centers, int dq, int dpb, const void *data,
 {
     if (n == 0) return 0;
     const int M = dq / dpb;
-    const size_t lds = (size_t)(16 * dq + 16 * M) * 4;
-    if (lds > 64 * 1024 || dpb > TK_ENC_MAX_DPB) return -1;
+    // codebook + four strip tiles + four label tiles
+    const size_t lds = (size_t)16 * M * (dpb + 1) * 4 +
+                       (size_t)4 * 64 * (TK_ENC_STRIP + 1) * (is_f64 ? 8 : 4) + (size_t)4 * 64 * M;
+    if (lds > 160 * 1024 || dpb > TK_ENC_MAX_DPB || TK_ENC_STRIP % dpb) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void *fns[] = {(const void *)encode_pq_kernel<float, 1>, (const void *)encode_pq_kernel<float, 2>,
+                             (const void *)encode_pq_kernel<float, 4>, (const void *)encode_pq_kernel<float, 8>,
+                             (const void *)encode_pq_kernel<float, 0>, (const void *)encode_pq_kernel<double, 1>,
+                             (const void *)encode_pq_kernel<double, 2>, (const void *)encode_pq_kernel<double, 4>,
+                             (const void *)encode_pq_kernel<double, 8>, (const void *)encode_pq_kernel<double, 0>};
+        for (const void *f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return -1;
+        attr_set = true;
+    }
     dim3 grid((unsigned)((n + 255) / 256));
-    if (is_f64)
-        hipLaunchKernelGGL(encode_pq_kernel<double>, grid, dim3(256), lds, s, centers, dq, dpb,
-                           (const double *)data, n, labels);
-    else
-        hipLaunchKernelGGL(encode_pq_kernel<float>, grid, dim3(256), lds, s, centers, dq, dpb,
-                           (const float *)data, n, labels);
+#define TK_ENC(T_, D_)                                                                          \
+    hipLaunchKernelGGL((encode_pq_kernel<T_, D_>), grid, dim3(256), lds, s, centers, dq, dpb,   \
+                       (const T_ *)data, n, labels)
+#define TK_ENC_T(T_)                                              \
+    do {                                                          \
+        if (dpb == 1) TK_ENC(T_, 1);                              \
+        else if (dpb == 2) TK_ENC(T_, 2);                         \
+        else if (dpb == 4) TK_ENC(T_, 4);                         \
+        else if (dpb == 8) TK_ENC(T_, 8);                         \
+        else TK_ENC(T_, 0);                                       \
+    } while (0)
+    if (is_f64) TK_ENC_T(double); else TK_ENC_T(float);
+#undef TK_ENC_T
+#undef TK_ENC
     return 0;
 }
 
@@ -143,45 +196,68 @@ __device__ __forceinline__ void cand_push(Cand<T> (&top)[3], T v, int j)
     }
 }
 
+#define TK_AS_C 4   // centres per thread and pass: each staged row value feeds 4 FMAs
+
 template <typename T>
 __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ X, int64_t n, int d,
                                                      const T *__restrict__ Yt,
                                                      const T *__restrict__ ynorm2, int L, int k,
                                                      int64_t *__restrict__ nearest)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *x2s = (T *)smem;                            // (d, TK_AS_ROWS): 2*x as T, row-interleaved
     __shared__ Cand<T> s_top[TK_AS_ROWS][4][3];   // the three best of each wave
     __shared__ T s_v0[TK_AS_ROWS];
     const int64_t r0 = (int64_t)blockIdx.x * TK_AS_ROWS;
     const int nr = n - r0 < TK_AS_ROWS ? (int)(n - r0) : TK_AS_ROWS;
+    for (int e = threadIdx.x; e < d * TK_AS_ROWS; e += 256) {
+        const int t = e / TK_AS_ROWS, r = e - t * TK_AS_ROWS;
+        x2s[e] = (T)(2.0f * X[(r0 + (r < nr ? r : 0)) * d + t]);
+    }
     // |x|^2 in float32 (np.einsum on the float32 rows), promoted when added to float64 |y|^2
     T xn[TK_AS_ROWS];
     for (int r = 0; r < TK_AS_ROWS; r++) {
         const float *x = X + (r0 + (r < nr ? r : 0)) * d;
         xn[r] = (T)einsum_selfdot<float>(x, d);
     }
+    __syncthreads();
     Cand<T> top[TK_AS_ROWS][3];
 #pragma unroll
     for (int r = 0; r < TK_AS_ROWS; r++)
 #pragma unroll
         for (int t = 0; t < 3; t++) top[r][t] = {(T)0, -1};
-    for (int j = threadIdx.x; j < L; j += 256) {
-        T p[TK_AS_ROWS];
+    for (int j0 = threadIdx.x; j0 < L; j0 += 256 * TK_AS_C) {
+        T p[TK_AS_C][TK_AS_ROWS];
+        int jj[TK_AS_C];
 #pragma unroll
-        for (int r = 0; r < TK_AS_ROWS; r++) p[r] = 0;
+        for (int c = 0; c < TK_AS_C; c++) {
+            jj[c] = j0 + c * 256 < L ? j0 + c * 256 : j0;   // out of range: recompute j0, ignored
+#pragma unroll
+            for (int r = 0; r < TK_AS_ROWS; r++) p[c][r] = 0;
+        }
         for (int t = 0; t < d; t++) {
-            const T y = Yt[(int64_t)t * L + j];
+            T y[TK_AS_C];
+#pragma unroll
+            for (int c = 0; c < TK_AS_C; c++) y[c] = Yt[(int64_t)t * L + jj[c]];
 #pragma unroll
             for (int r = 0; r < TK_AS_ROWS; r++) {
-                const float x2 = 2.0f * X[(r0 + (r < nr ? r : 0)) * d + t];   // wave-uniform
-                p[r] = Fma<T>::f((T)x2, y, p[r]);
+                const T x2 = x2s[t * TK_AS_ROWS + r];       // same address in every lane
+#pragma unroll
+                for (int c = 0; c < TK_AS_C; c++) p[c][r] = Fma<T>::f(x2, y[c], p[c][r]);
             }
         }
-        const T yn = ynorm2[j];
 #pragma unroll
-        for (int r = 0; r < TK_AS_ROWS; r++) {
-            const T part = (xn[r] + yn) - p[r];
-            cand_push(top[r], part, j);
-            if (j == 0) s_v0[r] = part;
+        for (int c = 0; c < TK_AS_C; c++) {
+            const int j = j0 + c * 256;
+            if (j < L) {
+                const T yn = ynorm2[j];
+#pragma unroll
+                for (int r = 0; r < TK_AS_ROWS; r++) {
+                    const T part = (xn[r] + yn) - p[c][r];
+                    cand_push(top[r], part, j);
+                    if (j == 0) s_v0[r] = part;
+                }
+            }
         }
     }
     // the three best of the wave: butterfly over the lanes, each step merging the partner's
@@ -246,10 +322,11 @@ void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const vo
 {
     if (n == 0) return;
     dim3 grid((unsigned)((n + TK_AS_ROWS - 1) / TK_AS_ROWS));
+    const size_t lds = (size_t)d * TK_AS_ROWS * (y_is_f64 ? 8 : 4);
     if (y_is_f64)
-        hipLaunchKernelGGL(assign_kernel<double>, grid, dim3(256), 0, s, X, n, d, (const double *)Yt,
+        hipLaunchKernelGGL(assign_kernel<double>, grid, dim3(256), lds, s, X, n, d, (const double *)Yt,
                            (const double *)ynorm2, L, k, nearest);
     else
-        hipLaunchKernelGGL(assign_kernel<float>, grid, dim3(256), 0, s, X, n, d, (const float *)Yt,
+        hipLaunchKernelGGL(assign_kernel<float>, grid, dim3(256), lds, s, X, n, d, (const float *)Yt,
                            (const float *)ynorm2, L, k, nearest);
 }
