@@ -216,7 +216,8 @@ def main():
                     help="synthetic stand-in: Gaussian clusters, or |N(0,1)|*40 clipped to [0,218]")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
-    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (tk_index_set_pipeline)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="replay streams (tk_index_set_pipeline): caller + coarse stream + these = 4 HW queues")
     ap.add_argument("--shard", choices=["auto", "none", "lists"], default="auto",
                     help="list-sharded leg after the replica measurement (auto: when N > 1)")
     ap.add_argument("--shard-limit", type=float, default=240.0,

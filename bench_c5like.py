@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--n-probes", type=int, default=10)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pipeline", type=int, default=3)
+    ap.add_argument("--pipeline", type=int, default=2)
     ap.add_argument("--check", type=int, default=300, help="queries compared with the oracle")
     args = ap.parse_args()
 

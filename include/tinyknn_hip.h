@@ -185,16 +185,16 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
                              int64_t *out_ids_dev, void *stream);
 
 /* Batches in flight.  depth = 1 (default): tk_index_query_batch_dev enqueues the whole
- * pipeline on the caller's stream.  depth > 1: the chip-filling, VALU-bound kernels (table
- * build, coarse scan, list scan) of all batches run on the caller's stream, in order; the
- * latency-bound kernels of a batch (heap replays: 157 waves per 10 000 queries; rescoring;
- * descriptors) run on one of `depth` internal streams and overlap the other batches'
- * scans.  A call enqueues the first half of its batch (tables, coarse stage, descriptors)
- * and the SECOND half of the previous call's batch (list scan, heap replay, rescoring), so
- * that the caller's stream reads  scan(b-1) | tables(b+1), coarse scan(b+1) | scan(b) | ...
- * and never waits for a coarse heap replay; tk_index_join enqueues the last second half.
- * The caller must not reuse the input/output buffers of a call before
- * tk_index_join(ix, stream), which also makes `stream` wait for every batch in flight. */
+ * pipeline on the caller's stream.  depth > 1: ALL code scans and the table builds run on
+ * the caller's stream, in order — call c launches ONE kernel there that carries the list
+ * scan of call c-2 and the coarse scan of call c as one pool of work — the coarse heap
+ * replays + descriptors of all batches on one internal stream, and the heap replay (157
+ * waves per 10 000 queries) + rescoring of a batch on one of `depth` more, handed over by
+ * events and overlapping the scans of the later batches.  depth = 2 keeps the total at the
+ * four hardware queues HIP maps streams onto (more streams share queues and serialise).
+ * tk_index_join enqueues the list scans still owed and their replays.  The caller must not
+ * reuse the input/output buffers of a call before tk_index_join(ix, stream), which also
+ * makes `stream` wait for every batch in flight. */
 int tk_index_set_pipeline(tk_index *ix, int depth);
 int tk_index_join(tk_index *ix, void *stream);
 
@@ -221,7 +221,8 @@ int tk_index_set_scan_mode(tk_index *ix, int mode);
  * milliseconds per stage over the batches recorded since the last read
  * [tables, coarse_scan, coarse_heap, coarse_rescore+slots, scan, heap, rescore],
  * their count, and the algorithmic bytes the list-scan kernel streamed for the
- * most recent batch (code bytes + table + heap per query). */
+ * most recent batch (code bytes + table + heap per query; with depth > 1 the
+ * timed launch also carries the next batch's coarse scan, whose bytes are included). */
 int tk_index_set_profiling(tk_index *ix, int on);
 int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches);
 

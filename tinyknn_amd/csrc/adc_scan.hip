@@ -343,28 +343,119 @@ __device__ __forceinline__ void finish_chunk(uint32_t (&a0)[8], uint4 &o, uint32
 #define TK_TICKETS 8
 #define TK_TICKET_OFF(n_lists) ((((n_lists) + 1 + 31) / 32 + 1) * 32)
 
-// COARSE only tags the instantiation used for the coded centres so that profilers
-// list the two launches of a batch separately.
-template <int ORDER, bool SIGNED, int MINW, bool COARSE>
-__global__ __launch_bounds__(256, MINW) void scan_units_kernel(
+// One scan job of the list-major kernel: everything tk_launch_scan_units takes.
+// (kernels.h: struct TkScanJob)
+
+// Block `blk` (64 consecutive units) of a job.
+template <int ORDER, bool SIGNED>
+__device__ __forceinline__ void scan_units_block(
     const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
-    const int64_t *__restrict__ list_chunk_off, int n_lists,
-    const int *__restrict__ unit_prefix,   // (n_lists+1) units before each list
-    const int *__restrict__ pair_off,      // (n_lists+1) first record of each list (x4 padded)
-    const int *__restrict__ pair_q,        // query of a record, -1 = padding
-    const int *__restrict__ pair_f0,       // first flat chunk of that (query, slot) row range
-    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride)
+    const int64_t *__restrict__ list_chunk_off, int n_lists, const int *__restrict__ unit_prefix,
+    const int *__restrict__ pair_off, const int *__restrict__ pair_q,
+    const int *__restrict__ pair_f0, uint4 *__restrict__ dist, int64_t cap,
+    uint8_t *__restrict__ mins, int64_t min_stride, int U, int blk)
 {
-    const int U = unit_prefix[n_lists];
     const uint32_t cA = 0x020c000cu, cB = 0x030c010cu;
-    // Blocks of 64 consecutive units.  Every wave takes one block statically; the rest are
-    // drawn from TK_TICKETS work counters (behind the prefix table, a cache line each,
-    // zeroed by the kernel that wrote the table; a wave starts at its home counter and moves
-    // on when a range is used up).  With other batches' heap replays sharing some SIMDs a
-    // static split leaves the kernel waiting for its slowest waves.  One counter would not
-    // do: same-address atomics retire at ~60 M/s and this kernel wants 70 M blocks/s.
-    int *ticket = const_cast<int *>(unit_prefix) + TK_TICKET_OFF(n_lists);
-    const int NB = (U + 63) >> 6;
+    const int u0 = blk << 6;
+    const int u = u0 + (threadIdx.x & 63);
+    const bool active = u < U;
+    const int uu = active ? u : U - 1;
+    int lo = 0, hi = n_lists;   // unit_prefix[lo] <= uu < unit_prefix[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (unit_prefix[mid] <= uu) lo = mid; else hi = mid;
+    }
+    const int l = lo;
+    const int64_t c0 = list_chunk_off[l];
+    const int C = (int)(list_chunk_off[l + 1] - c0);
+    const int local = uu - unit_prefix[l];
+    const int qg = local / C, c = local - qg * C;
+    const int rec = pair_off[l] + TK_UNIT_Q * qg;
+    // table row offsets (in uint4) of the four queries; q and f0 are re-read at the
+    // end instead of being held across the loop (register pressure)
+    int tq[TK_UNIT_Q];
+#pragma unroll
+    for (int i = 0; i < TK_UNIT_Q; i++) {
+        const int qi = pair_q[rec + i];
+        tq[i] = (qi < 0 ? 0 : qi) * M;
+    }
+    const int64_t gc = c0 + c;
+    const uint4 *src = codes + ((gc >> 3) * (int64_t)P) * 8 + (gc & 7);
+    uint32_t a0[TK_UNIT_Q][8], a1[TK_UNIT_Q][8];
+#pragma unroll
+    for (int i = 0; i < TK_UNIT_Q; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) a0[i][j] = a1[i][j] = 0;
+
+    const int steps = (ORDER == TK_ORDER_AVX) ? (P >> 1) : P;
+    for (int st = 0; st < steps; st++) {
+        // AVX: pairs 2*st (accumulator set 0) and 2*st+1 (set 1); SSE: pair st (set 0)
+        const int p0 = (ORDER == TK_ORDER_AVX) ? 2 * st : st;
+        const uint4 x0 = src[p0 * 8];
+        uint4 x1 = make_uint4(0, 0, 0, 0);
+        if (ORDER == TK_ORDER_AVX) x1 = src[(p0 + 1) * 8];
+        {   // pair p0 -> accumulator set 0.  Dword-outer / query-inner keeps the six
+            // selector words of one dword live instead of those of all eight.
+            uint4 tl[TK_UNIT_Q], th[TK_UNIT_Q];
+#pragma unroll
+            for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tables[tq[i] + 2 * p0]; th[i] = tables[tq[i] + 2 * p0 + 1]; }
+            const uint32_t xs0[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const Sel6 s = make_sel(xs0[j], cA, cB);
+#pragma unroll
+                for (int i = 0; i < TK_UNIT_Q; i++) {
+                    lut4x<SIGNED>(s.s_lo, s.kA_lo, s.kB_lo, tl[i], a0[i][2 * j], a0[i][2 * j + 1]);
+                    lut4x<SIGNED>(s.s_hi, s.kA_hi, s.kB_hi, th[i], a0[i][2 * j], a0[i][2 * j + 1]);
+                }
+            }
+        }
+        if (ORDER == TK_ORDER_AVX) {   // pair p0+1 -> accumulator set 1
+            uint4 tl[TK_UNIT_Q], th[TK_UNIT_Q];
+#pragma unroll
+            for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tables[tq[i] + 2 * p0 + 2]; th[i] = tables[tq[i] + 2 * p0 + 3]; }
+            const uint32_t xs1[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const Sel6 s = make_sel(xs1[j], cA, cB);
+#pragma unroll
+                for (int i = 0; i < TK_UNIT_Q; i++) {
+                    lut4x<SIGNED>(s.s_lo, s.kA_lo, s.kB_lo, tl[i], a1[i][2 * j], a1[i][2 * j + 1]);
+                    lut4x<SIGNED>(s.s_hi, s.kA_hi, s.kB_hi, th[i], a1[i][2 * j], a1[i][2 * j + 1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TK_UNIT_Q; i++) {
+        if (ORDER == TK_ORDER_AVX) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                a0[i][j] = sat_add2<SIGNED>(a0[i][j], a1[i][j] & 0xff00ff00u);
+        }
+        uint4 o;
+        uint32_t mn;
+        finish_chunk<SIGNED>(a0[i], o, mn);
+        const int qi = pair_q[rec + i];
+        if (active && qi >= 0) {
+            const int f0 = pair_f0[rec + i];
+            dist[(int64_t)qi * cap + f0 + c] = o;
+            if (mins) mins[(int64_t)qi * min_stride + f0 + c] = (uint8_t)mn;
+        }
+    }
+}
+
+// Blocks of 64 consecutive units.  Every wave takes one block statically; the rest are
+// drawn from TK_TICKETS work counters (behind the prefix table, a cache line each, zeroed
+// by the kernel that wrote the table; a wave starts at its home counter and moves on when a
+// range is used up), the draw for the NEXT block being issued before the current block's
+// work.  With other batches' heap replays sharing some SIMDs a static split leaves the
+// kernel waiting for its slowest waves.  One counter would not do: same-address atomics
+// retire at ~60 M/s and this kernel wants 70 M blocks/s.
+// `work(blk)` processes block blk of NB.
+template <typename F>
+__device__ __forceinline__ void ticketed_blocks(int NB, int *ticket, F work)
+{
     const int NW = gridDim.x * 4 < NB ? gridDim.x * 4 : NB;   // blocks handed out statically
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int dyn = NB - NW;
@@ -396,93 +487,7 @@ __global__ __launch_bounds__(256, MINW) void scan_units_kernel(
             nlen = (int)((int64_t)dyn * (tk + 1) / TK_TICKETS) - nlo;
             if ((threadIdx.x & 63) == 0) ngot = atomicAdd(ticket + tk * 32, 1);
         }
-        const int u0 = blk << 6;
-        const int u = u0 + (threadIdx.x & 63);
-        const bool active = u < U;
-        const int uu = active ? u : U - 1;
-        int lo = 0, hi = n_lists;   // unit_prefix[lo] <= uu < unit_prefix[hi]
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (unit_prefix[mid] <= uu) lo = mid; else hi = mid;
-        }
-        const int l = lo;
-        const int64_t c0 = list_chunk_off[l];
-        const int C = (int)(list_chunk_off[l + 1] - c0);
-        const int local = uu - unit_prefix[l];
-        const int qg = local / C, c = local - qg * C;
-        const int rec = pair_off[l] + TK_UNIT_Q * qg;
-        // table row offsets (in uint4) of the four queries; q and f0 are re-read at the
-        // end instead of being held across the loop (register pressure)
-        int tq[TK_UNIT_Q];
-#pragma unroll
-        for (int i = 0; i < TK_UNIT_Q; i++) {
-            const int qi = pair_q[rec + i];
-            tq[i] = (qi < 0 ? 0 : qi) * M;
-        }
-        const int64_t gc = c0 + c;
-        const uint4 *src = codes + ((gc >> 3) * (int64_t)P) * 8 + (gc & 7);
-        uint32_t a0[TK_UNIT_Q][8], a1[TK_UNIT_Q][8];
-#pragma unroll
-        for (int i = 0; i < TK_UNIT_Q; i++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) a0[i][j] = a1[i][j] = 0;
-
-        const int steps = (ORDER == TK_ORDER_AVX) ? (P >> 1) : P;
-        for (int st = 0; st < steps; st++) {
-            // AVX: pairs 2*st (accumulator set 0) and 2*st+1 (set 1); SSE: pair st (set 0)
-            const int p0 = (ORDER == TK_ORDER_AVX) ? 2 * st : st;
-            const uint4 x0 = src[p0 * 8];
-            uint4 x1 = make_uint4(0, 0, 0, 0);
-            if (ORDER == TK_ORDER_AVX) x1 = src[(p0 + 1) * 8];
-            {   // pair p0 -> accumulator set 0.  Dword-outer / query-inner keeps the six
-                // selector words of one dword live instead of those of all eight.
-                uint4 tl[TK_UNIT_Q], th[TK_UNIT_Q];
-#pragma unroll
-                for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tables[tq[i] + 2 * p0]; th[i] = tables[tq[i] + 2 * p0 + 1]; }
-                const uint32_t xs0[4] = {x0.x, x0.y, x0.z, x0.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const Sel6 s = make_sel(xs0[j], cA, cB);
-#pragma unroll
-                    for (int i = 0; i < TK_UNIT_Q; i++) {
-                        lut4x<SIGNED>(s.s_lo, s.kA_lo, s.kB_lo, tl[i], a0[i][2 * j], a0[i][2 * j + 1]);
-                        lut4x<SIGNED>(s.s_hi, s.kA_hi, s.kB_hi, th[i], a0[i][2 * j], a0[i][2 * j + 1]);
-                    }
-                }
-            }
-            if (ORDER == TK_ORDER_AVX) {   // pair p0+1 -> accumulator set 1
-                uint4 tl[TK_UNIT_Q], th[TK_UNIT_Q];
-#pragma unroll
-                for (int i = 0; i < TK_UNIT_Q; i++) { tl[i] = tables[tq[i] + 2 * p0 + 2]; th[i] = tables[tq[i] + 2 * p0 + 3]; }
-                const uint32_t xs1[4] = {x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const Sel6 s = make_sel(xs1[j], cA, cB);
-#pragma unroll
-                    for (int i = 0; i < TK_UNIT_Q; i++) {
-                        lut4x<SIGNED>(s.s_lo, s.kA_lo, s.kB_lo, tl[i], a1[i][2 * j], a1[i][2 * j + 1]);
-                        lut4x<SIGNED>(s.s_hi, s.kA_hi, s.kB_hi, th[i], a1[i][2 * j], a1[i][2 * j + 1]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TK_UNIT_Q; i++) {
-            if (ORDER == TK_ORDER_AVX) {
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    a0[i][j] = sat_add2<SIGNED>(a0[i][j], a1[i][j] & 0xff00ff00u);
-            }
-            uint4 o;
-            uint32_t mn;
-            finish_chunk<SIGNED>(a0[i], o, mn);
-            const int qi = pair_q[rec + i];
-            if (active && qi >= 0) {
-                const int f0 = pair_f0[rec + i];
-                dist[(int64_t)qi * cap + f0 + c] = o;
-                if (mins) mins[(int64_t)qi * min_stride + f0 + c] = (uint8_t)mn;
-            }
-        }
+        work(__builtin_amdgcn_readfirstlane(blk));   // wave-uniform, and known to be
         // next block
         blk = NB;
         if (!drawn) break;
@@ -495,6 +500,50 @@ __global__ __launch_bounds__(256, MINW) void scan_units_kernel(
         tk = (tk + 1) & (TK_TICKETS - 1);
         blk = draw();
     }
+}
+
+// COARSE only tags the instantiation used for the coded centres so that profilers
+// list the two launches of a batch separately.
+template <int ORDER, bool SIGNED, int MINW, bool COARSE>
+__global__ __launch_bounds__(256, MINW) void scan_units_kernel(
+    const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
+    const int64_t *__restrict__ list_chunk_off, int n_lists,
+    const int *__restrict__ unit_prefix,   // (n_lists+1) units before each list, then tickets
+    const int *__restrict__ pair_off,      // (n_lists+1) first record of each list (x4 padded)
+    const int *__restrict__ pair_q,        // query of a record, -1 = padding
+    const int *__restrict__ pair_f0,       // first flat chunk of that (query, slot) row range
+    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride)
+{
+    const int U = unit_prefix[n_lists];
+    int *ticket = const_cast<int *>(unit_prefix) + TK_TICKET_OFF(n_lists);
+    ticketed_blocks((U + 63) >> 6, ticket, [&](int blk) {
+        scan_units_block<ORDER, SIGNED>(codes, P, tables, M, list_chunk_off, n_lists, unit_prefix,
+                                        pair_off, pair_q, pair_f0, dist, cap, mins, min_stride, U,
+                                        blk);
+    });
+}
+
+// Two jobs in one launch, one pool of blocks: the list scan of batch b and the coarse scan
+// of batch b+1 (pipelined mode, api.hip).  Either job may be absent (unit_prefix == NULL).
+// The work counters are those of the first job present.
+template <int ORDER, bool SIGNED, int MINW>
+__global__ __launch_bounds__(256, MINW) void scan_units2_kernel(TkScanJob a, TkScanJob b, int P,
+                                                                int M)
+{
+    const int UA = a.unit_prefix ? a.unit_prefix[a.n_lists] : 0;
+    const int UB = b.unit_prefix ? b.unit_prefix[b.n_lists] : 0;
+    const int NBA = (UA + 63) >> 6, NBB = (UB + 63) >> 6;
+    int *ticket = a.unit_prefix ? const_cast<int *>(a.unit_prefix) + TK_TICKET_OFF(a.n_lists)
+                                : const_cast<int *>(b.unit_prefix) + TK_TICKET_OFF(b.n_lists);
+    ticketed_blocks(NBA + NBB, ticket, [&](int blk) {
+        // one copy of the block body: the job's fields are picked with wave-uniform selects
+        const bool first = blk < NBA;
+        const TkScanJob &j = first ? a : b;
+        scan_units_block<ORDER, SIGNED>(j.codes, P, j.tables, M, j.list_chunk_off, j.n_lists,
+                                        j.unit_prefix, j.pair_off, j.pair_q, j.pair_f0, j.dist,
+                                        j.cap, j.mins, j.min_stride, first ? UA : UB,
+                                        first ? blk : blk - NBA);
+    });
 }
 
 // ---- pair lists: (query, slot) pairs grouped by the list they probe ------------
@@ -646,4 +695,17 @@ void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_
     }
 #undef TK_LAUNCH
 #undef TK_LAUNCH2
+}
+
+void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
+                           hipStream_t s)
+{
+    if (!a.unit_prefix && !b.unit_prefix) return;
+    const int P = M / 2;
+    if (order == TK_ORDER_AVX)
+        hipLaunchKernelGGL((scan_units2_kernel<TK_ORDER_AVX, true, 3>), dim3(n_blocks), dim3(256), 0,
+                           s, a, b, P, M);
+    else
+        hipLaunchKernelGGL((scan_units2_kernel<TK_ORDER_SSE, true, 3>), dim3(n_blocks), dim3(256), 0,
+                           s, a, b, P, M);
 }

@@ -555,7 +555,8 @@ struct Work {
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
         c_pair_f0, spos, rpos;
     // pipelined mode (depth > 1): hand-offs between the caller's stream and a latency stream
-    hipEvent_t coarse_scanned = nullptr, front_done = nullptr, scanned = nullptr, done = nullptr;
+    hipEvent_t tables_done = nullptr, coarse_scanned = nullptr, front_done = nullptr,
+               scanned = nullptr, done = nullptr;
     bool busy = false;                                 // `done` has been recorded
     void release()
     {
@@ -565,7 +566,7 @@ struct Work {
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
                        &spos, &rpos};
         for (DevBuf *x : b) x->release();
-        hipEvent_t *evs[] = {&coarse_scanned, &front_done, &scanned, &done};
+        hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
             if (*e) (void)hipEventDestroy(*e);
             *e = nullptr;
@@ -613,7 +614,9 @@ struct tk_index {
     int depth = 1;
     uint64_t calls = 0;
     std::vector<hipStream_t> lat_streams;    // `depth` of them (pipelined mode)
-    struct Pending *pending = nullptr;   // second half of the previous call (pipelined mode)
+    hipEvent_t ev_in = nullptr;              // caller's stream -> a batch's stream
+    std::vector<struct Pending *> pending;   // calls whose list scan is still to be enqueued (<= 2)
+    hipStream_t front_stream = nullptr;      // coarse replays + descriptors of all batches, in order
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
     std::vector<hipEvent_t> evs;   // 8 per set
@@ -643,6 +646,8 @@ extern "C" void tk_index_destroy(tk_index *ix)
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
     for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
+    if (ix->front_stream) (void)hipStreamDestroy(ix->front_stream);
+    if (ix->ev_in) (void)hipEventDestroy(ix->ev_in);
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -943,46 +948,89 @@ static bool use_units(const tk_index *ix, int64_t nq, const Plan &p)
             (double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9);
 }
 
-// Stages 1-2 of a batch: tables, coarse stage, probe lists, per-slot descriptors.
-// `pair_count`: per-list (query, slot) pair counters for the list-major scan (or NULL);
-// with `owner` only the lists owned by `me` are counted (list-sharded index).
-static int stage_front(tk_index *ix, Work &w, const float *q_dev, const void *qpq_dev, int qpq_f64,
-                       int64_t nq, const Plan &p, int *pair_count, const int *owner, int me,
-                       hipStream_t st, hipStream_t sl, Prof &pf)
+// Stage 1 of a batch: distance tables (+ the descriptors of the list-major coarse scan).
+static bool coarse_units(const tk_index *ix, int64_t nq)
 {
-    // st: stream of the chip-filling kernels (table build, coarse scan); sl: stream of the
-    // latency-bound rest (== st unless the index is in pipelined mode)
-    const int M = ix->M;
+    return ix->scan_mode != 1 && nq >= 16 && (double)nq / 4 * ix->center_chunks < 2.0e9;
+}
+
+static int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_t nq,
+                        hipStream_t st, Prof &pf)
+{
     TRY(pf.mark(st));
     // 1. distance tables                                   fast_pq.py:186-222
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
                            qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>(), w.shift.p,
                            w.scale.as<double>(), st);
-    TRY(pf.mark(st));
-    // 2. coarse stage = dtable.top(centers)                 ivf.py:131, fast_pq.py:284-312
-    const bool cunits = ix->scan_mode != 1 && nq >= 16 &&
-                        (double)nq / 4 * ix->center_chunks < 2.0e9;
-    if (cunits) {
+    if (coarse_units(ix, nq))
         // every query scans the one list of coded centres: list-major, no idle lanes
         tk_launch_identity_pairs(nq, (int)ix->center_chunks, w.c_pair_off.as<int>(),
                                  w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
                                  w.c_pair_f0.as<int>(), st);
+    TRY(pf.mark(st));
+    return TK_OK;
+}
+
+// the coarse scan as a job of the list-major kernel
+static TkScanJob coarse_job(const tk_index *ix, const Work &w, const Plan &p)
+{
+    TkScanJob j;
+    j.codes = ix->center_codes.as<uint4>();
+    j.tables = w.tables.as<uint4>();
+    j.list_chunk_off = ix->c_chunk_off.as<int64_t>();
+    j.n_lists = 1;
+    j.unit_prefix = w.c_unit_prefix.as<int>();
+    j.pair_off = w.c_pair_off.as<int>();
+    j.pair_q = w.c_pair_q.as<int>();
+    j.pair_f0 = w.c_pair_f0.as<int>();
+    j.dist = w.cdist.as<uint4>();
+    j.cap = ix->center_chunks;
+    j.mins = w.cmins.as<uint8_t>();
+    j.min_stride = p.ccap_min;
+    return j;
+}
+
+static TkScanJob list_job(const tk_index *ix, const Work &w, const Plan &p)
+{
+    TkScanJob j;
+    j.codes = ix->codes.as<uint4>();
+    j.tables = w.tables.as<uint4>();
+    j.list_chunk_off = ix->list_chunk_off.as<int64_t>();
+    j.n_lists = (int)ix->n_lists;
+    j.unit_prefix = w.u_unit_prefix.as<int>();
+    j.pair_off = w.u_pair_off.as<int>();
+    j.pair_q = w.u_pair_q.as<int>();
+    j.pair_f0 = w.u_pair_f0.as<int>();
+    j.dist = w.dist.as<uint4>();
+    j.cap = p.cap;
+    j.mins = w.mins.as<uint8_t>();
+    j.min_stride = p.cap_min;
+    return j;
+}
+
+// 2a. coarse scan = the scan of dtable.top(centers)          ivf.py:131, fast_pq.py:284-312
+static void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st)
+{
+    const int M = ix->M;
+    if (coarse_units(ix, nq))
         tk_launch_scan_units(ix->center_codes.as<uint4>(), M, w.tables.as<uint4>(), nq, 1, 1,
                              ix->c_chunk_off.as<int64_t>(), w.c_pair_off.as<int>(),
                              w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
                              w.c_pair_f0.as<int>(), w.cdist.as<uint4>(), ix->center_chunks,
                              w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, 768, st);
-    } else {
+    else
         tk_launch_scan_flat(ix->center_codes.as<uint4>(), ix->center_chunks, M,
                             w.tables.as<uint4>(), nq, w.cdist.as<uint4>(), ix->center_chunks,
                             w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, st);
-    }
+}
+
+// 2b. rest of the coarse stage: heap replay over the coded centres, probe lists, per-slot
+// descriptors.  `pair_count`: per-list (query, slot) pair counters for the list-major scan
+// (or NULL); with `owner` only the lists owned by `me` are counted (list-sharded index).
+static int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
+                             int *pair_count, const int *owner, int me, hipStream_t st, Prof &pf)
+{
     TRY(pf.mark(st));
-    if (sl != st) {
-        HIPCHECK(hipEventRecord(w.coarse_scanned, st));
-        HIPCHECK(hipStreamWaitEvent(sl, w.coarse_scanned, 0));
-        st = sl;
-    }
     // positions of one list against a fresh heap are distinct labels: lane-per-query
     const bool fast_c = ix->heap_mode != 1 && ix->center_chunks * 16 <= 0xffffff;
     const bool lanes_c = fast_c && ix->heap_mode == 0 && p.rescore <= TK_LANES_MAX_R;
@@ -1078,20 +1126,25 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     return TK_OK;
 }
 
-// One sub-batch in two halves.  batch_front: tables, coarse stage, probe lists, scan
-// descriptors.  batch_back: list scan, heap replay, rescoring.
+// One sub-batch.
 //
-// depth == 1: back to back on the caller's stream.
-// depth  > 1: the chip-filling, VALU-bound kernels (table build, coarse scan, list scan) of
-// ALL batches run on the caller's stream, in order, back to back — two of them at once would
-// only stretch each other — and the latency-bound kernels of a batch (coarse heap replay,
-// probe rescoring, descriptors; heap replay over the lists, rescoring: 157 waves per 10 000
-// queries, 0.2 + 0.8 ms) on one of `depth` internal streams, handed over by events.  The
-// second half of call b is enqueued AFTER the first half of call b+1 (or by tk_index_join),
-// so that the caller's stream reads
-//     ... scan(b-1) | tables(b+1) coarse-scan(b+1) | scan(b) | tables(b+2) ...
-// and scan(b) finds its descriptors finished during scan(b-1) instead of stalling the
-// stream for them, while the heap replays of the previous batches overlap all of it.
+// depth == 1: seven stages back to back on the caller's stream.
+//
+// depth  > 1 (tk_index_set_pipeline): two kinds of kernels make up a batch — chip-filling,
+// VALU-bound scans and latency-bound rest (table build: many small workgroups; heap replays:
+// 157 waves per 10 000 queries; rescoring; descriptors).  Two scans at once only stretch each
+// other, so ALL scans (and the table builds) run on the caller's stream, in order, the coarse
+// replays + descriptors of all batches on one internal stream, and the heap replay +
+// rescoring of a batch on one of `depth` more, handed over by events.  Call c enqueues
+//     tables(c)                                    caller's stream
+//     [ list scan(c-2)  +  coarse scan(c) ]        ONE launch on the caller's stream: one pool
+//                                                  of 64-unit blocks, drawn by tickets
+//     coarse replay(c), probes, descriptors(c)     front stream
+//     heap replay(c-2), rescoring(c-2)             replay stream (c-2) mod depth
+// so the caller's stream is a chain of scan launches that never waits: scan(c) is launched
+// two calls after its coarse scan, which leaves a whole launch for the coarse replay and
+// the descriptors (latency-bound, 0.3 ms), and the replays of the previous batches overlap
+// all of it.  tk_index_join enqueues the list scans still owed and re-joins.
 struct Pending {
     Work *w;
     const float *q_dev;
@@ -1101,36 +1154,29 @@ struct Pending {
     int64_t *out_dev;
     bool units;
     Prof pf;
-    hipStream_t st, sl;   // chip-filling kernels / latency-bound kernels
+    hipStream_t st, sf, sl;   // scans (+ tables) / coarse replay + descriptors / replay + rescoring
 };
 
-static int batch_front(tk_index *ix, Pending &b, const void *qpq_dev, int qpq_f64)
+// depth == 1
+static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int qpq_f64)
 {
     Work &w = *b.w;
     const Plan &p = b.p;
-    TRY(prof_begin(ix, w, b.nq, p, b.sl, b.pf));
+    const int M = ix->M;
+    hipStream_t st = b.st;
+    TRY(prof_begin(ix, w, b.nq, p, st, b.pf));
     b.units = use_units(ix, b.nq, p);
-    TRY(stage_front(ix, w, b.q_dev, qpq_dev, qpq_f64, b.nq, p,
-                    b.units ? w.u_count.as<int>() : nullptr, nullptr, 0, b.st, b.sl, b.pf));
+    TRY(stage_tables(ix, w, qpq_dev, qpq_f64, b.nq, st, b.pf));
+    launch_coarse_scan(ix, w, b.nq, p, st);
+    TRY(stage_coarse_rest(ix, w, b.q_dev, b.nq, p, b.units ? w.u_count.as<int>() : nullptr, nullptr,
+                          0, st, b.pf));
     if (b.units)
         tk_launch_unit_pairs(b.nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
                              ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
                              w.u_count.as<int>(), w.u_pair_off.as<int>(),
                              w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
                              w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
-                             b.nq * p.S + 4 * ix->n_lists, b.sl);
-    HIPCHECK(hipGetLastError());
-    if (b.sl != b.st) HIPCHECK(hipEventRecord(w.front_done, b.sl));
-    return TK_OK;
-}
-
-static int batch_back(tk_index *ix, Pending &b)
-{
-    Work &w = *b.w;
-    const Plan &p = b.p;
-    const int M = ix->M;
-    hipStream_t st = b.st;
-    if (b.sl != b.st) HIPCHECK(hipStreamWaitEvent(st, w.front_done, 0));
+                             b.nq * p.S + 4 * ix->n_lists, st);
     TRY(b.pf.mark(st));
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
     if (b.units)
@@ -1145,26 +1191,76 @@ static int batch_back(tk_index *ix, Pending &b)
                               (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(),
                               p.cap_min, 1, ix->order, st);
     TRY(b.pf.mark(st));
-    if (b.sl != b.st) {
-        HIPCHECK(hipEventRecord(w.scanned, st));
-        HIPCHECK(hipStreamWaitEvent(b.sl, w.scanned, 0));
-    }
-    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, b.sl, b.pf));
+    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf));
     HIPCHECK(hipGetLastError());
-    if (b.sl != b.st) {
-        HIPCHECK(hipEventRecord(w.done, b.sl));
-        w.busy = true;
+    return TK_OK;
+}
+
+// depth > 1: the launch on the caller's stream that carries the list scan of `prev` (may be
+// NULL) and the coarse scan of `cur` (may be NULL), and what follows each on its stream
+static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
+{
+    const int M = ix->M;
+    hipStream_t st = prev ? prev->st : cur->st;
+    if (prev) {
+        HIPCHECK(hipStreamWaitEvent(st, prev->w->front_done, 0));
+        TRY(prev->pf.mark(st));
     }
+    const bool fuse_prev = prev && prev->units;
+    const bool fuse_cur = cur && coarse_units(ix, cur->nq);
+    if (prev && !fuse_prev)
+        tk_launch_scan_probes(ix->codes.as<uint4>(), M, prev->w->tables.as<uint4>(), prev->nq,
+                              prev->w->slot_prefix.as<int>(), prev->w->slot_chunk0.as<int64_t>(),
+                              prev->p.S, (int)prev->p.cap, prev->w->dist.as<uint4>(), prev->p.cap,
+                              prev->w->mins.as<uint8_t>(), prev->p.cap_min, 1, ix->order, st);
+    if (cur && !fuse_cur) launch_coarse_scan(ix, *cur->w, cur->nq, cur->p, st);
+    if (fuse_prev || fuse_cur) {
+        TkScanJob none;
+        memset(&none, 0, sizeof none);
+        tk_launch_scan_units2(fuse_prev ? list_job(ix, *prev->w, prev->p) : none,
+                              fuse_cur ? coarse_job(ix, *cur->w, cur->p) : none, M, ix->order, 768,
+                              st);
+    }
+    if (prev) {
+        // heap replay + rescoring of the previous batch on its stream
+        TRY(prev->pf.mark(st));
+        HIPCHECK(hipEventRecord(prev->w->scanned, st));
+        HIPCHECK(hipStreamWaitEvent(prev->sl, prev->w->scanned, 0));
+        TRY(stage_back(ix, *prev->w, prev->q_dev, 0, prev->nq, prev->k, prev->p, prev->out_dev,
+                       prev->sl, prev->pf));
+        HIPCHECK(hipEventRecord(prev->w->done, prev->sl));
+        prev->w->busy = true;
+    }
+    if (cur) {
+        // rest of the coarse stage + scan descriptors of this batch on its stream
+        Work &w = *cur->w;
+        HIPCHECK(hipEventRecord(w.coarse_scanned, st));
+        HIPCHECK(hipStreamWaitEvent(cur->sf, w.coarse_scanned, 0));
+        TRY(stage_coarse_rest(ix, w, cur->q_dev, cur->nq, cur->p,
+                              cur->units ? w.u_count.as<int>() : nullptr, nullptr, 0, cur->sf,
+                              cur->pf));
+        if (cur->units)
+            tk_launch_unit_pairs(cur->nq, w.probes.as<int64_t>(), cur->p.S, ix->n_lists,
+                                 ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
+                                 w.u_count.as<int>(), w.u_pair_off.as<int>(),
+                                 w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
+                                 w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
+                                 cur->nq * cur->p.S + 4 * ix->n_lists, cur->sf);
+        HIPCHECK(hipEventRecord(w.front_done, cur->sf));
+    }
+    HIPCHECK(hipGetLastError());
     return TK_OK;
 }
 
 static int flush_pending(tk_index *ix)
 {
-    if (!ix->pending) return TK_OK;
-    Pending *b = ix->pending;
-    ix->pending = nullptr;
-    int r = batch_back(ix, *b);
-    delete b;
+    int r = TK_OK;
+    while (!ix->pending.empty()) {
+        Pending *b = ix->pending.front();
+        ix->pending.erase(ix->pending.begin());
+        if (r == TK_OK) r = pipeline_step(ix, b, nullptr);
+        delete b;
+    }
     return r;
 }
 
@@ -1190,29 +1286,44 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
         b.p = p;
         b.out_dev = out_ids_dev + o * k;
         b.units = false;
-        b.st = b.sl = caller;
-        if (ix->depth > 1) {
-            while ((int)ix->lat_streams.size() < ix->depth) {
-                hipStream_t st;
-                HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-                ix->lat_streams.push_back(st);
-            }
-            b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
-            hipEvent_t *evs[] = {&w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
-            for (hipEvent_t *e : evs)
-                if (!*e) HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-            // the workspace is free once the second half of its previous batch is through
-            if (w.busy) HIPCHECK(hipStreamWaitEvent(caller, w.done, 0));
+        b.st = b.sf = b.sl = caller;
+        const void *qpq = (const char *)q_pq_dev + (size_t)o * ix->dq * esz;
+        if (ix->depth == 1) {
+            ix->calls++;
+            TRY(reserve(ix, w, sub, k, p));
+            TRY(run_batch_inline(ix, b, qpq, q_pq_is_f64));
+            continue;
         }
+        while ((int)ix->lat_streams.size() < ix->depth) {
+            hipStream_t st;
+            HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            ix->lat_streams.push_back(st);
+        }
+        if (!ix->front_stream)
+            HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking));
+        b.sf = ix->front_stream;
+        b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
         ix->calls++;
+        hipEvent_t *evs[] = {&w.tables_done, &w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
+        for (hipEvent_t *e : evs)
+            if (!*e) HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        // the workspace is free once the second half of its previous batch is through
+        if (w.busy) HIPCHECK(hipStreamWaitEvent(caller, w.done, 0));
         TRY(reserve(ix, w, sub, k, p));
-        TRY(batch_front(ix, b, (const char *)q_pq_dev + (size_t)o * ix->dq * esz, q_pq_is_f64));
-        if (ix->depth > 1) {
-            TRY(flush_pending(ix));              // second half of the previous call
-            ix->pending = new Pending(b);
-        } else {
-            TRY(batch_back(ix, b));
+        TRY(prof_begin(ix, w, b.nq, p, b.sl, b.pf));
+        b.units = use_units(ix, b.nq, p);
+        TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, caller, b.pf));
+        // this call's launch carries the list scan of the call before the previous one: the
+        // previous call's coarse replay and descriptors get a whole launch to finish in
+        Pending *prev = nullptr;
+        if (ix->pending.size() >= 2) {
+            prev = ix->pending.front();
+            ix->pending.erase(ix->pending.begin());
         }
+        int r = pipeline_step(ix, prev, &b);
+        delete prev;
+        TRY(r);
+        ix->pending.push_back(new Pending(b));
     }
     return TK_OK;
 }
@@ -1289,8 +1400,9 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     TRY(reserve_shard(ix, w, nq, qh, p));
     Prof pf;
     const int *owner = ix->owner.as<int>();
-    TRY(stage_front(ix, w, q_dev, q_pq_dev, q_pq_is_f64, nq, p, w.u_count.as<int>(), owner,
-                    ix->rank, st, st, pf));
+    TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
+    launch_coarse_scan(ix, w, nq, p, st);
+    TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf));
     tk_launch_shard_positions(w.probes.as<int64_t>(), w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
                               owner, ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
                               w.rpos.as<int>(), flag_dev, st);
@@ -1343,8 +1455,8 @@ extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
     ARGCHECK(depth >= 1 && depth <= 8, "depth must be in 1..8");
     TRY(flush_pending(ix));
     HIPCHECK(hipDeviceSynchronize());
-    // depth second halves in flight + the first half being built + the deferred one
-    const size_t n_works = depth > 1 ? (size_t)depth + 2 : 1;
+    // depth replays in flight + two calls waiting for their list scan + the one being built
+    const size_t n_works = depth > 1 ? (size_t)depth + 4 : 1;
     while (ix->works.size() > n_works) {
         ix->works.back().release();
         ix->works.pop_back();
@@ -1453,6 +1565,10 @@ extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_byte
     double bytes = 0;
     for (int64_t i = 0; i < ix->last_nq; i++)
         bytes += (double)pre[(size_t)i * (S + 1) + S] * ix->M * 8 + 16.0 * ix->M + 12.0 * ix->last_R;
+    if (ix->depth > 1)
+        // pipelined mode: the timed launch also carries the next batch's coarse scan
+        bytes += (double)ix->last_nq * ((double)ix->center_chunks * ix->M * 8 + 16.0 * ix->M +
+                                        12.0 * (2 * S + 10 < ix->n_lists ? 2 * S + 10 : (int)ix->n_lists));
     *scan_bytes = bytes;
     ix->ev_used = 0;
     return TK_OK;

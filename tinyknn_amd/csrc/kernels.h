@@ -60,6 +60,22 @@ void tk_launch_unit_pairs(int64_t nq, const int64_t *probes, int S, int64_t n_li
 // pair_q/pair_f0: nq rounded up to a multiple of 4)
 void tk_launch_identity_pairs(int64_t nq, int chunks, int *pair_off, int *unit_prefix, int *pair_q,
                               int *pair_f0, hipStream_t s);
+// one job of the list-major scan (what tk_launch_scan_units takes); unit_prefix == NULL: absent
+struct TkScanJob {
+    const uint4 *codes;
+    const uint4 *tables;
+    const int64_t *list_chunk_off;
+    int n_lists;
+    const int *unit_prefix, *pair_off, *pair_q, *pair_f0;
+    uint4 *dist;
+    int64_t cap;
+    uint8_t *mins;
+    int64_t min_stride;
+};
+// two jobs in ONE launch sharing one pool of 64-unit blocks (pipelined mode: the list scan
+// of one batch and the coarse scan of the next); signed tables
+void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
+                           hipStream_t s);
 void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq, int S,
                           int64_t n_lists, const int64_t *list_chunk_off, const int *pair_off,
                           const int *unit_prefix, const int *pair_q, const int *pair_f0,
