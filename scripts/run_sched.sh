@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/sc
 timeout 900 python -m pytest tests -x -q -m gpu -k "pipelined or larger" 2>&1 | tail -3
-for depth in 2 3; do
+for depth in 2; do
   python bench.py --no-cpu --shard none --steps 30 --recall-sample 10 --pipeline $depth > gpurun_out/sc/D${depth}.json 2>gpurun_out/sc/D${depth}.err
 done
 python - <<'PY'

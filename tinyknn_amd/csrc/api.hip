@@ -1133,18 +1133,18 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
 // depth  > 1 (tk_index_set_pipeline): two kinds of kernels make up a batch — chip-filling,
 // VALU-bound scans and latency-bound rest (table build: many small workgroups; heap replays:
 // 157 waves per 10 000 queries; rescoring; descriptors).  Two scans at once only stretch each
-// other, so ALL scans (and the table builds) run on the caller's stream, in order, the coarse
-// replays + descriptors of all batches on one internal stream, and the heap replay +
-// rescoring of a batch on one of `depth` more, handed over by events.  Call c enqueues
-//     tables(c)                                    caller's stream
-//     [ list scan(c-2)  +  coarse scan(c) ]        ONE launch on the caller's stream: one pool
-//                                                  of 64-unit blocks, drawn by tickets
-//     coarse replay(c), probes, descriptors(c)     front stream
-//     heap replay(c-2), rescoring(c-2)             replay stream (c-2) mod depth
-// so the caller's stream is a chain of scan launches that never waits: scan(c) is launched
-// two calls after its coarse scan, which leaves a whole launch for the coarse replay and
-// the descriptors (latency-bound, 0.3 ms), and the replays of the previous batches overlap
-// all of it.  tk_index_join enqueues the list scans still owed and re-joins.
+// other, so ALL scans run on the caller's stream, in order; the table builds and the coarse
+// replays + descriptors of all batches on one internal "front" stream; the heap replay +
+// rescoring of a batch on one of `depth` more; handed over by events.  Call c enqueues
+//     tables(c)                                      front stream
+//     [ list scan(c-3)  +  coarse scan(c-1) ]        ONE launch on the caller's stream: one
+//                                                    pool of 64-unit blocks, drawn by tickets
+//     coarse replay(c-1), probes, descriptors(c-1)   front stream
+//     heap replay(c-3), rescoring(c-3)               replay stream (c-3) mod depth
+// so the caller's stream is a chain of scan launches that never waits — every launch finds
+// its tables (built one call earlier) and its descriptors (two calls earlier) finished —
+// while the replays of the previous batches overlap all of it.
+// tk_index_join enqueues the launches still owed and re-joins.
 struct Pending {
     Work *w;
     const float *q_dev;
@@ -1153,6 +1153,7 @@ struct Pending {
     Plan p;
     int64_t *out_dev;
     bool units;
+    bool coarse_launched;   // its coarse scan has been enqueued
     Prof pf;
     hipStream_t st, sf, sl;   // scans (+ tables) / coarse replay + descriptors / replay + rescoring
 };
@@ -1202,6 +1203,10 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
 {
     const int M = ix->M;
     hipStream_t st = prev ? prev->st : cur->st;
+    if (cur) {
+        HIPCHECK(hipStreamWaitEvent(st, cur->w->tables_done, 0));
+        cur->coarse_launched = true;
+    }
     if (prev) {
         HIPCHECK(hipStreamWaitEvent(st, prev->w->front_done, 0));
         TRY(prev->pf.mark(st));
@@ -1252,15 +1257,33 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
     return TK_OK;
 }
 
+// the launch a call (or a flush) owes: the list scan of the oldest call once three are
+// pending (`drain`: of the oldest call in any case) + the coarse scan of the newest call
+// that has not had one
+static int pipeline_advance(tk_index *ix, bool drain)
+{
+    Pending *coarse = nullptr;
+    for (Pending *b : ix->pending)
+        if (!b->coarse_launched) { coarse = b; break; }
+    Pending *scan = nullptr;
+    if (!ix->pending.empty() && ix->pending.front()->coarse_launched &&
+        (drain || ix->pending.size() >= 3))
+        scan = ix->pending.front();
+    if (!scan && !coarse) return TK_OK;
+    int r = pipeline_step(ix, scan, coarse);
+    if (scan) {
+        ix->pending.erase(ix->pending.begin());
+        delete scan;
+    }
+    return r;
+}
+
 static int flush_pending(tk_index *ix)
 {
     int r = TK_OK;
-    while (!ix->pending.empty()) {
-        Pending *b = ix->pending.front();
-        ix->pending.erase(ix->pending.begin());
-        if (r == TK_OK) r = pipeline_step(ix, b, nullptr);
-        delete b;
-    }
+    while (!ix->pending.empty() && r == TK_OK) r = pipeline_advance(ix, true);
+    for (Pending *b : ix->pending) delete b;
+    ix->pending.clear();
     return r;
 }
 
@@ -1286,6 +1309,7 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
         b.p = p;
         b.out_dev = out_ids_dev + o * k;
         b.units = false;
+        b.coarse_launched = false;
         b.st = b.sf = b.sl = caller;
         const void *qpq = (const char *)q_pq_dev + (size_t)o * ix->dq * esz;
         if (ix->depth == 1) {
@@ -1307,22 +1331,20 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
         hipEvent_t *evs[] = {&w.tables_done, &w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
         for (hipEvent_t *e : evs)
             if (!*e) HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        // the workspace is free once the second half of its previous batch is through
-        if (w.busy) HIPCHECK(hipStreamWaitEvent(caller, w.done, 0));
+        if (!ix->ev_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_in, hipEventDisableTiming));
+        // the table build of this call goes to the front stream now (after the caller's work
+        // so far — its inputs — and once the workspace is free); its coarse scan rides in the
+        // NEXT call's launch, its list scan in the launch three calls later
+        HIPCHECK(hipEventRecord(ix->ev_in, caller));
+        HIPCHECK(hipStreamWaitEvent(b.sf, ix->ev_in, 0));
+        if (w.busy) HIPCHECK(hipStreamWaitEvent(b.sf, w.done, 0));
         TRY(reserve(ix, w, sub, k, p));
         TRY(prof_begin(ix, w, b.nq, p, b.sl, b.pf));
         b.units = use_units(ix, b.nq, p);
-        TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, caller, b.pf));
-        // this call's launch carries the list scan of the call before the previous one: the
-        // previous call's coarse replay and descriptors get a whole launch to finish in
-        Pending *prev = nullptr;
-        if (ix->pending.size() >= 2) {
-            prev = ix->pending.front();
-            ix->pending.erase(ix->pending.begin());
-        }
-        int r = pipeline_step(ix, prev, &b);
-        delete prev;
-        TRY(r);
+        TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, b.sf, b.pf));
+        HIPCHECK(hipEventRecord(w.tables_done, b.sf));
+        // this call's launch: list scan of call c-3 + coarse scan of call c-1
+        TRY(pipeline_advance(ix, false));
         ix->pending.push_back(new Pending(b));
     }
     return TK_OK;
@@ -1455,8 +1477,8 @@ extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
     ARGCHECK(depth >= 1 && depth <= 8, "depth must be in 1..8");
     TRY(flush_pending(ix));
     HIPCHECK(hipDeviceSynchronize());
-    // depth replays in flight + two calls waiting for their list scan + the one being built
-    const size_t n_works = depth > 1 ? (size_t)depth + 4 : 1;
+    // depth replays in flight + three calls waiting for their list scan + slack
+    const size_t n_works = depth > 1 ? (size_t)depth + 5 : 1;
     while (ix->works.size() > n_works) {
         ix->works.back().release();
         ix->works.pop_back();
