@@ -10,7 +10,7 @@ queries through the whole device pipeline (tables, coarse stage, list scan, exac
 heap replay, exact rescoring).  Queries are resident in HBM, already normalised as
 the reference's host code does (ivf.py:125-127), when the timed region starts.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: replicas — every rank holds the whole index (0.5 GB of 288 GB) and owns its
@@ -195,8 +195,8 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=1183514)
     ap.add_argument("--d", type=int, default=100)
     ap.add_argument("--n-clusters", type=int, default=1087)
@@ -383,7 +383,10 @@ def main():
                    "batches_in_flight": args.pipeline},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "scan_units_kernel<AVX,signed>" if args.scan_mode != 1 else "scan_probes_kernel<AVX,signed>",
+                     "kernel": ("scan_probes_kernel<AVX,signed>" if args.scan_mode == 1 else
+                                "scan_units_kernel<AVX,signed>" if args.pipeline == 1 else
+                                "scan_units2_kernel<AVX,signed> (one launch: list scan of a batch + coarse scan "
+                                "of a later one)"),
                      "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
                      "launches_timed": n_prof},
         "stage_ms": stages,
