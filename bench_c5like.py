@@ -6,8 +6,8 @@ k-means/encoding; what it exercises on the query path is big inverted lists
 (thousands of codes each, M = 32, rotated float64 table math) whose codes no longer
 fit the 256 MB Infinity Cache.  This script builds such an index DIRECTLY (no
 training): random unit-ish vectors, a random orthogonal rotation, random 16-entry
-codebooks, every vector encoded by its nearest codebook entry per block in numpy
-float64, lists assigned round-robin by a cheap hash — then runs the same device
+codebooks, every vector encoded by the product's device encoder (tk_encode_pq), lists
+assigned at random with lognormal weights — then runs the same device
 pipeline as bench.py and checks a sample against the CPU oracle.
 
     python bench_c5like.py --n 20000000 --n-clusters 4472 --nq 10000
@@ -60,14 +60,11 @@ def main():
     pq.R = ortho_group.rvs(dim=d, random_state=rng)[:rd]
     pq.centers = (rng.randn(16, rd) * 0.6).astype(np.float32)
     pq.sqrt_n_blocks = np.sqrt(M)
-    code_cols = torch.from_numpy(pq.centers.reshape(16, M, dpb).transpose(1, 0, 2).copy()).to(dev_t).double()
 
     def encode(Xb):
-        """nearest codebook entry per block (torch on the GPU: index construction only)"""
-        Xr = torch.from_numpy(Xb).to(dev_t).double() @ torch.from_numpy(pq.R.T).to(dev_t)
-        Xr = Xr.reshape(len(Xb), M, dpb)
-        d2 = ((Xr[:, :, None, :] - code_cols[None]) ** 2).sum(-1)      # (n, M, 16)
-        return d2.argmin(-1).to(torch.uint8).cpu().numpy()
+        """FastPQ.transform's body: rotation = numpy GEMM on the host (as the reference),
+        nearest centroids per block on the GPU (build.hip: tk_encode_pq)"""
+        return pq.encode_labels(Xb.astype(np.float64) @ pq.R.T, True)
 
     # --- vectors, list assignment, codes
     data = np.empty((n, d), dtype=np.float32)
