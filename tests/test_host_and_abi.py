@@ -47,6 +47,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+    # outside tests/, only bench.py (cpu_baseline leg) and __graft_entry__.smoke() may use it
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "*.py")) + glob.glob(os.path.join(ROOT, "examples", "*.py")) + \
+            glob.glob(os.path.join(ROOT, "include", "*.h")):
+        if os.path.basename(f) in ("bench.py", "__graft_entry__.py"):
+            continue
+        assert "oracle" not in open(f).read(), f"{f} mentions the oracle"
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
