@@ -124,3 +124,33 @@ def test_build_contracts():
         mask = (idx == g).any(axis=1)
         assert sorted(map(tuple, parts[g])) == sorted(map(tuple, np.vstack([X[:50][idx[:, j] == g] for j in range(2)])))
         assert set(ids[g]) == set(np.nonzero(mask)[0])
+
+
+def test_index_persistence_roundtrips(tmp_path):
+    """pickle (what the reference's bench does, examples/bench.py:88-103) and the flat
+    save/load give back the same index; no GPU involved."""
+    import pickle
+    from conftest import split_lists
+    from tinyknn_amd import IVF, FastPQ
+    from tinyknn_amd.fast_pq import TransformedData
+    g = golden("g6_ivf_eu128.npz")
+    codes, ids = split_lists(g)
+    ivf = IVF(str(g["metric"]), len(codes), FastPQ(2))
+    ivf.pq.centers, ivf.pq.sqrt_n_blocks, ivf.pq.R = g["pq_centers"], float(g["sqrt_n_blocks"]), g["R"]
+    ivf.active_centers = g["active_centers"]
+    ivf.pq_transformed_centers = TransformedData(int(g["center_size"]), g["center_codes"])
+    ivf.pq_transformed_points = [TransformedData(int(s), c) for s, c in zip(g["list_sizes"], codes)]
+    ivf.ids, ivf.data = ids, g["data"]
+    path = str(tmp_path / "index.npz")
+    ivf.save(path)
+    for other in (IVF.load(path), pickle.loads(pickle.dumps(ivf))):
+        assert other.metric == ivf.metric and other.pq.dims_per_block == 2
+        np.testing.assert_array_equal(other.pq.centers, ivf.pq.centers)
+        np.testing.assert_array_equal(other.pq.R, ivf.pq.R)
+        np.testing.assert_array_equal(other.active_centers, ivf.active_centers)
+        np.testing.assert_array_equal(other.pq_transformed_centers.packed, ivf.pq_transformed_centers.packed)
+        np.testing.assert_array_equal(other.data, ivf.data)
+        for a, b, ia, ib in zip(other.pq_transformed_points, ivf.pq_transformed_points, other.ids, ivf.ids):
+            assert a.size == b.size
+            np.testing.assert_array_equal(a.packed, b.packed)
+            np.testing.assert_array_equal(ia, ib)

@@ -137,3 +137,18 @@ def test_heap_invariant_and_heapq(tk):
         if v < top:
             heapq.heappop(py); heapq.heappush(py, (-v, t))
         assert set(val) == {-vi for vi, _ in py}
+
+
+@pytest.mark.gpu
+def test_saved_and_pickled_index_answers_identically(tmp_path):
+    """examples/bench.py:88-103 pickles (pq, ivf) and queries the loaded copy."""
+    import pickle
+    from conftest import golden
+    from test_hip_parity import ivf_from_fixture
+    from tinyknn_amd import IVF
+    g = golden("g6_ivf_an100b2.npz")
+    ivf = ivf_from_fixture(None, g)
+    path = str(tmp_path / "ix.npz")
+    ivf.save(path)
+    for other in (IVF.load(path), pickle.loads(pickle.dumps(ivf))):
+        np.testing.assert_array_equal(other.query_batch(g["qs"], 10, n_probes=5), g["ids_p5"])

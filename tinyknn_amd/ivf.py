@@ -312,6 +312,59 @@ class IVF:
                 lab = np.concatenate([lab, np.repeat(zero[None], padrows, axis=0)])
             self.pq_transformed_points[i] = TransformedData(len(sel), transform_data(lab))
 
+    # ---- persistence ---------------------------------------------------------
+    # The reference pickles (pq, ivf) (examples/bench.py:88-103); that works here too
+    # (__getstate__ drops the device handle).  save/load is the flat form the device upload
+    # wants: CSR offsets + one array per component, no Python objects.
+    def save(self, path):
+        """Flat binary (.npz): PQ codebook (+ rotation), coarse centres and their codes, list
+        sizes, packed codes and ids of all lists concatenated list-major, rescoring vectors."""
+        L = len(self.active_centers)
+        M = self.pq.centers.shape[1] // self.pq.dims_per_block
+        tds = [self.pq_transformed_points[i] for i in range(L)]
+        sizes = np.array([0 if isinstance(t, np.ndarray) else t.size for t in tds], dtype=np.int64)
+        codes = [t.packed for t in tds if not isinstance(t, np.ndarray)]
+        ids = [np.asarray(self.ids[i], dtype=np.int64)[:sizes[i]] for i in range(L)]
+        extra = {} if self.pq.R is None else {"R": self.pq.R}
+        if getattr(self, "all_centers", None) is not None:
+            extra["all_centers"] = self.all_centers
+        np.savez(path, format_version=1, metric=self.metric, n_clusters=self.n_clusters,
+                 dims_per_block=self.pq.dims_per_block, pq_centers=self.pq.centers,
+                 pq_centers_f_order=int(not self.pq.centers.flags.c_contiguous),
+                 sqrt_n_blocks=self.pq.sqrt_n_blocks, active_centers=self.active_centers,
+                 center_size=self.pq_transformed_centers.size,
+                 center_codes=self.pq_transformed_centers.packed, list_sizes=sizes,
+                 list_codes=(np.concatenate(codes) if codes else np.zeros((0, M), np.uint64)),
+                 ids=(np.concatenate(ids) if ids else np.zeros(0, np.int64)), data=self.data, **extra)
+
+    @classmethod
+    def load(cls, path, data=None):
+        """Inverse of save.  `data`: the rescoring vectors if the file was written without them
+        being wanted twice (pass the array to avoid keeping two copies)."""
+        from .fast_pq import TransformedData
+        z = np.load(path, allow_pickle=False)
+        assert int(z["format_version"]) == 1
+        ivf = cls(str(z["metric"]), int(z["n_clusters"]), FastPQ(int(z["dims_per_block"])))
+        c = z["pq_centers"]
+        ivf.pq.centers = np.asfortranarray(c) if int(z["pq_centers_f_order"]) else c
+        ivf.pq.sqrt_n_blocks = float(z["sqrt_n_blocks"])
+        ivf.pq.R = z["R"] if "R" in z else None
+        if "all_centers" in z:
+            ivf.all_centers = z["all_centers"]
+        ivf.active_centers = z["active_centers"]
+        ivf.pq_transformed_centers = TransformedData(int(z["center_size"]), z["center_codes"])
+        sizes = z["list_sizes"]
+        coff = np.concatenate([[0], np.cumsum((sizes + 15) // 16)])
+        ioff = np.concatenate([[0], np.cumsum(sizes)])
+        codes, ids = z["list_codes"], z["ids"]
+        d = ivf.active_centers.shape[1]
+        ivf.pq_transformed_points = [
+            TransformedData(int(sizes[i]), codes[coff[i]:coff[i + 1]]) if sizes[i] else np.empty((0, d))
+            for i in range(len(sizes))]
+        ivf.ids = [ids[ioff[i]:ioff[i + 1]] for i in range(len(sizes))]
+        ivf.data = z["data"] if data is None else data
+        return ivf
+
     # ---- queries (GPU) -----------------------------------------------------
     def device_index(self):
         if self._dev is None:
