@@ -226,6 +226,26 @@ int tk_index_set_scan_mode(tk_index *ix, int mode);
 int tk_index_set_profiling(tk_index *ix, int on);
 int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches);
 
+/* ---- device front end, "fast mode"  -----------------------------------
+ * What IVF.query does on the host before the table build (ivf.py:125-128,
+ * fast_pq.py:200-204): float32 normalisation for the angular metric, zero padding to dq,
+ * rotation by R.  NOT bit-identical to the host path, which is the default everywhere:
+ * numpy normalises with a BLAS dot and rotates with a BLAS GEMV whose summation orders are
+ * not restated.  Here the norm is numpy's pairwise float32 sum and the rotation a float64
+ * FMA chain; both results are within 1 ulp of the host's, and the ids differ only where
+ * that flips a quantised table entry or a rescoring tie (measured in DESIGN.md).
+ * tk_index_set_rotation: R (dq, d_pad) float64 row-major = FastPQ.R, or NULL (no rotation).
+ * tk_index_prepare_dev: q_raw_dev (nq, d) float32 -> qn_dev (nq, d) float32 (normalised if
+ * `angular`, else a copy; may alias q_raw_dev) and q_pq_dev (nq, dq) float64 when a rotation
+ * is set, float32 otherwise — the two inputs of tk_index_query_batch_dev. */
+int tk_index_set_rotation(tk_index *ix, const double *R, int d_pad);
+int tk_index_prepare_dev(tk_index *ix, const float *q_raw_dev, int64_t nq, int angular,
+                         float *qn_dev, void *q_pq_dev, void *stream);
+/* raw float32 queries on the host -> ids on the host through the fast front end (H2D,
+ * prepare, pipeline, D2H; synchronous) */
+int tk_index_query_batch_raw(tk_index *ix, const float *q_raw, int64_t nq, int angular, int k,
+                             int n_probes, int pass_1, int64_t *out_ids);
+
 /* ---- list-sharded index over `world` ranks, one process per GPU --------
  * The inverted lists (ivf.py:100-102) are partitioned by cluster id: owner[l] is the rank
  * that stores list l's packed codes.  PQ, coarse centres, ids and the rescoring vectors are

@@ -152,3 +152,23 @@ def test_saved_and_pickled_index_answers_identically(tmp_path):
     ivf.save(path)
     for other in (IVF.load(path), pickle.loads(pickle.dumps(ivf))):
         np.testing.assert_array_equal(other.query_batch(g["qs"], 10, n_probes=5), g["ids_p5"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["an100", "eu128", "eu20"])
+def test_fast_front_end_close_to_exact(tag):
+    """Device normalisation / padding / rotation (fast=True) against the exact host path: the
+    prepared queries agree to 1 ulp-level tolerances and nearly all result rows are equal."""
+    from conftest import golden
+    from test_hip_parity import ivf_from_fixture
+    g = golden(f"g6_ivf_{tag}.npz")
+    ivf = ivf_from_fixture(None, g)
+    for n_probes in (1, 5, 10):
+        exact = ivf.query_batch(g["qs"], 10, n_probes=n_probes)
+        np.testing.assert_array_equal(exact, g[f"ids_p{n_probes}"])
+        fast = ivf.query_batch(g["qs"], 10, n_probes=n_probes, fast=True)
+        same = (fast == exact).all(axis=1).mean()
+        assert same >= 0.9, f"{tag} n_probes={n_probes}: only {same:.2%} identical rows"
+        # whatever differs is a near-tie: the two id sets overlap almost entirely
+        overlap = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(fast, exact)])
+        assert overlap >= 0.98

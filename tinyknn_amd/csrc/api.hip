@@ -599,6 +599,8 @@ struct tk_index {
     // list_chunk_off stays the GLOBAL layout (every rank derives the same distance rows),
     // local_chunk_off addresses this rank's code storage (lists of other ranks: empty)
     DevBuf owner, local_chunk_off;
+    DevBuf rot_t;            // fast mode: R transposed (d_pad, dq) float64, or empty
+    int rot_d_pad = 0;
     int rank = 0, world = 1;
     bool sharded = false;
     // vectors
@@ -642,7 +644,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
     DevBuf *bufs[] = {&ix->pq_centers, &ix->active_centers, &ix->center_codes, &ix->list_chunk_off,
                       &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->ids32, &ix->data, &ix->cslots_i,
                       &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage, &ix->owner,
-                      &ix->local_chunk_off};
+                      &ix->local_chunk_off, &ix->rot_t};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
     for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
@@ -1469,6 +1471,73 @@ extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_
     }
     HIPCHECK(hipGetLastError());
     return TK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device front end ("fast mode")
+extern "C" int tk_index_set_rotation(tk_index *ix, const double *R, int d_pad)
+{
+    ARGCHECK(ix && ix->have_pq && ix->have_centers, "set_pq and set_centers first");
+    if (!R) {
+        ix->rot_t.release();
+        ix->rot_d_pad = 0;
+        return TK_OK;
+    }
+    ARGCHECK(d_pad >= ix->d && d_pad <= 16384, "d_pad");
+    std::vector<double> rt((size_t)d_pad * ix->dq);
+    for (int j = 0; j < ix->dq; j++)
+        for (int t = 0; t < d_pad; t++) rt[(size_t)t * ix->dq + j] = R[(size_t)j * d_pad + t];
+    TRY(ix->rot_t.ensure(rt.size() * 8));
+    HIPCHECK(hipMemcpy(ix->rot_t.p, rt.data(), rt.size() * 8, hipMemcpyHostToDevice));
+    ix->rot_d_pad = d_pad;
+    return TK_OK;
+}
+
+extern "C" int tk_index_prepare_dev(tk_index *ix, const float *q_raw_dev, int64_t nq, int angular,
+                                    float *qn_dev, void *q_pq_dev, void *stream)
+{
+    ARGCHECK(ix && ix->have_pq && ix->have_centers, "set_pq and set_centers first");
+    ARGCHECK(nq >= 0 && q_raw_dev && qn_dev && q_pq_dev, "buffers");
+    ARGCHECK(!angular || ix->d <= 128, "device normalisation needs d <= 128");
+    ARGCHECK(ix->rot_d_pad > 0 || ix->dq >= ix->d, "unrotated PQ: dq >= d");
+    hipStream_t st = (hipStream_t)stream;
+    if (angular)
+        tk_launch_normalise_rows(q_raw_dev, nq, ix->d, qn_dev, st);
+    else if (qn_dev != q_raw_dev)
+        HIPCHECK(hipMemcpyAsync(qn_dev, q_raw_dev, (size_t)nq * ix->d * 4, hipMemcpyDeviceToDevice, st));
+    tk_launch_prepare_queries(qn_dev, nq, ix->d, ix->rot_d_pad ? ix->rot_t.as<double>() : nullptr,
+                              ix->dq, ix->rot_d_pad ? ix->rot_d_pad : ix->dq, q_pq_dev, st);
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+extern "C" int tk_index_query_batch_raw(tk_index *ix, const float *q_raw, int64_t nq, int angular,
+                                        int k, int n_probes, int pass_1, int64_t *out_ids)
+{
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    ARGCHECK(nq >= 0 && q_raw && out_ids, "buffers");
+    if (nq == 0) return TK_OK;
+    const int f64 = ix->rot_d_pad > 0;
+    DevBuf raw, outbuf;
+    TRY(raw.ensure((size_t)nq * ix->d * 4));
+    TRY(ix->q.ensure((size_t)nq * ix->d * 4));
+    TRY(ix->qpq.ensure((size_t)nq * ix->dq * (f64 ? 8 : 4)));
+    TRY(outbuf.ensure((size_t)nq * k * 8));
+    HIPCHECK(hipMemcpy(raw.p, q_raw, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice));
+    int r = tk_index_prepare_dev(ix, raw.as<float>(), nq, angular, ix->q.as<float>(), ix->qpq.p, nullptr);
+    if (r == TK_OK)
+        r = tk_index_query_batch_dev(ix, ix->q.as<float>(), ix->qpq.p, f64, nq, k, n_probes, pass_1,
+                                     outbuf.as<int64_t>(), nullptr);
+    if (r == TK_OK) r = flush_pending(ix);
+    if (r == TK_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(out_ids, outbuf.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) r = fail(TK_ERR_HIP, hipGetErrorString(e));
+    }
+    raw.release();
+    outbuf.release();
+    return r;
 }
 
 extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)

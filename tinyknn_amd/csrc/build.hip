@@ -330,3 +330,51 @@ void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const vo
         hipLaunchKernelGGL(assign_kernel<float>, grid, dim3(256), lds, s, X, n, d, (const float *)Yt,
                            (const float *)ynorm2, L, k, nearest);
 }
+
+// ---------------------------------------------------------------------------
+// Device front end ("fast mode"): what IVF.query does on the host before
+// the table build (ivf.py:125-128, fast_pq.py:200-204).  NOT bit-identical to the host path:
+// numpy normalises a query with a BLAS dot and rotates it with a BLAS GEMV, whose summation
+// orders are not restated; here the norm is numpy's pairwise float32 sum (the order of
+// np.linalg.norm(axis=1)) and the rotation a float64 FMA chain over k ascending.
+// One workgroup of 64 lanes per query; Rt is R transposed (d_pad, dq) so that lane j reads
+// consecutive addresses.
+__global__ __launch_bounds__(64) void rotate_rows_kernel(const float *__restrict__ X, int64_t n,
+                                                         int d, int d_pad,
+                                                         const double *__restrict__ Rt, int dq,
+                                                         double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *x = (float *)smem;
+    const int64_t i = blockIdx.x;
+    for (int t = threadIdx.x; t < d_pad; t += 64) x[t] = t < d ? X[i * d + t] : 0.0f;
+    __syncthreads();
+    for (int j = threadIdx.x; j < dq; j += 64) {
+        double acc = 0.0;
+        for (int t = 0; t < d_pad; t++) acc = __builtin_fma((double)x[t], Rt[(int64_t)t * dq + j], acc);
+        out[i * dq + j] = acc;
+    }
+}
+
+// zero padding only (no rotation): out (n, dq) float32
+__global__ void pad_rows_kernel(const float *__restrict__ X, int64_t n, int d, int dq,
+                                float *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * dq) return;
+    const int64_t i = e / dq;
+    const int t = (int)(e - i * dq);
+    out[e] = t < d ? X[i * d + t] : 0.0f;
+}
+
+void tk_launch_prepare_queries(const float *X, int64_t n, int d, const double *Rt, int dq, int d_pad,
+                               void *out, hipStream_t s)
+{
+    if (n == 0) return;
+    if (Rt)
+        hipLaunchKernelGGL(rotate_rows_kernel, dim3((unsigned)n), dim3(64), (size_t)d_pad * 4, s, X, n,
+                           d, d_pad, Rt, dq, (double *)out);
+    else
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n * dq + 255) / 256)), dim3(256), 0, s, X,
+                           n, d, dq, (float *)out);
+}

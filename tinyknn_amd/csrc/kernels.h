@@ -181,3 +181,7 @@ void tk_launch_normalise_rows(const float *X, int64_t n, int d, float *out, hipS
 // float32 or float64 both; nearest (n, k)
 void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const void *ynorm2,
                       int y_is_f64, int L, int k, int64_t *nearest, hipStream_t s);
+// device front end (fast mode): padded (Rt == NULL: float32 (n, dq)) or rotated (float64 (n, dq),
+// Rt = R transposed (d_pad, dq)) table-build queries from raw/normalised float32 rows
+void tk_launch_prepare_queries(const float *X, int64_t n, int d, const double *Rt, int dq, int d_pad,
+                               void *out, hipStream_t s);

@@ -76,6 +76,10 @@ class DeviceIndex:
         _lib.check(L.tk_index_set_data(self._h, data.ctypes.data, int(is64), data.shape[0],
                                        data.shape[1]))
         self.code_bytes = int(codes.nbytes)
+        self.angular = ivf.metric == "angular"
+        if pq.R is not None:    # fast mode (device front end) needs the rotation on the device
+            R = np.ascontiguousarray(pq.R, dtype=np.float64)
+            _lib.check(L.tk_index_set_rotation(self._h, R.ctypes.data, R.shape[1]))
 
     @property
     def handle(self):
@@ -114,6 +118,17 @@ class DeviceIndex:
             None if hval is None else _lib.ptr(hval, _lib._i32p)))
         if debug:
             return out, dict(probes=probes, heap_idx=hidx, heap_val=hval)
+        return out
+
+    def query_batch_raw(self, qs, k, n_probes, pass_1=None):
+        """Fast mode: raw float32 queries, normalisation / padding / rotation on the device
+        (tk_index_prepare_dev: within 1 ulp of the host's BLAS results, not bit-identical)."""
+        qs = np.ascontiguousarray(qs, dtype=np.float32)
+        assert qs.shape[1] == self.d
+        out = np.full((qs.shape[0], k), -1, dtype=np.int64)
+        _lib.check(_lib.lib().tk_index_query_batch_raw(
+            self._h, _lib.ptr(qs, _lib._f32p), qs.shape[0], int(self.angular), int(k), int(n_probes),
+            int(pass_1 or 0), _lib.ptr(out, _lib._i64p)))
         return out
 
     def query_batch_dev(self, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, out_ptr,
@@ -396,11 +411,15 @@ class IVF:
         out = self.device_index().query_batch(qn, qp, k, n_probes, pass_1)[0]
         return out[out != -1] if out[-1] == -1 else out
 
-    def query_batch(self, qs, k, n_probes=1, pass_1=None):
+    def query_batch(self, qs, k, n_probes=1, pass_1=None, fast=False):
         """(nq, d) queries -> (nq, k) int64 ids, rows padded with -1 when the
         reference would return fewer than k ids.  (The reference's README shows a
         2-d `ivf.query(queries, ...)` that its code does not support; this is that
-        call.)"""
+        call.)  fast=True: normalisation, padding and rotation run on the device instead
+        of numpy's per-query BLAS calls (35 ms per 10 000 queries on the host) — within
+        1 ulp of them, so a rare id can differ from the reference's; the default is exact."""
+        if fast:
+            return self.device_index().query_batch_raw(qs, k, n_probes, pass_1)
         qs = np.array(qs, dtype=np.float32, order="C", copy=True)
         qn, qp = self._prepare(qs)
         return self.device_index().query_batch(qn, qp, k, n_probes, pass_1)
