@@ -166,11 +166,11 @@ __global__ void normalise_rows_kernel(const float *__restrict__ X, int64_t n, in
     for (int t = 0; t < d; t++) out[i * d + t] = x[t] / nr;
 }
 
-// knn_brute for TK_AS_ROWS rows per workgroup: thread t scores centres t, t+256, ...; the
+// knn_brute, ROWS rows per workgroup: thread t scores centres t, t+256, ...; the
 // rows are wave-uniform (scalar loads feed the FMAs), Yt is (d, L) so that a wave reads
 // consecutive centres.  Every thread keeps its three best (value, index) per row, the
 // workgroup merges them, and dumb_select's answer follows from the three best overall.
-#define TK_AS_ROWS 8
+
 
 template <typename T>
 struct Cand {
@@ -196,101 +196,117 @@ __device__ __forceinline__ void cand_push(Cand<T> (&top)[3], T v, int j)
     }
 }
 
-#define TK_AS_C 4   // centres per thread and pass: each staged row value feeds 4 FMAs
-
-template <typename T>
+// ROWS rows per workgroup, C centres per thread and pass (each staged row value feeds C FMAs,
+// each centre value ROWS FMAs), NTOP candidates kept per row: 1 when k == 1, 3 when k == 2
+// (dumb_select's second pass needs the three best overall and part[0]).
+template <typename T, int ROWS, int C, int NTOP>
 __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ X, int64_t n, int d,
                                                      const T *__restrict__ Yt,
                                                      const T *__restrict__ ynorm2, int L, int k,
                                                      int64_t *__restrict__ nearest)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *x2s = (T *)smem;                            // (d, TK_AS_ROWS): 2*x as T, row-interleaved
-    __shared__ Cand<T> s_top[TK_AS_ROWS][4][3];   // the three best of each wave
-    __shared__ T s_v0[TK_AS_ROWS];
-    const int64_t r0 = (int64_t)blockIdx.x * TK_AS_ROWS;
-    const int nr = n - r0 < TK_AS_ROWS ? (int)(n - r0) : TK_AS_ROWS;
-    for (int e = threadIdx.x; e < d * TK_AS_ROWS; e += 256) {
-        const int t = e / TK_AS_ROWS, r = e - t * TK_AS_ROWS;
+    T *x2s = (T *)smem;                            // (d, ROWS): 2*x as T, row-interleaved
+    __shared__ Cand<T> s_top[ROWS][4][NTOP];       // the best of each wave
+    __shared__ T s_v0[ROWS];
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+    const int nr = n - r0 < ROWS ? (int)(n - r0) : ROWS;
+    for (int e = threadIdx.x; e < d * ROWS; e += 256) {
+        const int t = e / ROWS, r = e - t * ROWS;
         x2s[e] = (T)(2.0f * X[(r0 + (r < nr ? r : 0)) * d + t]);
     }
     // |x|^2 in float32 (np.einsum on the float32 rows), promoted when added to float64 |y|^2
-    T xn[TK_AS_ROWS];
-    for (int r = 0; r < TK_AS_ROWS; r++) {
+    T xn[ROWS];
+    for (int r = 0; r < ROWS; r++) {
         const float *x = X + (r0 + (r < nr ? r : 0)) * d;
         xn[r] = (T)einsum_selfdot<float>(x, d);
     }
     __syncthreads();
-    Cand<T> top[TK_AS_ROWS][3];
+    Cand<T> top[ROWS][NTOP];
 #pragma unroll
-    for (int r = 0; r < TK_AS_ROWS; r++)
+    for (int r = 0; r < ROWS; r++)
 #pragma unroll
-        for (int t = 0; t < 3; t++) top[r][t] = {(T)0, -1};
-    for (int j0 = threadIdx.x; j0 < L; j0 += 256 * TK_AS_C) {
-        T p[TK_AS_C][TK_AS_ROWS];
-        int jj[TK_AS_C];
+        for (int t = 0; t < NTOP; t++) top[r][t] = {(T)0, -1};
+    auto push = [&](Cand<T> (&tp)[NTOP], T v, int j) {
+        if (NTOP == 1) {
+            if (cand_lt(v, j, tp[0])) tp[0] = {v, j};
+        } else {
+            if (cand_lt(v, j, tp[0])) {
+                tp[NTOP - 1] = tp[NTOP > 2 ? 1 : 0]; tp[NTOP > 1 ? 1 : 0] = tp[0]; tp[0] = {v, j};
+            } else if (cand_lt(v, j, tp[NTOP > 1 ? 1 : 0])) {
+                tp[NTOP - 1] = tp[NTOP > 1 ? 1 : 0]; tp[NTOP > 1 ? 1 : 0] = {v, j};
+            } else if (cand_lt(v, j, tp[NTOP - 1])) {
+                tp[NTOP - 1] = {v, j};
+            }
+        }
+    };
+    for (int j0 = threadIdx.x; j0 < L; j0 += 256 * C) {
+        T p[C][ROWS];
+        int jj[C];
 #pragma unroll
-        for (int c = 0; c < TK_AS_C; c++) {
+        for (int c = 0; c < C; c++) {
             jj[c] = j0 + c * 256 < L ? j0 + c * 256 : j0;   // out of range: recompute j0, ignored
 #pragma unroll
-            for (int r = 0; r < TK_AS_ROWS; r++) p[c][r] = 0;
+            for (int r = 0; r < ROWS; r++) p[c][r] = 0;
         }
         for (int t = 0; t < d; t++) {
-            T y[TK_AS_C];
+            T y[C];
 #pragma unroll
-            for (int c = 0; c < TK_AS_C; c++) y[c] = Yt[(int64_t)t * L + jj[c]];
+            for (int c = 0; c < C; c++) y[c] = Yt[(int64_t)t * L + jj[c]];
 #pragma unroll
-            for (int r = 0; r < TK_AS_ROWS; r++) {
-                const T x2 = x2s[t * TK_AS_ROWS + r];       // same address in every lane
+            for (int r = 0; r < ROWS; r++) {
+                const T x2 = x2s[t * ROWS + r];             // same address in every lane
 #pragma unroll
-                for (int c = 0; c < TK_AS_C; c++) p[c][r] = Fma<T>::f(x2, y[c], p[c][r]);
+                for (int c = 0; c < C; c++) p[c][r] = Fma<T>::f(x2, y[c], p[c][r]);
             }
         }
 #pragma unroll
-        for (int c = 0; c < TK_AS_C; c++) {
+        for (int c = 0; c < C; c++) {
             const int j = j0 + c * 256;
             if (j < L) {
                 const T yn = ynorm2[j];
 #pragma unroll
-                for (int r = 0; r < TK_AS_ROWS; r++) {
+                for (int r = 0; r < ROWS; r++) {
                     const T part = (xn[r] + yn) - p[c][r];
-                    cand_push(top[r], part, j);
+                    push(top[r], part, j);
                     if (j == 0) s_v0[r] = part;
                 }
             }
         }
     }
-    // the three best of the wave: butterfly over the lanes, each step merging the partner's
-    // three into mine (both lanes end up with the same list)
+    // the best of the wave: butterfly over the lanes, each step merging the partner's list
+    // into mine (both lanes end up with the same list)
 #pragma unroll
-    for (int r = 0; r < TK_AS_ROWS; r++) {
+    for (int r = 0; r < ROWS; r++) {
         for (int o = 32; o > 0; o >>= 1) {
-            Cand<T> other[3];
+            Cand<T> other[NTOP];
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
+            for (int t = 0; t < NTOP; t++) {
                 other[t].v = __shfl_xor(top[r][t].v, o, 64);
                 other[t].j = __shfl_xor(top[r][t].j, o, 64);
             }
 #pragma unroll
-            for (int t = 0; t < 3; t++)
-                if (other[t].j >= 0) cand_push(top[r], other[t].v, other[t].j);
+            for (int t = 0; t < NTOP; t++)
+                if (other[t].j >= 0) push(top[r], other[t].v, other[t].j);
         }
         if ((threadIdx.x & 63) == 0)
 #pragma unroll
-            for (int t = 0; t < 3; t++) s_top[r][threadIdx.x >> 6][t] = top[r][t];
+            for (int t = 0; t < NTOP; t++) s_top[r][threadIdx.x >> 6][t] = top[r][t];
     }
     __syncthreads();
     if ((int)threadIdx.x < nr) {
         const int r = threadIdx.x;
-        Cand<T> best[3] = {{(T)0, -1}, {(T)0, -1}, {(T)0, -1}};
+        Cand<T> best[NTOP];
+#pragma unroll
+        for (int t = 0; t < NTOP; t++) best[t] = {(T)0, -1};
         for (int t = 0; t < 4; t++)
-            for (int u = 0; u < 3; u++) {
+            for (int u = 0; u < NTOP; u++) {
                 const Cand<T> c = s_top[r][t][u];
-                if (c.j >= 0) cand_push(best, c.v, c.j);
+                if (c.j >= 0) push(best, c.v, c.j);
             }
         const int m0 = best[0].j;          // first occurrence of the minimum
         nearest[(r0 + r) * k] = m0;
-        if (k == 2) {
+        if (NTOP > 1 && k == 2) {
             // dumb_select, second pass: positions 0 and m0 were swapped, so the scan order
             // is 1 .. m0-1, (element 0 at position m0), m0+1 .. L-1, strict "<"
             int second;
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ X
             } else {
                 int s = -1;
                 T sv = 0;
-                for (int u = 1; u < 3; u++)
+                for (int u = 1; u < NTOP; u++)
                     if (best[u].j > 0) { s = best[u].j; sv = best[u].v; break; }
                 const T v0 = s_v0[r];
                 if (s < 0 || v0 < sv || (v0 == sv && m0 < s)) second = 0;
@@ -321,14 +337,18 @@ void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const vo
                       int y_is_f64, int L, int k, int64_t *nearest, hipStream_t s)
 {
     if (n == 0) return;
-    dim3 grid((unsigned)((n + TK_AS_ROWS - 1) / TK_AS_ROWS));
-    const size_t lds = (size_t)d * TK_AS_ROWS * (y_is_f64 ? 8 : 4);
-    if (y_is_f64)
-        hipLaunchKernelGGL(assign_kernel<double>, grid, dim3(256), lds, s, X, n, d, (const double *)Yt,
-                           (const double *)ynorm2, L, k, nearest);
-    else
-        hipLaunchKernelGGL(assign_kernel<float>, grid, dim3(256), lds, s, X, n, d, (const float *)Yt,
-                           (const float *)ynorm2, L, k, nearest);
+    // k == 1: 16 rows per workgroup (the centre matrix is re-read from L2 once per workgroup:
+    // twice the rows, half the traffic), one candidate per row; k == 2: 8 rows, three candidates
+#define TK_ASSIGN(T_, ROWS_, C_, NTOP_)                                                              \
+    hipLaunchKernelGGL((assign_kernel<T_, ROWS_, C_, NTOP_>), dim3((unsigned)((n + ROWS_ - 1) / ROWS_)), \
+                       dim3(256), (size_t)d * ROWS_ * sizeof(T_), s, X, n, d, (const T_ *)Yt,         \
+                       (const T_ *)ynorm2, L, k, nearest)
+    if (k == 1) {
+        if (y_is_f64) TK_ASSIGN(double, 16, 2, 1); else TK_ASSIGN(float, 16, 2, 1);
+    } else {
+        if (y_is_f64) TK_ASSIGN(double, 8, 4, 3); else TK_ASSIGN(float, 8, 4, 3);
+    }
+#undef TK_ASSIGN
 }
 
 // ---------------------------------------------------------------------------
