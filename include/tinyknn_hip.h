@@ -215,8 +215,8 @@ int tk_index_set_heap_mode(tk_index *ix, int mode);
  * 1 = always query-major, 2 = always list-major.  Identical outputs. */
 int tk_index_set_scan_mode(tk_index *ix, int mode);
 
-/* Stage timing.  With profiling on, every (sub-)batch records HIP events on its
- * stream around the stages (no synchronisation in the query call).
+/* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
+ * around the stages (no synchronisation in the query call; 1 = every batch).
  * tk_index_last_profile synchronises that stream and returns the mean
  * milliseconds per stage over the batches recorded since the last read
  * [tables, coarse_scan, coarse_heap, coarse_rescore+slots, scan, heap, rescore],

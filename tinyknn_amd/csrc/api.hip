@@ -621,6 +621,7 @@ struct tk_index {
     hipStream_t front_stream = nullptr;      // coarse replays + descriptors of all batches, in order
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
+    uint64_t prof_seen = 0;
     std::vector<hipEvent_t> evs;   // 8 per set
     std::vector<hipStream_t> ev_streams;
     size_t ev_used = 0;            // sets recorded since the last read
@@ -925,7 +926,9 @@ struct Prof {
 
 static int prof_begin(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st, Prof &pf)
 {
-    if (ix->profiling == 0 || ix->ev_used >= 4096) return TK_OK;
+    // profiling = n: every n-th batch is timed (1 = every batch)
+    if (ix->profiling == 0 || ix->ev_used >= 4096 || (ix->prof_seen++ % (uint64_t)ix->profiling) != 0)
+        return TK_OK;
     while (ix->evs.size() < (ix->ev_used + 1) * 8) {
         hipEvent_t e;
         HIPCHECK(hipEventCreate(&e));
@@ -1627,7 +1630,8 @@ extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
 extern "C" int tk_index_set_profiling(tk_index *ix, int on)
 {
     ARGCHECK(ix, "null index");
-    ix->profiling = on;
+    ix->profiling = on < 0 ? 0 : on;
+    ix->prof_seen = 0;
     ix->ev_used = 0;
     return TK_OK;
 }
