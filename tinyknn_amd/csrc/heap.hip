@@ -318,6 +318,9 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
     const unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
     int64_t cap_min, const int32_t *__restrict__ labels32)
 {
+    // the replay is a chain of dependent LDS round trips on 157 waves; when it shares SIMDs
+    // with other batches' VALU-bound scan waves, let the arbiter issue its instructions first
+    __builtin_amdgcn_s_setprio(3);
     // LDS: H[R+2][64] heap columns (+2 sentinel rows) | DEDUPE: LAB[ceil(R/4)][64][4]
     //      labels by slot, CNT[256][64] label-hash counters | ST[nbuf][16][64] staged blocks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
