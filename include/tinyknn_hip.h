@@ -194,7 +194,8 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
  * four hardware queues HIP maps streams onto (more streams share queues and serialise).
  * tk_index_join enqueues the list scans still owed and their replays.  The caller must not
  * reuse the input/output buffers of a call before tk_index_join(ix, stream), which also
- * makes `stream` wait for every batch in flight. */
+ * makes `stream` wait for every batch in flight.  Stream capture (hipGraph) of a batch
+ * needs depth = 1: the pipelined mode hands work to streams outside the capture. */
 int tk_index_set_pipeline(tk_index *ix, int depth);
 int tk_index_join(tk_index *ix, void *stream);
 
