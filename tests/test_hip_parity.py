@@ -533,6 +533,59 @@ def test_pipelined_batches_and_join(tk, oracle):
         dev.set_pipeline(1)
 
 
+def test_pipelined_calls_of_different_shapes(tk, oracle):
+    """Pipelined mode with calls that differ in batch size, k and n_probes, more calls than
+    workspaces, a join in the middle: every call's ids equal the oracle's."""
+    import ctypes as C
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(6)
+    n, d = 30000, 100
+    cent = np.random.randn(50, d)
+    X = (cent[np.random.randint(50, size=n)] + 0.6 * np.random.randn(n, d)).astype(np.float32)
+    ivf = IVF("angular", 120, FastPQ(2))
+    ivf.fit(X[:6000]).build(X, n_probes=1)
+    ox = _oracle_index(oracle, ivf)
+    dev = ivf.device_index()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+
+    shapes = [(300, 10, 8), (17, 5, 1), (1000, 10, 20), (64, 1, 3), (1, 10, 8), (513, 20, 5),
+              (300, 10, 8), (2000, 10, 10), (3, 50, 100), (257, 10, 2), (1000, 10, 20), (40, 10, 8),
+              (700, 3, 15)]
+    dev.set_pipeline(2)
+    try:
+        calls = []
+        for i, (nq, k, n_probes) in enumerate(shapes):
+            qs = (cent[np.random.randint(50, size=nq)] + 0.6 * np.random.randn(nq, d)).astype(np.float32)
+            qn, qp = ivf._prepare(qs)
+            qn = np.ascontiguousarray(qn, np.float32)
+            qp = np.ascontiguousarray(qp, np.float32)
+            dq_, dp_, do_ = dmalloc(qn.nbytes), dmalloc(qp.nbytes), dmalloc(nq * k * 8)
+            assert hip.hipMemcpy(dq_, qn.ctypes.data, qn.nbytes, 1) == 0
+            assert hip.hipMemcpy(dp_, qp.ctypes.data, qp.nbytes, 1) == 0
+            dev.query_batch_dev(dq_, dp_, False, nq, k, n_probes, do_)
+            calls.append((qn, nq, k, n_probes, dq_, dp_, do_))
+            if i == 6:
+                dev.join(0)                      # a join with calls on both sides of it
+        dev.join(0)
+        assert hip.hipDeviceSynchronize() == 0
+        for qn, nq, k, n_probes, dq_, dp_, do_ in calls:
+            out = np.zeros((nq, k), np.int64)
+            assert hip.hipMemcpy(out.ctypes.data, do_, out.nbytes, 2) == 0
+            np.testing.assert_array_equal(out, ox.query_batch(qn, k, n_probes),
+                                          err_msg=f"nq={nq} k={k} n_probes={n_probes}")
+            for p in (dq_, dp_, do_):
+                hip.hipFree(p)
+    finally:
+        dev.set_pipeline(1)
+
+
 def test_hipgraph_captured_batch(tk):
     """BASELINE configs[3]: the whole batch pipeline captured as ONE hipGraph and
     replayed (fixed-shape launches, no host sync, no allocation after reserve)."""
