@@ -472,8 +472,8 @@ extern "C" int tk_encode_pq(const float *centers, int dq, int dpb, const void *d
     ARGCHECK(dpb >= 1 && dpb <= 32 && dq >= dpb && dq % dpb == 0, "dq/dpb");
     ARGCHECK(n >= 0, "n");
     const int M = dq / dpb;
-    ARGCHECK(32 % dpb == 0, "dims_per_block must divide 32 for the device encoder");
-    ARGCHECK((size_t)16 * M * (dpb + 1) * 4 + 4 * 64 * 33 * 8 + 4 * 64 * (size_t)M <= 160 * 1024,
+    ARGCHECK(16 % dpb == 0, "dims_per_block must divide 16 for the device encoder");
+    ARGCHECK((size_t)16 * M * (dpb + 1) * 4 + 4 * 64 * 17 * 8 + 4 * 64 * (size_t)M <= 160 * 1024,
              "codebook larger than the LDS budget");
     const size_t esz = data_is_f64 ? 8 : 4;
     const int64_t slab = 1 << 20;

@@ -27,7 +27,7 @@ template <>
 struct Fma<double> { static __device__ __forceinline__ double f(double a, double b, double c) { return __builtin_fma(a, b, c); } };
 
 #define TK_ENC_MAX_DPB 32
-#define TK_ENC_STRIP 32    // elements per staged column strip (a multiple of every dims_per_block <= 32 that divides it)
+#define TK_ENC_STRIP 16    // elements per staged column strip; dims_per_block must divide it
 
 // DPB > 0: dims_per_block known at compile time (the row slice stays in registers);
 // DPB == 0: any dims_per_block <= 32.

@@ -115,7 +115,7 @@ class FastPQ:
         dpb = self.dims_per_block
         n, d = data.shape
         M = d // dpb
-        if (device_build if device is None else device) and 32 % dpb == 0:
+        if (device_build if device is None else device) and 16 % dpb == 0:
             is64 = data.dtype != np.float32
             data = np.ascontiguousarray(data, dtype=np.float64 if is64 else np.float32)
             c32 = np.ascontiguousarray(self.centers, dtype=np.float32)
