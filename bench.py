@@ -88,7 +88,7 @@ def build_index(args, device):
     driver runs N = 1, 2, 4, 8 back to back on one box."""
     from tinyknn_amd import IVF, FastPQ
     from tinyknn_amd.fast_pq import TransformedData
-    tag = f"n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}_b{args.build_probes}_{args.metric}_{args.data}"
+    tag = f"n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}_b{args.build_probes}_{args.metric}_{args.data}_c32"
     cache = os.path.join(args.cache_dir, f"tinyknn_bench_{tag}.npz")
     X, cent = synth(args.n, 0, args.d, args.seed, kind=args.data)
     ang = args.metric == "angular"
@@ -115,6 +115,7 @@ def build_index(args, device):
     if ang:
         sample = sample / np.linalg.norm(sample, axis=1, keepdims=True)
     C = quick_kmeans(sample, args.n_clusters, 8, args.seed, device)
+    C = C.astype(np.float32)          # what sklearn's KMeans returns for float32 data (ivf.py:31-45)
     ivf.all_centers = C / np.linalg.norm(C, axis=1, keepdims=True) if ang else C   # ivf.py:36-45
     ivf.pq.fit(sample[:min(len(sample), 30000)])
     log(f"[bench] fit done in {time.time() - t0:.1f}s")

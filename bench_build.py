@@ -39,6 +39,7 @@ def main():
         sample = sample / np.linalg.norm(sample, axis=1, keepdims=True)
     C = bench.quick_kmeans(sample, args.n_clusters, 8, 10, torch.device("cuda", 0))
     ivf = IVF(args.metric, args.n_clusters, FastPQ(2))
+    C = C.astype(np.float32)          # what sklearn's KMeans returns for float32 data
     ivf.all_centers = C / np.linalg.norm(C, axis=1, keepdims=True) if ang else C
     ivf.pq.fit(sample[:30000])
     data = X.copy()
@@ -78,9 +79,22 @@ def main():
     t = time.perf_counter()
     want = ivf.pq.encode_labels(rows[:cs], False)
     tcpu = time.perf_counter() - t
+    # labels may differ from numpy's only where numpy's own distances of the two centroids are
+    # EXACTLY equal (its AVX-512 argselect need not return the first of tied entries)
+    bad = np.argwhere(lab[:cs] != want)
+    ties = 0
+    for i, m in bad:
+        lo = i - i % 100
+        xc = rows[lo:lo + 100, 2 * m:2 * m + 2]
+        code = ivf.pq.centers[:, 2 * m:2 * m + 2]
+        part = (np.einsum("ij,ij->i", xc, xc)[:, None] + np.einsum("ij,ij->i", code, code)[None]
+                - 2 * xc @ code.T)[i - lo]
+        ties += int(part[lab[i, m]] == part[want[i, m]] == part.min())
     out["encode"] = {"device_rows_per_s_incl_pcie": args.n / min(ts), "device_s": min(ts),
                      "numpy_rows_per_s": cs / tcpu, "numpy_sample_rows": cs,
-                     "identical_on_sample": bool((lab[:cs] == want).all()),
+                     "identical_on_sample": bool(len(bad) == 0),
+                     "labels_differing": int(len(bad)), "of_which_exact_ties_in_numpy": ties,
+                     "labels_compared": int(want.size),
                      "bytes_per_row": rows.shape[1] * rows.itemsize + M}
     # ---- whole build
     t = time.perf_counter()

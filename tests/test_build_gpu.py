@@ -89,6 +89,7 @@ def _assign(X, Y, k, metric):
 
 
 @pytest.mark.parametrize("metric,y64,k,L", [("euclidean", False, 1, 244), ("angular", False, 2, 1087),
+                                            ("angular", False, 1, 1087), ("euclidean", False, 1, 33),
                                             ("angular", True, 1, 40), ("euclidean", True, 2, 300),
                                             ("euclidean", False, 2, 2)])
 def test_assign_vs_oracle_and_numpy(oracle, metric, y64, k, L):

@@ -326,6 +326,161 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ X
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same assignment on the matrix cores, float32 centres (what sklearn's KMeans leaves for
+// float32 data).  v_mfma_f32_32x32x2_f32 is bit-for-bit the f32 FMA chain over k ascending
+// (MI355X guide, "FP32-input MFMA") — exactly what OpenBLAS returns for (2X) @ Y.T — so this
+// is the one GEMM-shaped operation of the package on MFMA with NO change of results.
+// One wave = 32 rows against all centres, 32 at a time:
+//   A[i = lane & 31][k = lane >> 5] = 2 * x[i][2t + (lane >> 5)]   staged once per wave in LDS
+//   B[k = lane >> 5][j = lane & 31] = Yt[2t + (lane >> 5)][j0 + (lane & 31)]   coalesced
+//   D: lane holds column j = lane & 31, rows i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+// Each lane keeps the running best (NTOP per row) of ITS columns for its 16 rows; one
+// butterfly over the 32 lanes of a half at the end.  d <= 2 * TK_MF_KT (LDS: 4 waves x d/2 x 256 B).
+#define TK_MF_KT 64
+typedef float tk_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NTOP>
+__global__ __launch_bounds__(256) void assign_mfma_kernel(const float *__restrict__ X, int64_t n,
+                                                          int d, const float *__restrict__ Yt,
+                                                          const float *__restrict__ ynorm2, int L,
+                                                          int k, int64_t *__restrict__ nearest)
+{
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    // (waves past the last row still take part in the workgroup's barriers)
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    const int64_t my_row = r0 + col < n ? r0 + col : n - 1;     // A-operand row of this lane
+    const int KT = (d + 1) >> 1;
+    // LDS: the A operands of each wave, [t][lane] (one conflict-free read per MFMA), and the B
+    // operands of the workgroup's current column tile, [t][lane], double-buffered: the four
+    // waves work on different rows of the SAME 32 centres, so a tile is fetched once per
+    // workgroup (a 256-byte operand per MFMA straight from L2 would need 9.7 TB/s at the MFMA
+    // peak)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *a = (float *)smem + (size_t)(threadIdx.x >> 6) * KT * 64;
+    float *bt = (float *)smem + (size_t)4 * KT * 64;         // [2][KT][64]
+    for (int t = 0; t < KT; t++) {
+        const int kk = 2 * t + half;
+        a[t * 64 + lane] = kk < d ? 2.0f * X[my_row * d + kk] : 0.0f;
+    }
+    // |x|^2 of the 16 rows this lane sees in D (np.einsum on the float32 rows)
+    float xn[16];
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const int64_t row = r0 + (v & 3) + 8 * (v >> 2) + 4 * half;
+        xn[v] = einsum_selfdot<float>(X + (row < n ? row : n - 1) * d, d);
+    }
+    Cand<float> top[16][NTOP];
+    float v0[16];
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        v0[v] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NTOP; t++) top[v][t] = {0.0f, -1};
+    }
+    auto push = [&](Cand<float> (&tp)[NTOP], float val, int j) {
+        if (NTOP == 1) {
+            if (cand_lt(val, j, tp[0])) tp[0] = {val, j};
+        } else {
+            if (cand_lt(val, j, tp[0])) {
+                tp[NTOP - 1] = tp[NTOP > 2 ? 1 : 0]; tp[NTOP > 1 ? 1 : 0] = tp[0]; tp[0] = {val, j};
+            } else if (cand_lt(val, j, tp[NTOP > 1 ? 1 : 0])) {
+                tp[NTOP - 1] = tp[NTOP > 1 ? 1 : 0]; tp[NTOP > 1 ? 1 : 0] = {val, j};
+            } else if (cand_lt(val, j, tp[NTOP - 1])) {
+                tp[NTOP - 1] = {val, j};
+            }
+        }
+    };
+    // element e of a B tile: t = e / 64, lane' = e % 64 -> Yt[2t + (lane' >> 5)][j0 + (lane' & 31)]
+    const int per_thread = (KT * 64 + 255) / 256;
+    float stage[TK_MF_KT / 4];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < TK_MF_KT / 4; u++) {
+            const int e = u * 256 + (int)threadIdx.x;
+            float val = 0.0f;
+            if (u < per_thread && e < KT * 64) {
+                const int t = e >> 6, l2 = e & 63;
+                const int kk = 2 * t + (l2 >> 5), j = j0 + (l2 & 31);
+                if (kk < d) val = Yt[(int64_t)kk * L + (j < L ? j : L - 1)];
+            }
+            stage[u] = val;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < TK_MF_KT / 4; u++) {
+            const int e = u * 256 + (int)threadIdx.x;
+            if (u < per_thread && e < KT * 64) bt[(size_t)buf * KT * 64 + e] = stage[u];
+        }
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int j0 = 0; j0 < L; j0 += 32, buf ^= 1) {
+        const bool more = j0 + 32 < L;
+        if (more) fetch(j0 + 32);                        // global loads in flight over the MFMAs
+        const int j = j0 + col;
+        tk_f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[v] = 0.0f;
+        const float *bb = bt + (size_t)buf * KT * 64;
+#pragma unroll 4
+        for (int t = 0; t < KT; t++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t * 64 + lane], bb[t * 64 + lane], acc, 0, 0, 0);
+        if (j < L) {
+            const float yn = ynorm2[j];
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const float part = (xn[v] + yn) - acc[v];
+                push(top[v], part, j);
+                if (j == 0) v0[v] = part;
+            }
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+    }
+    // merge over the 32 lanes (columns) of the half; part[0] lives in lane `half * 32`
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        for (int o = 16; o > 0; o >>= 1) {
+            Cand<float> other[NTOP];
+#pragma unroll
+            for (int t = 0; t < NTOP; t++) {
+                other[t].v = __shfl_xor(top[v][t].v, o, 64);
+                other[t].j = __shfl_xor(top[v][t].j, o, 64);
+            }
+#pragma unroll
+            for (int t = 0; t < NTOP; t++)
+                if (other[t].j >= 0) push(top[v], other[t].v, other[t].j);
+        }
+    }
+    if (col == 0) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const int64_t row = r0 + (v & 3) + 8 * (v >> 2) + 4 * half;
+            if (row >= n) continue;
+            const int m0 = top[v][0].j;
+            nearest[row * k] = m0;
+            if (NTOP > 1 && k == 2) {
+                int second;
+                if (m0 == 0) {
+                    second = top[v][1].j;
+                } else {
+                    int s = -1;
+                    float sv = 0;
+                    for (int u = 1; u < NTOP; u++)
+                        if (top[v][u].j > 0) { s = top[v][u].j; sv = top[v][u].v; break; }
+                    if (s < 0 || v0[v] < sv || (v0[v] == sv && m0 < s)) second = 0;
+                    else second = s;
+                }
+                nearest[row * k + 1] = second;
+            }
+        }
+    }
+}
+
 void tk_launch_normalise_rows(const float *X, int64_t n, int d, float *out, hipStream_t s)
 {
     if (n == 0) return;
@@ -343,7 +498,20 @@ void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const vo
     hipLaunchKernelGGL((assign_kernel<T_, ROWS_, C_, NTOP_>), dim3((unsigned)((n + ROWS_ - 1) / ROWS_)), \
                        dim3(256), (size_t)d * ROWS_ * sizeof(T_), s, X, n, d, (const T_ *)Yt,         \
                        (const T_ *)ynorm2, L, k, nearest)
-    if (k == 1) {
+    if (!y_is_f64 && k == 1 && d <= 2 * TK_MF_KT) {
+        // float32 centres, nearest centre only: the matrix cores, same bits (see
+        // assign_mfma_kernel; the three-candidate form for k == 2 spills and stays on the VALU)
+        dim3 grid((unsigned)((n + 127) / 128));
+        const size_t mf_lds = (size_t)(4 + 2) * ((d + 1) / 2) * 64 * 4;     // <= 96 KiB
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)assign_mfma_kernel<1>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(assign_mfma_kernel<1>, grid, dim3(256), mf_lds, s, X, n, d, (const float *)Yt,
+                           (const float *)ynorm2, L, k, nearest);
+    } else if (k == 1) {
         if (y_is_f64) TK_ASSIGN(double, 16, 2, 1); else TK_ASSIGN(float, 16, 2, 1);
     } else {
         if (y_is_f64) TK_ASSIGN(double, 8, 4, 3); else TK_ASSIGN(float, 8, 4, 3);
