@@ -376,6 +376,8 @@ def main():
     # one batch in flight) and replayed: BASELINE configs[3] asks for a graph-captured batch
     graph = None
     try:
+        if world > 1:      # RCCL's watchdog thread touches the device during a global-mode capture
+            raise RuntimeError("skipped at N > 1")
         g = torch.cuda.CUDAGraph()
         gout = torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)
         with torch.cuda.graph(g):
