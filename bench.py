@@ -451,8 +451,16 @@ def main():
 
     # -- recall against brute force (torch matmul on the GPU: measurement plumbing)
     rs = min(args.recall_sample, args.nq)
+    truth_s = None
     if args.workload == "c5like":
         recall = None        # iid random vectors: no neighbourhood structure to recall
+    elif ivf.data.dtype == np.float32 and args.d <= 128:
+        # exact ground truth on the f32 matrix cores (brute.hip: numpy's knn_brute distances
+        # bit for bit); qn and IVF.data are normalised for the angular metric
+        tg = time.perf_counter()
+        truth = dev.knn_brute(qn[:rs], args.k)
+        truth_s = time.perf_counter() - tg
+        recall = float(np.mean([len(set(truth[i]) & set(got[i])) / args.k for i in range(rs)]))
     else:
         data_t = torch.from_numpy(ivf.data).to(device)
         sims = q_dev[:rs] @ data_t.T
@@ -498,7 +506,11 @@ def main():
                                f"build_probes={args.build_probes} FastPQ dpb=2 M={M}",
                    "queries_per_step_per_gpu": args.nq, "k": args.k, "n_probes": args.n_probes,
                    "pass_1": (args.n_probes + 1) * args.k + 1, "recall10@10": recall,
-                   "recall_queries": rs, "parallelism": f"replica x{world} (queries sharded)",
+                   "recall_queries": rs,
+                   "recall_ground_truth": (None if truth_s is None else
+                                           f"tk_index_knn_brute (f32 MFMA, exact): {rs} queries x {args.n} vectors "
+                                           f"in {truth_s * 1e3:.0f} ms"),
+                   "parallelism": f"replica x{world} (queries sharded)",
                    "batches_in_flight": args.pipeline},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

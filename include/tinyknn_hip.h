@@ -247,6 +247,16 @@ int tk_index_prepare_dev(tk_index *ix, const float *q_raw_dev, int64_t nq, int a
 int tk_index_query_batch_raw(tk_index *ix, const float *q_raw, int64_t nq, int angular, int k,
                              int n_probes, int pass_1, int64_t *out_ids);
 
+/* ---- exact k nearest vectors: the ground truth of recall --------------
+ * knn_brute(q, IVF.data, k, "euclidean") (utils.py:66-86, as examples/bench.py:85 uses it) on
+ * the f32 matrix cores: part = (|q|^2 + |y|^2) - (2q).y with numpy's einsum norms and the
+ * GEMM as the f32 FMA chain (v_mfma_f32_32x32x2_f32) — numpy's part values bit for bit — and
+ * the k smallest in ascending (part, row) order (numpy's argpartition leaves the order of
+ * the first k, and the choice among exact ties at the k-th value, unspecified).
+ * q: (nq, d) float32 host, already normalised for the angular metric like IVF.data;
+ * out_ids: (nq, k) int64 host.  float32 vectors, d <= 128. */
+int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int k, int64_t *out_ids);
+
 /* ---- list-sharded index over `world` ranks, one process per GPU --------
  * The inverted lists (ivf.py:100-102) are partitioned by cluster id: owner[l] is the rank
  * that stores list l's packed codes.  PQ, coarse centres, ids and the rescoring vectors are

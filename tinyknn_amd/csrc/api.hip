@@ -600,6 +600,7 @@ struct tk_index {
     // local_chunk_off addresses this rank's code storage (lists of other ranks: empty)
     DevBuf owner, local_chunk_off;
     DevBuf rot_t;            // fast mode: R transposed (d_pad, dq) float64, or empty
+    DevBuf br_ynorm, br_vals, br_tau, br_cand, br_count, br_out, br_q;   // tk_index_knn_brute
     int rot_d_pad = 0;
     int rank = 0, world = 1;
     bool sharded = false;
@@ -645,7 +646,8 @@ extern "C" void tk_index_destroy(tk_index *ix)
     DevBuf *bufs[] = {&ix->pq_centers, &ix->active_centers, &ix->center_codes, &ix->list_chunk_off,
                       &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->ids32, &ix->data, &ix->cslots_i,
                       &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage, &ix->owner,
-                      &ix->local_chunk_off, &ix->rot_t};
+                      &ix->local_chunk_off, &ix->rot_t, &ix->br_ynorm, &ix->br_vals, &ix->br_tau,
+                      &ix->br_cand, &ix->br_count, &ix->br_out, &ix->br_q};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
     for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
@@ -1541,6 +1543,43 @@ extern "C" int tk_index_query_batch_raw(tk_index *ix, const float *q_raw, int64_
     raw.release();
     outbuf.release();
     return r;
+}
+
+// ---------------------------------------------------------------------------
+// exact k nearest vectors of IVF.data: the ground truth of recall (brute.hip)
+extern "C" int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int k, int64_t *out_ids)
+{
+    ARGCHECK(ix && ix->have_data, "set_data first");
+    ARGCHECK(!ix->data_is_f64, "float32 vectors only");
+    ARGCHECK(ix->d <= 128, "d <= 128");
+    ARGCHECK(nq >= 0 && q && out_ids, "buffers");
+    ARGCHECK(k >= 1 && k <= 1024 && k <= ix->N, "1 <= k <= min(1024, N)");
+    ARGCHECK(ix->N < (1ll << 31), "N < 2^31");
+    if (nq == 0) return TK_OK;
+    TRY(flush_pending(ix));
+    const int64_t ns = ix->N < 8192 ? ix->N : 8192;
+    const int cap = 8192;
+    TRY(ix->br_ynorm.ensure((size_t)ix->N * 4));
+    TRY(ix->br_tau.ensure((size_t)nq * 4));
+    TRY(ix->br_vals.ensure((size_t)nq * ns * 4));
+    TRY(ix->br_cand.ensure((size_t)nq * cap * 8));
+    TRY(ix->br_count.ensure((size_t)nq * 4 + 4));
+    TRY(ix->br_out.ensure((size_t)nq * k * 8));
+    TRY(ix->br_q.ensure((size_t)nq * ix->d * 4));
+    HIPCHECK(hipMemcpy(ix->br_q.p, q, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice));
+    int *overflow = ix->br_count.as<int>() + nq;
+    if (tk_launch_knn_brute(ix->br_q.as<float>(), nq, ix->d, ix->data.as<float>(), ix->N, k,
+                            ix->br_ynorm.as<float>(), ix->br_vals.as<float>(), ns,
+                            ix->br_tau.as<float>(), ix->br_cand.as<unsigned long long>(), cap,
+                            ix->br_count.as<int>(), overflow, ix->br_out.as<int64_t>(), nullptr))
+        return fail(TK_ERR_HIP, "tk_launch_knn_brute: unsupported size / LDS attribute");
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    int ov = 0;
+    HIPCHECK(hipMemcpy(&ov, overflow, 4, hipMemcpyDeviceToHost));
+    if (ov) return fail(TK_ERR_HIP, "knn_brute: candidate list overflow (more than 8192 rows within the sampled k-th distance)");
+    HIPCHECK(hipMemcpy(out_ids, ix->br_out.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    return TK_OK;
 }
 
 extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)

@@ -185,3 +185,10 @@ void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const vo
 // Rt = R transposed (d_pad, dq)) table-build queries from raw/normalised float32 rows
 void tk_launch_prepare_queries(const float *X, int64_t n, int d, const double *Rt, int dq, int d_pad,
                                void *out, hipStream_t s);
+
+// ---- exact k nearest rows on the f32 matrix cores (brute.hip) ----
+// see brute.hip for the work buffers; returns -1 on unsupported sizes
+int tk_launch_knn_brute(const float *X, int64_t nq, int d, const float *Y, int64_t N, int k,
+                        float *ynorm2, float *vals, int64_t ns, float *tau,
+                        unsigned long long *cand, int cap, int *count, int *overflow, int64_t *out,
+                        hipStream_t s);

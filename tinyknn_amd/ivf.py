@@ -131,6 +131,16 @@ class DeviceIndex:
             int(pass_1 or 0), _lib.ptr(out, _lib._i64p)))
         return out
 
+    def knn_brute(self, qn, k):
+        """Exact k nearest rows of IVF.data for normalised queries (ground truth of recall;
+        tk_index_knn_brute: f32 MFMA, numpy's distances bit for bit), ascending."""
+        qn = np.ascontiguousarray(qn, dtype=np.float32)
+        assert qn.shape[1] == self.d
+        out = np.empty((qn.shape[0], k), dtype=np.int64)
+        _lib.check(_lib.lib().tk_index_knn_brute(self._h, _lib.ptr(qn, _lib._f32p), qn.shape[0],
+                                                 int(k), _lib.ptr(out, _lib._i64p)))
+        return out
+
     def query_batch_dev(self, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, out_ptr,
                         pass_1=None, stream=0):
         """Device pointers in, device pointer out, enqueued on `stream` (no sync)."""
