@@ -406,11 +406,14 @@ def main():
     host_qps = 3 * args.nq / (time.perf_counter() - th)
     # the same RAW queries through the device front end ("fast mode": normalisation, padding,
     # rotation on the GPU instead of numpy's per-query BLAS calls; within 1 ulp, not exact)
-    fast_ids = dev.query_batch_raw(qs, args.k, args.n_probes)
-    th = time.perf_counter()
-    for _ in range(3):
+    try:
         fast_ids = dev.query_batch_raw(qs, args.k, args.n_probes)
-    fast_qps = 3 * args.nq / (time.perf_counter() - th)
+        th = time.perf_counter()
+        for _ in range(3):
+            fast_ids = dev.query_batch_raw(qs, args.k, args.n_probes)
+        fast_qps = 3 * args.nq / (time.perf_counter() - th)
+    except (AssertionError, RuntimeError) as e:     # e.g. angular with d > 128: an extra only
+        fast_ids, fast_qps = None, repr(e)
     t = torch.tensor([elapsed], dtype=torch.float64,
                      device=device if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -537,7 +540,8 @@ def main():
                            "note": "raw float32 queries in, ids out (H2D + device normalisation/padding/rotation "
                                    "+ pipeline + D2H, synchronous); within 1 ulp of the host preparation, not "
                                    "bit-identical: never `value`",
-                           "rows_identical_to_exact_path": int((fast_ids == got).all(axis=1).sum()),
+                           "rows_identical_to_exact_path": (None if fast_ids is None else
+                                                            int((fast_ids == got).all(axis=1).sum())),
                            "rows": args.nq},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
