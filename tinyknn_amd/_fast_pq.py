@@ -7,7 +7,7 @@ bound to the gfx950 kernels through the C ABI (include/tinyknn_hip.h).
 import numpy as np
 
 from . import _lib
-from ._lib import ORDER_AVX, ORDER_SSE
+from ._lib import ORDER_AVX, ORDER_SSE  # noqa: F401  (re-exported for _fast_pq_avx)
 
 
 def _buf(a, dtype, ndim, name):

@@ -223,8 +223,8 @@ int tk_launch_knn_brute(const float *X, int64_t nq, int d, const float *Y, int64
                        ns, nullptr, nullptr, 0, nullptr);
     hipLaunchKernelGGL(brute_select_kernel<0>, dim3((unsigned)nq), dim3(1024), (size_t)TK_BR_SORT * 8, s,
                        vals, ns, nullptr, 0, nullptr, k, tau, nullptr, nullptr);
-    hipMemsetAsync(count, 0, (size_t)nq * 4, s);
-    hipMemsetAsync(overflow, 0, 4, s);
+    (void)hipMemsetAsync(count, 0, (size_t)nq * 4, s);
+    (void)hipMemsetAsync(overflow, 0, 4, s);
     hipLaunchKernelGGL(brute_tiles_kernel<1>, dim3(qt, splits(N)), dim3(256), tile_lds, s, X, nq, d, Y, ynorm2, N, nullptr,
                        0, tau, cand, cap, count);
     hipLaunchKernelGGL(brute_select_kernel<1>, dim3((unsigned)nq), dim3(1024), (size_t)TK_BR_SORT * 8, s,

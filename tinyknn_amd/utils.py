@@ -3,7 +3,6 @@
 Only knn_brute1 is on the hot path; it runs on the GPU (tk_knn_brute1).  The rest
 are host-side bookkeeping used by fit/build and by the recall measurements.
 """
-import ctypes as C
 import time
 from contextlib import contextmanager
 
