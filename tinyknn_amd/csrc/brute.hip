@@ -71,23 +71,25 @@ __global__ __launch_bounds__(256) void brute_tiles_kernel(
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int e = u * 256 + (int)threadIdx.x;
+            // rows past the range read as zeros: element e belongs to row j0 + e / d, so it is
+            // in range iff e < (ncols - j0) * d
             float val = 0.0f;
-            if (e < tile_f) {
-                const int64_t j = j0 + e / d;
-                if (j < ncols) val = Y[j0 * d + e];
-            }
+            if (e < tile_f && (int64_t)e < (ncols - j0) * d) val = Y[j0 * d + e];
             stage[u] = val;
         }
     };
+    // operand position of this thread's tile elements (the same for every tile)
+    int dst[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int e = u * 256 + (int)threadIdx.x;
+        const int jj = e / d, kk = e - jj * d;
+        dst[u] = e < tile_f ? (kk >> 1) * 64 + (kk & 1) * 32 + jj : -1;
+    }
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int e = u * 256 + (int)threadIdx.x;
-            if (e < tile_f) {
-                const int jj = e / d, kk = e - jj * d;
-                bt[(size_t)buf * KT * 64 + (kk >> 1) * 64 + (kk & 1) * 32 + jj] = stage[u];
-            }
-        }
+        for (int u = 0; u < PER; u++)
+            if (dst[u] >= 0) bt[(size_t)buf * KT * 64 + dst[u]] = stage[u];
     };
     if (d & 1)      // odd d: the k = d operands of the upper half-wave are zero in both buffers
         for (int e = threadIdx.x; e < 2 * 32; e += 256)
