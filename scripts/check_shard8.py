@@ -1,0 +1,17 @@
+"""Eight list-shards of the bench index simulated on ONE GPU (tests/test_shard_gpu.py's
+simulate_world): default capacity does not overflow, ids equal the unsharded index's."""
+import sys, types, time, numpy as np, torch
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import bench
+from test_shard_gpu import simulate_world
+args = types.SimpleNamespace(n=1183514, d=100, n_clusters=1087, seed=10, build_probes=1, metric="angular",
+                             data="glove-like", cache_dir="/tmp", fit_sample=100000, workload="glove")
+ivf, cent = bench.build_index(args, torch.device("cuda", 0))
+qs = bench.synth_queries(cent, 10000, 110)
+qn, qp = ivf._prepare(qs.copy())
+want = ivf.device_index().query_batch(qn, qp, 10, 10)
+for W in (8, 4):
+    t = time.time()
+    ids, flags, cap = simulate_world(ivf, W, qn, qp, 10, 10)
+    print(f"W={W}: capacity {cap} uint4 per region ({W * cap * 16 / 1e6:.1f} MB all-to-all per rank), overflow flags {flags.tolist()}, "
+          f"identical rows {int((ids == want).all(axis=1).sum())}/10000, {time.time() - t:.1f}s")
