@@ -452,6 +452,21 @@ def main():
         except Exception:
             traffic = None
 
+    # the box's device-copy bandwidth (read + write), the practical HBM ceiling next to the spec
+    try:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=device)      # 1 GiB
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        for _ in range(5):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * src.numel() * 4 / (time.perf_counter() - tc0) / 1e9
+        del src, dst
+    except Exception:
+        copy_gbps = None
+
     # -- recall against brute force (torch matmul on the GPU: measurement plumbing)
     rs = min(args.recall_sample, args.nq)
     truth_s = None
@@ -517,6 +532,7 @@ def main():
                    "batches_in_flight": args.pipeline},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "device_copy_GBps_measured": copy_gbps,
                      "kernel": ("scan_probes_kernel<AVX,signed>" if args.scan_mode == 1 else
                                 "scan_units_kernel<AVX,signed>" if args.pipeline == 1 else
                                 "scan_units2_kernel<AVX,signed> (one launch: list scan of a batch + coarse scan "
