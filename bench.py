@@ -248,11 +248,154 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
             "code_chunks_per_rank": [int(x) for x in load], "batches_in_flight": args.pipeline}
 
 
+def raw_stream_leg(args, dev, qs, out_dev, device, world):
+    """RAW queries on the host in, ids on the host out: what a caller of the drop-in API gets.
+    Every step = the exact host preparation of ivf.py:125-128 (numpy's own BLAS calls on a
+    thread pool, tinyknn_amd/_front.py), pinned H2D, the device pipeline, D2H of the ids —
+    all inside the timed region, batches overlapped by a streaming session (tk_stream_*)."""
+    import torch
+    import torch.distributed as dist
+    from tinyknn_amd import _front
+    if not _front.bind():
+        return {"error": "numpy's BLAS could not be bound: " + str(_front.info()["why"])}
+    slots = 8
+    st = dev.stream(args.nq, args.k, args.n_probes, slots=slots)
+    outs = [np.full((args.nq, args.k), -1, dtype=np.int64) for _ in range(slots)]
+    for i in range(max(args.warmup, slots)):
+        st.submit(qs, outs[i % slots])
+    st.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    p0 = st.prepare_seconds()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        st.submit(qs, outs[i % slots])
+    st.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    prep = (st.prepare_seconds() - p0) / args.steps
+    # one batch at a time, for the latency of a single call
+    t1 = time.perf_counter()
+    for i in range(5):
+        st.wait(st.submit(qs, outs[0]))
+    lat = (time.perf_counter() - t1) / 5
+    st.close()
+    t = torch.tensor([el], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    ref = out_dev.cpu().numpy()
+    fi = _front.info()
+    return {"queries_per_s": args.nq * world * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+            "steps": args.steps,
+            "rows_identical_to_device_resident_path": int(min((o == ref).all(axis=1).sum() for o in outs)),
+            "rows": args.nq,
+            "host_prepare_ms_per_batch": prep * 1e3, "host_threads": fi["threads"],
+            "host_blas": os.path.basename(fi["path"]),
+            "single_batch_latency_ms": lat * 1e3,
+            "note": "raw float32 queries (host) -> ids (host), EXACT: normalisation/rotation by numpy's own "
+                    "cblas_sdot/cblas_dgemv on a thread pool, pinned async H2D/D2H on a copy stream, "
+                    "8 batches outstanding; preparation + copies + kernels all inside the timed region"}
+
+
+def hbm_scale_leg(device):
+    """The code scan where it IS HBM-bound: 1 GiB of random packed codes (M = 32, 2^26 codes —
+    four times the 256 MiB Infinity Cache), every byte streamed once per pass.  nq = 1: the
+    query-major kernel, algorithmic bytes == fetched bytes; nq = 4 / 16: the list-major kernel
+    (each code byte fetched once per 4 queries)."""
+    import torch
+    from tinyknn_amd import _lib
+    L = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    M, n = 32, 1 << 26
+    chunks = n // 16
+    rng = np.random.default_rng(0)
+    packed = rng.integers(0, 2**63, size=(chunks, M), dtype=np.int64).view(np.uint64)
+    h = L.tk_codes_upload(_lib.ptr(packed, _lib._u64p), chunks, M)
+    del packed
+    if not h:
+        return {"error": L.tk_last_error().decode()}
+    res = {"code_bytes": n * M // 2, "M": M, "codes": n, "cases": []}
+    try:
+        for nq in (1, 4, 16):
+            tables = rng.integers(-4, 24, size=(nq, M, 16)).astype(np.int8).view(np.uint8)
+            t_dev = torch.from_numpy(tables).to(device)
+            out = torch.empty((nq, chunks * 16), dtype=torch.uint8, device=device)
+            run = lambda: _lib.check(L.tk_codes_estimate_dev(h, t_dev.data_ptr(), nq, out.data_ptr(), 1, 1, stream))
+            run()
+            torch.cuda.synchronize()
+            reps = 20 if nq == 1 else 8
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            alg = nq * n * (M // 2) + nq * n          # code bytes per (query, code) + int8 out
+            hbm = -(-nq // 4) * n * (M // 2) + nq * n if nq >= 4 else alg     # bytes that must cross HBM
+            res["cases"].append({"kernel": "scan_units_kernel (list-major)" if nq >= 4 else "scan_flat_kernel (query-major)",
+                                 "nq": nq, "ms": ms, "algorithmic_GBps": alg / ms / 1e6,
+                                 "min_hbm_GBps": hbm / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBPS})
+            del out
+    finally:
+        L.tk_codes_free(h)
+    c1 = res["cases"][0]
+    res["GBps"], res["frac"] = c1["algorithmic_GBps"], c1["frac"]
+    res["note"] = ("GBps/frac: nq = 1, where every code byte is fetched from HBM exactly once per launch "
+                   "(algorithmic = real traffic); HIP events on the launch stream")
+    return res
+
+
+def measure_traffic(args):
+    """HBM bytes per scan launch from PMC counters, measured NOW: two child runs of this script
+    under rocprofv3 (--pmc FETCH_SIZE, then --pmc WRITE_SIZE: they do not fit one pass), one
+    batch in flight so that the list scan and the coarse scan are separate launches.  gfx950
+    correction of MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half the bytes of wide coalesced
+    reads -> x2; WRITE_SIZE exact; both in KiB."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    me = os.path.abspath(__file__)
+    tot = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="tk_pmc_")
+        cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", tmp, "--", sys.executable, me,
+               "--steps", "3", "--warmup", "1", "--pipeline", "1", "--profile-only", "--shard", "none",
+               "--cache-dir", args.cache_dir]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=420, check=True)
+            acc = {}
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == c and "scan_units_kernel" in r["Kernel_Name"]:
+                        coarse = r["Kernel_Name"].split("(")[0].rstrip(">").rstrip().endswith("true")
+                        acc.setdefault(coarse, []).append(float(r["Counter_Value"]))
+            if False not in acc:
+                return None, f"no scan_units_kernel rows in the {c} pass"
+            tot[c] = sum(sum(v) / len(v) for v in acc.values())     # list scan + coarse scan, KiB
+        except Exception as e:     # noqa: BLE001 - profiling is an extra
+            return None, f"{c} pass failed: {e!r}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024, \
+        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this script in this run (pipeline 1: list " \
+        "scan + coarse scan launches summed; FETCH x2 per the gfx950 correction)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=1183514)
     ap.add_argument("--d", type=int, default=100)
     ap.add_argument("--n-clusters", type=int, default=1087)
@@ -279,6 +422,14 @@ def main():
                          "implies --n 20000000 --d 128 --n-clusters 4472 --metric euclidean unless given")
     ap.add_argument("--shard", choices=["auto", "none", "lists"], default="auto",
                     help="list-sharded leg after the replica measurement (auto: when N > 1)")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the >= 1 GiB streaming scan leg")
+    ap.add_argument("--traffic", choices=["auto", "none"], default="auto",
+                    help="auto: HBM bytes of the scan launch from rocprofv3 --pmc child runs of this "
+                         "script (N = 1, default workload only)")
+    ap.add_argument("--py-cpu-sample", type=int, default=300,
+                    help="queries of the per-query Python-loop CPU baseline (examples/bench.py:118-137)")
+    ap.add_argument("--profile-only", action="store_true",
+                    help="stop after the timed region + the isolated stages (profiler runs)")
     ap.add_argument("--shard-limit", type=float, default=240.0,
                     help="seconds after which a stuck list-sharded leg is abandoned")
     args = ap.parse_args()
@@ -361,6 +512,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     stages, scan_bytes, n_prof = dev.last_profile()
+    raw_leg = None if args.profile_only else raw_stream_leg(args, dev, qs, out_dev, device, world)
     # the same kernels with ONE batch in flight (no co-running batches), for reference
     dev.set_pipeline(1)
     dev.reserve(args.nq, args.k, args.n_probes)
@@ -372,6 +524,14 @@ def main():
     torch.cuda.synchronize()
     iso_stages, iso_bytes, _ = dev.last_profile()
     dev.set_profiling(False)
+    if args.profile_only:
+        if rank == 0:
+            print(json.dumps({"profile_only": True, "ms_per_step": elapsed / args.steps * 1e3,
+                              "stage_ms": stages, "isolated_stage_ms": iso_stages,
+                              "scan_bytes": scan_bytes, "iso_scan_bytes": iso_bytes}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     # the same batch captured ONCE into a hipGraph (stream capture of the seven-stage pipeline,
     # one batch in flight) and replayed: BASELINE configs[3] asks for a graph-captured batch
     graph = None
@@ -425,7 +585,11 @@ def main():
     if rank != 0:
         if do_shard:
             import threading
-            wd = threading.Timer(args.shard_limit + 120.0, lambda: os._exit(0))
+            def give_up():
+                log(f"[bench] rank {rank}: list-sharded leg stuck for {args.shard_limit + 120:.0f}s, exiting 3")
+                os._exit(3)
+
+            wd = threading.Timer(args.shard_limit + 120.0, give_up)
             wd.daemon = True
             wd.start()
             try:
@@ -440,17 +604,18 @@ def main():
     qps = args.nq * world * args.steps / elapsed
     scan_ms = stages["scan"]
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
-    # the PMC passes were taken on the default workload only
+    traffic, traffic_src = None, "not measured"
     default_wl = (args.workload, args.n, args.d, args.n_clusters, args.nq, args.n_probes, args.metric,
                   args.data, args.build_probes) == ("glove", 1183514, 100, 1087, 10000, 10, "angular",
                                                     "glove-like", 1)
-    if default_wl and os.path.exists(tpath):
+    if args.traffic == "auto" and default_wl and world == 1:
+        traffic, traffic_src = measure_traffic(args)
+    hbm_leg = None
+    if not args.no_hbm_leg and world == 1:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            hbm_leg = hbm_scale_leg(device)
+        except Exception as e:      # noqa: BLE001 - an extra leg must not lose the line
+            hbm_leg = {"error": repr(e)}
 
     # the box's device-copy bandwidth (read + write), the practical HBM ceiling next to the spec
     try:
@@ -502,9 +667,25 @@ def main():
                "sample": f"first {cs} queries of the same batch, oracle/tinyknn_oracle.c "
                          f"(AVX2 pshufb scan + sequential heap), {tcpu:.2f}s"}
         parity = {"queries_checked": cs, "identical_rows": int((want == got[:cs]).all(axis=1).sum())}
+        # like-for-like with examples/bench.py:118-137: ONE Python-level query() per query
+        # (normalise, table, coarse top, chained list scans, rescoring per call), one thread
+        ps = min(args.py_cpu_sample, args.nq)
+        tp = time.perf_counter()
+        for i in range(ps):
+            q = np.ascontiguousarray(qs[i], dtype=np.float32).copy()      # ivf.py:125-127
+            if ang:
+                q /= np.linalg.norm(q)
+            ox.query(q, args.k, args.n_probes)
+        tpy = time.perf_counter() - tp
+        cpu["python_loop"] = {"value": ps / tpy, "unit": "queries/s", "cores": 1,
+                              "sample": f"first {ps} raw queries, one Python-level query() per query as "
+                                        f"examples/bench.py:118-137 times the reference; the per-query work is the C port's "
+                                        f"(table build and rescoring in C, where the reference runs numpy), {tpy:.2f}s"}
+        cpu["note"] = ("value = C batch loop of the port (no per-query Python overhead: the STRONGER "
+                       "baseline); python_loop = the reference's own measurement protocol")
 
     line = {
-        "metric": "queries/sec at Recall10@10 on GloVe-100 angular (synthetic stand-in), IVF+4-bit PQ"
+        "metric": f"queries/sec at Recall10@10 on GloVe-100 angular (synthetic stand-in), IVF+4-bit PQ, build_probes={args.build_probes}"
                   if (args.workload, args.data, args.metric, args.d) == ("glove", "glove-like", "angular", 100) else
                   f"queries/sec, c5like stand-in for 100M x 128 (N={args.n} random vectors, big lists), IVF+4-bit PQ"
                   if args.workload == "c5like" else
@@ -531,7 +712,10 @@ def main():
                    "parallelism": f"replica x{world} (queries sharded)",
                    "batches_in_flight": args.pipeline},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "achieved_is": "ALGORITHMIC GB/s (one code byte per (query, code) pair); the fabric "
+                                    "carries `traffic` bytes per launch: four queries share each fetched "
+                                    "code byte and the code set sits in L2/Infinity Cache",
                      "device_copy_GBps_measured": copy_gbps,
                      "kernel": ("scan_probes_kernel<AVX,signed>" if args.scan_mode == 1 else
                                 "scan_units_kernel<AVX,signed>" if args.pipeline == 1 else
@@ -539,6 +723,8 @@ def main():
                                 "of a later one)"),
                      "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
                      "launches_timed": n_prof},
+        "raw_in_ids_out": raw_leg,
+        "roofline_hbm_scale": hbm_leg,
         "stage_ms": stages,
         "isolated": {"note": "same batch with one batch in flight (5 steps after the timed region)",
                      "stage_ms": iso_stages, "ms_per_step": sum(iso_stages.values()),
@@ -570,7 +756,7 @@ def main():
         def bail():
             line["list_sharded"] = {"error": f"abandoned after {args.shard_limit:.0f}s"}
             print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)      # a GPU process that abandoned a collective never reports success
 
         wd = threading.Timer(args.shard_limit, bail)
         wd.daemon = True
@@ -581,7 +767,7 @@ def main():
             # the other ranks may be waiting in a collective: do not join them again
             line["list_sharded"] = {"error": repr(e)}
             print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
         wd.cancel()
     print(json.dumps(line), flush=True)
     if world > 1:

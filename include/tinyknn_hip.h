@@ -247,6 +247,64 @@ int tk_index_prepare_dev(tk_index *ix, const float *q_raw_dev, int64_t nq, int a
 int tk_index_query_batch_raw(tk_index *ix, const float *q_raw, int64_t nq, int angular, int k,
                              int n_probes, int pass_1, int64_t *out_ids);
 
+/* ---- exact host front end + streaming sessions (front.hip) ------------------------------
+ * The host side of IVF.query (ivf.py:125-128, fast_pq.py:200-204): float32 normalisation
+ * by np.linalg.norm = sqrtf(cblas_sdot(x, x)), pad1, and the float64 rotation
+ * q @ R.T = cblas_dgemv(ColMajor, Trans, d_pad, dq, 1, R, d_pad, x, 1, 0, y, 1).  The
+ * summation orders of those two calls belong to the BLAS build numpy links and are not
+ * restated: tk_host_blas_bind resolves both symbols from THAT library (path of the shared
+ * object numpy loaded; ILP64 "64_"-suffixed and "scipy_"-prefixed names are tried first),
+ * and tk_prepare_queries_host calls them row by row from a thread pool — the reference's
+ * arithmetic, bit for bit, without the Python loop.  No restated CPU arithmetic: without a
+ * bound BLAS the call fails (TK_ERR_STATE).
+ * tk_host_threads(n): pool size (n <= 0: keep / create the default = min(cores, 32), env
+ * TINYKNN_HOST_THREADS); returns the size in use.
+ * tk_prepare_queries_host: q_raw (nq, d) float32 -> qn (nq, d) float32 (normalised when
+ * `angular`; may alias q_raw: the reference normalises in place) and, with R (dq, d_pad)
+ * float64 row-major = FastPQ.R, q_pq (nq, dq) float64 = pad1(qn) @ R.T.  Without R the
+ * table-build query is pad1(qn) (zeros appended), which needs no arithmetic. */
+int tk_host_blas_bind(const char *blas_shared_object_path);
+int tk_host_blas_bound(void);
+int tk_host_threads(int n);
+int tk_prepare_queries_host(const float *q_raw, int64_t nq, int d, int angular, float *qn,
+                            const double *R, int dq, int d_pad, double *q_pq);
+
+/* tk_index_query_batch_dev with a completion hook: behind the batch's last kernel the ids
+ * are copied into out_ids_pinned (page-locked host memory, or NULL) and done_event (a
+ * hipEvent_t, or NULL) is recorded.  With tk_index_set_pipeline(depth > 1) that happens up
+ * to three calls later (or at tk_index_join); tk_index_pending = number of calls whose last
+ * stage is not enqueued yet.  nq must fit one sub-batch (tk_index_max_sub_batch). */
+int tk_index_query_batch_dev_ex(tk_index *ix, const float *q_dev, const void *q_pq_dev,
+                                int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                                int64_t *out_ids_dev, int64_t *out_ids_pinned, void *done_event,
+                                void *stream);
+int64_t tk_index_max_sub_batch(tk_index *ix, int k, int n_probes, int pass_1);
+int tk_index_pending(tk_index *ix);
+/* info8 = {d, dq, M, n_lists, rotation d_pad (0: none), pipeline depth, N, total chunks} */
+int tk_index_info(tk_index *ix, int64_t *info8);
+
+/* Streaming session: IVF.query for a stream of batches, raw float32 queries on the host in,
+ * ids on the host out (ivf.py:106-163 per row).  submit = exact host preparation on the
+ * pool (above) into page-locked staging, H2D on a copy stream, the device pipeline on a
+ * compute stream, D2H of the ids behind the last kernel; it returns a ticket at once, so
+ * that the preparation and the copies of a batch overlap the kernels of the batches before
+ * it.  out_ids (nq, k) is written by tk_stream_wait(ticket) / tk_stream_drain (or by a later
+ * submit that reuses the slot: n_slots batches may be outstanding) and must stay valid
+ * until then.  R / d_pad as in tk_prepare_queries_host (NULL: unrotated PQ).
+ * tk_stream_submit_prepared: the same from already prepared rows (qn, q_pq as
+ * tk_index_query_batch takes them).  A session owns its index while batches are
+ * outstanding; one thread at a time. */
+typedef struct tk_stream tk_stream;
+tk_stream *tk_stream_create(tk_index *ix, int64_t max_nq, int k, int n_probes, int pass_1,
+                            int angular, const double *R, int d_pad, int n_slots);
+int64_t tk_stream_submit(tk_stream *s, const float *q_raw, int64_t nq, int64_t *out_ids);
+int64_t tk_stream_submit_prepared(tk_stream *s, const float *qn, const void *q_pq, int64_t nq,
+                                  int64_t *out_ids);
+int tk_stream_wait(tk_stream *s, int64_t ticket);
+int tk_stream_drain(tk_stream *s);
+double tk_stream_prepare_seconds(tk_stream *s);
+void tk_stream_destroy(tk_stream *s);
+
 /* ---- exact k nearest vectors: the ground truth of recall --------------
  * knn_brute(q, IVF.data, k, "euclidean") (utils.py:66-86, as examples/bench.py:85 uses it) on
  * the f32 matrix cores: part = (|q|^2 + |y|^2) - (2q).y with numpy's einsum norms and the

@@ -80,6 +80,26 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "tk_index_query_batch_raw": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, _i64p]),
+    "tk_host_blas_bind": (C.c_int, [C.c_char_p]),
+    "tk_host_blas_bound": (C.c_int, []),
+    "tk_host_threads": (C.c_int, [C.c_int]),
+    "tk_prepare_queries_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tk_index_query_batch_dev_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                              C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "tk_index_max_sub_batch": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tk_index_pending": (C.c_int, [C.c_void_p]),
+    "tk_index_info": (C.c_int, [C.c_void_p, _i64p]),
+    "tk_stream_create": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_int]),
+    "tk_stream_submit": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "tk_stream_submit_prepared": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_void_p]),
+    "tk_stream_wait": (C.c_int, [C.c_void_p, C.c_int64]),
+    "tk_stream_drain": (C.c_int, [C.c_void_p]),
+    "tk_stream_prepare_seconds": (C.c_double, [C.c_void_p]),
+    "tk_stream_destroy": (None, [C.c_void_p]),
     "tk_index_knn_brute": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _i64p]),
     "tk_index_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_join": (C.c_int, [C.c_void_p, C.c_void_p]),

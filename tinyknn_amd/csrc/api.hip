@@ -21,6 +21,7 @@ static int fail(int code, const std::string &msg)
     g_err = msg;
     return code;
 }
+int tk_fail(int code, const std::string &msg) { return fail(code, msg); }   // front.hip
 
 #define HIPCHECK(x)                                                                          \
     do {                                                                                     \
@@ -577,6 +578,7 @@ struct Work {
 
 struct Pending;
 static int flush_pending(struct tk_index *ix);
+static int batch_epilogue(const struct Pending &b, hipStream_t st);
 
 struct tk_index {
     // FastPQ
@@ -1161,6 +1163,8 @@ struct Pending {
     int64_t *out_dev;
     bool units;
     bool coarse_launched;   // its coarse scan has been enqueued
+    int64_t *host_out;      // pinned host copy of the ids, enqueued behind the rescoring (or NULL)
+    hipEvent_t user_ev;     // recorded behind that copy (or NULL)
     Prof pf;
     hipStream_t st, sf, sl;   // scans (+ tables) / coarse replay + descriptors / replay + rescoring
 };
@@ -1200,6 +1204,7 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
                               p.cap_min, 1, ix->order, st);
     TRY(b.pf.mark(st));
     TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf));
+    TRY(batch_epilogue(b, st));
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
@@ -1240,6 +1245,7 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         HIPCHECK(hipStreamWaitEvent(prev->sl, prev->w->scanned, 0));
         TRY(stage_back(ix, *prev->w, prev->q_dev, 0, prev->nq, prev->k, prev->p, prev->out_dev,
                        prev->sl, prev->pf));
+        TRY(batch_epilogue(*prev, prev->sl));
         HIPCHECK(hipEventRecord(prev->w->done, prev->sl));
         prev->w->busy = true;
     }
@@ -1285,6 +1291,15 @@ static int pipeline_advance(tk_index *ix, bool drain)
     return r;
 }
 
+// what the caller of tk_index_query_batch_dev_ex asked for behind a batch's last kernel
+static int batch_epilogue(const Pending &b, hipStream_t st)
+{
+    if (b.host_out)
+        HIPCHECK(hipMemcpyAsync(b.host_out, b.out_dev, (size_t)b.nq * b.k * 8, hipMemcpyDeviceToHost, st));
+    if (b.user_ev) HIPCHECK(hipEventRecord(b.user_ev, st));
+    return TK_OK;
+}
+
 static int flush_pending(tk_index *ix)
 {
     int r = TK_OK;
@@ -1294,9 +1309,10 @@ static int flush_pending(tk_index *ix)
     return r;
 }
 
-extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_dev,
-                                        int q_pq_is_f64, int64_t nq, int k, int n_probes,
-                                        int pass_1, int64_t *out_ids_dev, void *stream)
+static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_pq_dev,
+                                int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                                int64_t *out_ids_dev, int64_t *out_ids_pinned, hipEvent_t done_ev,
+                                void *stream)
 {
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
@@ -1305,6 +1321,8 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
     hipStream_t caller = (hipStream_t)stream;
     const size_t esz = q_pq_is_f64 ? 8 : 4;
     const int64_t ms = sub_batch(p);
+    ARGCHECK(!(out_ids_pinned || done_ev) || (nq >= 1 && nq <= ms),
+             "a completion event / host copy belongs to ONE sub-batch (tk_index_max_sub_batch)");
     for (int64_t o = 0; o < nq; o += ms) {
         int64_t sub = nq - o < ms ? nq - o : ms;
         Work &w = ix->works[ix->calls % ix->works.size()];
@@ -1317,6 +1335,8 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
         b.out_dev = out_ids_dev + o * k;
         b.units = false;
         b.coarse_launched = false;
+        b.host_out = out_ids_pinned;
+        b.user_ev = done_ev;
         b.st = b.sf = b.sl = caller;
         const void *qpq = (const char *)q_pq_dev + (size_t)o * ix->dq * esz;
         if (ix->depth == 1) {
@@ -1354,6 +1374,41 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
         TRY(pipeline_advance(ix, false));
         ix->pending.push_back(new Pending(b));
     }
+    return TK_OK;
+}
+
+extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_dev,
+                                        int q_pq_is_f64, int64_t nq, int k, int n_probes,
+                                        int pass_1, int64_t *out_ids_dev, void *stream)
+{
+    return query_batch_dev_impl(ix, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1,
+                                out_ids_dev, nullptr, nullptr, stream);
+}
+
+extern "C" int tk_index_query_batch_dev_ex(tk_index *ix, const float *q_dev, const void *q_pq_dev,
+                                           int q_pq_is_f64, int64_t nq, int k, int n_probes,
+                                           int pass_1, int64_t *out_ids_dev,
+                                           int64_t *out_ids_pinned, void *done_event, void *stream)
+{
+    return query_batch_dev_impl(ix, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1,
+                                out_ids_dev, out_ids_pinned, (hipEvent_t)done_event, stream);
+}
+
+extern "C" int64_t tk_index_max_sub_batch(tk_index *ix, int k, int n_probes, int pass_1)
+{
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    return sub_batch(p);
+}
+
+extern "C" int tk_index_pending(tk_index *ix) { return ix ? (int)ix->pending.size() : 0; }
+
+extern "C" int tk_index_info(tk_index *ix, int64_t *info8)
+{
+    ARGCHECK(ix && info8, "null index / buffer");
+    ARGCHECK(ix->have_pq && ix->have_centers, "set_pq and set_centers first");
+    info8[0] = ix->d; info8[1] = ix->dq; info8[2] = ix->M; info8[3] = ix->n_lists;
+    info8[4] = ix->rot_d_pad; info8[5] = ix->depth; info8[6] = ix->N; info8[7] = ix->total_chunks;
     return TK_OK;
 }
 

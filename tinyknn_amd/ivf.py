@@ -10,9 +10,70 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _front, _lib
 from .fast_pq import FastPQ, avx, dpad
 from .utils import group_data_by_indices, knn_brute, timer
+
+
+class QueryStream:
+    """Streaming session on a DeviceIndex (C ABI: tk_stream_*): raw float32 queries on the
+    host in, ids on the host out, batch after batch; the exact host preparation
+    (ivf.py:125-128 through numpy's own BLAS, see _front.py), the copies and the kernels of
+    consecutive batches overlap.  submit() returns a ticket; the ids land in the array given
+    to submit() by wait(ticket) / drain()."""
+
+    def __init__(self, dev, max_nq, k, n_probes, pass_1=None, slots=8):
+        if not _front.bind():
+            raise _lib.TinyKnnHipError("no BLAS bound for the exact host front end: " +
+                                       str(_front.info()["why"]))
+        self._dev = dev                 # keeps the index alive
+        self.max_nq, self.k = int(max_nq), int(k)
+        R = dev._R
+        self._s = _lib.lib().tk_stream_create(
+            dev.handle, self.max_nq, self.k, int(n_probes), int(pass_1 or 0), int(dev.angular),
+            None if R is None else R.ctypes.data, 0 if R is None else R.shape[1], int(slots))
+        if not self._s:
+            raise _lib.TinyKnnHipError(_lib.lib().tk_last_error().decode())
+        self._keep = {}
+
+    def submit(self, qs, out):
+        """qs (nq, d) float32 C-contiguous raw queries (not modified); out (nq, k) int64."""
+        assert qs.dtype == np.float32 and qs.flags.c_contiguous and qs.shape[1] == self._dev.d
+        assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (len(qs), self.k)
+        t = _lib.check(_lib.lib().tk_stream_submit(self._s, qs.ctypes.data, len(qs), out.ctypes.data))
+        self._keep[t % 64] = (qs, out)
+        return t
+
+    def submit_prepared(self, qn, q_pq, out):
+        """Already prepared rows (what DeviceIndex.query_batch takes)."""
+        assert qn.dtype == np.float32 and qn.flags.c_contiguous and qn.shape[1] == self._dev.d
+        assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (len(qn), self.k)
+        t = _lib.check(_lib.lib().tk_stream_submit_prepared(
+            self._s, qn.ctypes.data, None if q_pq is None else q_pq.ctypes.data, len(qn),
+            out.ctypes.data))
+        self._keep[t % 64] = (qn, q_pq, out)
+        return t
+
+    def wait(self, ticket):
+        _lib.check(_lib.lib().tk_stream_wait(self._s, int(ticket)))
+
+    def drain(self):
+        _lib.check(_lib.lib().tk_stream_drain(self._s))
+        self._keep.clear()
+
+    def prepare_seconds(self):
+        return _lib.lib().tk_stream_prepare_seconds(self._s)
+
+    def close(self):
+        if getattr(self, "_s", None):
+            _lib.lib().tk_stream_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceIndex:
@@ -77,18 +138,63 @@ class DeviceIndex:
                                        data.shape[1]))
         self.code_bytes = int(codes.nbytes)
         self.angular = ivf.metric == "angular"
+        self._R = None
+        self._streams = {}
         if pq.R is not None:    # fast mode (device front end) needs the rotation on the device
             R = np.ascontiguousarray(pq.R, dtype=np.float64)
             _lib.check(L.tk_index_set_rotation(self._h, R.ctypes.data, R.shape[1]))
+            self._R = R
 
     @property
     def handle(self):
         return self._h
 
     def close(self):
+        for st in getattr(self, "_streams", {}).values():
+            st.close()
+        self._streams = {}
         if getattr(self, "_h", None):
             _lib.lib().tk_index_destroy(self._h)
             self._h = None
+
+    # ---- streaming (exact) ---------------------------------------------------
+    def max_sub_batch(self, k, n_probes, pass_1=None):
+        return _lib.check(_lib.lib().tk_index_max_sub_batch(self._h, int(k), int(n_probes),
+                                                            int(pass_1 or 0)))
+
+    def stream(self, max_nq, k, n_probes, pass_1=None, slots=8):
+        """A new streaming session (see QueryStream); the caller closes it."""
+        return QueryStream(self, max_nq, k, n_probes, pass_1, slots)
+
+    CHUNK = 10000       # queries per sub-batch of the chunked host API
+
+    def _cached_stream(self, nq, k, n_probes, pass_1):
+        key = (int(k), int(n_probes), int(pass_1 or 0))
+        chunk = min(self.CHUNK, self.max_sub_batch(k, n_probes, pass_1))
+        want = min(int(nq), chunk)
+        st = self._streams.get(key)
+        if st is None or st.max_nq < want:
+            if st is not None:
+                st.close()
+            cap = min(chunk, max(64, 1 << (want - 1).bit_length()))
+            st = self._streams[key] = QueryStream(self, cap, k, n_probes, pass_1)
+        return st
+
+    def query_raw(self, qs, k, n_probes, pass_1=None):
+        """Exact IVF.query for every row of qs (raw float32 queries on the host): chunks of
+        up to CHUNK rows through a streaming session, so that the host preparation and the
+        copies of a chunk overlap the kernels of the chunks before it."""
+        qs = np.ascontiguousarray(qs, dtype=np.float32)
+        nq = qs.shape[0]
+        assert qs.shape[1] == self.d
+        out = np.full((nq, k), -1, dtype=np.int64)
+        if nq == 0:
+            return out
+        st = self._cached_stream(nq, k, n_probes, pass_1)
+        for o in range(0, nq, st.max_nq):
+            st.submit(qs[o:o + st.max_nq], out[o:o + st.max_nq])
+        st.drain()
+        return out
 
     def __del__(self):
         try:
@@ -104,6 +210,16 @@ class DeviceIndex:
         nq = qn.shape[0]
         assert qn.shape[1] == self.d and q_pq.shape == (nq, self.dq)
         out = np.full((nq, k), -1, dtype=np.int64)
+        # the session pads unrotated queries on the device: only for q_pq = pad1(qn)
+        plain = is64 or (np.array_equal(q_pq[:, :self.d], qn) and not q_pq[:, self.d:].any())
+        if not debug and nq > 0 and plain and _front.bind():
+            # prepared rows through the streaming session (pinned staging, async copies)
+            st = self._cached_stream(nq, k, n_probes, pass_1)
+            for o in range(0, nq, st.max_nq):
+                st.submit_prepared(qn[o:o + st.max_nq],
+                                   q_pq[o:o + st.max_nq] if is64 else None, out[o:o + st.max_nq])
+            st.drain()
+            return out
         R = pass_1 if pass_1 else (n_probes + 1) * k + 1
         probes = hidx = hval = None
         if debug:
@@ -404,14 +520,15 @@ class IVF:
         dq = pq.centers.shape[1]
         d = qs.shape[1]
         pad = (-d) % (dpad * pq.dims_per_block)
-        if self.metric == "angular":
-            for row in qs:
-                row /= np.linalg.norm(row)
-        qp = qs if pad == 0 else np.concatenate([qs, np.zeros((len(qs), pad), qs.dtype)], axis=1)
-        if pq.R is not None:
-            qp = np.stack([row @ pq.R.T for row in qp])   # per-row GEMV, as the reference
+        R = pq.R
+        if R is not None and (min(R.shape) < 2 or R.dtype != np.float64):
+            # 1-row / 1-column products take other numpy code paths (dot, no BLAS)
+            qn, qp = _front.numpy_prepare(qs, self.metric == "angular", R, pad)
+        else:
+            # the same two BLAS calls numpy makes per row, from a thread pool (_front.py)
+            qn, qp = _front.prepare(qs, self.metric == "angular", R, pad)
         assert qp.shape[1] == dq
-        return qs, qp
+        return qn, qp
 
     def query(self, q, k, n_probes=1, pass_1=None):
         """Top-k ids for one query.  reference: ivf.py:106-163"""
@@ -430,6 +547,11 @@ class IVF:
         1 ulp of them, so a rare id can differ from the reference's; the default is exact."""
         if fast:
             return self.device_index().query_batch_raw(qs, k, n_probes, pass_1)
+        R = self.pq.R
+        if _front.bind() and (R is None or (min(R.shape) >= 2 and R.dtype == np.float64)):
+            # exact: chunks stream through preparation (numpy's BLAS on a thread pool),
+            # pinned H2D, the kernels and D2H, overlapped
+            return self.device_index().query_raw(qs, k, n_probes, pass_1)
         qs = np.array(qs, dtype=np.float32, order="C", copy=True)
         qn, qp = self._prepare(qs)
         return self.device_index().query_batch(qn, qp, k, n_probes, pass_1)
