@@ -16,6 +16,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tinyknn_amd import FastPQ, knn_brute, utils            # noqa: E402
 from tinyknn_amd.fast_pq import estimate_batch             # noqa: E402
+from tinyknn_amd import _fast_pq                           # noqa: E402
+
+# the code array of this script is written once and scanned 1000 times: keep it in HBM
+# between calls (opt-in; the default re-reads the live host buffer like the reference kernels)
+_fast_pq.cache_device_codes = True
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--input", default="random-16000-128", help=".npy file or random-n-d")

@@ -216,6 +216,13 @@ int tk_index_set_heap_mode(tk_index *ix, int mode);
  * 1 = always query-major, 2 = always list-major.  Identical outputs. */
 int tk_index_set_scan_mode(tk_index *ix, int mode);
 
+/* Form of the list-major scan kernel (process-wide; A/B timing, identical outputs).
+ * 1 (default) = the table rows a 64-unit block needs are staged once per block in the wave's
+ * LDS region and read with ds_read_b128, one query's rows live at a time (4 waves per SIMD);
+ * 2 = rows through LDS, 3 waves per SIMD; 0 = per-lane global loads of the rows (round-1
+ * form).  Tables with more than 156 blocks fall back to 0. */
+int tk_set_scan_form(int form);
+
 /* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
  * around the stages (no synchronisation in the query call; 1 = every batch).
  * tk_index_last_profile synchronises that stream and returns the mean

@@ -434,21 +434,34 @@ def test_config_c1_flat_scan(tk, oracle):
             exp = np.zeros(2 * len(data.packed), dtype=np.uint64)
             oracle.estimate_pq(data.packed, dt.tables, exp, signed, oracle.ORDER_AVX)
             np.testing.assert_array_equal(est, exp.view(np.int8 if signed else np.uint8)[:n])
-    # the batched form (one launch for all queries, codes resident in HBM)
+    # the batched form (one launch for all queries); default: the live host buffer, like the
+    # reference kernels; opt-in: codes resident in HBM between calls
     from tinyknn_amd.fast_pq import estimate_batch
     from tinyknn_amd import _fast_pq
-    assert _fast_pq.device_codes(data.packed)          # resident after the calls above
-    for signed in (True, False):
-        allq = estimate_batch(pq, data, qs, signed)
-        for i in (0, 3, 39):
-            dt = pq.distance_table(qs[i]) if signed else pq.udistance_table(qs[i])
-            np.testing.assert_array_equal(allq[i], dt.estimate_distances(data))
-    _fast_pq.cache_device_codes = False               # and the uncached host-buffer path
+    assert _fast_pq.cache_device_codes is False and _fast_pq.device_codes(data.packed) is None
+    dt0 = pq.distance_table(qs[0])
+    live = estimate_batch(pq, data, qs[:1])[0]
+    np.testing.assert_array_equal(dt0.estimate_distances(data), live)
+    _fast_pq.cache_device_codes = True
     try:
-        dt = pq.distance_table(qs[0])
-        np.testing.assert_array_equal(dt.estimate_distances(data), estimate_batch(pq, data, qs[:1])[0])
+        assert _fast_pq.device_codes(data.packed)
+        for signed in (True, False):
+            allq = estimate_batch(pq, data, qs, signed)
+            for i in (0, 3, 39):
+                dt = pq.distance_table(qs[i]) if signed else pq.udistance_table(qs[i])
+                np.testing.assert_array_equal(allq[i], dt.estimate_distances(data))
     finally:
-        _fast_pq.cache_device_codes = True
+        _fast_pq.cache_device_codes = False
+        _fast_pq.forget_device_codes()
+    # in-place mutation of the packed array is seen by the next call (no stale device copy)
+    saved = data.packed[:8].copy()
+    data.packed[:8] = data.packed[8:16]
+    est = dt0.estimate_distances(data)
+    exp = np.zeros(2 * len(data.packed), dtype=np.uint64)
+    oracle.estimate_pq(data.packed, dt0.tables, exp, True, oracle.ORDER_AVX)
+    np.testing.assert_array_equal(est, exp.view(np.int8)[:n])
+    assert not np.array_equal(est, live)
+    data.packed[:8] = saved
     for q in qs:
         dt = pq.distance_table(q)
         got = dt.top(data, X, k=10)

@@ -143,7 +143,14 @@ def test_index_persistence_roundtrips(tmp_path):
     ivf.ids, ivf.data = ids, g["data"]
     path = str(tmp_path / "index.npz")
     ivf.save(path)
-    for other in (IVF.load(path), pickle.loads(pickle.dumps(ivf))):
+    # a path without the suffix: np.savez appends ".npz", load must find the same file
+    ivf.pq.use_kmeans, ivf.pq.rotate_dim = False, 32
+    bare = str(tmp_path / "idx")
+    ivf.save(bare)
+    assert (tmp_path / "idx.npz").exists()
+    other = IVF.load(bare)
+    assert other.pq.use_kmeans is False and other.pq.rotate_dim == 32
+    for other in (IVF.load(path), other, pickle.loads(pickle.dumps(ivf))):
         assert other.metric == ivf.metric and other.pq.dims_per_block == 2
         np.testing.assert_array_equal(other.pq.centers, ivf.pq.centers)
         np.testing.assert_array_equal(other.pq.R, ivf.pq.R)

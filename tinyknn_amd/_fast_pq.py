@@ -21,24 +21,28 @@ def _buf(a, dtype, ndim, name):
     return a
 
 
-# Code arrays that are scanned repeatedly (FastPQ.transform output: one array,
-# thousands of queries, examples/example.py:60-66) are kept in HBM between calls,
-# keyed by the identity of the numpy array and released when it is garbage
-# collected.  The device copy is NOT refreshed if the caller mutates the array in
-# place afterwards; set cache_device_codes = False (or call forget_device_codes)
-# for that usage.
-cache_device_codes = True
+# Opt-in: code arrays that are scanned repeatedly (FastPQ.transform output: one array,
+# thousands of queries, examples/example.py:60-66) can be kept in HBM between calls, keyed
+# by the identity of the numpy array and released when it is garbage collected.  OFF by
+# default: the reference kernels always read the live buffer, and a resident copy cannot see
+# an in-place mutation of the numpy array (set cache_device_codes = True only for arrays that
+# are not written to afterwards; forget_device_codes drops a copy).
+cache_device_codes = False
 _CACHE_MIN_BYTES = 16 * 1024
-_codes_cache = {}
+_CACHE_MAX_ARRAYS = 512
+_codes_cache = {}      # id(array) -> (weakref, handle, (data pointer, shape))
+
+
+def _drop(key):
+    ent = _codes_cache.pop(key, None)
+    if ent is not None:
+        _lib.lib().tk_codes_free(ent[1])
 
 
 def forget_device_codes(data=None):
-    """Drop the HBM copy of one packed array (or of all of them)."""
-    keys = list(_codes_cache) if data is None else [id(data)]
-    for k in keys:
-        ent = _codes_cache.pop(k, None)
-        if ent is not None:
-            _lib.lib().tk_codes_free(ent[1])
+    """Drop the HBM copy of one packed array (or, with no argument, of all of them)."""
+    for k in (list(_codes_cache) if data is None else [id(data)]):
+        _drop(k)
 
 
 def device_codes(data):
@@ -50,8 +54,7 @@ def device_codes(data):
     ent = _codes_cache.get(key)
     if ent is not None and ent[0]() is data and ent[2] == sig:
         return ent[1]
-    if ent is not None:
-        forget_device_codes(data)
+    _drop(key)                      # a stale entry of a dead array with the same id
     h = _lib.lib().tk_codes_upload(_lib.ptr(data, _lib._u64p), data.shape[0], data.shape[1])
     if not h:
         _lib.check(-2)
@@ -60,15 +63,17 @@ def device_codes(data):
     def _gone(_ref, key=key, h=h):
         ent = _codes_cache.get(key)
         if ent is not None and ent[1] == h:
-            del _codes_cache[key]
             try:
-                _lib.lib().tk_codes_free(h)
+                _drop(key)
             except Exception:
                 pass
 
     _codes_cache[key] = (weakref.ref(data, _gone), h, sig)
-    if len(_codes_cache) > 512:          # bound the number of resident arrays
-        forget_device_codes(next(iter(_codes_cache.values()))[0]())
+    while len(_codes_cache) > _CACHE_MAX_ARRAYS:     # evict the oldest entry BY KEY
+        oldest = next(iter(_codes_cache))
+        if oldest == key:
+            break
+        _drop(oldest)
     return h
 
 

@@ -445,6 +445,124 @@ __device__ __forceinline__ void scan_units_block(
     }
 }
 
+// ---- the same block with the table rows in LDS --------------------------------------------
+// In scan_units_block every pair-step issues 8 per-lane global_load_dwordx4 of table rows
+// (4 queries x 2 rows of 16 entries): 234 vector-memory instructions per 64-unit block against
+// ~6400 VALU, all through the CU's one texture-address path, which 12 waves share.  Here the
+// rows a block needs are copied ONCE per block into the wave's own LDS region and read back
+// with ds_read_b128 (64 dwords/clk, identical addresses broadcast): the units of a block are
+// consecutive, so they belong to a few consecutive groups of 4 queries (`grp` = record / 4 is
+// monotone in the unit number), typically one or two.  A wave whose block spans more groups
+// than its region holds (short lists) makes several passes over windows of `gmax` groups with
+// the lanes of other windows idle — same code, no second path.  Per-wave regions: no
+// workgroup barrier, waves keep drawing blocks independently.
+template <int ORDER, bool SIGNED, bool TIGHT>
+__device__ __forceinline__ void scan_units_block_lds(
+    const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
+    const int64_t *__restrict__ list_chunk_off, int n_lists, const int *__restrict__ unit_prefix,
+    const int *__restrict__ pair_off, const int *__restrict__ pair_q,
+    const int *__restrict__ pair_f0, uint4 *__restrict__ dist, int64_t cap,
+    uint8_t *__restrict__ mins, int64_t min_stride, int U, int blk, uint4 *lw, int gmax)
+{
+    const uint32_t cA = 0x020c000cu, cB = 0x030c010cu;
+    const int lane = threadIdx.x & 63;
+    const int u = (blk << 6) + lane;
+    const bool active = u < U;
+    const int uu = active ? u : U - 1;
+    int lo = 0, hi = n_lists;   // unit_prefix[lo] <= uu < unit_prefix[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (unit_prefix[mid] <= uu) lo = mid; else hi = mid;
+    }
+    const int l = lo;
+    const int64_t c0 = list_chunk_off[l];
+    const int C = (int)(list_chunk_off[l + 1] - c0);
+    const int local = uu - unit_prefix[l];
+    const int qg = local / C, c = local - qg * C;
+    const int rec = pair_off[l] + TK_UNIT_Q * qg;
+    const int grp = rec >> 2;
+    const int g_first = __builtin_amdgcn_readfirstlane(grp);
+    const int g_last = __builtin_amdgcn_readlane(grp, 63);
+    const int64_t gc = c0 + c;
+    const uint4 *src = codes + ((gc >> 3) * (int64_t)P) * 8 + (gc & 7);
+    const int steps = (ORDER == TK_ORDER_AVX) ? (P >> 1) : P;
+
+    for (int gw = g_first; gw <= g_last; gw += gmax) {
+        const int gn = g_last - gw + 1 < gmax ? g_last - gw + 1 : gmax;
+        // fill: record r of the window -> M rows at lw[r * M]; the query of a record is
+        // wave-uniform, lanes copy consecutive rows
+        for (int r = 0; r < gn * TK_UNIT_Q; r++) {
+            int qi = pair_q[gw * TK_UNIT_Q + r];
+            qi = __builtin_amdgcn_readfirstlane(qi < 0 ? 0 : qi);
+            const uint4 *trow = tables + (int64_t)qi * M;
+            for (int m = lane; m < M; m += 64) lw[r * M + m] = trow[m];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool mine = grp >= gw && grp < gw + gn;
+        const uint4 *lt = lw + (mine ? (grp - gw) : 0) * (TK_UNIT_Q * M);
+
+        uint32_t a0[TK_UNIT_Q][8], a1[TK_UNIT_Q][8];
+#pragma unroll
+        for (int i = 0; i < TK_UNIT_Q; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) a0[i][j] = a1[i][j] = 0;
+        for (int st = 0; st < steps; st++) {
+            const int p0 = (ORDER == TK_ORDER_AVX) ? 2 * st : st;
+            // pair p0 -> accumulator set 0 (and, AVX, pair p0+1 -> set 1).  Pair-outer,
+            // query-inner: the 24 selector words of a pair's four dwords are shared by the four
+            // queries, whose table rows arrive just in time from LDS (8 VGPRs per query instead
+            // of 32 for all four: that is what lets this form run 4 waves per SIMD).
+#pragma unroll
+            for (int h = 0; h < (ORDER == TK_ORDER_AVX ? 2 : 1); h++) {
+                const uint4 x = src[(p0 + h) * 8];
+                const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+                Sel6 sl[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) sl[j] = make_sel(xs[j], cA, cB);
+#pragma unroll
+                for (int i = 0; i < TK_UNIT_Q; i++) {
+                    const uint4 tl = lt[i * M + 2 * (p0 + h)], th = lt[i * M + 2 * (p0 + h) + 1];
+                    uint32_t(&acc)[8] = h == 0 ? a0[i] : a1[i];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        lut4x<SIGNED>(sl[j].s_lo, sl[j].kA_lo, sl[j].kB_lo, tl, acc[2 * j], acc[2 * j + 1]);
+                        lut4x<SIGNED>(sl[j].s_hi, sl[j].kA_hi, sl[j].kB_hi, th, acc[2 * j], acc[2 * j + 1]);
+                    }
+                    // keep the next query's rows from being hoisted above this one's work:
+                    // 8 live row registers instead of 32 (the difference is a spill at 128)
+                    if (TIGHT) asm volatile("" ::: "memory");
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TK_UNIT_Q; i++) {
+            if (ORDER == TK_ORDER_AVX) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    a0[i][j] = sat_add2<SIGNED>(a0[i][j], a1[i][j] & 0xff00ff00u);
+            }
+            uint4 o;
+            uint32_t mn;
+            finish_chunk<SIGNED>(a0[i], o, mn);
+            const int qi = pair_q[rec + i];
+            if (active && mine && qi >= 0) {
+                const int f0 = pair_f0[rec + i];
+                dist[(int64_t)qi * cap + f0 + c] = o;
+                if (mins) mins[(int64_t)qi * min_stride + f0 + c] = (uint8_t)mn;
+            }
+        }
+        // the next window (or block) overwrites the region: every lane's reads come first
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// bytes of LDS per wave for the table rows: 16 waves per CU x 9984 B = 156 KiB of the 160
+// (form 1, 4 waves/SIMD); 12 waves x 13312 B (form 2, 3 waves/SIMD)
+#define TK_LDS_WAVE_BYTES 9984
+#define TK_LDS_WAVE_BYTES_MAX 13312
+
 // Blocks of 64 consecutive units.  Every wave takes one block statically; the rest are
 // drawn from TK_TICKETS work counters (behind the prefix table, a cache line each, zeroed
 // by the kernel that wrote the table; a wave starts at its home counter and moves on when a
@@ -503,33 +621,45 @@ __device__ __forceinline__ void ticketed_blocks(int NB, int *ticket, F work)
 }
 
 // COARSE only tags the instantiation used for the coded centres so that profilers
-// list the two launches of a batch separately.
-template <int ORDER, bool SIGNED, int MINW, bool COARSE>
-__global__ __launch_bounds__(256, MINW) void scan_units_kernel(
+// list the two launches of a batch separately.  LDS_T: table rows through LDS (gmax > 0).
+// FORM: 0 = table rows by per-lane global loads (3 waves/SIMD), 1 = rows through LDS, rows of
+// one query live at a time (127 VGPRs, 4 waves/SIMD), 2 = rows through LDS, scheduler free
+// (3 waves/SIMD)
+template <int ORDER, bool SIGNED, int FORM, bool COARSE>
+__global__ __launch_bounds__(256, (FORM == 1 ? 4 : 3)) void scan_units_kernel(
     const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
     const int64_t *__restrict__ list_chunk_off, int n_lists,
     const int *__restrict__ unit_prefix,   // (n_lists+1) units before each list, then tickets
     const int *__restrict__ pair_off,      // (n_lists+1) first record of each list (x4 padded)
     const int *__restrict__ pair_q,        // query of a record, -1 = padding
     const int *__restrict__ pair_f0,       // first flat chunk of that (query, slot) row range
-    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride)
+    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride, int gmax)
 {
+    extern __shared__ uint4 tk_lds_tables[];
+    uint4 *lw = tk_lds_tables + (threadIdx.x >> 6) * (gmax * TK_UNIT_Q * M);
     const int U = unit_prefix[n_lists];
     int *ticket = const_cast<int *>(unit_prefix) + TK_TICKET_OFF(n_lists);
     ticketed_blocks((U + 63) >> 6, ticket, [&](int blk) {
-        scan_units_block<ORDER, SIGNED>(codes, P, tables, M, list_chunk_off, n_lists, unit_prefix,
-                                        pair_off, pair_q, pair_f0, dist, cap, mins, min_stride, U,
-                                        blk);
+        if (FORM != 0)
+            scan_units_block_lds<ORDER, SIGNED, FORM == 1>(codes, P, tables, M, list_chunk_off, n_lists,
+                                                unit_prefix, pair_off, pair_q, pair_f0, dist, cap,
+                                                mins, min_stride, U, blk, lw, gmax);
+        else
+            scan_units_block<ORDER, SIGNED>(codes, P, tables, M, list_chunk_off, n_lists, unit_prefix,
+                                            pair_off, pair_q, pair_f0, dist, cap, mins, min_stride, U,
+                                            blk);
     });
 }
 
 // Two jobs in one launch, one pool of blocks: the list scan of batch b and the coarse scan
 // of batch b+1 (pipelined mode, api.hip).  Either job may be absent (unit_prefix == NULL).
 // The work counters are those of the first job present.
-template <int ORDER, bool SIGNED, int MINW>
-__global__ __launch_bounds__(256, MINW) void scan_units2_kernel(TkScanJob a, TkScanJob b, int P,
-                                                                int M)
+template <int ORDER, bool SIGNED, int FORM>
+__global__ __launch_bounds__(256, (FORM == 1 ? 4 : 3)) void scan_units2_kernel(TkScanJob a, TkScanJob b, int P,
+                                                                int M, int gmax)
 {
+    extern __shared__ uint4 tk_lds_tables[];
+    uint4 *lw = tk_lds_tables + (threadIdx.x >> 6) * (gmax * TK_UNIT_Q * M);
     const int UA = a.unit_prefix ? a.unit_prefix[a.n_lists] : 0;
     const int UB = b.unit_prefix ? b.unit_prefix[b.n_lists] : 0;
     const int NBA = (UA + 63) >> 6, NBB = (UB + 63) >> 6;
@@ -539,10 +669,16 @@ __global__ __launch_bounds__(256, MINW) void scan_units2_kernel(TkScanJob a, TkS
         // one copy of the block body: the job's fields are picked with wave-uniform selects
         const bool first = blk < NBA;
         const TkScanJob &j = first ? a : b;
-        scan_units_block<ORDER, SIGNED>(j.codes, P, j.tables, M, j.list_chunk_off, j.n_lists,
-                                        j.unit_prefix, j.pair_off, j.pair_q, j.pair_f0, j.dist,
-                                        j.cap, j.mins, j.min_stride, first ? UA : UB,
-                                        first ? blk : blk - NBA);
+        if (FORM != 0)
+            scan_units_block_lds<ORDER, SIGNED, FORM == 1>(j.codes, P, j.tables, M, j.list_chunk_off, j.n_lists,
+                                                j.unit_prefix, j.pair_off, j.pair_q, j.pair_f0, j.dist,
+                                                j.cap, j.mins, j.min_stride, first ? UA : UB,
+                                                first ? blk : blk - NBA, lw, gmax);
+        else
+            scan_units_block<ORDER, SIGNED>(j.codes, P, j.tables, M, j.list_chunk_off, j.n_lists,
+                                            j.unit_prefix, j.pair_off, j.pair_q, j.pair_f0, j.dist,
+                                            j.cap, j.mins, j.min_stride, first ? UA : UB,
+                                            first ? blk : blk - NBA);
     });
 }
 
@@ -669,6 +805,29 @@ void tk_launch_identity_pairs(int64_t nq, int chunks, int *pair_off, int *unit_p
                        nq, chunks, pair_off, unit_prefix, pair_q, pair_f0);
 }
 
+// form of the list-major kernel (tk_set_scan_tables: A/B switch; see scan_units_kernel)
+static int g_scan_form = 1;
+void tk_set_scan_tables(int form) { g_scan_form = form < 0 || form > 2 ? 1 : form; }
+int tk_get_scan_tables(void) { return g_scan_form; }
+
+template <typename K>
+static void lds_attr(K kern)
+{
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * TK_LDS_WAVE_BYTES_MAX);
+}
+
+// groups of 4 queries whose rows fit a wave's LDS region (0: use the global form)
+static int scan_form_gmax(int M, int &form)
+{
+    if (form == 0) return 0;
+    const int bytes = form == 1 ? TK_LDS_WAVE_BYTES : TK_LDS_WAVE_BYTES_MAX;
+    int g = bytes / (TK_UNIT_Q * 16 * M);
+    g = g > 8 ? 8 : g;
+    if (g < 1) form = 0;
+    return g;
+}
+
 void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq, int S,
                           int64_t n_lists, const int64_t *list_chunk_off, const int *pair_off,
                           const int *unit_prefix, const int *pair_q, const int *pair_f0,
@@ -678,23 +837,36 @@ void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_
     if (nq == 0 || S == 0) return;
     const int P = M / 2;
     const bool coarse = n_lists == 1 && S == 1;
-#define TK_LAUNCH2(O, S_, W, C_)                                                                \
-    hipLaunchKernelGGL((scan_units_kernel<O, S_, W, C_>), dim3(n_blocks), dim3(256), 0, s, codes, \
-                       P, tables, M, list_chunk_off, (int)n_lists, unit_prefix, pair_off,         \
-                       pair_q, pair_f0, dist, cap, mins, min_stride)
-#define TK_LAUNCH(O, S_, W)                                            \
+    int form = g_scan_form;
+    const int gmax = scan_form_gmax(M, form);
+    const size_t lds = (size_t)4 * gmax * TK_UNIT_Q * M * 16;
+#define TK_LAUNCH3(O, S_, F_, C_)                                                                \
+    do {                                                                                         \
+        static bool attr_ = false;                                                               \
+        if (F_ != 0 && !attr_) { lds_attr(scan_units_kernel<O, S_, F_, C_>); attr_ = true; }     \
+        hipLaunchKernelGGL((scan_units_kernel<O, S_, F_, C_>), dim3(n_blocks), dim3(256), lds, s, \
+                           codes, P, tables, M, list_chunk_off, (int)n_lists, unit_prefix, pair_off, \
+                           pair_q, pair_f0, dist, cap, mins, min_stride, gmax);                      \
+    } while (0)
+#define TK_LAUNCH2(O, S_, C_)                                          \
     do {                                                               \
-        if (coarse) TK_LAUNCH2(O, S_, W, true);                        \
-        else TK_LAUNCH2(O, S_, W, false);                              \
+        if (form == 1) TK_LAUNCH3(O, S_, 1, C_);                       \
+        else if (form == 2) TK_LAUNCH3(O, S_, 2, C_);                  \
+        else TK_LAUNCH3(O, S_, 0, C_);                                 \
+    } while (0)
+#define TK_LAUNCH(O, S_)                                               \
+    do {                                                               \
+        if (coarse) TK_LAUNCH2(O, S_, true);                           \
+        else TK_LAUNCH2(O, S_, false);                                 \
     } while (0)
     if (order == TK_ORDER_AVX) {
-        // 3 waves/SIMD: 138 VGPRs; forcing 4 (128 VGPRs) spills in the loop and is slower
-        if (signd) TK_LAUNCH(TK_ORDER_AVX, true, 3); else TK_LAUNCH(TK_ORDER_AVX, false, 3);
+        if (signd) TK_LAUNCH(TK_ORDER_AVX, true); else TK_LAUNCH(TK_ORDER_AVX, false);
     } else {
-        if (signd) TK_LAUNCH(TK_ORDER_SSE, true, 3); else TK_LAUNCH(TK_ORDER_SSE, false, 3);
+        if (signd) TK_LAUNCH(TK_ORDER_SSE, true); else TK_LAUNCH(TK_ORDER_SSE, false);
     }
 #undef TK_LAUNCH
 #undef TK_LAUNCH2
+#undef TK_LAUNCH3
 }
 
 void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
@@ -702,10 +874,23 @@ void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int or
 {
     if (!a.unit_prefix && !b.unit_prefix) return;
     const int P = M / 2;
-    if (order == TK_ORDER_AVX)
-        hipLaunchKernelGGL((scan_units2_kernel<TK_ORDER_AVX, true, 3>), dim3(n_blocks), dim3(256), 0,
-                           s, a, b, P, M);
-    else
-        hipLaunchKernelGGL((scan_units2_kernel<TK_ORDER_SSE, true, 3>), dim3(n_blocks), dim3(256), 0,
-                           s, a, b, P, M);
+    int form = g_scan_form;
+    const int gmax = scan_form_gmax(M, form);
+    const size_t lds = (size_t)4 * gmax * TK_UNIT_Q * M * 16;
+#define TK_LAUNCH(O, F_)                                                                          \
+    do {                                                                                          \
+        static bool attr_ = false;                                                                \
+        if (F_ != 0 && !attr_) { lds_attr(scan_units2_kernel<O, true, F_>); attr_ = true; }       \
+        hipLaunchKernelGGL((scan_units2_kernel<O, true, F_>), dim3(n_blocks), dim3(256), lds, s, a, \
+                           b, P, M, gmax);                                                        \
+    } while (0)
+#define TK_LAUNCH1(O)                                  \
+    do {                                               \
+        if (form == 1) TK_LAUNCH(O, 1);                \
+        else if (form == 2) TK_LAUNCH(O, 2);           \
+        else TK_LAUNCH(O, 0);                          \
+    } while (0)
+    if (order == TK_ORDER_AVX) TK_LAUNCH1(TK_ORDER_AVX); else TK_LAUNCH1(TK_ORDER_SSE);
+#undef TK_LAUNCH1
+#undef TK_LAUNCH
 }

@@ -1712,6 +1712,13 @@ extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
     return TK_OK;
 }
 
+extern "C" int tk_set_scan_form(int form)
+{
+    ARGCHECK(form >= 0 && form <= 2, "form must be 0, 1 or 2");
+    tk_set_scan_tables(form);
+    return TK_OK;
+}
+
 extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
 {
     ARGCHECK(ix, "null index");

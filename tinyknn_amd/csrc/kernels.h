@@ -72,6 +72,10 @@ struct TkScanJob {
     uint8_t *mins;
     int64_t min_stride;
 };
+// table rows of the list-major kernel: 1 = staged per block in LDS (default), 0 = per-lane
+// global loads (the round-1 form; A/B switch)
+void tk_set_scan_tables(int lds);
+int tk_get_scan_tables(void);
 // two jobs in ONE launch sharing one pool of 64-unit blocks (pipelined mode: the list scan
 // of one batch and the coarse scan of the next); signed tables
 void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,

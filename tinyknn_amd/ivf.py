@@ -432,6 +432,7 @@ class IVF:
         zero = pq.encode_labels(np.zeros((16, dq), dtype=np.float64 if pq.R is not None else data.dtype),
                                 True)[0]
         # grouping as group_data_by_indices does (utils.py:95-162), without copying the vectors
+        assert 0 <= nearest.min() and nearest.max() < n_active       # utils.py:128
         ids = [[] for _ in range(n_active)]
         for j in range(nearest.shape[1]):
             col = nearest[:, j]
@@ -469,7 +470,9 @@ class IVF:
         extra = {} if self.pq.R is None else {"R": self.pq.R}
         if getattr(self, "all_centers", None) is not None:
             extra["all_centers"] = self.all_centers
+        path = self._npz_path(path)
         np.savez(path, format_version=1, metric=self.metric, n_clusters=self.n_clusters,
+                 use_kmeans=int(self.pq.use_kmeans), rotate_dim=-1 if self.pq.rotate_dim is None else int(self.pq.rotate_dim),
                  dims_per_block=self.pq.dims_per_block, pq_centers=self.pq.centers,
                  pq_centers_f_order=int(not self.pq.centers.flags.c_contiguous),
                  sqrt_n_blocks=self.pq.sqrt_n_blocks, active_centers=self.active_centers,
@@ -478,14 +481,23 @@ class IVF:
                  list_codes=(np.concatenate(codes) if codes else np.zeros((0, M), np.uint64)),
                  ids=(np.concatenate(ids) if ids else np.zeros(0, np.int64)), data=self.data, **extra)
 
+    @staticmethod
+    def _npz_path(path):
+        """np.savez appends '.npz' to a path without that suffix; save and load agree on it."""
+        path = str(path)
+        return path if path.endswith(".npz") else path + ".npz"
+
     @classmethod
     def load(cls, path, data=None):
         """Inverse of save.  `data`: the rescoring vectors if the file was written without them
         being wanted twice (pass the array to avoid keeping two copies)."""
         from .fast_pq import TransformedData
-        z = np.load(path, allow_pickle=False)
+        z = np.load(cls._npz_path(path), allow_pickle=False)
         assert int(z["format_version"]) == 1
-        ivf = cls(str(z["metric"]), int(z["n_clusters"]), FastPQ(int(z["dims_per_block"])))
+        pq = FastPQ(int(z["dims_per_block"]),
+                    use_kmeans=bool(int(z["use_kmeans"])) if "use_kmeans" in z else True,
+                    rotate_dim=(None if int(z["rotate_dim"]) < 0 else int(z["rotate_dim"])) if "rotate_dim" in z else 64)
+        ivf = cls(str(z["metric"]), int(z["n_clusters"]), pq)
         c = z["pq_centers"]
         ivf.pq.centers = np.asfortranarray(c) if int(z["pq_centers_f_order"]) else c
         ivf.pq.sqrt_n_blocks = float(z["sqrt_n_blocks"])
