@@ -415,8 +415,9 @@ def main():
                     help="synthetic stand-in: Gaussian clusters, or |N(0,1)|*40 clipped to [0,218]")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
-    ap.add_argument("--scan-form", type=int, default=1,
-                    help="tk_set_scan_form (A/B): 1 table rows through LDS, 4 waves/SIMD; 2 LDS, 3 waves; 0 global loads")
+    ap.add_argument("--scan-form", type=int, default=0,
+                    help="tk_set_scan_form (A/B): 0 table rows by per-lane global loads (default, fastest); "
+                         "1 rows through LDS, 4 waves/SIMD; 2 LDS, 3 waves/SIMD")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="replay streams (tk_index_set_pipeline): caller + coarse stream + these = 4 HW queues")
     ap.add_argument("--workload", choices=["glove", "c5like"], default="glove",

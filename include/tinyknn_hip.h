@@ -217,10 +217,11 @@ int tk_index_set_heap_mode(tk_index *ix, int mode);
 int tk_index_set_scan_mode(tk_index *ix, int mode);
 
 /* Form of the list-major scan kernel (process-wide; A/B timing, identical outputs).
- * 1 (default) = the table rows a 64-unit block needs are staged once per block in the wave's
+ * 1 = the table rows a 64-unit block needs are staged once per block in the wave's
  * LDS region and read with ds_read_b128, one query's rows live at a time (4 waves per SIMD);
  * 2 = rows through LDS, 3 waves per SIMD; 0 = per-lane global loads of the rows (round-1
- * form).  Tables with more than 156 blocks fall back to 0. */
+ * form; DEFAULT: measured faster, profiles/r02_scan_forms.md).  Tables with more than 156 blocks
+ * fall back to 0. */
 int tk_set_scan_form(int form);
 
 /* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
@@ -286,6 +287,9 @@ int tk_index_query_batch_dev_ex(tk_index *ix, const float *q_dev, const void *q_
                                 int64_t *out_ids_dev, int64_t *out_ids_pinned, void *done_event,
                                 void *stream);
 int64_t tk_index_max_sub_batch(tk_index *ix, int k, int n_probes, int pass_1);
+/* hipStream_t on which to copy a batch's inputs in (pipelined mode: the index's front stream,
+ * where the batch's first kernel runs; NULL: use the stream the batch is enqueued on) */
+void *tk_index_input_stream(tk_index *ix);
 int tk_index_pending(tk_index *ix);
 /* info8 = {d, dq, M, n_lists, rotation d_pad (0: none), pipeline depth, N, total chunks} */
 int tk_index_info(tk_index *ix, int64_t *info8);

@@ -55,24 +55,24 @@ def test_wait_in_any_order_and_prepared_rows(tk):
     qs = np.ascontiguousarray(g["qs"], dtype=np.float32)
     k, n_probes = 10, 5
     want = g[f"ids_p{n_probes}"]
-    st = dev.stream(8, k, n_probes, slots=8)
+    st = dev.stream(4, k, n_probes, slots=8)
     outs, tickets = [], []
-    for o in range(0, 48, 8):
-        out = np.full((8, k), -7, dtype=np.int64)
-        tickets.append(st.submit(qs[o:o + 8], out))
+    for o in range(0, 24, 4):
+        out = np.full((4, k), -7, dtype=np.int64)
+        tickets.append(st.submit(qs[o:o + 4], out))
         outs.append(out)
     for j in (5, 0, 3):            # newest first: forces the pipeline flush
         st.wait(tickets[j])
-        np.testing.assert_array_equal(outs[j], want[8 * j:8 * j + 8])
+        np.testing.assert_array_equal(outs[j], want[4 * j:4 * j + 4])
     st.wait(tickets[5])            # twice is harmless
     # prepared rows through the same session
-    qn, qp = ivf._prepare(qs[:8].copy())
-    out = np.full((8, k), -7, dtype=np.int64)
+    qn, qp = ivf._prepare(qs[:4].copy())
+    out = np.full((4, k), -7, dtype=np.int64)
     st.wait(st.submit_prepared(qn, None, out))
-    np.testing.assert_array_equal(out, want[:8])
+    np.testing.assert_array_equal(out, want[:4])
     st.drain()
     for j in range(6):
-        np.testing.assert_array_equal(outs[j], want[8 * j:8 * j + 8])
+        np.testing.assert_array_equal(outs[j], want[4 * j:4 * j + 4])
     st.close()
     dev.set_pipeline(1)
 

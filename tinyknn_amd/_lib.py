@@ -90,6 +90,7 @@ SIGNATURES = {
                                               C.c_void_p, C.c_void_p]),
     "tk_index_max_sub_batch": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tk_index_pending": (C.c_int, [C.c_void_p]),
+    "tk_index_input_stream": (C.c_void_p, [C.c_void_p]),
     "tk_index_info": (C.c_int, [C.c_void_p, _i64p]),
     "tk_stream_create": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_int, C.c_int]),

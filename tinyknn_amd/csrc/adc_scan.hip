@@ -806,8 +806,8 @@ void tk_launch_identity_pairs(int64_t nq, int chunks, int *pair_off, int *unit_p
 }
 
 // form of the list-major kernel (tk_set_scan_tables: A/B switch; see scan_units_kernel)
-static int g_scan_form = 1;
-void tk_set_scan_tables(int form) { g_scan_form = form < 0 || form > 2 ? 1 : form; }
+static int g_scan_form = 0;   // measured (profiles/r02_scan_forms.md): the global-load form wins
+void tk_set_scan_tables(int form) { g_scan_form = form < 0 || form > 2 ? 0 : form; }
 int tk_get_scan_tables(void) { return g_scan_form; }
 
 template <typename K>

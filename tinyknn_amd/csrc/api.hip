@@ -1401,6 +1401,19 @@ extern "C" int64_t tk_index_max_sub_batch(tk_index *ix, int k, int n_probes, int
     return sub_batch(p);
 }
 
+// Stream on which a caller should copy a batch's inputs in: the front stream in pipelined
+// mode (the table build, a batch's first kernel, runs there; a fifth stream of the caller's
+// would share one of HIP's four hardware queues and serialise with a replay stream), NULL
+// = the stream the batch is enqueued on.
+extern "C" void *tk_index_input_stream(tk_index *ix)
+{
+    if (!ix || ix->depth <= 1) return nullptr;
+    if (!ix->front_stream &&
+        hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking) != hipSuccess)
+        return nullptr;
+    return ix->front_stream;
+}
+
 extern "C" int tk_index_pending(tk_index *ix) { return ix ? (int)ix->pending.size() : 0; }
 
 extern "C" int tk_index_info(tk_index *ix, int64_t *info8)

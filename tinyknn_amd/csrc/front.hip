@@ -297,7 +297,7 @@ struct tk_stream {
     std::vector<double> R;
     int64_t max_nq = 0;
     std::vector<StreamSlot> slots;
-    hipStream_t copy_st = nullptr, comp_st = nullptr;
+    hipStream_t comp_st = nullptr;
     int64_t submitted = 0;
     double prep_s = 0;      // host preparation time, summed over submits
 };
@@ -315,7 +315,6 @@ static void stream_free(tk_stream *s)
         if (x.in_done) (void)hipEventDestroy(x.in_done);
         if (x.out_done) (void)hipEventDestroy(x.out_done);
     }
-    if (s->copy_st) (void)hipStreamDestroy(s->copy_st);
     if (s->comp_st) (void)hipStreamDestroy(s->comp_st);
     delete s;
 }
@@ -352,8 +351,7 @@ extern "C" tk_stream *tk_stream_create(tk_index *ix, int64_t max_nq, int k, int 
     s->angular = angular; s->rotated = R != nullptr; s->d_pad = R ? d_pad : dq; s->max_nq = max_nq;
     if (R) s->R.assign(R, R + (size_t)dq * d_pad);
     s->slots.resize((size_t)n_slots);
-    bool ok = hipStreamCreateWithFlags(&s->copy_st, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&s->comp_st, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&s->comp_st, hipStreamNonBlocking) == hipSuccess;
     for (StreamSlot &x : s->slots) {
         if (!ok) break;
         ok = hipHostMalloc((void **)&x.h_q, (size_t)max_nq * d * 4, hipHostMallocDefault) == hipSuccess &&
@@ -394,17 +392,23 @@ static int stream_collect(tk_stream *s, StreamSlot &x)
 // stage 2 of a submit: slot x holds the prepared rows in pinned memory
 static int64_t stream_enqueue(tk_stream *s, StreamSlot &x, int64_t nq, int64_t *out_ids)
 {
-    FHIP(hipMemcpyAsync(x.d_q, x.h_q, (size_t)nq * s->d * 4, hipMemcpyHostToDevice, s->copy_st));
+    // inputs go in on the stream where the batch's first kernel runs (no stream of our own:
+    // HIP has four hardware queues and the pipelined index uses them all)
+    hipStream_t in_st = (hipStream_t)tk_index_input_stream(s->ix);
+    if (!in_st) in_st = s->comp_st;
+    FHIP(hipMemcpyAsync(x.d_q, x.h_q, (size_t)nq * s->d * 4, hipMemcpyHostToDevice, in_st));
     if (s->rotated)
-        FHIP(hipMemcpyAsync(x.d_qp, x.h_qp, (size_t)nq * s->dq * 8, hipMemcpyHostToDevice, s->copy_st));
-    FHIP(hipEventRecord(x.in_done, s->copy_st));
-    FHIP(hipStreamWaitEvent(s->comp_st, x.in_done, 0));
+        FHIP(hipMemcpyAsync(x.d_qp, x.h_qp, (size_t)nq * s->dq * 8, hipMemcpyHostToDevice, in_st));
     const void *qp = x.d_q;
     if (!s->rotated && s->dq > s->d) {     // pad1: zeros behind the row, exact
-        tk_launch_prepare_queries(x.d_q, nq, s->d, nullptr, s->dq, s->dq, x.d_qp, s->comp_st);
+        tk_launch_prepare_queries(x.d_q, nq, s->d, nullptr, s->dq, s->dq, x.d_qp, in_st);
         qp = x.d_qp;
     } else if (s->rotated) {
         qp = x.d_qp;
+    }
+    if (in_st != s->comp_st) {
+        FHIP(hipEventRecord(x.in_done, in_st));
+        FHIP(hipStreamWaitEvent(s->comp_st, x.in_done, 0));
     }
     int r = tk_index_query_batch_dev_ex(s->ix, x.d_q, qp, s->rotated ? 1 : 0, nq, s->k, s->n_probes,
                                         s->pass_1, x.d_out, x.h_out, x.out_done, s->comp_st);
