@@ -4,6 +4,12 @@ import sys
 import numpy as np
 import pytest
 
+# torch first: its wheel bundles its own HIP runtime under the soname libtinyknn_hip.so asks
+# for, so loaded in this order the process holds ONE runtime (as bench.py's does).  The other
+# order maps /opt/rocm's runtime for the library and a second one for torch, whose
+# initialisation then fails on the GPU box ("No HIP GPUs are available").
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

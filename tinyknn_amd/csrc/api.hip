@@ -613,6 +613,7 @@ struct tk_index {
     // index-static descriptors of the coarse stage, staging buffers of the host API
     DevBuf cslots_i, cslots_l, c_chunk_off, q, qpq, stage;
     int scan_mode = 0;         // 0 auto, 1 query-major kernel, 2 list-major (units) kernel
+    bool host_out_kernel = false;   // a batch's pinned host copy of the ids is written by a kernel
     // per-batch workspaces: `depth` batches may be in flight (tk_index_set_pipeline),
     // each on its own internal stream
     std::vector<Work> works;
@@ -1164,6 +1165,7 @@ struct Pending {
     bool units;
     bool coarse_launched;   // its coarse scan has been enqueued
     int64_t *host_out;      // pinned host copy of the ids, enqueued behind the rescoring (or NULL)
+    bool host_out_kernel;   // ... written by copy_words_kernel instead of the copy engine
     hipEvent_t user_ev;     // recorded behind that copy (or NULL)
     Prof pf;
     hipStream_t st, sf, sl;   // scans (+ tables) / coarse replay + descriptors / replay + rescoring
@@ -1294,7 +1296,9 @@ static int pipeline_advance(tk_index *ix, bool drain)
 // what the caller of tk_index_query_batch_dev_ex asked for behind a batch's last kernel
 static int batch_epilogue(const Pending &b, hipStream_t st)
 {
-    if (b.host_out)
+    if (b.host_out && b.host_out_kernel)
+        tk_launch_copy_words(b.out_dev, b.nq * b.k, b.host_out, st);
+    else if (b.host_out)
         HIPCHECK(hipMemcpyAsync(b.host_out, b.out_dev, (size_t)b.nq * b.k * 8, hipMemcpyDeviceToHost, st));
     if (b.user_ev) HIPCHECK(hipEventRecord(b.user_ev, st));
     return TK_OK;
@@ -1336,6 +1340,7 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         b.units = false;
         b.coarse_launched = false;
         b.host_out = out_ids_pinned;
+        b.host_out_kernel = ix->host_out_kernel;
         b.user_ev = done_ev;
         b.st = b.sf = b.sl = caller;
         const void *qpq = (const char *)q_pq_dev + (size_t)o * ix->dq * esz;
@@ -1393,6 +1398,8 @@ extern "C" int tk_index_query_batch_dev_ex(tk_index *ix, const float *q_dev, con
     return query_batch_dev_impl(ix, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1,
                                 out_ids_dev, out_ids_pinned, (hipEvent_t)done_event, stream);
 }
+
+void tk_index_host_out_by_kernel(tk_index *ix, bool on) { ix->host_out_kernel = on; }   // front.hip
 
 extern "C" int64_t tk_index_max_sub_batch(tk_index *ix, int k, int n_probes, int pass_1)
 {

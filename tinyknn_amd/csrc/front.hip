@@ -276,6 +276,80 @@ extern "C" int tk_prepare_queries_host(const float *q_raw, int64_t nq, int d, in
         }                                                                                    \
     } while (0)
 
+// How a session moves a batch's rows between page-locked host memory and HBM.
+//   0  hipMemcpyAsync (copy engine) on the index's input stream + the pad kernel; ids back by
+//      hipMemcpyAsync behind the rescoring kernel
+//   1  (default) kernels that read / write the page-locked buffers directly over PCIe: one
+//      ingest launch (copy + pad1 in one pass) and one egress launch, so that a stream never
+//      alternates between copy-engine commands and kernel dispatches
+// env TINYKNN_STREAM_COPY; A/B in profiles/r02_raw_stream_ab.md
+static int stream_copy_mode()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("TINYKNN_STREAM_COPY");
+        mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return mode;
+}
+
+// rows of page-locked host memory -> q (nq, d) and, when dq > d, the zero-padded table-build
+// rows (nq, dq) (fast_pq.py:202 pad1), 16 bytes per lane and load where the row length allows
+__global__ void ingest_rows_kernel(const float *__restrict__ src, int64_t nq, int d, int dq,
+                                   float *__restrict__ q, float *__restrict__ qpad)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nt = (int64_t)gridDim.x * blockDim.x;
+    if ((d & 3) == 0 && (dq & 3) == 0) {
+        const int d4 = d >> 2, dq4 = dq >> 2;
+        const float4 *s4 = (const float4 *)src;
+        float4 *q4 = (float4 *)q, *p4 = (float4 *)qpad;
+        for (int64_t i = tid; i < nq * d4; i += nt) {
+            const float4 v = s4[i];
+            q4[i] = v;
+            if (qpad) {
+                const int64_t r = i / d4;
+                p4[r * dq4 + (i - r * d4)] = v;
+            }
+        }
+        if (qpad)
+            for (int64_t i = tid; i < nq * (dq4 - d4); i += nt) {
+                const int64_t r = i / (dq4 - d4);
+                p4[r * dq4 + d4 + (i - r * (dq4 - d4))] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        return;
+    }
+    for (int64_t i = tid; i < nq * d; i += nt) {
+        const float v = src[i];
+        q[i] = v;
+        if (qpad) {
+            const int64_t r = i / d;
+            qpad[r * dq + (i - r * d)] = v;
+        }
+    }
+    if (qpad)
+        for (int64_t i = tid; i < nq * (dq - d); i += nt) {
+            const int64_t r = i / (dq - d);
+            qpad[r * dq + d + (i - r * (dq - d))] = 0.f;
+        }
+}
+
+// n 8-byte words HBM -> page-locked host memory (or any other pair of device-visible buffers)
+__global__ void copy_words_kernel(const uint64_t *__restrict__ src, int64_t n, uint64_t *__restrict__ dst)
+{
+    const int64_t nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nt) dst[i] = src[i];
+}
+
+void tk_launch_copy_words(const void *src, int64_t n_words, void *dst, hipStream_t st)
+{
+    if (n_words <= 0) return;
+    int64_t g = (n_words + 255) / 256;
+    if (g > 128) g = 128;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)g), dim3(256), 0, st, (const uint64_t *)src,
+                       n_words, (uint64_t *)dst);
+}
+
 struct StreamSlot {
     float *h_q = nullptr;
     double *h_qp = nullptr;
@@ -351,7 +425,16 @@ extern "C" tk_stream *tk_stream_create(tk_index *ix, int64_t max_nq, int k, int 
     s->angular = angular; s->rotated = R != nullptr; s->d_pad = R ? d_pad : dq; s->max_nq = max_nq;
     if (R) s->R.assign(R, R + (size_t)dq * d_pad);
     s->slots.resize((size_t)n_slots);
-    bool ok = hipStreamCreateWithFlags(&s->comp_st, hipStreamNonBlocking) == hipSuccess;
+    // The scan chain of the session runs on the NULL stream: HIP maps streams onto four
+    // hardware queues and the pipelined index already owns three (front + two replay streams);
+    // a stream of our own would be a fifth whenever anything in the process has touched the
+    // NULL stream (torch does), and was seen to land on the queue of a replay stream, which
+    // serialised the two replays: 1.03 ms per batch instead of 0.7 (profiles/r02_raw_stream_ab.md).
+    // TINYKNN_STREAM_OWN_STREAM=1 creates one anyway (a caller that keeps the NULL stream busy).
+    bool ok = true;
+    const char *own = getenv("TINYKNN_STREAM_OWN_STREAM");
+    if (own && own[0] == '1')
+        ok = hipStreamCreateWithFlags(&s->comp_st, hipStreamNonBlocking) == hipSuccess;
     for (StreamSlot &x : s->slots) {
         if (!ok) break;
         ok = hipHostMalloc((void **)&x.h_q, (size_t)max_nq * d * 4, hipHostMallocDefault) == hipSuccess &&
@@ -396,20 +479,30 @@ static int64_t stream_enqueue(tk_stream *s, StreamSlot &x, int64_t nq, int64_t *
     // HIP has four hardware queues and the pipelined index uses them all)
     hipStream_t in_st = (hipStream_t)tk_index_input_stream(s->ix);
     if (!in_st) in_st = s->comp_st;
-    FHIP(hipMemcpyAsync(x.d_q, x.h_q, (size_t)nq * s->d * 4, hipMemcpyHostToDevice, in_st));
-    if (s->rotated)
-        FHIP(hipMemcpyAsync(x.d_qp, x.h_qp, (size_t)nq * s->dq * 8, hipMemcpyHostToDevice, in_st));
     const void *qp = x.d_q;
-    if (!s->rotated && s->dq > s->d) {     // pad1: zeros behind the row, exact
-        tk_launch_prepare_queries(x.d_q, nq, s->d, nullptr, s->dq, s->dq, x.d_qp, in_st);
-        qp = x.d_qp;
-    } else if (s->rotated) {
-        qp = x.d_qp;
+    const bool pad = !s->rotated && s->dq > s->d;     // pad1: zeros behind the row, exact
+    if (stream_copy_mode() == 1) {
+        const int64_t items = nq * (int64_t)s->d / 4;
+        int64_t g = (items + 255) / 256;
+        g = g < 1 ? 1 : (g > 256 ? 256 : g);
+        hipLaunchKernelGGL(ingest_rows_kernel, dim3((unsigned)g), dim3(256), 0, in_st, x.h_q, nq, s->d,
+                           s->dq, x.d_q, pad ? (float *)x.d_qp : nullptr);
+        if (s->rotated)
+            tk_launch_copy_words(x.h_qp, nq * (int64_t)s->dq, x.d_qp, in_st);
+    } else {
+        FHIP(hipMemcpyAsync(x.d_q, x.h_q, (size_t)nq * s->d * 4, hipMemcpyHostToDevice, in_st));
+        if (s->rotated)
+            FHIP(hipMemcpyAsync(x.d_qp, x.h_qp, (size_t)nq * s->dq * 8, hipMemcpyHostToDevice, in_st));
+        if (pad) tk_launch_prepare_queries(x.d_q, nq, s->d, nullptr, s->dq, s->dq, x.d_qp, in_st);
     }
-    if (in_st != s->comp_st) {
-        FHIP(hipEventRecord(x.in_done, in_st));
-        FHIP(hipStreamWaitEvent(s->comp_st, x.in_done, 0));
-    }
+    if (pad || s->rotated) qp = x.d_qp;
+    // No hand-over to the compute stream: in pipelined mode the rows arrive on the index's front
+    // stream, where the batch's first kernel (the table build) is enqueued next, and every
+    // later consumer of the batch is ordered behind that kernel by the index's own events.
+    // (Making the compute stream wait for them put each scan launch behind the previous
+    // batch's coarse replay: 0.5 ms of idle chip per batch, profiles/r02_raw_stream_ab.md.)
+    // mode 1: the ids leave through copy_words_kernel instead of the copy engine
+    tk_index_host_out_by_kernel(s->ix, stream_copy_mode() == 1);
     int r = tk_index_query_batch_dev_ex(s->ix, x.d_q, qp, s->rotated ? 1 : 0, nq, s->k, s->n_probes,
                                         s->pass_1, x.d_out, x.h_out, x.out_done, s->comp_st);
     if (r != TK_OK) return r;
@@ -483,6 +576,6 @@ extern "C" void tk_stream_destroy(tk_stream *s)
 {
     if (!s) return;
     (void)tk_stream_drain(s);
-    (void)hipStreamSynchronize(s->comp_st);
+    (void)hipStreamSynchronize(s->comp_st);      // (the NULL stream when comp_st is null)
     stream_free(s);
 }

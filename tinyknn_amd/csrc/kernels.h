@@ -180,6 +180,10 @@ void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_
 int tk_launch_encode_pq(const float *centers, int dq, int dpb, const void *data, int is_f64,
                         int64_t n, uint8_t *labels, hipStream_t s);
 // out = X / np.linalg.norm(X, axis=1, keepdims=True), float32 rows, d <= 128
+// front.hip <-> api.hip (not part of the C ABI)
+struct tk_index;
+void tk_launch_copy_words(const void *src, int64_t n_words, void *dst, hipStream_t st);
+void tk_index_host_out_by_kernel(tk_index *ix, bool on);
 void tk_launch_normalise_rows(const float *X, int64_t n, int d, float *out, hipStream_t s);
 // knn_brute(X, Y, k <= 2, "euclidean"): Yt (d, L) = Y transposed, ynorm2 (L,) = einsum |y|^2,
 // float32 or float64 both; nearest (n, k)
