@@ -13,13 +13,17 @@ the reference's host code does (ivf.py:125-127), when the timed region starts.
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: replicas — every rank holds the whole index (0.5 GB of 288 GB) and owns its
-own batch of queries; no data-path collective; "weak".
-After that measurement a second, untimed-for-`value` leg runs the LIST-SHARDED index
-(lists partitioned by cluster id, one RCCL all-to-all of int8 distance bytes + the
-all-gather of the ids per batch) on one shared batch, checks its ids
-against the replica's and reports it under "list_sharded" (`--shard lists` forces it
-at N = 1, `--shard none` skips it).  Prints ONE JSON line on rank 0.
+N > 1: `value` is the LIST-SHARDED index (north_star's split): inverted
+lists partitioned by cluster id over the ranks, ONE shared batch of --nq queries per
+step ("strong": the work per step does not grow with N), per batch the coarse stage
+of a rank's home queries, an all-gather of the probe lists, the scan of the owned
+(query, list) segments, one RCCL all-to-all of int8 distance bytes, the exact replay
+on the home rank and the all-gather of the ids; its ids are checked against the
+unsharded pipeline's.  The replica rate (every rank holds the whole index and answers
+its own batch, no data-path collective, "weak") is measured first and reported under
+"replica"; it is what `value` falls back to, with "list_sharded.error" set and a
+non-zero exit code, if the sharded leg fails (`--shard lists` forces the leg at N = 1,
+`--shard none` skips it).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -215,7 +219,7 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
                         args.n_probes, want.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     want = want.cpu().numpy()
-    idx = ListShardedIndex(ivf, depth=args.pipeline)
+    idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse)
     got = idx.query_prepared(qn_t, qp_t, args.k, args.n_probes)     # also settles the capacity
     same = int((got == want).all(axis=1).sum())
     for _ in range(max(1, args.warmup)):
@@ -244,8 +248,14 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
             "overflow_in_timed_steps": bool(g.cpu().numpy()[:, -1].any()),
             "exchange": {"all_to_all_bytes_per_rank_per_step": int(world * cap * 16),
                          "region_capacity_uint4": int(cap),
+                         "probe_all_gather_bytes_per_rank_per_step":
+                             int(-(-args.nq // world) * min(args.n_probes, len(idx.list_sizes)) * 8)
+                             if args.shard_coarse == "home" else 0,
                          "all_gather_bytes_per_rank_per_step": int((-(-args.nq // world) * args.k + 1) * 8)},
-            "code_chunks_per_rank": [int(x) for x in load], "batches_in_flight": args.pipeline}
+            "coarse_stage": args.shard_coarse + (" (tables for all queries, coarse scan/replay/rescoring of the "
+                                                 "rank's nq/W home queries, probe lists all-gathered)"
+                                                 if args.shard_coarse == "home" else " on every rank"),
+            "code_chunks_per_rank": [int(x) for x in load], "batches_in_flight": args.shard_depth}
 
 
 def raw_stream_leg(args, dev, qs, out_dev, device, world):
@@ -425,6 +435,11 @@ def main():
                          "implies --n 20000000 --d 128 --n-clusters 4472 --metric euclidean unless given")
     ap.add_argument("--shard", choices=["auto", "none", "lists"], default="auto",
                     help="list-sharded leg after the replica measurement (auto: when N > 1)")
+    ap.add_argument("--shard-depth", type=int, default=3,
+                    help="list-sharded leg: batches in flight (each on its own stream)")
+    ap.add_argument("--shard-coarse", choices=["home", "replicated"], default="home",
+                    help="list-sharded leg: coarse stage of the home queries + probe all-gather, or of all "
+                         "queries on every rank")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the >= 1 GiB streaming scan leg")
     ap.add_argument("--traffic", choices=["auto", "none"], default="auto",
                     help="auto: HBM bytes of the scan launch from rocprofv3 --pmc child runs of this "
@@ -766,13 +781,33 @@ def main():
         wd.daemon = True
         wd.start()
         try:
-            line["list_sharded"] = list_sharded_leg(args, ivf, cent, dev, device, world, rank)
+            line["list_sharded"] = ls = list_sharded_leg(args, ivf, cent, dev, device, world, rank)
         except Exception as e:
             # the other ranks may be waiting in a collective: do not join them again
             line["list_sharded"] = {"error": repr(e)}
             print(json.dumps(line), flush=True)
             os._exit(3)
         wd.cancel()
+        if world > 1:
+            # N > 1: the north_star split is the measured one; the replica rate stays beside it
+            line["replica"] = {"queries_per_s": line["value"], "ms_per_step": line["ms_per_step"],
+                               "scaling": "weak (every rank its own batch of %d queries, whole index per rank, "
+                                          "no data-path collective)" % args.nq}
+            line["value"] = ls["queries_per_s"]
+            line["ms_per_step"] = ls["ms_per_step"]
+            line["scaling"] = "strong"
+            line["config"]["parallelism"] = (f"inverted lists sharded by cluster id x{world}, queries broadcast "
+                                             f"(one shared batch of {args.nq} per step), RCCL all-gather of probe "
+                                             "lists + all-to-all of int8 distances + all-gather of ids")
+            line["config"]["queries_per_step_total"] = args.nq
+            line["config"]["batches_in_flight"] = args.shard_depth
+            for key in ("roofline", "stage_ms", "isolated", "hipgraph", "host_boundary", "fast_front_end",
+                        "raw_in_ids_out"):
+                if key in line:      # measured in the replica region: say so
+                    line["replica"][key] = line.pop(key)
+            line["roofline"] = dict(line["replica"]["roofline"],
+                                    note="scan launch of the REPLICA region (the sharded leg runs the same "
+                                         "kernel on this rank's 1/%d of the (query, list) segments)" % world)
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

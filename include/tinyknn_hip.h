@@ -235,6 +235,42 @@ int tk_set_scan_form(int form);
 int tk_index_set_profiling(tk_index *ix, int on);
 int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches);
 
+/* ---- device-resident build ----------------------------------------
+ * IVF.build(X, n_probes = 1) (ivf.py:77-102) for float32 vectors that are produced IN HBM
+ * and never visit the host — how the 100M x 128 configuration is assembled ("per-GPU
+ * generation on device (seeded per shard), codes produced by the build's encoder").
+ * tk_index_alloc_data: after tk_index_set_pq; the index allocates its (N, d) float32
+ *   rescoring vectors and returns the device pointer for the caller to fill (NULL on error).
+ * tk_index_synth_data: fills rows [row0, row0 + n) with centres[c(row)] + sigma * N(0, 1)
+ *   from a counter-based generator — a pure function of (seed, row, column), independent of
+ *   how the rows are split over calls or ranks; centres: host (n_centres, d) float32 or NULL
+ *   (noise only).  tk_synth_rows: the same generator into a host buffer (queries, samples).
+ * tk_index_build_dev: normalise != 0 divides every row by its norm first (ivf.py:78-79);
+ *   nearest of the C centres per row (knn_brute(data, all_centers, 1), ivf.py:85:
+ *   search_centers (C, d) float32 = all_centers after knn_brute's own normalisation for the
+ *   angular metric (utils.py:75; NULL: all_centers themselves), ynorm2 its einsum norms),
+ *   active centres = the rows of all_centers that own a vector, in id order (ivf.py:91), PQ codes of
+ *   every row and of the active centres (R (dq, d_pad) float64 = FastPQ.R or NULL; the
+ *   rotation is the float64 FMA chain of the device front end, not numpy's DGEMM), rows
+ *   grouped by list in ASCENDING ROW ORDER (numpy's unstable argsort leaves the order inside
+ *   a list unspecified, utils.py:131), packed into the Quick-ADC layout.  The index is then
+ *   complete (centres, lists, data).  n_active_out: number of lists.
+ * tk_index_export_lists / _centers / tk_index_read_rows: what a built index holds, back on
+ *   the host in the reference's formats (list_sizes (n_lists,), packed codes (sum
+ *   ceil(size/16), M) uint64, ids (sum size,); active centres and their packed codes; rows of
+ *   IVF.data by id) — any output may be NULL. */
+float *tk_index_alloc_data(tk_index *ix, int64_t N, int d);
+int tk_index_synth_data(tk_index *ix, int64_t row0, int64_t n, uint64_t seed, const float *centres,
+                        int n_centres, float sigma);
+int tk_synth_rows(float *out, int64_t row0, int64_t n, int d, uint64_t seed, const float *centres,
+                  int n_centres, float sigma);
+int tk_index_build_dev(tk_index *ix, int normalise, const float *all_centers,
+                       const float *search_centers, const float *ynorm2, int64_t C, const double *R,
+                       int d_pad, int64_t *n_active_out);
+int tk_index_export_lists(tk_index *ix, int64_t *list_sizes, uint64_t *codes, int64_t *ids);
+int tk_index_export_centers(tk_index *ix, float *active_centers, uint64_t *center_codes);
+int tk_index_read_rows(tk_index *ix, const int64_t *rows, int64_t n, float *out);
+
 /* ---- device front end, "fast mode"  -----------------------------------
  * What IVF.query does on the host before the table build (ivf.py:125-128,
  * fast_pq.py:200-204): float32 normalisation for the angular metric, zero padding to dq,
@@ -338,25 +374,38 @@ int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int k, int64_t 
  * (ivf.py:137-150), so partial top-k's do not merge; the exchange carries the int8 distance
  * bytes to the query's home rank (query i lives on rank i / ceil(nq/world)), which replays
  * the heap exactly as the unsharded index does.  One batch =
- *   tk_index_shard_scan_dev    tables + coarse stage for all nq queries, then the owned
- *                              (query, list) segments scored straight into `send_dev`:
- *                              `world` regions of `capacity` uint4 (16 distances each),
- *                              region h = my segments of rank h's queries, in (query,
+ *   tk_index_shard_coarse_dev  distance tables for all nq queries, then the coarse stage
+ *                              (dtable.top(centers), ivf.py:131) of this rank's HOME queries
+ *                              only; probes_home_dev: int64 (ceil(nq/world), min(n_probes,
+ *                              n_lists)), rows past nq = 0;
+ *   all-gather of the probes   -> probes_all (world * ceil(nq/world), ...) = the probe lists
+ *                              of all queries in query order (RCCL, by the caller);
+ *   tk_index_shard_scan_dev    the owned (query, list) segments scored straight into
+ *                              `send_dev`: `world` regions of `capacity` uint4 (16 distances
+ *                              each), region h = my segments of rank h's queries, in (query,
  *                              probe slot) order; *flag_dev |= 1 if a region overflowed
- *                              (repeat the batch with a larger capacity);
+ *                              (repeat the batch with a larger capacity).  probes_all_dev ==
+ *                              NULL: the replicated form — this call builds the tables and
+ *                              runs the coarse stage for ALL queries itself (no coarse call,
+ *                              no probe all-gather; 1/3 of a batch's work is then not
+ *                              divided by `world`);
  *   all-to-all(send -> recv)   equal splits of capacity*16 bytes (RCCL, by the caller);
  *   tk_index_shard_finish_dev  received segments -> distance rows of the home queries,
  *                              heap replay, rescoring; out_ids_home_dev: int64
  *                              (ceil(nq/world), k), rows past nq and missing ids = -1;
  *   all-gather of the id rows  (by the caller).
- * Both calls enqueue on `stream` and use workspace `slot` (< pipeline depth), so that
+ * All calls enqueue on `stream` and use workspace `slot` (< pipeline depth), so that
  * several batches can be in flight on different streams.  nq <= 32768 per batch. */
 int tk_index_set_lists_shard(tk_index *ix, const int64_t *list_sizes, const int32_t *owner,
                              int rank, int world, const uint64_t *codes_owned,
                              const int64_t *ids);
+int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
+                              int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                              int64_t *probes_home_dev, void *stream);
 int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
                             int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
-                            int64_t capacity, void *send_dev, int *flag_dev, void *stream);
+                            const int64_t *probes_all_dev, int64_t capacity, void *send_dev,
+                            int *flag_dev, void *stream);
 int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq, int k,
                               int n_probes, int pass_1, int64_t capacity, const void *recv_dev,
                               int64_t *out_ids_home_dev, void *stream);

@@ -34,9 +34,27 @@ class OracleShardEngine:
             self.O.estimate_pq(codes, table, out, True)
         return out.view(np.uint8)
 
-    def scan(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag):
+    def coarse(self, slot, qn, qp, k, n_probes, pass_1, probes_home):
+        """Probe lists of this rank's home queries only (rows past nq: 0)."""
+        qn = qn.numpy()
+        qh = -(-len(qn) // self.world)
+        out = probes_home.numpy().reshape(qh, -1)
+        out[:] = 0
+        lo, hi = self.rank * qh, min(len(qn), (self.rank + 1) * qh)
+        if hi > lo:
+            for i in range(lo, hi):
+                _, dbg = self.ox.query(qn[i], k, n_probes, pass_1, debug=True)
+                out[i - lo] = dbg["probes"]        # unwrapped, as the coarse stage leaves them
+        self.coarse_calls = getattr(self, "coarse_calls", 0) + 1
+
+    def scan(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None):
         qn = qn.numpy()
         probes, tables = self._front(qn, k, n_probes, pass_1)
+        if probes_all is not None:
+            # the gathered probe lists must be what every rank would have derived itself
+            got = probes_all.numpy().reshape(-1, probes.shape[1])[:len(qn)].copy()
+            got[got < 0] += self.ox.n_lists
+            np.testing.assert_array_equal(got, probes)
         src, pos = shard_positions(probes, self.chunks, self.owner, self.world, capacity)
         buf = send.numpy().reshape(self.world, capacity * 16)
         buf[:] = 0xAB                               # stale bytes must never be consumed

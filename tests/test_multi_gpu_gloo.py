@@ -53,7 +53,7 @@ def test_replica_group_two_ranks(nq):
         np.testing.assert_array_equal(ret[r], exp)
 
 
-def _shard_worker(rank, world, port, tag, nq, k, n_probes, tiny, ret):
+def _shard_worker(rank, world, port, tag, nq, k, n_probes, tiny, coarse, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -74,33 +74,39 @@ def _shard_worker(rank, world, port, tag, nq, k, n_probes, tiny, ret):
 
         owner = shard_lists(g["list_sizes"], world)
         eng = OracleShardEngine(O, ox, owner, rank, world)
-        idx = ListShardedIndex(HostSide(), engine=eng, owner=owner, list_sizes=g["list_sizes"])
+        idx = ListShardedIndex(HostSide(), engine=eng, owner=owner, list_sizes=g["list_sizes"],
+                               coarse=coarse)
         if tiny:
             idx.capacity[(nq, n_probes)] = 3      # overflows: the batch must be repeated
         out = idx.query_batch(g["qn"][:nq], k, n_probes)
-        ret[rank] = (out, idx.capacity[(nq, n_probes)])
+        ret[rank] = (out, idx.capacity[(nq, n_probes)], getattr(eng, "coarse_calls", 0))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nq,tiny", [(2, 24, False), (2, 7, True), (3, 24, False), (2, 1, False)])
-def test_list_sharded_index_gloo(world, nq, tiny):
-    """Lists sharded by cluster id over `world` gloo ranks: the all-to-all carries every
-    segment to the right place of the right home rank (checked byte for byte by the CPU
-    engine), overflow repeats the batch, ids equal the reference's on every rank."""
+@pytest.mark.parametrize("world,nq,tiny,coarse", [(2, 24, False, "home"), (2, 7, True, "home"),
+                                                  (3, 24, False, "home"), (2, 1, False, "home"),
+                                                  (3, 23, False, "home"), (2, 24, False, "replicated"),
+                                                  (3, 7, True, "replicated")])
+def test_list_sharded_index_gloo(world, nq, tiny, coarse):
+    """Lists sharded by cluster id over `world` gloo ranks: the probe lists of the home queries
+    are all-gathered (coarse="home": checked against every rank's own derivation by the CPU
+    engine), the all-to-all carries every segment to the right place of the right home rank
+    (checked byte for byte), overflow repeats the batch, ids equal the reference's on every rank."""
     import torch.multiprocessing as mp
     from conftest import golden
     tag, k, n_probes = "an100", 10, 5
     port = 31500 + (os.getpid() * 7 + nq + world) % 2000
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_shard_worker, args=(world, port, tag, nq, k, n_probes, tiny, ret), nprocs=world,
+    mp.spawn(_shard_worker, args=(world, port, tag, nq, k, n_probes, tiny, coarse, ret), nprocs=world,
              join=True)
     g = golden(f"g6_ivf_{tag}.npz")
     exp = g[f"ids_p{n_probes}"][:nq]
     for r in range(world):
         np.testing.assert_array_equal(ret[r][0], exp)
         assert not tiny or ret[r][1] > 3
+        assert (ret[r][2] > 0) == (coarse == "home")
 
 
 def test_shard_lists_and_capacity():

@@ -1,0 +1,119 @@
+"""Device-resident build (tk_index_build_dev): vectors generated in HBM,
+lists and codes built on the device.  Checked (a) against IVF.build on the same vectors brought
+to the host — same active centres, same list memberships, same codes — and (b) end to end
+against the CPU oracle fed with what the index exports: probe lists, heap arrays (layout
+included) and final ids."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_rows(n, d, seed, centres=None, sigma=1.0, row0=0):
+    from tinyknn_amd import _lib
+    out = np.zeros((n, d), dtype=np.float32)
+    c = None if centres is None else np.ascontiguousarray(centres, dtype=np.float32)
+    _lib.check(_lib.lib().tk_synth_rows(_lib.ptr(out, _lib._f32p), row0, n, d, seed,
+                                        None if c is None else c.ctypes.data,
+                                        0 if c is None else len(c), float(sigma)))
+    return out
+
+
+def oracle_from_resident(O, ivf):
+    """OracleIndex over what a resident index exports; the rescoring vectors are fetched whole
+    (small test sizes)."""
+    dev = ivf.device_index()
+    sizes, codes, ids = dev.export_lists()
+    chunks = (sizes + 15) // 16
+    coff = np.concatenate([[0], np.cumsum(chunks)])
+    ioff = np.concatenate([[0], np.cumsum(sizes)])
+    L = len(sizes)
+    data = dev.read_rows(np.arange(dev.N))
+    return O.OracleIndex(ivf.pq.centers, ivf.pq.dims_per_block, ivf.pq.R, ivf.pq.sqrt_n_blocks,
+                         ivf.active_centers, ivf.pq_transformed_centers.packed,
+                         [codes[coff[i]:coff[i + 1]] for i in range(L)], list(sizes),
+                         [ids[ioff[i]:ioff[i + 1]] for i in range(L)], data), (sizes, codes, ids)
+
+
+def test_generator_is_a_function_of_seed_and_row():
+    cent = np.random.RandomState(0).randn(7, 33).astype(np.float32)
+    a = synth_rows(1000, 33, 5, cent, 0.7)
+    b = np.concatenate([synth_rows(300, 33, 5, cent, 0.7), synth_rows(700, 33, 5, cent, 0.7, row0=300)])
+    np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(a, synth_rows(1000, 33, 6, cent, 0.7))
+    z = synth_rows(200000, 8, 1)                      # plain N(0, 1)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.01
+
+
+@pytest.mark.parametrize("metric", ["angular", "euclidean"])
+def test_resident_build_equals_host_build(oracle, metric):
+    """Unrotated PQ (d = 100 as GloVe: fast_pq.py:77 skips the rotation), N a multiple of 100:
+    every arithmetic step is the one IVF.build(device=True) / numpy takes, so active centres,
+    list memberships and codes must agree; only the order inside a list may differ."""
+    from tinyknn_amd import IVF, FastPQ
+    untransform_data = oracle.unpack
+    n, d, nq, seed = 30000, 100, 300, 11
+    cent = np.random.RandomState(1).randn(40, d).astype(np.float32)
+    X = synth_rows(n, d, seed, cent, 0.7)
+    host = IVF(metric, 60, FastPQ(2))
+    host.fit(X[:8000])
+    host.build(X, n_probes=1, device=True)
+    res = IVF(metric, 60, FastPQ(2))
+    res.all_centers, res.pq = host.all_centers, host.pq
+    res.build_resident(n, d, seed, cent, 0.7)
+    dev = res.device_index()
+    np.testing.assert_array_equal(res.active_centers, host.active_centers)
+    np.testing.assert_array_equal(res.pq_transformed_centers.packed, host.pq_transformed_centers.packed)
+    np.testing.assert_array_equal(dev.read_rows(np.arange(n)), host.data)
+    sizes, codes, ids = dev.export_lists()
+    chunks = (sizes + 15) // 16
+    coff = np.concatenate([[0], np.cumsum(chunks)])
+    ioff = np.concatenate([[0], np.cumsum(sizes)])
+    for i in range(len(sizes)):
+        hi = np.asarray(host.ids[i], dtype=np.int64)
+        mine = ids[ioff[i]:ioff[i + 1]]
+        np.testing.assert_array_equal(mine, np.sort(hi))            # ascending row order here
+        hl = untransform_data(host.pq_transformed_points[i].packed)[:len(hi)]
+        ml = untransform_data(codes[coff[i]:coff[i + 1]])
+        np.testing.assert_array_equal(ml[:len(hi)], hl[np.argsort(hi, kind="stable")])
+        # rows that pad the last chunk carry the zero vector's code, as the host build's do
+        full = untransform_data(host.pq_transformed_points[i].packed)
+        if len(full) > len(hi):
+            np.testing.assert_array_equal(ml[len(hi):], full[len(hi):])
+    # end to end vs the oracle on the exported index
+    ox, _ = oracle_from_resident(oracle, res)
+    qs = synth_rows(nq, d, seed + 1, cent, 0.7)
+    qn, qp = res._prepare(qs.copy())
+    for n_probes in (1, 5, 10):
+        got, dbg = dev.query_batch(qn, qp, 10, n_probes, debug=True)
+        np.testing.assert_array_equal(got, ox.query_batch(qn, 10, n_probes))
+        for i in range(0, nq, 37):
+            _, want = ox.query(qn[i], 10, n_probes, debug=True)
+            np.testing.assert_array_equal(dbg["probes"][i], want["probes"])
+            np.testing.assert_array_equal(dbg["heap_idx"][i], want["heap_idx"])
+            np.testing.assert_array_equal(dbg["heap_val"][i], want["heap_val"])
+
+
+def test_resident_build_rotated_vs_oracle(oracle):
+    """Rotated PQ (128 -> 64 dims, float64 tables), euclidean, ragged list sizes: the index as
+    built on the device answers exactly as the oracle does on the exported lists."""
+    from tinyknn_amd import IVF, FastPQ
+    n, d, nq, seed = 40037, 128, 200, 3
+    cent = np.random.RandomState(2).randn(25, d).astype(np.float32)
+    sample = synth_rows(6000, d, seed, cent, 0.9)
+    ivf = IVF("euclidean", 50, FastPQ(2))
+    ivf.fit(sample)
+    assert ivf.pq.R is not None and ivf.pq.R.shape == (64, 128)
+    ivf.build_resident(n, d, seed, cent, 0.9)
+    dev = ivf.device_index()
+    ox, (sizes, codes, ids) = oracle_from_resident(oracle, ivf)
+    assert sizes.sum() == n and len(np.unique(ids)) == n
+    qs = synth_rows(nq, d, seed + 1, cent, 0.9)
+    qn, qp = ivf._prepare(qs.copy())
+    for n_probes in (1, 4, 12):
+        for depth in (1, 2):
+            dev.set_pipeline(depth)
+            np.testing.assert_array_equal(dev.query_batch(qn, qp, 10, n_probes), ox.query_batch(qn, 10, n_probes))
+    dev.set_pipeline(1)
+    np.testing.assert_array_equal(ivf.query_batch(qs, 10, n_probes=4), ox.query_batch(qn, 10, 4))

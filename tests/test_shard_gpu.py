@@ -15,8 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, owner=None):
-    """-> (ids (nq, k), overflow flags (world,), capacity)"""
+def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, owner=None,
+                   coarse="home"):
+    """-> (ids (nq, k), overflow flags (world,), capacity).  coarse="home": every simulated rank
+    runs the coarse stage of its home queries only and the probe lists are gathered by hand;
+    "replicated": every rank derives all probe lists itself."""
     import torch
     from tinyknn_amd.multi_gpu import _HipShardEngine, shard_capacity, shard_lists
     L = ivf.active_centers.shape[0]
@@ -34,8 +37,15 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
     sends = [torch.full((world, capacity * 16), 0xAB, dtype=torch.uint8, device="cuda")
              for _ in range(world)]
     flags = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(world)]
+    p_all = None
+    if coarse == "home":
+        kc = min(n_probes, L)
+        homes_p = [torch.full((qh * kc,), -7, dtype=torch.int64, device="cuda") for _ in range(world)]
+        for r, e in enumerate(engines):
+            e.coarse(0, qn_t, qp_t, k, n_probes, pass_1, homes_p[r])
+        p_all = torch.cat(homes_p).contiguous()                                 # all-gather
     for r, e in enumerate(engines):
-        e.scan(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r])
+        e.scan(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], probes_all=p_all)
     homes = []
     for h, e in enumerate(engines):
         recv = torch.stack([sends[s][h] for s in range(world)]).contiguous()   # all-to-all
@@ -51,14 +61,14 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
 
 
 @pytest.mark.parametrize("tag", G6_TAGS)
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_golden(tag, world):
+@pytest.mark.parametrize("world,coarse", [(1, "home"), (2, "home"), (3, "home"), (2, "replicated")])
+def test_sharded_golden(tag, world, coarse):
     from test_hip_parity import ivf_from_fixture
     g = golden(f"g6_ivf_{tag}.npz")
     ivf = ivf_from_fixture(None, g)
     for n_probes in g["probes_list"]:
         n_probes = int(n_probes)
-        ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes)
+        ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, coarse=coarse)
         assert not flags.any()
         np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
 
@@ -86,8 +96,9 @@ def test_sharded_overflow_is_flagged_and_harmless():
     assert flags.any()
 
 
-@pytest.mark.parametrize("build_probes,world", [(1, 4), (2, 3), (1, 8)])
-def test_sharded_vs_unsharded_larger(oracle, build_probes, world):
+@pytest.mark.parametrize("build_probes,world,coarse", [(1, 4, "home"), (2, 3, "home"), (1, 8, "home"),
+                                                       (1, 8, "replicated")])
+def test_sharded_vs_unsharded_larger(oracle, build_probes, world, coarse):
     """60k x 100 angular index, 1003 queries (not a multiple of the world size): the sharded
     pipeline returns the ids of the unsharded one (itself pinned to the oracle), for distinct
     (lane replay) and repeating labels (duplicate test); a sample is checked against the
@@ -105,7 +116,7 @@ def test_sharded_vs_unsharded_larger(oracle, build_probes, world):
     ox = _oracle_index(oracle, ivf)
     for n_probes in (1, 10, 30):
         want = ivf.device_index().query_batch(qn, qp, 10, n_probes)
-        ids, flags, cap = simulate_world(ivf, world, qn, qp, 10, n_probes)
+        ids, flags, cap = simulate_world(ivf, world, qn, qp, 10, n_probes, coarse=coarse)
         assert not flags.any(), f"default capacity {cap} overflowed"
         np.testing.assert_array_equal(ids, want)
         np.testing.assert_array_equal(ids[:60], ox.query_batch(qn[:60], 10, n_probes))

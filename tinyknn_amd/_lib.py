@@ -63,12 +63,25 @@ SIGNATURES = {
     "tk_index_set_centers": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _u64p, C.c_int64]),
     "tk_index_set_lists": (C.c_int, [C.c_void_p, _i64p, _u64p, _i64p]),
     "tk_index_set_lists_shard": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int, C.c_int, _u64p, _i64p]),
+    "tk_index_shard_coarse_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p]),
     "tk_index_shard_scan_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                          C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
-                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+                                          C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_shard_finish_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                             C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                             C.c_void_p]),
+    "tk_index_alloc_data": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int]),
+    "tk_index_synth_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int,
+                                      C.c_float]),
+    "tk_synth_rows": (C.c_int, [_f32p, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_void_p, C.c_int,
+                                C.c_float]),
+    "tk_index_build_dev": (C.c_int, [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p,
+                                     C.c_int, _i64p]),
+    "tk_index_export_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_export_centers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_read_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f32p]),
     "tk_index_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]),
     "tk_index_reserve": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "tk_index_query_batch": (C.c_int, [C.c_void_p, _f32p, C.c_void_p, C.c_int, C.c_int64, C.c_int,

@@ -1019,26 +1019,29 @@ static TkScanJob list_job(const tk_index *ix, const Work &w, const Plan &p)
 }
 
 // 2a. coarse scan = the scan of dtable.top(centers)          ivf.py:131, fast_pq.py:284-312
-static void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st)
+static void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st,
+                               const uint4 *tables = nullptr)
 {
     const int M = ix->M;
+    if (!tables) tables = w.tables.as<uint4>();
     if (coarse_units(ix, nq))
-        tk_launch_scan_units(ix->center_codes.as<uint4>(), M, w.tables.as<uint4>(), nq, 1, 1,
+        tk_launch_scan_units(ix->center_codes.as<uint4>(), M, tables, nq, 1, 1,
                              ix->c_chunk_off.as<int64_t>(), w.c_pair_off.as<int>(),
                              w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
                              w.c_pair_f0.as<int>(), w.cdist.as<uint4>(), ix->center_chunks,
                              w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, 768, st);
     else
         tk_launch_scan_flat(ix->center_codes.as<uint4>(), ix->center_chunks, M,
-                            w.tables.as<uint4>(), nq, w.cdist.as<uint4>(), ix->center_chunks,
+                            tables, nq, w.cdist.as<uint4>(), ix->center_chunks,
                             w.cmins.as<uint8_t>(), p.ccap_min, 1, ix->order, st);
 }
 
 // 2b. rest of the coarse stage: heap replay over the coded centres, probe lists, per-slot
 // descriptors.  `pair_count`: per-list (query, slot) pair counters for the list-major scan
 // (or NULL); with `owner` only the lists owned by `me` are counted (list-sharded index).
-static int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
-                             int *pair_count, const int *owner, int me, hipStream_t st, Prof &pf)
+// `probes_out`: (nq, kc) int64, the probe lists (ivf.py:131) — w.probes, or a caller's buffer.
+static int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
+                                int64_t *probes_out, hipStream_t st, Prof &pf)
 {
     TRY(pf.mark(st));
     // positions of one list against a fresh heap are distinct labels: lane-per-query
@@ -1068,14 +1071,26 @@ static int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t 
     }
     TRY(pf.mark(st));
     tk_launch_rescore(q_dev, 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
-                      w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0,
-                      w.probes.as<int64_t>(), nullptr, st);
-    tk_launch_make_slots(w.probes.as<int64_t>(), nullptr, p.S, nq, ix->n_lists,
-                         ix->list_chunk_off.as<int64_t>(), ix->list_n.as<int64_t>(),
-                         ix->ids_off.as<int64_t>(), w.slot_prefix.as<int>(),
-                         w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
-                         w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(),
-                         pair_count, owner, me, st);
+                      w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0, probes_out, nullptr, st);
+    return TK_OK;
+}
+
+// per-slot descriptors of the probed lists of `nq` queries
+static void coarse_slots(tk_index *ix, Work &w, const int64_t *probes, int64_t nq, const Plan &p,
+                         int *pair_count, const int *owner, int me, hipStream_t st)
+{
+    tk_launch_make_slots(probes, nullptr, p.S, nq, ix->n_lists, ix->list_chunk_off.as<int64_t>(),
+                         ix->list_n.as<int64_t>(), ix->ids_off.as<int64_t>(),
+                         w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
+                         w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(), pair_count,
+                         owner, me, st);
+}
+
+static int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
+                             int *pair_count, const int *owner, int me, hipStream_t st, Prof &pf)
+{
+    TRY(coarse_replay_probes(ix, w, q_dev, nq, p, w.probes.as<int64_t>(), st, pf));
+    coarse_slots(ix, w, w.probes.as<int64_t>(), nq, p, pair_count, owner, me, st);
     return TK_OK;
 }
 
@@ -1489,10 +1504,45 @@ static int shard_args(tk_index *ix, int slot, int64_t nq, int64_t capacity, cons
     return TK_OK;
 }
 
+// Coarse stage sharded by HOME rank: tables for all nq queries (every rank scores segments of
+// every query), coarse scan + replay + rescoring only for this rank's ceil(nq/world) home
+// queries; the caller all-gathers the probe lists and hands them to tk_index_shard_scan_dev.
+extern "C" int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_dev,
+                                         const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
+                                         int n_probes, int pass_1, int64_t *probes_home_dev,
+                                         void *stream)
+{
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, 1, p, qh));
+    ARGCHECK(probes_home_dev, "probes buffer");
+    Work &w = ix->works[(size_t)slot];
+    hipStream_t st = (hipStream_t)stream;
+    TRY(reserve_shard(ix, w, nq, qh, p));
+    Prof pf;
+    TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
+    const int64_t q0 = (int64_t)ix->rank * qh;
+    int64_t nqh = nq - q0;
+    nqh = nqh < 0 ? 0 : (nqh > qh ? qh : nqh);
+    // rows past nq: list 0 (never read by a consumer; defined for the all-gather)
+    HIPCHECK(hipMemsetAsync(probes_home_dev, 0, (size_t)qh * p.kc * 8, st));
+    if (nqh > 0) {
+        if (coarse_units(ix, nqh))     // identity pairs of the home range (stage_tables: of all nq)
+            tk_launch_identity_pairs(nqh, (int)ix->center_chunks, w.c_pair_off.as<int>(),
+                                     w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
+                                     w.c_pair_f0.as<int>(), st);
+        launch_coarse_scan(ix, w, nqh, p, st, w.tables.as<uint4>() + q0 * ix->M);
+        TRY(coarse_replay_probes(ix, w, q_dev + q0 * ix->d, nqh, p, probes_home_dev, st, pf));
+    }
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
 extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_dev,
                                        const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
-                                       int n_probes, int pass_1, int64_t capacity, void *send_dev,
-                                       int *flag_dev, void *stream)
+                                       int n_probes, int pass_1, const int64_t *probes_all_dev,
+                                       int64_t capacity, void *send_dev, int *flag_dev, void *stream)
 {
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
@@ -1504,16 +1554,25 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     TRY(reserve_shard(ix, w, nq, qh, p));
     Prof pf;
     const int *owner = ix->owner.as<int>();
-    TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
-    launch_coarse_scan(ix, w, nq, p, st);
-    TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf));
-    tk_launch_shard_positions(w.probes.as<int64_t>(), w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
+    const int64_t *probes = probes_all_dev;
+    if (probes) {
+        // the tables of this slot were built by tk_index_shard_coarse_dev; the probe lists of
+        // all queries arrive gathered from their home ranks
+        coarse_slots(ix, w, probes, nq, p, w.u_count.as<int>(), owner, ix->rank, st);
+    } else {
+        // replicated coarse stage: every rank derives every probe list itself
+        TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
+        launch_coarse_scan(ix, w, nq, p, st);
+        TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf));
+        probes = w.probes.as<int64_t>();
+    }
+    tk_launch_shard_positions(probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
                               owner, ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
                               w.rpos.as<int>(), flag_dev, st);
     tk_launch_pairs_scan(w.u_count.as<int>(), ix->local_chunk_off.as<int64_t>(), ix->n_lists,
                          w.u_pair_off.as<int>(), w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
                          w.u_pair_q.as<int>(), st);
-    tk_launch_shard_pairs_fill(w.probes.as<int64_t>(), p.S, nq, ix->n_lists, owner, ix->rank,
+    tk_launch_shard_pairs_fill(probes, p.S, nq, ix->n_lists, owner, ix->rank,
                                w.spos.as<int>(), w.u_pair_off.as<int>(), w.u_cursor.as<int>(),
                                w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(), st);
     // the owned segments are scored straight into the send buffer (row stride 0, the
@@ -1554,6 +1613,307 @@ extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_
 }
 
 // ---------------------------------------------------------------------------
+// device-resident build (devbuild.hip): IVF.build for vectors that live in HBM
+static int upload_rotation(tk_index *ix, const double *R, int d_pad)
+{
+    std::vector<double> rt((size_t)d_pad * ix->dq);
+    for (int j = 0; j < ix->dq; j++)
+        for (int t = 0; t < d_pad; t++) rt[(size_t)t * ix->dq + j] = R[(size_t)j * d_pad + t];
+    TRY(ix->rot_t.ensure(rt.size() * 8));
+    HIPCHECK(hipMemcpy(ix->rot_t.p, rt.data(), rt.size() * 8, hipMemcpyHostToDevice));
+    ix->rot_d_pad = d_pad;
+    return TK_OK;
+}
+
+extern "C" float *tk_index_alloc_data(tk_index *ix, int64_t N, int d)
+{
+    if (!ix || !ix->have_pq || N < 1 || d < 1) {
+        fail(TK_ERR_ARG, "bad argument: tk_index_alloc_data (set_pq first, N >= 1, d >= 1)");
+        return nullptr;
+    }
+    if (ix->data.ensure((size_t)N * d * 4) != TK_OK) return nullptr;
+    ix->N = N;
+    ix->d = d;
+    ix->data_is_f64 = 0;
+    ix->have_data = ix->have_centers = ix->have_lists = false;   // until tk_index_build_dev
+    return ix->data.as<float>();
+}
+
+static int synth_centres(DevBuf &buf, const float *centres, int n_centres, int d, const float **dev)
+{
+    *dev = nullptr;
+    if (!centres || n_centres <= 0) return TK_OK;
+    TRY(buf.ensure((size_t)n_centres * d * 4));
+    HIPCHECK(hipMemcpy(buf.p, centres, (size_t)n_centres * d * 4, hipMemcpyHostToDevice));
+    *dev = buf.as<float>();
+    return TK_OK;
+}
+
+extern "C" int tk_index_synth_data(tk_index *ix, int64_t row0, int64_t n, uint64_t seed,
+                                   const float *centres, int n_centres, float sigma)
+{
+    ARGCHECK(ix && ix->data.p && ix->N > 0, "tk_index_alloc_data first");
+    ARGCHECK(row0 >= 0 && n >= 0 && row0 + n <= ix->N, "row range");
+    const float *cd = nullptr;
+    TRY(synth_centres(ix->stage, centres, n_centres, ix->d, &cd));
+    tk_launch_synth_rows(ix->data.as<float>() + row0 * ix->d, row0, n, ix->d, seed, cd, n_centres, sigma, 0);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    return TK_OK;
+}
+
+// the same generator into host memory (queries, training samples)
+extern "C" int tk_synth_rows(float *out, int64_t row0, int64_t n, int d, uint64_t seed,
+                             const float *centres, int n_centres, float sigma)
+{
+    TRY(require_gpu());
+    ARGCHECK(out && n >= 0 && d >= 1 && row0 >= 0, "buffers / sizes");
+    DevBuf cb, xb;
+    const float *cd = nullptr;
+    int rc = synth_centres(cb, centres, n_centres, d, &cd);
+    const int64_t slab = 1 << 20;
+    for (int64_t o = 0; o < n && rc == TK_OK; o += slab) {
+        const int64_t m = n - o < slab ? n - o : slab;
+        if ((rc = xb.ensure((size_t)m * d * 4)) != TK_OK) break;
+        tk_launch_synth_rows(xb.as<float>(), row0 + o, m, d, seed, cd, n_centres, sigma, 0);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(out + (size_t)o * d, xb.p, (size_t)m * d * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TK_ERR_HIP, hipGetErrorString(e));
+    }
+    cb.release();
+    xb.release();
+    return rc;
+}
+
+// labels (m, M) of `m` float32 rows (m, d) on the device: pad1 / rotation (float64 FMA chain,
+// as the device front end) into `rows`, then the nearest centroid per block
+static int encode_rows_dev(tk_index *ix, const float *x, int64_t m, DevBuf &rows, uint8_t *labels)
+{
+    const bool rot = ix->rot_d_pad > 0;
+    TRY(rows.ensure((size_t)m * ix->dq * (rot ? 8 : 4)));
+    tk_launch_prepare_queries(x, m, ix->d, rot ? ix->rot_t.as<double>() : nullptr, ix->dq,
+                              rot ? ix->rot_d_pad : ix->dq, rows.p, 0);
+    if (tk_launch_encode_pq(ix->pq_centers.as<float>(), ix->dq, ix->dpb, rows.p, rot ? 1 : 0, m, labels, 0))
+        return fail(TK_ERR_HIP, "encode_pq_kernel: LDS budget / attribute");
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_centers,
+                                  const float *search_centers, const float *ynorm2, int64_t C,
+                                  const double *R, int d_pad, int64_t *n_active_out)
+{
+    if (!search_centers) search_centers = all_centers;
+    ARGCHECK(ix && ix->have_pq && ix->data.p && ix->N > 0, "set_pq and tk_index_alloc_data first");
+    ARGCHECK(all_centers && ynorm2 && C >= 1 && C < (1ll << 31), "centres");
+    ARGCHECK(ix->N < (1ll << 31), "N < 2^31");
+    ARGCHECK(ix->d <= 384 && (!normalise || ix->d <= 128), "d <= 384 (128 with normalisation)");
+    ARGCHECK(16 % ix->dpb == 0, "dims_per_block must divide 16 for the device encoder");
+    ARGCHECK(R ? (d_pad >= ix->d && d_pad <= 16384) : ix->dq >= ix->d, "rotation / padding");
+    TRY(flush_pending(ix));
+    const int64_t N = ix->N;
+    const int d = ix->d, M = ix->M;
+    float *X = ix->data.as<float>();
+    if (R) TRY(upload_rotation(ix, R, d_pad));
+    else { ix->rot_t.release(); ix->rot_d_pad = 0; }
+    const int64_t slab = 1 << 20;
+    DevBuf yt, yn, near, keys, rows, keys2, rows2, count, remap, labels, rot, tmp, zero, crow, clab;
+    struct Cleanup {
+        std::vector<DevBuf *> v;
+        ~Cleanup() { for (DevBuf *b : v) b->release(); }
+    } cl{{&yt, &yn, &near, &keys, &rows, &keys2, &rows2, &count, &remap, &labels, &rot, &tmp, &zero, &crow, &clab}};
+    // ---- 1. data = X / |X| (ivf.py:78-79), nearest centre per row (ivf.py:85)
+    {
+        std::vector<float> ytv((size_t)C * d);
+        for (int64_t j = 0; j < C; j++)
+            for (int t = 0; t < d; t++) ytv[(size_t)t * C + j] = search_centers[(size_t)j * d + t];
+        TRY(yt.ensure(ytv.size() * 4));
+        TRY(yn.ensure((size_t)C * 4));
+        HIPCHECK(hipMemcpy(yt.p, ytv.data(), ytv.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(yn.p, ynorm2, (size_t)C * 4, hipMemcpyHostToDevice));
+    }
+    TRY(near.ensure((size_t)slab * 8));
+    TRY(keys.ensure((size_t)N * 4));
+    TRY(rows.ensure((size_t)N * 4));
+    TRY(count.ensure((size_t)C * 4));
+    HIPCHECK(hipMemset(count.p, 0, (size_t)C * 4));
+    for (int64_t o = 0; o < N; o += slab) {
+        const int64_t m = N - o < slab ? N - o : slab;
+        if (normalise) tk_launch_normalise_rows(X + o * d, m, d, X + o * d, 0);
+        tk_launch_assign(X + o * d, m, d, yt.p, yn.p, 0, (int)C, 1, near.as<int64_t>(), 0);
+        tk_launch_keys_count(near.as<int64_t>(), m, o, keys.as<int>(), rows.as<int>(), count.as<int>(), 0);
+        HIPCHECK(hipGetLastError());
+    }
+    HIPCHECK(hipDeviceSynchronize());
+    // ---- 2. active centres (ivf.py:91: all_centers[np.unique(nearest)]) and the CSR offsets
+    std::vector<int> cnt((size_t)C), rm((size_t)C, -1);
+    HIPCHECK(hipMemcpy(cnt.data(), count.p, (size_t)C * 4, hipMemcpyDeviceToHost));
+    std::vector<float> act;
+    std::vector<int64_t> sizes;
+    for (int64_t j = 0; j < C; j++)
+        if (cnt[(size_t)j] > 0) {
+            rm[(size_t)j] = (int)sizes.size();
+            sizes.push_back(cnt[(size_t)j]);
+            act.insert(act.end(), all_centers + (size_t)j * d, all_centers + (size_t)(j + 1) * d);
+        }
+    const int64_t L = (int64_t)sizes.size();
+    std::vector<int64_t> coff((size_t)L + 1, 0), ioff((size_t)L + 1, 0);
+    int64_t maxc = 0;
+    for (int64_t i = 0; i < L; i++) {
+        const int64_t c = (sizes[(size_t)i] + 15) / 16;
+        coff[(size_t)i + 1] = coff[(size_t)i] + c;
+        ioff[(size_t)i + 1] = ioff[(size_t)i] + sizes[(size_t)i];
+        if (c > maxc) maxc = c;
+    }
+    ARGCHECK(maxc < (1ll << 26), "list too long");
+    TRY(remap.ensure((size_t)C * 4));
+    HIPCHECK(hipMemcpy(remap.p, rm.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+    tk_launch_remap_keys(keys.as<int>(), N, remap.as<int>(), 0);
+    // ---- 3. rows grouped by list: stable sort of (list, row)
+    int bits = 1;
+    while ((1ll << bits) < L) bits++;
+    TRY(keys2.ensure((size_t)N * 4));
+    TRY(rows2.ensure((size_t)N * 4));
+    size_t tmp_bytes = 0;
+    if (tk_sort_pairs(nullptr, &tmp_bytes, keys.as<int>(), keys2.as<int>(), rows.as<int>(), rows2.as<int>(), N, bits, 0))
+        return fail(TK_ERR_HIP, "radix sort: size query failed");
+    TRY(tmp.ensure(tmp_bytes > 0 ? tmp_bytes : 16));
+    if (tk_sort_pairs(tmp.p, &tmp_bytes, keys.as<int>(), keys2.as<int>(), rows.as<int>(), rows2.as<int>(), N, bits, 0))
+        return fail(TK_ERR_HIP, "radix sort failed");
+    HIPCHECK(hipDeviceSynchronize());
+    keys.release(); rows.release(); keys2.release(); tmp.release(); near.release();
+    // ---- 4. PQ codes of every row (a row's code does not depend on its list), of the zero
+    //         vector (list padding, fast_pq.py:165) and of the active centres (ivf.py:92-96)
+    TRY(labels.ensure((size_t)N * M));
+    for (int64_t o = 0; o < N; o += slab) {
+        const int64_t m = N - o < slab ? N - o : slab;
+        TRY(encode_rows_dev(ix, X + o * d, m, rot, labels.as<uint8_t>() + (size_t)o * M));
+    }
+    const int64_t L16 = (L + 15) / 16 * 16;
+    TRY(crow.ensure((size_t)(L16 + 16) * d * 4));
+    TRY(clab.ensure((size_t)(L16 + 16) * M));
+    HIPCHECK(hipMemset(crow.p, 0, (size_t)(L16 + 16) * d * 4));
+    HIPCHECK(hipMemcpy(crow.p, act.data(), (size_t)L * d * 4, hipMemcpyHostToDevice));
+    TRY(encode_rows_dev(ix, crow.as<float>(), L16 + 16, rot, clab.as<uint8_t>()));
+    const uint8_t *zero_code = clab.as<uint8_t>() + (size_t)L16 * M;     // code of a zero row
+    // ---- 5. the index: centres
+    TRY(ix->active_centers.ensure((size_t)L * d * 4));
+    HIPCHECK(hipMemcpy(ix->active_centers.p, act.data(), (size_t)L * d * 4, hipMemcpyHostToDevice));
+    const int64_t center_chunks = L16 / 16;
+    const int P = M / 2;
+    TRY(ix->center_codes.ensure((size_t)tk_tiled_uint4s(center_chunks, P) * 16));
+    HIPCHECK(hipMemset(ix->center_codes.p, 0, (size_t)tk_tiled_uint4s(center_chunks, P) * 16));
+    int64_t cco[2] = {0, center_chunks};
+    int64_t cio[2] = {0, L};
+    int64_t cn[1] = {L};
+    TRY(ix->c_chunk_off.ensure(sizeof cco));
+    HIPCHECK(hipMemcpy(ix->c_chunk_off.p, cco, sizeof cco, hipMemcpyHostToDevice));
+    TRY(ix->stage.ensure(64));
+    HIPCHECK(hipMemcpy(ix->stage.p, cio, sizeof cio, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy((char *)ix->stage.p + 32, cn, sizeof cn, hipMemcpyHostToDevice));
+    tk_launch_pack_lists(clab.as<uint8_t>(), M, nullptr, ix->stage.as<int64_t>(), ix->c_chunk_off.as<int64_t>(),
+                         (const int64_t *)((char *)ix->stage.p + 32), 1, zero_code,
+                         ix->center_codes.as<uint4>(), center_chunks, 0);
+    ix->n_lists = L; ix->center_chunks = center_chunks;
+    int ci[3] = {0, (int)center_chunks, (int)L};
+    int64_t cl1[1] = {-1};
+    TRY(ix->cslots_i.ensure(sizeof ci));
+    TRY(ix->cslots_l.ensure(sizeof cl1));
+    HIPCHECK(hipMemcpy(ix->cslots_i.p, ci, sizeof ci, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ix->cslots_l.p, cl1, sizeof cl1, hipMemcpyHostToDevice));
+    // ---- 6. the index: lists
+    TRY(ix->list_chunk_off.ensure((size_t)(L + 1) * 8));
+    TRY(ix->ids_off.ensure((size_t)(L + 1) * 8));
+    TRY(ix->list_n.ensure((size_t)L * 8));
+    TRY(ix->ids.ensure((size_t)N * 8));
+    HIPCHECK(hipMemcpy(ix->list_chunk_off.p, coff.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ix->ids_off.p, ioff.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ix->list_n.p, sizes.data(), (size_t)L * 8, hipMemcpyHostToDevice));
+    const size_t tiled_bytes = (size_t)tk_tiled_uint4s(coff[(size_t)L], P) * 16;
+    TRY(ix->codes.ensure(tiled_bytes));
+    HIPCHECK(hipMemset(ix->codes.p, 0, tiled_bytes));
+    tk_launch_pack_lists(labels.as<uint8_t>(), M, rows2.as<int>(), ix->ids_off.as<int64_t>(),
+                         ix->list_chunk_off.as<int64_t>(), ix->list_n.as<int64_t>(), (int)L, zero_code,
+                         ix->codes.as<uint4>(), coff[(size_t)L], 0);
+    tk_launch_widen_ids(rows2.as<int>(), N, ix->ids.as<int64_t>(), 0);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    ix->ids_unique = true;          // every row sits in exactly one list
+    ix->have_ids32 = false;
+    ix->sharded = false; ix->rank = 0; ix->world = 1;
+    ix->total_chunks = coff[(size_t)L];
+    ix->total_ids = N;
+    ix->max_list_chunks = (int)maxc;
+    ix->have_centers = ix->have_lists = ix->have_data = true;
+    if (n_active_out) *n_active_out = L;
+    return TK_OK;
+}
+
+// what a built index holds, back on the host in the reference's formats: list_sizes
+// (n_lists,), codes (total chunks, M) uint64 Quick-ADC layout, ids (sum sizes,) — any NULL
+extern "C" int tk_index_export_lists(tk_index *ix, int64_t *list_sizes, uint64_t *codes, int64_t *ids)
+{
+    ARGCHECK(ix && ix->have_lists && !ix->sharded, "an unsharded index with lists");
+    if (list_sizes)
+        HIPCHECK(hipMemcpy(list_sizes, ix->list_n.p, (size_t)ix->n_lists * 8, hipMemcpyDeviceToHost));
+    if (ids && ix->total_ids > 0)
+        HIPCHECK(hipMemcpy(ids, ix->ids.p, (size_t)ix->total_ids * 8, hipMemcpyDeviceToHost));
+    if (codes && ix->total_chunks > 0) {
+        const int P = ix->M / 2;
+        const int64_t n4 = tk_tiled_uint4s(ix->total_chunks, P);
+        std::vector<uint4> t((size_t)n4);
+        HIPCHECK(hipMemcpy(t.data(), ix->codes.p, (size_t)n4 * 16, hipMemcpyDeviceToHost));
+        uint4 *ref = (uint4 *)codes;
+        for (int64_t c = 0; c < ix->total_chunks; c++)
+            for (int p = 0; p < P; p++) ref[c * P + p] = t[(size_t)(((c >> 3) * P + p) * 8 + (c & 7))];
+    }
+    return TK_OK;
+}
+
+// active_centers (n_lists, d) float32, center_codes (ceil(n_lists/16), M) uint64 — any NULL
+extern "C" int tk_index_export_centers(tk_index *ix, float *active_centers, uint64_t *center_codes)
+{
+    ARGCHECK(ix && ix->have_centers, "an index with centres");
+    if (active_centers)
+        HIPCHECK(hipMemcpy(active_centers, ix->active_centers.p, (size_t)ix->n_lists * ix->d * 4,
+                           hipMemcpyDeviceToHost));
+    if (center_codes) {
+        const int P = ix->M / 2;
+        const int64_t n4 = tk_tiled_uint4s(ix->center_chunks, P);
+        std::vector<uint4> t((size_t)n4);
+        HIPCHECK(hipMemcpy(t.data(), ix->center_codes.p, (size_t)n4 * 16, hipMemcpyDeviceToHost));
+        uint4 *ref = (uint4 *)center_codes;
+        for (int64_t c = 0; c < ix->center_chunks; c++)
+            for (int p = 0; p < P; p++) ref[c * P + p] = t[(size_t)(((c >> 3) * P + p) * 8 + (c & 7))];
+    }
+    return TK_OK;
+}
+
+// rows of IVF.data by id (float32 vectors), e.g. the candidates a checker wants to rescore
+extern "C" int tk_index_read_rows(tk_index *ix, const int64_t *rows, int64_t n, float *out)
+{
+    ARGCHECK(ix && ix->have_data && !ix->data_is_f64, "an index with float32 vectors");
+    ARGCHECK(n >= 0 && (n == 0 || (rows && out)), "buffers");
+    for (int64_t i = 0; i < n; i++) ARGCHECK(rows[i] >= 0 && rows[i] < ix->N, "row id out of range");
+    if (n == 0) return TK_OK;
+    DevBuf r, o;
+    int rc = r.ensure((size_t)n * 8);
+    if (rc == TK_OK) rc = o.ensure((size_t)n * ix->d * 4);
+    if (rc == TK_OK) {
+        hipError_t e = hipMemcpy(r.p, rows, (size_t)n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            tk_launch_gather_rows(ix->data.as<float>(), ix->d, r.as<int64_t>(), n, o.as<float>(), 0);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, o.p, (size_t)n * ix->d * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TK_ERR_HIP, hipGetErrorString(e));
+    }
+    r.release();
+    o.release();
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
 // device front end ("fast mode")
 extern "C" int tk_index_set_rotation(tk_index *ix, const double *R, int d_pad)
 {
@@ -1564,13 +1924,7 @@ extern "C" int tk_index_set_rotation(tk_index *ix, const double *R, int d_pad)
         return TK_OK;
     }
     ARGCHECK(d_pad >= ix->d && d_pad <= 16384, "d_pad");
-    std::vector<double> rt((size_t)d_pad * ix->dq);
-    for (int j = 0; j < ix->dq; j++)
-        for (int t = 0; t < d_pad; t++) rt[(size_t)t * ix->dq + j] = R[(size_t)j * d_pad + t];
-    TRY(ix->rot_t.ensure(rt.size() * 8));
-    HIPCHECK(hipMemcpy(ix->rot_t.p, rt.data(), rt.size() * 8, hipMemcpyHostToDevice));
-    ix->rot_d_pad = d_pad;
-    return TK_OK;
+    return upload_rotation(ix, R, d_pad);
 }
 
 extern "C" int tk_index_prepare_dev(tk_index *ix, const float *q_raw_dev, int64_t nq, int angular,

@@ -1,0 +1,186 @@
+// devbuild.hip — IVF.build for vectors that already live in HBM, and the seeded generator
+// of the synthetic 100M x 128 configuration ("per-GPU generation on device
+// (seeded per shard), codes produced by the build's encoder"; 8f.1).
+//
+// What IVF.build does (ivf.py:77-102, build n_probes = 1) without the vectors ever visiting
+// the host: nearest centre per row (assign kernels of build.hip), nearest centroid per block
+// (encode_pq_kernel), rows grouped by list (stable radix sort of (list, row): a list holds its
+// rows in ascending row order, where numpy's unstable argsort leaves the order unspecified),
+// 16-row chunks packed into the Quick-ADC byte layout (_transform.py:4-77) directly in the
+// tiled order the scan kernels read.  api.hip drives these kernels (tk_index_build_dev).
+#include <hipcub/hipcub.hpp>
+
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------
+// counter-based generator: every value is a pure function of (seed, row, column pair), so a
+// data set does not depend on how its rows are split over calls, slabs or ranks
+__device__ __forceinline__ uint64_t tk_mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// X[i] = centres[c(row)] + sigma * N(0, 1), c(row) uniform in [0, n_centres) (no centres: the
+// noise alone).  One thread per (row, pair of columns): Box-Muller gives two normals.
+__global__ void synth_rows_kernel(float *__restrict__ X, int64_t row0, int64_t n, int d, uint64_t seed,
+                                  const float *__restrict__ centres, int n_centres, float sigma)
+{
+    const int hp = (d + 1) >> 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * hp) return;
+    const int64_t r = i / hp;
+    const int pr = (int)(i - r * hp);
+    const uint64_t row = (uint64_t)(row0 + r);
+    const uint64_t u = tk_mix64(seed ^ tk_mix64(row * 0x100000001B3ull + (uint64_t)pr));
+    const float u1 = ((float)(uint32_t)(u >> 32) + 1.0f) * 2.3283064365386963e-10f;   // (0, 1]
+    const float u2 = (float)(uint32_t)u * 2.3283064365386963e-10f;                    // [0, 1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float z0 = rad * cosf(6.283185307179586f * u2), z1 = rad * sinf(6.283185307179586f * u2);
+    float b0 = 0.f, b1 = 0.f;
+    const int c0 = 2 * pr, c1 = 2 * pr + 1;
+    if (centres) {
+        const int64_t c = (int64_t)(tk_mix64(seed * 31 + row) % (uint64_t)n_centres);
+        b0 = centres[c * d + c0];
+        if (c1 < d) b1 = centres[c * d + c1];
+    }
+    X[r * d + c0] = b0 + sigma * z0;
+    if (c1 < d) X[r * d + c1] = b1 + sigma * z1;
+}
+
+void tk_launch_synth_rows(float *X, int64_t row0, int64_t n, int d, uint64_t seed, const float *centres,
+                          int n_centres, float sigma, hipStream_t s)
+{
+    const int64_t items = n * ((d + 1) / 2);
+    if (items <= 0) return;
+    hipLaunchKernelGGL(synth_rows_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, X, row0,
+                       n, d, seed, centres, n_centres, sigma);
+}
+
+// ---------------------------------------------------------------------------
+// nearest (n,) int64 of a slab -> sort keys / values + the per-centre histogram
+__global__ void keys_count_kernel(const int64_t *__restrict__ nearest, int64_t n, int64_t row0,
+                                  int *__restrict__ keys, int *__restrict__ rows, int *__restrict__ count)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = (int)nearest[i];
+    keys[row0 + i] = k;
+    rows[row0 + i] = (int)(row0 + i);
+    atomicAdd(&count[k], 1);
+}
+
+void tk_launch_keys_count(const int64_t *nearest, int64_t n, int64_t row0, int *keys, int *rows, int *count,
+                          hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(keys_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nearest, n,
+                       row0, keys, rows, count);
+}
+
+// centre id -> active-list id (ivf.py:91: active_centers = all_centers[np.unique(nearest)])
+__global__ void remap_keys_kernel(int *__restrict__ keys, int64_t n, const int *__restrict__ remap)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = remap[keys[i]];
+}
+
+void tk_launch_remap_keys(int *keys, int64_t n, const int *remap, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(remap_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, n, remap);
+}
+
+// stable sort of (list, row) pairs by list; tmp == NULL: size query
+int tk_sort_pairs(void *tmp, size_t *tmp_bytes, const int *keys_in, int *keys_out, const int *vals_in,
+                  int *vals_out, int64_t n, int bits, hipStream_t s)
+{
+    size_t bytes = *tmp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out,
+                                                      (int)n, 0, bits, s);
+    *tmp_bytes = bytes;
+    return e == hipSuccess ? 0 : -1;
+}
+
+__global__ void widen_ids_kernel(const int *__restrict__ rows, int64_t n, int64_t *__restrict__ ids)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ids[i] = rows[i];
+}
+
+void tk_launch_widen_ids(const int *rows, int64_t n, int64_t *ids, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(widen_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, n, ids);
+}
+
+// ---------------------------------------------------------------------------
+// labels (rows, M) uint8 -> tiled Quick-ADC chunks of all lists.  One thread per (global chunk
+// c, block pair p): byte r of its 16-byte group = code[row_r][2p] | code[row_r][2p+1] << 4,
+// row_r = the r-th row of the chunk in list order (rows_sorted; NULL: rows are already in list
+// order); rows past the list's end carry the zero vector's code (pad2 + transform,
+// fast_pq.py:165).
+__global__ void pack_lists_kernel(const uint8_t *__restrict__ labels, int M,
+                                  const int *__restrict__ rows_sorted,
+                                  const int64_t *__restrict__ ids_off,
+                                  const int64_t *__restrict__ chunk_off,
+                                  const int64_t *__restrict__ list_n, int n_lists,
+                                  const uint8_t *__restrict__ zero_code, uint4 *__restrict__ tiled,
+                                  int64_t total_chunks)
+{
+    const int P = M >> 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_chunks * P) return;
+    const int64_t c = i / P;
+    const int p = (int)(i - c * P);
+    int lo = 0, hi = n_lists;   // chunk_off[lo] <= c < chunk_off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    const int64_t j = c - chunk_off[lo];
+    const int64_t base = ids_off[lo] + 16 * j;
+    const int64_t left = list_n[lo] - 16 * j;
+    const uint32_t zb = (uint32_t)zero_code[2 * p] | ((uint32_t)zero_code[2 * p + 1] << 4);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        uint32_t b = zb;
+        if (r < left) {
+            const int64_t row = rows_sorted ? (int64_t)rows_sorted[base + r] : base + r;
+            const uint8_t *lab = labels + row * M + 2 * p;
+            b = (uint32_t)lab[0] | ((uint32_t)lab[1] << 4);
+        }
+        w[r >> 2] |= b << (8 * (r & 3));
+    }
+    tiled[((c >> 3) * P + p) * 8 + (c & 7)] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+void tk_launch_pack_lists(const uint8_t *labels, int M, const int *rows_sorted, const int64_t *ids_off,
+                          const int64_t *chunk_off, const int64_t *list_n, int n_lists,
+                          const uint8_t *zero_code, uint4 *tiled, int64_t total_chunks, hipStream_t s)
+{
+    const int64_t items = total_chunks * (M / 2);
+    if (items <= 0) return;
+    hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, labels, M,
+                       rows_sorted, ids_off, chunk_off, list_n, n_lists, zero_code, tiled, total_chunks);
+}
+
+// rows of a float32 (N, d) matrix gathered by id (rescoring vectors for the checker)
+__global__ void gather_rows_kernel(const float *__restrict__ X, int d, const int64_t *__restrict__ rows,
+                                   int64_t n, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    const int64_t r = i / d;
+    out[i] = X[rows[r] * d + (i - r * d)];
+}
+
+void tk_launch_gather_rows(const float *X, int d, const int64_t *rows, int64_t n, float *out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, s, X, d, rows,
+                       n, out);
+}

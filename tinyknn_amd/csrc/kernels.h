@@ -194,6 +194,20 @@ void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const vo
 void tk_launch_prepare_queries(const float *X, int64_t n, int d, const double *Rt, int dq, int d_pad,
                                void *out, hipStream_t s);
 
+// ---- device-resident build + seeded generator (devbuild.hip) ----
+void tk_launch_synth_rows(float *X, int64_t row0, int64_t n, int d, uint64_t seed, const float *centres,
+                          int n_centres, float sigma, hipStream_t s);
+void tk_launch_keys_count(const int64_t *nearest, int64_t n, int64_t row0, int *keys, int *rows, int *count,
+                          hipStream_t s);
+void tk_launch_remap_keys(int *keys, int64_t n, const int *remap, hipStream_t s);
+int tk_sort_pairs(void *tmp, size_t *tmp_bytes, const int *keys_in, int *keys_out, const int *vals_in,
+                  int *vals_out, int64_t n, int bits, hipStream_t s);
+void tk_launch_widen_ids(const int *rows, int64_t n, int64_t *ids, hipStream_t s);
+void tk_launch_pack_lists(const uint8_t *labels, int M, const int *rows_sorted, const int64_t *ids_off,
+                          const int64_t *chunk_off, const int64_t *list_n, int n_lists,
+                          const uint8_t *zero_code, uint4 *tiled, int64_t total_chunks, hipStream_t s);
+void tk_launch_gather_rows(const float *X, int d, const int64_t *rows, int64_t n, float *out, hipStream_t s);
+
 // ---- exact k nearest rows on the f32 matrix cores (brute.hip) ----
 // see brute.hip for the work buffers; returns -1 on unsupported sizes
 int tk_launch_knn_brute(const float *X, int64_t nq, int d, const float *Y, int64_t N, int k,

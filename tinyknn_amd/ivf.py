@@ -76,6 +76,23 @@ class QueryStream:
             pass
 
 
+class ResidentData:
+    """Stands where IVF.data stood when the vectors live in HBM only (IVF.build_resident):
+    shape, dtype and rows by id (tk_index_read_rows)."""
+
+    def __init__(self, dev):
+        self._dev = dev
+        self.shape = (dev.N, dev.d)
+        self.dtype = np.dtype(np.float32)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, rows):
+        rows = np.asarray(rows, dtype=np.int64)
+        return self._dev.read_rows(rows).reshape(rows.shape + (self.shape[1],))
+
+
 class DeviceIndex:
     """HBM-resident copy of a built IVF (C ABI: tk_index_*)."""
 
@@ -144,6 +161,89 @@ class DeviceIndex:
             R = np.ascontiguousarray(pq.R, dtype=np.float64)
             _lib.check(L.tk_index_set_rotation(self._h, R.ctypes.data, R.shape[1]))
             self._R = R
+
+    @classmethod
+    def resident(cls, ivf, N, d):
+        """An index whose N float32 vectors are produced IN HBM and never visit the host
+        (tk_index_alloc_data; filled by synth_data or through `data_ptr`, then build_dev)."""
+        L = _lib.lib()
+        pq = ivf.pq
+        self = cls.__new__(cls)
+        self._h = L.tk_index_create()
+        if not self._h:
+            raise _lib.TinyKnnHipError(L.tk_last_error().decode() or "tk_index_create failed")
+        c32 = np.ascontiguousarray(pq.centers, dtype=np.float32)
+        self.dq, self.dpb = c32.shape[1], pq.dims_per_block
+        _lib.check(L.tk_index_set_pq(self._h, _lib.ptr(c32, _lib._f32p), self.dq, self.dpb,
+                                     int(not pq.centers.flags.c_contiguous), float(pq.sqrt_n_blocks),
+                                     _lib.ORDER_AVX if avx else _lib.ORDER_SSE))
+        self.data_ptr = L.tk_index_alloc_data(self._h, int(N), int(d))
+        if not self.data_ptr:
+            raise _lib.TinyKnnHipError(L.tk_last_error().decode() or "tk_index_alloc_data failed")
+        self.N, self.d, self.n_lists = int(N), int(d), 0
+        self.rank, self.world = 0, 1
+        self.angular = ivf.metric == "angular"
+        self._R = None if pq.R is None else np.ascontiguousarray(pq.R, dtype=np.float64)
+        self._streams = {}
+        self.list_sizes = None
+        self.code_bytes = 0
+        return self
+
+    def synth_data(self, seed, centres=None, sigma=1.0, row0=0, n=None):
+        """rows [row0, row0 + n) = centres[c(row)] + sigma * N(0, 1) from the seeded
+        counter-based generator (devbuild.hip): a pure function of (seed, row)."""
+        n = self.N - row0 if n is None else n
+        c = None if centres is None else np.ascontiguousarray(centres, dtype=np.float32)
+        _lib.check(_lib.lib().tk_index_synth_data(
+            self._h, int(row0), int(n), int(seed), None if c is None else c.ctypes.data,
+            0 if c is None else len(c), float(sigma)))
+
+    def build_dev(self, all_centers):
+        """IVF.build(n_probes=1) on the resident vectors (tk_index_build_dev) -> n_active."""
+        A = np.ascontiguousarray(all_centers, dtype=np.float32)
+        Y = A
+        if self.angular:
+            Y = np.ascontiguousarray(Y / np.linalg.norm(Y, axis=1, keepdims=True))   # utils.py:75
+        ynorm2 = np.ascontiguousarray(np.einsum("ij,ij->i", Y, Y))    # utils.py:80
+        n_active = C.c_int64(0)
+        R = self._R
+        _lib.check(_lib.lib().tk_index_build_dev(
+            self._h, int(self.angular), _lib.ptr(A, _lib._f32p), _lib.ptr(Y, _lib._f32p),
+            _lib.ptr(ynorm2, _lib._f32p), len(Y),
+            None if R is None else R.ctypes.data, 0 if R is None else R.shape[1], C.byref(n_active)))
+        self.n_lists = int(n_active.value)
+        self.list_sizes = self.export_lists(codes=False, ids=False)[0]
+        self.code_bytes = int(((self.list_sizes + 15) // 16).sum()) * (self.dq // self.dpb) * 8
+        return self.n_lists
+
+    def export_lists(self, codes=True, ids=True):
+        """(list_sizes, packed codes (chunks, M) uint64 or None, ids or None) back on the host
+        in the reference's formats (tk_index_export_lists)."""
+        L = _lib.lib()
+        sizes = np.zeros(self.n_lists, dtype=np.int64)
+        _lib.check(L.tk_index_export_lists(self._h, sizes.ctypes.data, None, None))
+        M = self.dq // self.dpb
+        pk = np.zeros((int(((sizes + 15) // 16).sum()), M), dtype=np.uint64) if codes else None
+        lab = np.zeros(int(sizes.sum()), dtype=np.int64) if ids else None
+        if codes or ids:
+            _lib.check(L.tk_index_export_lists(self._h, None, None if pk is None else pk.ctypes.data,
+                                               None if lab is None else lab.ctypes.data))
+        return sizes, pk, lab
+
+    def export_centers(self):
+        """(active_centers (n_lists, d) float32, their packed codes) (tk_index_export_centers)."""
+        ac = np.zeros((self.n_lists, self.d), dtype=np.float32)
+        cc = np.zeros(((self.n_lists + 15) // 16, self.dq // self.dpb), dtype=np.uint64)
+        _lib.check(_lib.lib().tk_index_export_centers(self._h, ac.ctypes.data, cc.ctypes.data))
+        return ac, cc
+
+    def read_rows(self, rows):
+        """IVF.data[rows] for float32 vectors held in HBM (tk_index_read_rows)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64).ravel()
+        out = np.zeros((len(rows), self.d), dtype=np.float32)
+        _lib.check(_lib.lib().tk_index_read_rows(self._h, _lib.ptr(rows, _lib._i64p), len(rows),
+                                                 _lib.ptr(out, _lib._f32p)))
+        return out
 
     @property
     def handle(self):
@@ -264,12 +364,21 @@ class DeviceIndex:
             self._h, qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
             int(pass_1 or 0), out_ptr, stream))
 
+    def shard_coarse_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1,
+                         probes_home_ptr, stream=0):
+        """Tables for all queries + the coarse stage of this rank's home queries
+        (tk_index_shard_coarse_dev); the caller all-gathers the probe lists."""
+        _lib.check(_lib.lib().tk_index_shard_coarse_dev(
+            self._h, int(slot), qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
+            int(pass_1 or 0), probes_home_ptr, stream))
+
     def shard_scan_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1, capacity,
-                       send_ptr, flag_ptr, stream=0):
-        """First half of a list-sharded batch (tk_index_shard_scan_dev)."""
+                       send_ptr, flag_ptr, stream=0, probes_all_ptr=None):
+        """Scan of the owned segments into the send buffer (tk_index_shard_scan_dev);
+        probes_all_ptr None: the replicated coarse stage runs inside this call."""
         _lib.check(_lib.lib().tk_index_shard_scan_dev(
             self._h, int(slot), qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
-            int(pass_1 or 0), int(capacity), send_ptr, flag_ptr, stream))
+            int(pass_1 or 0), probes_all_ptr, int(capacity), send_ptr, flag_ptr, stream))
 
     def shard_finish_dev(self, slot, qn_ptr, nq, k, n_probes, pass_1, capacity, recv_ptr, out_ptr,
                          stream=0):
@@ -517,6 +626,32 @@ class IVF:
         ivf.ids = [ids[ioff[i]:ioff[i + 1]] for i in range(len(sizes))]
         ivf.data = z["data"] if data is None else data
         return ivf
+
+    def build_resident(self, N, d, seed, centres=None, sigma=1.0, verbose=False):
+        """IVF.build(X, n_probes=1) (ivf.py:53-104) for N synthetic float32 vectors that are
+        generated IN HBM (seeded, devbuild.hip) and never visit the host — the way the
+        100M x 128 configuration is assembled.  Needs all_centers and a
+        fitted pq (fit()).  Everything runs on the device: nearest centre per row, PQ codes,
+        grouping by list (rows of a list in ascending row order, where numpy's unstable
+        argsort leaves their order unspecified), packing.  The rotation of a rotated PQ is
+        the device front end's float64 FMA chain, not numpy's DGEMM, so a code can differ
+        from IVF.build's where that flips a nearest centroid.  Afterwards: active_centers,
+        pq_transformed_centers and list_sizes on the host; data / ids / codes stay in HBM
+        (device_index().export_lists() / read_rows() fetch them for a checker)."""
+        from .fast_pq import TransformedData
+        assert self.pq.centers is not None and getattr(self, "all_centers", None) is not None
+        with timer(verbose, "Generating vectors in HBM..."):
+            dev = DeviceIndex.resident(self, N, d)
+            dev.synth_data(seed, centres, sigma)
+        with timer(verbose, "Building lists on the device..."):
+            L = dev.build_dev(self.all_centers)
+        self.active_centers, cc = dev.export_centers()
+        self.pq_transformed_centers = TransformedData(L, cc)
+        self.list_sizes = dev.list_sizes
+        self.data = ResidentData(dev)
+        self.ids = self.pq_transformed_points = None
+        self._dev = dev
+        return self
 
     # ---- queries (GPU) -----------------------------------------------------
     def device_index(self):

@@ -136,12 +136,19 @@ class _HipShardEngine:
         self.dev.set_pipeline(depth)
         self.device = "cuda"
 
-    def scan(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag):
+    def coarse(self, slot, qn, qp, k, n_probes, pass_1, probes_home):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_coarse_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
+                                  qn.shape[0], k, n_probes, pass_1, probes_home.data_ptr(), stream=st)
+
+    def scan(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None):
         import torch
         st = torch.cuda.current_stream().cuda_stream
         self.dev.shard_scan_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
                                 qn.shape[0], k, n_probes, pass_1, capacity, send.data_ptr(),
-                                flag.data_ptr(), stream=st)
+                                flag.data_ptr(), stream=st,
+                                probes_all_ptr=None if probes_all is None else probes_all.data_ptr())
 
     def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home):
         import torch
@@ -153,18 +160,21 @@ class _HipShardEngine:
 class ListShardedIndex:
     """One rank of an IVF index whose inverted lists are sharded by cluster id.
 
-    Every rank passes the same batch.  Per batch and rank: tables + coarse stage for all
-    queries (replicated, so the probe order needs no communication), scan of the owned
+    Every rank passes the same batch; query i lives on its home rank i // ceil(nq/world).
+    Per batch and rank: distance tables for all queries, the coarse stage for the HOME
+    queries, all-gather of the probe lists (nq x n_probes x 8 B), scan of the owned
     (query, list) segments straight into the send buffer, ONE all-to-all of int8 distance
-    bytes (query i is replayed on rank i // ceil(nq/world); 1/26-1/16 of the code bytes
-    scanned), exact heap replay + rescoring of the home queries, all-gather of the ids.
-    Results are identical to the unsharded index (and to the reference) by construction:
-    the home rank replays the same distance rows in the same order.
+    bytes (1/26-1/16 of the code bytes scanned), exact heap replay + rescoring of the home
+    queries, all-gather of the ids.  `coarse="replicated"` runs the coarse stage for all
+    queries on every rank instead (no probe all-gather, but a third of a batch's work is then
+    not divided by the world size).  Results are identical to the unsharded index (and to the
+    reference) by construction: the home rank replays the same distance rows in the same order.
 
-    `engine`: object with scan/finish (default: the HIP engine); tests inject a CPU one.
+    `engine`: object with coarse/scan/finish (default: the HIP engine); tests inject a CPU one.
     """
 
-    def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None):
+    def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None,
+                 coarse="home"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -179,11 +189,14 @@ class ListShardedIndex:
         self.list_sizes = np.array(list_sizes, dtype=np.int64)
         self.owner = shard_lists(self.list_sizes, self.world) if owner is None else owner
         self.depth = depth
+        assert coarse in ("home", "replicated")
+        self.coarse = coarse
         self.engine = engine if engine is not None else _HipShardEngine(
             ivf, self.owner, self.rank, self.world, depth)
         self.device = self.engine.device
         self.capacity = {}          # (nq, n_probes) -> uint4 per region, grows on overflow
         self._bufs = {}
+        self._pbufs = {}
         self._calls = 0
         self._streams = ([torch.cuda.Stream() for _ in range(depth)]
                          if self.device == "cuda" and depth > 1 else None)
@@ -221,6 +234,16 @@ class ListShardedIndex:
                 flag=mk(1, t.int32), home=mk(qh * k + 1, t.int64), all=mk(W * (qh * k + 1), t.int64)))
         return self._bufs[slot][1]
 
+    def _probe_buffers(self, slot, nq, n_probes):
+        kc = min(n_probes, len(self.list_sizes))
+        key = (nq, kc)
+        if self._pbufs.get(slot, (None,))[0] != key:
+            t, W = self.torch, self.world
+            qh = -(-nq // W)
+            self._pbufs[slot] = (key, t.empty(qh * kc, dtype=t.int64, device=self.device),
+                                 t.empty(W * qh * kc, dtype=t.int64, device=self.device))
+        return self._pbufs[slot][1:]
+
     def _enqueue(self, qn, qp, k, n_probes, pass_1, capacity):
         """One batch on the current stream; returns the gathered (world, qh*k+1) tensor
         (last column: the rank's overflow flag)."""
@@ -230,7 +253,14 @@ class ListShardedIndex:
         b = self._buffers(slot, nq, k, capacity)
         qh = -(-nq // self.world)
         b["flag"].zero_()
-        self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"])
+        if self.coarse == "home":
+            p_home, p_all = self._probe_buffers(slot, nq, n_probes)
+            self.engine.coarse(slot, qn, qp, k, n_probes, pass_1, p_home)
+            self._all_gather(p_all, p_home)
+            self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"],
+                             probes_all=p_all)
+        else:
+            self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"])
         self._all_to_all(b["recv"], b["send"])
         self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, b["recv"], b["home"][:qh * k])
         b["home"][qh * k:] = b["flag"]
