@@ -139,59 +139,71 @@ def build_index(args, device):
     return ivf, cent
 
 
-def build_index_c5like(args):
-    """Structural stand-in for BASELINE configs[4] (100M x 128, sharded) on ONE GPU.  The real
-    configuration needs 51 GB of vectors and hours of host-side k-means; what it exercises on
-    the query path is big inverted lists (thousands of codes each, M = 32, rotated float64
-    table math) whose codes no longer fit the 256 MB Infinity Cache.  Such an index is
-    assembled DIRECTLY: random vectors, a random orthogonal rotation, random 16-entry
-    codebooks, codes by the product's device encoder (tk_encode_pq), lists assigned at random
-    with lognormal weights."""
-    from scipy.stats import ortho_group
+def synth_rows_host(n, d, seed, cent, sigma, row0=0):
+    """Rows of the seeded device generator (devbuild.hip), copied to the host."""
+    from tinyknn_amd import _lib
+    out = np.zeros((n, d), dtype=np.float32)
+    c = None if cent is None else np.ascontiguousarray(cent, dtype=np.float32)
+    _lib.check(_lib.lib().tk_synth_rows(_lib.ptr(out, _lib._f32p), row0, n, d, seed,
+                                        None if c is None else c.ctypes.data, 0 if c is None else len(c),
+                                        float(sigma)))
+    return out
+
+
+def build_index_c5(args, device):
+    """BASELINE configs[4] on ONE GPU at full size: N = 100M x 128 float32 (51 GB), generated IN
+    HBM by the seeded counter-based generator (3000 Gaussian clusters, sigma 0.7; SURVEY 8d C5:
+    "per-GPU generation on device"), IVF n_clusters = 10 000 fitted on a 1M-row sample, PQ rotated
+    128 -> 64 dims (M = 32, float64 table math), lists and codes built on the device
+    (tk_index_build_dev).  The vectors never visit the host."""
+    import torch
     from tinyknn_amd import IVF, FastPQ
-    from tinyknn_amd.fast_pq import TransformedData
-    from tinyknn_amd._transform import transform_data
-    rng = np.random.RandomState(args.seed)
-    n, d, L = args.n, args.d, args.n_clusters
-    rd, dpb = 64, 2
-    M = rd // dpb
     t0 = time.time()
-    ivf = IVF("euclidean", L, FastPQ(dpb))
-    pq = ivf.pq
-    pq.R = ortho_group.rvs(dim=d, random_state=rng)[:rd]
-    pq.centers = (rng.randn(16, rd) * 0.6).astype(np.float32)
-    pq.sqrt_n_blocks = np.sqrt(M)
+    cent = np.random.RandomState(args.seed).randn(3000, args.d).astype(np.float32)
+    ns = min(args.n, 1_000_000)
+    sample = synth_rows_host(ns, args.d, args.seed, cent, 0.7)   # rows 0..ns: a uniform sample of the clusters
+    ivf = IVF("euclidean", args.n_clusters, FastPQ(2))
+    ivf.all_centers = quick_kmeans(sample, args.n_clusters, 6, args.seed, device).astype(np.float32)
+    ivf.pq.fit(sample[:30000])
+    del sample
+    torch.cuda.empty_cache()
+    log(f"[bench] c5 fit done in {time.time() - t0:.1f}s")
+    ivf.build_resident(args.n, args.d, args.seed, cent, 0.7)
+    sz = ivf.list_sizes
+    log(f"[bench] c5 index built on the device in {time.time() - t0:.1f}s: {len(sz)} lists of "
+        f"{sz.min()}..{sz.max()} rows, codes {int(((sz + 15) // 16).sum()) * 16 * (ivf.pq.centers.shape[1] // 4) / 1e6:.0f} MB, "
+        f"vectors {args.n * args.d * 4 / 1e9:.1f} GB in HBM")
+    return ivf, cent
 
-    def encode(Xb):     # FastPQ.transform's body: numpy GEMM on the host, centroids on the GPU
-        return pq.encode_labels(Xb.astype(np.float64) @ pq.R.T, True)
 
-    data = np.empty((n, d), dtype=np.float32)
-    codes = np.empty((n, M), dtype=np.uint8)
-    for i in range(0, n, 1_000_000):
-        m = min(1_000_000, n - i)
-        data[i:i + m] = rng.randn(m, d).astype(np.float32)
-        codes[i:i + m] = encode(data[i:i + m])
-    w = rng.lognormal(0.0, 0.6, size=L)
-    assign = rng.choice(L, size=n, p=w / w.sum()).astype(np.int32)
-    order = np.argsort(assign, kind="stable")
-    sizes = np.bincount(assign, minlength=L).astype(np.int64)
+def oracle_index_resident(ivf, cache_dir):
+    """CPU oracle over what a device-resident index exports.  The 51 GB of vectors stay in HBM:
+    the oracle's `data` is a sparse memory-mapped file into which only the rows a check needs
+    (the heap candidates of the sampled queries) are copied (fill_rows)."""
+    from oracle import oracle as O
+    dev = ivf.device_index()
+    sizes, codes, ids = dev.export_lists()
+    chunks = (sizes + 15) // 16
+    coff = np.concatenate([[0], np.cumsum(chunks)])
     ioff = np.concatenate([[0], np.cumsum(sizes)])
-    ivf.data = data
-    ivf.active_centers = rng.randn(L, d).astype(np.float32)
-    cc = encode(np.concatenate([ivf.active_centers, np.zeros(((-L) % 16, d), np.float32)]))
-    ivf.pq_transformed_centers = TransformedData(L, transform_data(cc))
-    lists, ids = [], []
-    for l in range(L):
-        sel = order[ioff[l]:ioff[l + 1]]
-        pad = (-len(sel)) % 16
-        c = np.concatenate([codes[sel], np.zeros((pad, M), np.uint8)]) if len(sel) else np.zeros((0, M), np.uint8)
-        lists.append(TransformedData(len(sel), transform_data(c) if len(c) else np.zeros((0, M), np.uint64)))
-        ids.append(sel.astype(np.int64))
-    ivf.pq_transformed_points = lists
-    ivf.ids = ids
-    log(f"[bench] c5like index assembled in {time.time() - t0:.0f}s; lists {sizes.min()}..{sizes.max()} rows, "
-        f"codes {n * M // 2 / 1e6:.0f} MB, vectors {data.nbytes / 1e9:.1f} GB")
-    return ivf, None
+    L = len(sizes)
+    path = os.path.join(cache_dir, f"tinyknn_c5_rows_{os.getpid()}.f32")
+    data = np.memmap(path, dtype=np.float32, mode="w+", shape=(dev.N, dev.d))
+    ox = O.OracleIndex(ivf.pq.centers, 2, ivf.pq.R, ivf.pq.sqrt_n_blocks, ivf.active_centers,
+                       ivf.pq_transformed_centers.packed, [codes[coff[i]:coff[i + 1]] for i in range(L)],
+                       list(sizes), [ids[ioff[i]:ioff[i + 1]] for i in range(L)], data)
+    assert ox.data is data or np.may_share_memory(ox.data, data), "the oracle copied the sparse vector file"
+
+    def fill_rows(rows):
+        rows = np.unique(rows[rows >= 0])
+        data[rows] = dev.read_rows(rows)
+
+    def cleanup():
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return ox, fill_rows, cleanup
 
 
 def oracle_index(ivf):
@@ -268,11 +280,25 @@ def raw_stream_leg(args, dev, qs, out_dev, device, world):
     from tinyknn_amd import _front
     if not _front.bind():
         return {"error": "numpy's BLAS could not be bound: " + str(_front.info()["why"])}
-    slots = 8
-    st = dev.stream(args.nq, args.k, args.n_probes, slots=slots)
-    outs = [np.full((args.nq, args.k), -1, dtype=np.int64) for _ in range(slots)]
-    for i in range(max(args.warmup, slots)):
-        st.submit(qs, outs[i % slots])
+    # a step = one batch of args.nq queries, submitted in pieces of at most one sub-batch of the
+    # index (distance rows of a sub-batch stay under ~4 GiB: long lists mean fewer queries)
+    piece = min(args.nq, dev.max_sub_batch(args.k, args.n_probes))
+    cuts = list(range(0, args.nq, piece))
+    slots = 8 * len(cuts)
+    st = dev.stream(piece, args.k, args.n_probes, slots=min(slots, 64))
+    nbuf = max(2, min(slots, 64) // len(cuts))
+    outs = [np.full((args.nq, args.k), -1, dtype=np.int64) for _ in range(nbuf)]
+    qparts = [np.ascontiguousarray(qs[c:c + piece]) for c in cuts]
+
+    def submit(i):
+        o = outs[i % nbuf]
+        t = None
+        for c, qp_ in zip(cuts, qparts):
+            t = st.submit(qp_, o[c:c + piece])
+        return t
+
+    for i in range(max(args.warmup, nbuf)):
+        submit(i)
     st.drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -280,7 +306,7 @@ def raw_stream_leg(args, dev, qs, out_dev, device, world):
     p0 = st.prepare_seconds()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        st.submit(qs, outs[i % slots])
+        submit(i)
     st.drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -290,7 +316,8 @@ def raw_stream_leg(args, dev, qs, out_dev, device, world):
     # one batch at a time, for the latency of a single call
     t1 = time.perf_counter()
     for i in range(5):
-        st.wait(st.submit(qs, outs[0]))
+        submit(0)
+        st.drain()
     lat = (time.perf_counter() - t1) / 5
     st.close()
     t = torch.tensor([el], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
@@ -308,7 +335,8 @@ def raw_stream_leg(args, dev, qs, out_dev, device, world):
             "single_batch_latency_ms": lat * 1e3,
             "note": "raw float32 queries (host) -> ids (host), EXACT: normalisation/rotation by numpy's own "
                     "cblas_sdot/cblas_dgemv on a thread pool, pinned async H2D/D2H on a copy stream, "
-                    "8 batches outstanding; preparation + copies + kernels all inside the timed region"}
+                    "8 batches outstanding; preparation + copies + kernels all inside the timed region",
+            "queries_per_submit": piece}
 
 
 def hbm_scale_leg(device):
@@ -430,9 +458,9 @@ def main():
                          "1 rows through LDS, 4 waves/SIMD; 2 LDS, 3 waves/SIMD")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="replay streams (tk_index_set_pipeline): caller + coarse stream + these = 4 HW queues")
-    ap.add_argument("--workload", choices=["glove", "c5like"], default="glove",
-                    help="c5like: 20M x 128 random vectors in 4472 big lists (stand-in for configs[4]); "
-                         "implies --n 20000000 --d 128 --n-clusters 4472 --metric euclidean unless given")
+    ap.add_argument("--workload", choices=["glove", "c5"], default="glove",
+                    help="c5: BASELINE configs[4] on one GPU, 100M x 128 generated and built in HBM; "
+                         "implies --n 100000000 --d 128 --n-clusters 10000 --metric euclidean unless given")
     ap.add_argument("--shard", choices=["auto", "none", "lists"], default="auto",
                     help="list-sharded leg after the replica measurement (auto: when N > 1)")
     ap.add_argument("--shard-depth", type=int, default=3,
@@ -451,14 +479,15 @@ def main():
     ap.add_argument("--shard-limit", type=float, default=240.0,
                     help="seconds after which a stuck list-sharded leg is abandoned")
     args = ap.parse_args()
-    if args.workload == "c5like":
+    if args.workload == "c5":
         dflt = ap.parse_args([])
-        if args.n == dflt.n: args.n = 20_000_000
+        if args.n == dflt.n: args.n = 100_000_000
         if args.d == dflt.d: args.d = 128
-        if args.n_clusters == dflt.n_clusters: args.n_clusters = 4472
+        if args.n_clusters == dflt.n_clusters: args.n_clusters = 10000
         args.metric = "euclidean"
         args.cpu_sample = min(args.cpu_sample, 300)
-        if args.shard == "auto": args.shard = "none"
+        args.py_cpu_sample = min(args.py_cpu_sample, 50)
+        args.shard = "none"
 
     import torch
     import torch.distributed as dist
@@ -482,8 +511,8 @@ def main():
     # -- index: rank 0 builds (or loads) first so that the cache exists for the others
     if world > 1 and rank != 0:
         dist.barrier()
-    if args.workload == "c5like":
-        ivf, cent = build_index_c5like(args)
+    if args.workload == "c5":
+        ivf, cent = build_index_c5(args, device)
     else:
         ivf, cent = build_index(args, device)
     if world > 1 and rank == 0:
@@ -492,8 +521,8 @@ def main():
     M = ivf.pq.centers.shape[1] // 2
 
     # -- this rank's batch, normalised on the host exactly like ivf.py:125-127
-    if args.workload == "c5like":
-        qs = np.random.RandomState(args.seed + 100 + rank).randn(args.nq, args.d).astype(np.float32)
+    if args.workload == "c5":
+        qs = synth_rows_host(args.nq, args.d, args.seed + 100 + rank, cent, 0.7)
     else:
         qs = synth_queries(cent, args.nq, args.seed + 100 + rank, kind=args.data)
     t_prep = time.perf_counter()
@@ -654,9 +683,7 @@ def main():
     # -- recall against brute force (torch matmul on the GPU: measurement plumbing)
     rs = min(args.recall_sample, args.nq)
     truth_s = None
-    if args.workload == "c5like":
-        recall = None        # iid random vectors: no neighbourhood structure to recall
-    elif ivf.data.dtype == np.float32 and args.d <= 128:
+    if ivf.data.dtype == np.float32 and args.d <= 128:
         # exact ground truth on the f32 matrix cores (brute.hip: numpy's knn_brute distances
         # bit for bit); qn and IVF.data are normalised for the angular metric
         tg = time.perf_counter()
@@ -677,8 +704,25 @@ def main():
     cpu = None
     parity = None
     if not args.no_cpu and world == 1:
-        ox = oracle_index(ivf)
         cs = min(args.cpu_sample, args.nq)
+        heap_parity = None
+        if args.workload == "c5":
+            ox, fill_rows, ox_cleanup = oracle_index_resident(ivf, args.cache_dir)
+            # the rows the oracle will rescore = the heap candidates; the device's heaps are
+            # compared with the oracle's first (probe lists and heap arrays, layout included)
+            dev.set_pipeline(1)
+            _, dbg = dev.query_batch(qn[:cs], qp[:cs], args.k, args.n_probes, debug=True)
+            fill_rows(dbg["heap_idx"])
+            same_h = same_p = 0
+            hs = min(cs, 40)
+            for i in range(hs):
+                _, w = ox.query(qn[i], args.k, args.n_probes, debug=True)
+                same_p += int(np.array_equal(w["probes"], dbg["probes"][i]))
+                same_h += int(np.array_equal(w["heap_idx"], dbg["heap_idx"][i]) and
+                              np.array_equal(w["heap_val"], dbg["heap_val"][i]))
+            heap_parity = {"queries": hs, "identical_probe_lists": same_p, "identical_heap_arrays": same_h}
+        else:
+            ox = oracle_index(ivf)
         tc = time.perf_counter()
         want = ox.query_batch(qn[:cs], args.k, args.n_probes)
         tcpu = time.perf_counter() - tc
@@ -686,6 +730,8 @@ def main():
                "sample": f"first {cs} queries of the same batch, oracle/tinyknn_oracle.c "
                          f"(AVX2 pshufb scan + sequential heap), {tcpu:.2f}s"}
         parity = {"queries_checked": cs, "identical_rows": int((want == got[:cs]).all(axis=1).sum())}
+        if heap_parity:
+            parity.update(heap_parity)
         # like-for-like with examples/bench.py:118-137: ONE Python-level query() per query
         # (normalise, table, coarse top, chained list scans, rescoring per call), one thread
         ps = min(args.py_cpu_sample, args.nq)
@@ -700,22 +746,26 @@ def main():
                               "sample": f"first {ps} raw queries, one Python-level query() per query as "
                                         f"examples/bench.py:118-137 times the reference; the per-query work is the C port's "
                                         f"(table build and rescoring in C, where the reference runs numpy), {tpy:.2f}s"}
+        if args.workload == "c5":
+            ox_cleanup()
         cpu["note"] = ("value = C batch loop of the port (no per-query Python overhead: the STRONGER "
                        "baseline); python_loop = the reference's own measurement protocol")
 
     line = {
         "metric": f"queries/sec at Recall10@10 on GloVe-100 angular (synthetic stand-in), IVF+4-bit PQ, build_probes={args.build_probes}"
                   if (args.workload, args.data, args.metric, args.d) == ("glove", "glove-like", "angular", 100) else
-                  f"queries/sec, c5like stand-in for 100M x 128 (N={args.n} random vectors, big lists), IVF+4-bit PQ"
-                  if args.workload == "c5like" else
+                  f"queries/sec at Recall10@10, synthetic {args.n} x {args.d} float32 (BASELINE configs[4] on one GPU), "
+                  f"IVF n_clusters={args.n_clusters} + 4-bit PQ"
+                  if args.workload == "c5" else
                   f"queries/sec at Recall10@10, {args.data} {args.metric} d={args.d} (synthetic), IVF+4-bit PQ",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8 (saturating PQ sums) + f32 (tables, rescoring)", "data": "synthetic",
-        "config": {"workload": ("c5like (stand-in for 100M x 128): random N(0,1) vectors, random rotation to 64 "
-                                "dims, random codebooks, lognormal list sizes, euclidean, "
-                                if args.workload == "c5like" else
+        "config": {"workload": ("c5 (BASELINE configs[4] on one GPU): 3000 Gaussian clusters sigma 0.7 generated in "
+                                "HBM (seeded counter-based generator), index built on the device, PQ rotated to 64 "
+                                "dims, euclidean, "
+                                if args.workload == "c5" else
                                 f"{args.data} {args.metric} stand-in "
                                 "(glove-like: 300 Gaussian clusters sigma 0.7; sift-like: |N(0,1)|*40 clipped): "
                                 if (args.data, args.metric) != ("glove-like", "angular") else

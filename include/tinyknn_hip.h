@@ -178,7 +178,7 @@ int tk_index_query_batch(tk_index *ix, const float *q, const void *q_pq, int q_p
                          int64_t *out_probes, int64_t *out_heap_idx, int32_t *out_heap_val);
 
 /* Same with device-resident inputs/outputs, enqueued on `stream`, no sync.  Large
- * batches are processed in sub-batches whose distance buffers stay under ~4 GiB.
+ * batches are processed in sub-batches whose distance buffers stay under 12 GB (TINYKNN_WORKSPACE_GB).
  * An index handle is not thread-safe: one caller at a time per tk_index. */
 int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_dev,
                              int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,

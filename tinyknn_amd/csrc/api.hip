@@ -602,7 +602,7 @@ struct tk_index {
     // local_chunk_off addresses this rank's code storage (lists of other ranks: empty)
     DevBuf owner, local_chunk_off;
     DevBuf rot_t;            // fast mode: R transposed (d_pad, dq) float64, or empty
-    DevBuf br_ynorm, br_vals, br_tau, br_cand, br_count, br_out, br_q;   // tk_index_knn_brute
+    DevBuf br_ynorm, br_vals, br_tau, br_cand, br_count, br_out, br_q, br_sample;   // tk_index_knn_brute
     int rot_d_pad = 0;
     int rank = 0, world = 1;
     bool sharded = false;
@@ -650,7 +650,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->ids32, &ix->data, &ix->cslots_i,
                       &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage, &ix->owner,
                       &ix->local_chunk_off, &ix->rot_t, &ix->br_ynorm, &ix->br_vals, &ix->br_tau,
-                      &ix->br_cand, &ix->br_count, &ix->br_out, &ix->br_q};
+                      &ix->br_cand, &ix->br_count, &ix->br_out, &ix->br_q, &ix->br_sample};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
     for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
@@ -899,10 +899,24 @@ static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
 static const int64_t MAX_SUB = 32768;  // gridDim.y limit of the scan kernels is 65535
 
 // Queries per sub-batch: the distance buffer is nq * cap * 17 bytes (16 int8 + 1 minimum
-// per chunk, cap = n_probes * longest list); keep it under ~4 GiB per workspace.
+// per chunk, cap = n_probes * longest list); one workspace keeps it under 12 GB (env
+// TINYKNN_WORKSPACE_GB; up to depth + 5 workspaces exist — sized for 288 GB of HBM: at
+// 100M x 128 with 10 000 lists a 4 GB workspace cut a batch of 10 000 queries in two, and the
+// list-major scan then found 5 instead of 10 queries per list to share a fetched chunk).
+static double workspace_bytes()
+{
+    static double b = 0;
+    if (b == 0) {
+        const char *e = getenv("TINYKNN_WORKSPACE_GB");
+        const double g = e ? atof(e) : 0.0;
+        b = (g >= 0.25 ? g : 12.0) * 1.0e9;
+    }
+    return b;
+}
+
 static int64_t sub_batch(const Plan &p)
 {
-    int64_t s = (int64_t)(4.0e9 / ((double)p.cap * 17.0));
+    int64_t s = (int64_t)(workspace_bytes() / ((double)p.cap * 17.0));
     s = s < 64 ? 64 : s;
     return s < MAX_SUB ? s : MAX_SUB;
 }
@@ -1995,18 +2009,20 @@ extern "C" int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int 
     TRY(ix->br_count.ensure((size_t)nq * 4 + 4));
     TRY(ix->br_out.ensure((size_t)nq * k * 8));
     TRY(ix->br_q.ensure((size_t)nq * ix->d * 4));
+    TRY(ix->br_sample.ensure((size_t)ns * (ix->d + 1) * 4));
     HIPCHECK(hipMemcpy(ix->br_q.p, q, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice));
     int *overflow = ix->br_count.as<int>() + nq;
     if (tk_launch_knn_brute(ix->br_q.as<float>(), nq, ix->d, ix->data.as<float>(), ix->N, k,
                             ix->br_ynorm.as<float>(), ix->br_vals.as<float>(), ns,
                             ix->br_tau.as<float>(), ix->br_cand.as<unsigned long long>(), cap,
-                            ix->br_count.as<int>(), overflow, ix->br_out.as<int64_t>(), nullptr))
+                            ix->br_count.as<int>(), overflow, ix->br_out.as<int64_t>(),
+                            ix->br_sample.as<float>(), nullptr))
         return fail(TK_ERR_HIP, "tk_launch_knn_brute: unsupported size / LDS attribute");
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipDeviceSynchronize());
     int ov = 0;
     HIPCHECK(hipMemcpy(&ov, overflow, 4, hipMemcpyDeviceToHost));
-    if (ov) return fail(TK_ERR_HIP, "knn_brute: candidate list overflow (more than 8192 rows within the sampled k-th distance)");
+    if (ov) return fail(TK_ERR_HIP, "knn_brute: candidate list overflow (a 2^20-row segment holds more than 8192 rows within the running k-th distance)");
     HIPCHECK(hipMemcpy(out_ids, ix->br_out.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
     return TK_OK;
 }

@@ -7,11 +7,14 @@
 // ascending (MI355X guide, "FP32-input MFMA"), i.e. what OpenBLAS returns for (2X) @ Y.T, and
 // the norms use numpy's einsum order (np_order.h) — the part values are numpy's.
 // Selection of the k smallest without data-dependent loops:
-//   pass A  part values of the first `ns` rows of Y -> (nq, ns) floats
+//   pass A  part values of `ns` rows of Y taken at a constant stride over the whole matrix
+//           (not its first rows: cluster-ordered data would give a useless bound) -> (nq, ns)
 //   sort    per query: k-th smallest of them = tau_q           (bitonic sort in LDS)
-//   pass B  all rows of Y: every (part, j) with part <= tau_q is appended to the query's
-//           candidate list (atomic counter; expected k * N / ns entries, capacity `cap`)
-//   sort    per query: candidates by (part, j) ascending -> the first k.  Ties: lower j first.
+//   pass B  the rows of Y in segments of 2^20: every (part, j) with part <= tau_q is appended
+//           to the query's candidate list (atomic counter, capacity `cap`); after each
+//           segment the list is sorted, cut to its k best and tau_q tightened to the k-th of
+//           them, so a segment adds about k * 2^20 / max(ns, rows seen) entries whatever N is
+//   result  the k best after the last segment, by (part, j) ascending.  Ties: lower j first.
 // One workgroup = 4 waves = 128 query rows against 32 rows of Y at a time; the Y tile (32
 // consecutive rows = one contiguous block of memory) is fetched once per workgroup into LDS
 // in MFMA operand order, double-buffered.
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(256) void brute_tiles_kernel(
     const float *__restrict__ X, int64_t nq, int d, const float *__restrict__ Y,
     const float *__restrict__ ynorm2, int64_t N, float *__restrict__ vals, int64_t ns,
     const float *__restrict__ tau, unsigned long long *__restrict__ cand, int cap,
-    int *__restrict__ count)
+    int *__restrict__ count, int64_t j_base)
 {
     const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void brute_tiles_kernel(
                             // order-preserving key: float bits made monotone, then the index
                             uint32_t u = __float_as_uint(part);
                             u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                            cand[row * (int64_t)cap + pos] = ((unsigned long long)u << 32) | (uint32_t)j;
+                            cand[row * (int64_t)cap + pos] = ((unsigned long long)u << 32) | (uint32_t)(j_base + j);
                         }
                     }
                 }
@@ -139,12 +142,14 @@ __global__ __launch_bounds__(256) void brute_tiles_kernel(
 
 // Bitonic sort of up to TK_BR_SORT 64-bit keys per query in LDS (one workgroup per query).
 // MODE 0: keys = part values of the sample (index ignored) -> tau[q] = k-th smallest.
-// MODE 1: keys = candidates (part, j) -> out[q][0..k) = j of the k smallest.
+// MODE 1: keys = candidates (part, j) -> out[q][0..k) = j of the k smallest; the k smallest
+//         stay at the head of the query's list (count = min(k, n)) and tau[q] becomes the
+//         k-th part value once k candidates exist: the next segment of rows appends to that.
 #define TK_BR_SORT 8192
 template <int MODE>
 __global__ __launch_bounds__(1024) void brute_select_kernel(
-    const float *__restrict__ vals, int64_t ns, const unsigned long long *__restrict__ cand, int cap,
-    const int *__restrict__ count, int k, float *__restrict__ tau, int64_t *__restrict__ out,
+    const float *__restrict__ vals, int64_t ns, unsigned long long *__restrict__ cand, int cap,
+    int *__restrict__ count, int k, float *__restrict__ tau, int64_t *__restrict__ out,
     int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -187,20 +192,41 @@ __global__ __launch_bounds__(1024) void brute_select_kernel(
             tau[q] = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
         }
     } else {
-        for (int e = threadIdx.x; e < k; e += 1024) out[q * k + e] = e < n ? (int64_t)(uint32_t)key[e] : -1;
+        for (int e = threadIdx.x; e < k; e += 1024) {
+            out[q * k + e] = e < n ? (int64_t)(uint32_t)key[e] : -1;
+            if (e < n) cand[q * (int64_t)cap + e] = key[e];
+        }
+        if (threadIdx.x == 0) {
+            count[q] = n < k ? n : k;
+            if (n >= k) {
+                const uint32_t u = (uint32_t)(key[k - 1] >> 32);
+                tau[q] = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+            }
+        }
     }
+}
+
+// `ns` rows of Y at stride N / ns (row i * stride) -> a contiguous sample
+__global__ void sample_rows_kernel(const float *__restrict__ Y, int d, int64_t ns, int64_t stride,
+                                   float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns * d) return;
+    const int64_t r = i / d;
+    out[i] = Y[r * stride * d + (i - r * d)];
 }
 
 // X (nq, d), Y (N, d) float32 on the device, d <= 128, N < 2^31; out (nq, k) int64.
 // Work buffers are the caller's: ynorm2 (N), vals (nq * ns), tau (nq), cand (nq * cap) u64,
-// count (nq) int, overflow (1) int.  ns <= TK_BR_SORT, cap <= TK_BR_SORT, k <= ns.
+// count (nq) int, overflow (1) int, sample (ns * (d + 1)) floats.
+// ns <= TK_BR_SORT, cap <= TK_BR_SORT, k <= ns <= N, 2k <= cap.
 int tk_launch_knn_brute(const float *X, int64_t nq, int d, const float *Y, int64_t N, int k,
                         float *ynorm2, float *vals, int64_t ns, float *tau,
                         unsigned long long *cand, int cap, int *count, int *overflow, int64_t *out,
-                        hipStream_t s)
+                        float *sample, hipStream_t s)
 {
     if (nq == 0) return 0;
-    if (d > 128 || ns > TK_BR_SORT || cap > TK_BR_SORT || k > ns || ns > N) return -1;
+    if (d > 128 || ns > TK_BR_SORT || cap > TK_BR_SORT || k > ns || ns > N || 2 * k > cap) return -1;
     static bool attr_set = false;
     if (!attr_set) {
         const void *fns[] = {(const void *)brute_tiles_kernel<0>, (const void *)brute_tiles_kernel<1>,
@@ -221,15 +247,25 @@ int tk_launch_knn_brute(const float *X, int64_t nq, int d, const float *Y, int64
         return (unsigned)(s < 1 ? 1 : s);
     };
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Y, N, d, ynorm2);
-    hipLaunchKernelGGL(brute_tiles_kernel<0>, dim3(qt, splits(ns)), dim3(256), tile_lds, s, X, nq, d, Y, ynorm2, N, vals,
-                       ns, nullptr, nullptr, 0, nullptr);
+    // tau from a strided sample of the whole matrix (its rows are rows of Y: tau >= the true
+    // k-th smallest part, bit for bit the same arithmetic)
+    float *snorm = sample + (size_t)ns * d;
+    hipLaunchKernelGGL(sample_rows_kernel, dim3((unsigned)((ns * d + 255) / 256)), dim3(256), 0, s, Y, d, ns,
+                       N / ns, sample);
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, sample, ns, d, snorm);
+    hipLaunchKernelGGL(brute_tiles_kernel<0>, dim3(qt, splits(ns)), dim3(256), tile_lds, s, X, nq, d, sample, snorm,
+                       ns, vals, ns, nullptr, nullptr, 0, nullptr, (int64_t)0);
     hipLaunchKernelGGL(brute_select_kernel<0>, dim3((unsigned)nq), dim3(1024), (size_t)TK_BR_SORT * 8, s,
                        vals, ns, nullptr, 0, nullptr, k, tau, nullptr, nullptr);
     (void)hipMemsetAsync(count, 0, (size_t)nq * 4, s);
     (void)hipMemsetAsync(overflow, 0, 4, s);
-    hipLaunchKernelGGL(brute_tiles_kernel<1>, dim3(qt, splits(N)), dim3(256), tile_lds, s, X, nq, d, Y, ynorm2, N, nullptr,
-                       0, tau, cand, cap, count);
-    hipLaunchKernelGGL(brute_select_kernel<1>, dim3((unsigned)nq), dim3(1024), (size_t)TK_BR_SORT * 8, s,
-                       nullptr, 0, cand, cap, count, k, nullptr, out, overflow);
+    const int64_t seg = 1 << 20;
+    for (int64_t s0 = 0; s0 < N; s0 += seg) {
+        const int64_t m = N - s0 < seg ? N - s0 : seg;
+        hipLaunchKernelGGL(brute_tiles_kernel<1>, dim3(qt, splits(m)), dim3(256), tile_lds, s, X, nq, d,
+                           Y + s0 * d, ynorm2 + s0, m, nullptr, 0, tau, cand, cap, count, s0);
+        hipLaunchKernelGGL(brute_select_kernel<1>, dim3((unsigned)nq), dim3(1024), (size_t)TK_BR_SORT * 8, s,
+                           nullptr, 0, cand, cap, count, k, tau, out, overflow);
+    }
     return 0;
 }

@@ -53,10 +53,14 @@ __global__ void synth_rows_kernel(float *__restrict__ X, int64_t row0, int64_t n
 void tk_launch_synth_rows(float *X, int64_t row0, int64_t n, int d, uint64_t seed, const float *centres,
                           int n_centres, float sigma, hipStream_t s)
 {
-    const int64_t items = n * ((d + 1) / 2);
-    if (items <= 0) return;
-    hipLaunchKernelGGL(synth_rows_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, X, row0,
-                       n, d, seed, centres, n_centres, sigma);
+    // slabs: a launch addresses at most 2^32 - 1 threads (grid x block)
+    const int hp = (d + 1) / 2;
+    const int64_t slab = (int64_t)1 << 22;
+    for (int64_t o = 0; o < n; o += slab) {
+        const int64_t m = n - o < slab ? n - o : slab;
+        hipLaunchKernelGGL(synth_rows_kernel, dim3((unsigned)((m * hp + 255) / 256)), dim3(256), 0, s,
+                           X + o * d, row0 + o, m, d, seed, centres, n_centres, sigma);
+    }
 }
 
 // ---------------------------------------------------------------------------

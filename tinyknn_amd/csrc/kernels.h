@@ -213,4 +213,4 @@ void tk_launch_gather_rows(const float *X, int d, const int64_t *rows, int64_t n
 int tk_launch_knn_brute(const float *X, int64_t nq, int d, const float *Y, int64_t N, int k,
                         float *ynorm2, float *vals, int64_t ns, float *tau,
                         unsigned long long *cand, int cap, int *count, int *overflow, int64_t *out,
-                        hipStream_t s);
+                        float *sample, hipStream_t s);
