@@ -1240,18 +1240,41 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
     return TK_OK;
 }
 
+// Persistent workgroups of the fused scan launch in the pipelined mode: 512 = two per CU.
+// Three per CU (768) is the residency the kernel's 145 VGPRs allow on an EMPTY chip and is the
+// faster grid for a launch that runs alone; next to the other batches' kernels a CU that hosts a
+// replay wave (120+ VGPRs) has no room for a third scan workgroup, which then waits for a slot
+// while its share of the work is drawn by others — measured per 10 000 queries: 768 -> 0.705 ms,
+// 640 -> 0.703, 576 -> 0.682, 512 -> 0.657, 448 -> 0.678, 384 -> 0.743 (profiles/r02_scan_grid.md).
+// A/B: TINYKNN_SCAN_BLOCKS.
+static int scan_blocks_pipelined()
+{
+    static int n = 0;
+    if (n == 0) {
+        const char *e = getenv("TINYKNN_SCAN_BLOCKS");
+        n = e ? atoi(e) : 512;
+        n = n < 64 ? 512 : n;
+    }
+    return n;
+}
+
 // depth > 1: the launch on the caller's stream that carries the list scan of `prev` (may be
 // NULL) and the coarse scan of `cur` (may be NULL), and what follows each on its stream
 static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
 {
     const int M = ix->M;
     hipStream_t st = prev ? prev->st : cur->st;
+    // what the launch waits for lives on the front stream, in order: ..., front_done(c-3),
+    // tables_done(c-1), ... — the later event covers the earlier one, and every hand-over
+    // between streams is a barrier packet the command processor spends microseconds on
+    static const bool merge = !(getenv("TINYKNN_MERGE_EVENTS") && getenv("TINYKNN_MERGE_EVENTS")[0] == '0');
     if (cur) {
         HIPCHECK(hipStreamWaitEvent(st, cur->w->tables_done, 0));
         cur->coarse_launched = true;
     }
     if (prev) {
-        HIPCHECK(hipStreamWaitEvent(st, prev->w->front_done, 0));
+        if (!(merge && cur && prev->sf == cur->sf))
+            HIPCHECK(hipStreamWaitEvent(st, prev->w->front_done, 0));
         TRY(prev->pf.mark(st));
     }
     const bool fuse_prev = prev && prev->units;
@@ -1266,8 +1289,8 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         TkScanJob none;
         memset(&none, 0, sizeof none);
         tk_launch_scan_units2(fuse_prev ? list_job(ix, *prev->w, prev->p) : none,
-                              fuse_cur ? coarse_job(ix, *cur->w, cur->p) : none, M, ix->order, 768,
-                              st);
+                              fuse_cur ? coarse_job(ix, *cur->w, cur->p) : none, M, ix->order,
+                              scan_blocks_pipelined(), st);
     }
     if (prev) {
         // heap replay + rescoring of the previous batch on its stream
@@ -1281,10 +1304,15 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         prev->w->busy = true;
     }
     if (cur) {
-        // rest of the coarse stage + scan descriptors of this batch on its stream
+        // rest of the coarse stage + scan descriptors of this batch on its stream (one event
+        // behind the launch serves both consumers)
         Work &w = *cur->w;
-        HIPCHECK(hipEventRecord(w.coarse_scanned, st));
-        HIPCHECK(hipStreamWaitEvent(cur->sf, w.coarse_scanned, 0));
+        if (merge && prev) {
+            HIPCHECK(hipStreamWaitEvent(cur->sf, prev->w->scanned, 0));
+        } else {
+            HIPCHECK(hipEventRecord(w.coarse_scanned, st));
+            HIPCHECK(hipStreamWaitEvent(cur->sf, w.coarse_scanned, 0));
+        }
         TRY(stage_coarse_rest(ix, w, cur->q_dev, cur->nq, cur->p,
                               cur->units ? w.u_count.as<int>() : nullptr, nullptr, 0, cur->sf,
                               cur->pf));

@@ -305,25 +305,82 @@ __device__ __forceinline__ uint32_t mask_lt16(const uint4 v, uint32_t bound8)
     return m;
 }
 
+// `pos < n` (_fast_pq_256.pyx:111) once, ahead of the replay: the rows that pad the last chunk
+// of a probed list (code of the zero vector, fast_pq.py:165) get the largest distance value —
+// nothing is ever below a bound with it, which is exactly what the reference's row test
+// achieves — and the chunk's minimum is recomputed.  One thread per (query, slot).
+template <bool SIGNED>
+__global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq,
+                               const int *__restrict__ slot_prefix, const int *__restrict__ slot_n,
+                               int S, int slots_uniform, uint8_t *__restrict__ mins, int64_t cap_min)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * S) return;
+    const int64_t q = i / S;
+    const int sl = (int)(i - q * S);
+    const int64_t qs = slots_uniform ? 0 : q;
+    const int f0 = slot_prefix[qs * (S + 1) + sl], f1 = slot_prefix[qs * (S + 1) + sl + 1];
+    int n = slot_n[qs * S + sl];
+    n = n < 0 ? 0 : n;
+    const uint32_t fill = SIGNED ? 0x7f7f7f7fu : 0xffffffffu;
+    for (int c = n >> 4; c < f1 - f0; c++) {
+        const int keep = n - 16 * c;                   // valid rows of this chunk: 0..15
+        uint4 v = dist[q * cap + f0 + c];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        int m = SIGNED ? 127 : 255;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int km = keep - 4 * j;
+            km = km < 0 ? 0 : (km > 4 ? 4 : km);
+            const uint32_t kmask = km >= 4 ? 0xffffffffu : ((1u << (8 * km)) - 1u);
+            w[j] = (w[j] & kmask) | (fill & ~kmask);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t b = (w[j] >> (8 * t)) & 0xffu;
+                const int x = SIGNED ? (int)(int8_t)b : (int)b;
+                m = x < m ? x : m;
+            }
+        }
+        dist[q * cap + f0 + c] = make_uint4(w[0], w[1], w[2], w[3]);
+        mins[q * cap_min + f0 + c] = (uint8_t)m;
+    }
+}
+
 // DEDUPE (labels may repeat, IVF.build(n_probes >= 2)): the low 24 bits of an entry are
 // a SLOT, LAB[slot][lane] holds the slot's 32-bit label, `insert` first scans LAB for
 // the candidate's label (the reference's duplicate test, _fast_pq.pyx:284-287) and a
 // new entry inherits the slot of the root it evicts.  labels32 = the ids as int32.
 template <bool SIGNED, bool DEDUPE>
-__global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
+__global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
     const unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
-    int64_t cap_min, const int32_t *__restrict__ labels32)
+    int64_t cap_min, const int32_t *__restrict__ labels32, unsigned long long *__restrict__ dbg,
+    int prio, int wave_lds)
 {
+    // dbg != NULL (tk_debug_replay_timers): cycle counters of the wave's phases, 8 per workgroup:
+    // total, block search, insert (all of it), LDS sift levels, rounds, LDS iterations, search
+    // iterations, segments
+#ifdef TK_REPLAY_TIMERS
+#define TK_TICK() (dbg ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#define TK_DBG(x) x
+#else        // the production build carries no timer code (it cost 10 % even when disarmed)
+#define TK_TICK() 0ull
+#define TK_DBG(x)
+#endif
+    unsigned long long d_search = 0, d_ins = 0, d_lds = 0, d_rounds = 0, d_ldsit = 0, d_sit = 0;
+    const unsigned long long d_t0 = TK_TICK();
     // the replay is a chain of dependent LDS round trips on 157 waves; when it shares SIMDs
     // with other batches' VALU-bound scan waves, let the arbiter issue its instructions first
-    __builtin_amdgcn_s_setprio(3);
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     // LDS: H[R+2][64] heap columns (+2 sentinel rows) | DEDUPE: LAB[ceil(R/4)][64][4]
     //      labels by slot, CNT[256][64] label-hash counters | ST[nbuf][16][64] staged blocks
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
+    unsigned char *smem = smem_wg + (size_t)(threadIdx.x >> 6) * wave_lds;
     uint32_t *H = (uint32_t *)smem;
     const int R4 = (R + 3) >> 2;
     uint32_t *LAB = (uint32_t *)(smem + (size_t)(R + 2) * 256);
@@ -332,14 +389,14 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
                           (DEDUPE ? (size_t)R4 * 1024 + 256 * 64 : 0));
 #define TK_LAB(slot) LAB[(((slot) >> 2) * 64 + lane) * 4 + ((slot) & 3)]
 #define TK_HASH(label) (((uint32_t)(label) * 0x9E3779B1u) >> 24)
-    const int lane = threadIdx.x;
-    const int64_t q = (int64_t)blockIdx.x * 64 + lane;
+    // a workgroup = blockDim.x / 64 independent query-waves, each with its own LDS region
+    const int lane = threadIdx.x & 63;
+    const int64_t q = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64 + lane;
     // `skip`: queries whose probe list may repeat a list (left to the wave kernel)
     const bool valid = q < nq && !(skip && skip[q]);
     const int64_t qc = q < nq ? q : nq - 1;
     const int64_t qs = slots_uniform ? 0 : qc;
     const int *prefix = slot_prefix + qs * (S + 1);
-    const int *sn = slot_n + qs * S;
     const uint4 *drow = dist + qc * cap;
 
     const uint32_t fresh_val = SIGNED ? 0x7f000000u : 0xff000000u;
@@ -371,40 +428,46 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
     max_nseg = __builtin_amdgcn_readfirstlane(max_nseg);
 
     // slot cursor (monotonic): flat chunks [s_begin, s_end) belong to slot s with n rows
-    int s = 0, s_begin = 0, s_end = 0, n = 0;
+    int s = 0, s_begin = 0, s_end = 0;
     int64_t s_loff = 0;   // DEDUPE: label offset of the current slot
     if (total > 0) {
         s_end = prefix[1];
-        n = sn[0];
         if (DEDUPE) s_loff = slot_label_off[qs * S];
     }
 
-    // stage segment g (16 blocks per lane, each lane from its own row) by LDS-DMA:
-    // one global_load_lds_dwordx4 per block row k writes ST[buf][k][0..63]
-    auto stage = [&](int g, int buf) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int blk = 16 * g + k;
-            if (blk < total)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(drow + blk),
-                    (__attribute__((address_space(3))) void *)(ST + (buf * 16 + k) * 64), 16, 0, 0);
-        }
-    };
-
-    uint4 mins_next = make_uint4(0, 0, 0, 0);
-    if (max_nseg > 0) {
-        stage(0, 0);
-        if (total > 0) mins_next = mrow[0];
+    // Segment g + 1 (16 blocks per lane, each lane from its own row, + its 16 block minima) is
+    // fetched into REGISTERS while segment g is replayed and dropped into the LDS staging rows
+    // ST[k][lane] — from where the replay picks blocks by a run-time index — when segment g is
+    // done.  (Round 1 staged by LDS-DMA, global_load_lds_dwordx4: the compiler must put
+    // s_waitcnt vmcnt(0) in front of every LDS read that follows such an operation — it cannot
+    // tell that the read does not alias the DMA's target — so the "next" segment was always
+    // waited for before the current one was touched.  Fetching only the blocks whose minimum
+    // passes the previous bound, predicated per lane, was measured slower: the exec-mask
+    // handling costs more than the addresses it saves; profiles/r02_replay_phases.md.)
+    // Blocks past the lane's row are clamped to its last valid address and never looked at.
+    const int last_blk = (int)(cap > 0 ? cap - 1 : 0);
+    const int last_m = (int)(cap_min / 16) - 1;
+    uint4 nx[16];
+    uint4 mins_nx = make_uint4(0, 0, 0, 0);
+#define TK_FETCH_SEGMENT(g_)                                                      \
+    {                                                                             \
+        _Pragma("unroll") for (int k = 0; k < 16; k++) {                          \
+            int blk_ = 16 * (g_) + k;                                             \
+            blk_ = blk_ < last_blk ? blk_ : last_blk;                             \
+            nx[k] = drow[blk_];                                                   \
+        }                                                                         \
+        const int mg_ = (g_) < last_m ? (g_) : (last_m > 0 ? last_m : 0);         \
+        mins_nx = mrow[mg_];                                                      \
     }
+#pragma unroll
+    for (int k = 0; k < 16; k++) nx[k] = make_uint4(0, 0, 0, 0);
+    if (max_nseg > 0) TK_FETCH_SEGMENT(0)
     for (int g = 0; g < max_nseg; g++) {
-        const int buf = nbuf > 1 ? (g & 1) : 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // segment g (and its minima) landed
-        const uint4 mins_cur = mins_next;
-        if (nbuf > 1 && g + 1 < max_nseg) {
-            stage(g + 1, buf ^ 1);
-            if (16 * (g + 1) < total) mins_next = mrow[g + 1];
-        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) ST[k * 64 + lane] = nx[k];
+        const uint4 mins_cur = mins_nx;
+        if (g + 1 < max_nseg) TK_FETCH_SEGMENT(g + 1)
+        const int buf = 0;
         int kmax = total - 16 * g;
         kmax = kmax < 0 ? 0 : (kmax > 16 ? 16 : kmax);
         // blocks whose minimum is below the bound at segment start: a superset of the
@@ -418,27 +481,32 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
         int64_t lab_base = 0;         //         first label of the current block
         for (;;) {
             // next block of this segment with a byte below the live bound
+            const unsigned long long d_ts = TK_TICK();
             while (bits == 0 && hit) {
+                TK_DBG(if (dbg) d_sit++;)
                 const int k = __builtin_ctz(hit);
                 hit &= hit - 1;
                 dd = ST[(buf * 16 + k) * 64 + lane];
                 cur = 16 * g + k;
-                while (cur >= s_end) {   // next probed list (empty lists are stepped over)
-                    s++;
-                    s_begin = s_end;
-                    s_end = prefix[s + 1];
-                    n = sn[s];
-                    if (DEDUPE) s_loff = slot_label_off[qs * S + s];
-                }
+                // `pos < n` (:111): the rows that pad a list's last chunk were set to the largest
+                // value by pad_fix_kernel and can never be below a bound — no row count, and
+                // with distinct labels no slot cursor at all, is needed here
                 bits = mask_lt16<SIGNED>(dd, bound);          // cmp_mask, _fast_pq_256.pyx:81-90
-                const int rows = n - 16 * (cur - s_begin);    // `pos < n`, :111
-                if (rows < 16) bits &= rows > 0 ? ((1u << rows) - 1u) : 0u;
                 if (DEDUPE && bits) {
+                    while (cur >= s_end) {   // next probed list (empty lists are stepped over)
+                        s++;
+                        s_begin = s_end;
+                        s_end = prefix[s + 1];
+                        s_loff = slot_label_off[qs * S + s];
+                    }
                     lab_base = s_loff + 16 * (int64_t)(cur - s_begin);
                     lab_next = (uint32_t)labels32[lab_base + __builtin_ctz(bits)];
                 }
             }
+            const unsigned long long d_ti = TK_TICK();
+            d_search += d_ti - d_ts;
             if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
+            TK_DBG(if (dbg) d_rounds++;)
             if (bits) {   // one insert per lane with a pending candidate
                 const int r = __builtin_ctz(bits);
                 bits &= bits - 1;
@@ -498,7 +566,9 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
                         if (ca | cb) {   // node 3..6, children in LDS
                             int j = (c2 ? 5 : 3) + (cb ? 1 : 0);
                             bool first = true, go = true;
+                            const unsigned long long d_tl = TK_TICK();
                             do {
+                                TK_DBG(if (dbg) d_ldsit++;)
                                 const int l = 2 * j + 1;
                                 const int lc = l < R ? l : R;
                                 const uint32_t el = H[lc * 64 + lane];
@@ -521,17 +591,24 @@ __global__ __launch_bounds__(64) void heap_replay_lanes_kernel(
                                 go = nxt != j;
                                 j = nxt;
                             } while (go);
+                            d_lds += TK_TICK() - d_tl;
                         }
                     }
                 }
                 if (bits == 0) bound = h0 >> 24;          // refresh after the block, :123
             }
-        }
-        if (nbuf == 1 && g + 1 < max_nseg) {
-            stage(g + 1, 0);
-            if (16 * (g + 1) < total) mins_next = mrow[g + 1];
+            d_ins += TK_TICK() - d_ti;
         }
     }
+#undef TK_FETCH_SEGMENT
+    TK_DBG(if (dbg && lane == 0) {
+        unsigned long long *o = dbg + (size_t)blockIdx.x * 8;
+        o[0] = TK_TICK() - d_t0; o[1] = d_search; o[2] = d_ins; o[3] = d_lds;
+        o[4] = d_rounds; o[5] = d_ldsit; o[6] = d_sit; o[7] = (unsigned long long)max_nseg;
+    })
+    (void)d_search; (void)d_ins; (void)d_lds; (void)d_rounds; (void)d_ldsit; (void)d_sit; (void)d_t0;
+#undef TK_TICK
+#undef TK_DBG
     // registers back to their heap rows
     if (R > 0) H[0 * 64 + lane] = h0;
     if (R > 1) H[1 * 64 + lane] = h1;
@@ -748,6 +825,39 @@ void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, co
 #undef TK_LAB
 #undef TK_HASH
 
+// phase timers of the lane kernel (debug tooling, scripts/replay_timers.py; the kernel carries
+// the timer code only when the library is built with -DTK_REPLAY_TIMERS): while armed, every
+// launch with at least `min_nq` queries writes 8 counters per workgroup
+#define TK_REPLAY_DBG_WG 4096
+static unsigned long long *g_replay_dbg = nullptr;
+static int64_t g_replay_dbg_min_nq = 0;
+static int g_replay_dbg_wgs = 0;
+
+extern "C" int tk_debug_replay_timers(int arm, int64_t min_nq, unsigned long long *sums8, int *workgroups)
+{
+    if (arm) {
+        if (!g_replay_dbg &&
+            hipMalloc((void **)&g_replay_dbg, (size_t)TK_REPLAY_DBG_WG * 8 * 8) != hipSuccess)
+            return -2;
+        (void)hipMemset(g_replay_dbg, 0, (size_t)TK_REPLAY_DBG_WG * 8 * 8);
+        g_replay_dbg_min_nq = min_nq;
+        g_replay_dbg_wgs = 0;
+        return 0;
+    }
+    if (!g_replay_dbg) return -1;
+    (void)hipDeviceSynchronize();
+    unsigned long long *h = (unsigned long long *)malloc((size_t)TK_REPLAY_DBG_WG * 8 * 8);
+    (void)hipMemcpy(h, g_replay_dbg, (size_t)TK_REPLAY_DBG_WG * 8 * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 8; i++) sums8[i] = 0;
+    for (int w = 0; w < g_replay_dbg_wgs; w++)
+        for (int i = 0; i < 8; i++) sums8[i] += h[(size_t)w * 8 + i];
+    free(h);
+    *workgroups = g_replay_dbg_wgs;
+    (void)hipFree(g_replay_dbg);
+    g_replay_dbg = nullptr;
+    return 0;
+}
+
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
@@ -757,11 +867,12 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
 {
     if (nq == 0 || R == 0) return 0;
     const int dedupe = labels32 != nullptr;
-    // heap columns (+ label slots) + 16 staged blocks per lane, double-buffered when it fits
+    // heap columns (+ label slots) + 16 staged blocks per lane
     const size_t fixed = (size_t)(R + 2) * 256 +
                          (dedupe ? (size_t)((R + 3) / 4) * 1024 + 256 * 64 : 0);
-    int nbuf = (fixed + 2 * 16384 <= 160 * 1024) ? 2 : 1;
-    size_t lds = fixed + (size_t)nbuf * 16384;
+    // one staged segment (16 blocks x 64 lanes x 16 B); the next one waits in registers
+    const int nbuf = 1;
+    size_t lds = fixed + 16384;
     static bool attr_set = false;
     if (!attr_set) {
         const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false>,
@@ -774,11 +885,48 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                 return -1;
         attr_set = true;
     }
-    dim3 grid((unsigned)((nq + 63) / 64));
+    {   // padding rows out of the way first (the kernels below no longer test `pos < n`)
+        const int64_t items = nq * S;
+        const unsigned pg = (unsigned)((items + 255) / 256);
+        if (items > 0 && signd)
+            hipLaunchKernelGGL(pad_fix_kernel<true>, dim3(pg), dim3(256), 0, s, (uint4 *)dist, cap, nq,
+                               slot_prefix, slot_n, S, slots_uniform, (uint8_t *)mins, cap_min);
+        else if (items > 0)
+            hipLaunchKernelGGL(pad_fix_kernel<false>, dim3(pg), dim3(256), 0, s, (uint4 *)dist, cap, nq,
+                               slot_prefix, slot_n, S, slots_uniform, (uint8_t *)mins, cap_min);
+    }
+    // query-waves per workgroup: a replay wave needs 130+ VGPRs, so a CU that hosts one cannot
+    // hold the third workgroup of the persistent scan kernel beside it; packing the replay's
+    // 157 waves into workgroups keeps them on fewer CUs (A/B: TINYKNN_REPLAY_WAVES)
+    static int wpw = -1;
+    if (wpw < 0) {
+        const char *e = getenv("TINYKNN_REPLAY_WAVES");
+        wpw = e ? atoi(e) : 1;
+        wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);
+    }
+    // (the short coarse replay, one list against a small heap, stays one wave per workgroup:
+    // multi-wave workgroups are placed only when a whole CU has room, which next to the
+    // persistent scan kernel means at its launch boundaries)
+    int waves = slots_uniform ? 1 : wpw;
+    while (waves > 1 && lds * waves > 160 * 1024) waves--;
+    const int wave_lds = (int)lds;
+    const int64_t n_waves = (nq + 63) / 64;
+    dim3 grid((unsigned)((n_waves + waves - 1) / waves));
+    const size_t lds_wg = lds * waves;
+    static int prio = -1;       // s_setprio of the replay waves (A/B: TINYKNN_REPLAY_PRIO)
+    if (prio < 0) {
+        const char *e = getenv("TINYKNN_REPLAY_PRIO");
+        prio = e ? atoi(e) : 3;
+    }
+    unsigned long long *dbg = nullptr;
+    if (g_replay_dbg && nq >= g_replay_dbg_min_nq && grid.x <= TK_REPLAY_DBG_WG) {
+        dbg = g_replay_dbg;
+        g_replay_dbg_wgs = (int)grid.x;
+    }
 #define TK_LAUNCH(S_, D_)                                                                       \
-    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_>), grid, dim3(64), lds, s, dist, cap, nq, \
+    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
-                       slots_uniform, skip, nbuf, mins, cap_min, labels32)
+                       slots_uniform, skip, nbuf, mins, cap_min, labels32, dbg, prio, wave_lds)
     if (signd) { if (dedupe) TK_LAUNCH(true, true); else TK_LAUNCH(true, false); }
     else { if (dedupe) TK_LAUNCH(false, true); else TK_LAUNCH(false, false); }
 #undef TK_LAUNCH
