@@ -403,7 +403,7 @@ def measure_traffic(args):
         return None, "rocprofv3 not found"
     me = os.path.abspath(__file__)
     tot = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         tmp = tempfile.mkdtemp(prefix="tk_pmc_")
         cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", tmp, "--", sys.executable, me,
                "--steps", "3", "--warmup", "1", "--pipeline", "1", "--profile-only", "--shard", "none",
@@ -418,15 +418,42 @@ def measure_traffic(args):
                         coarse = r["Kernel_Name"].split("(")[0].rstrip(">").rstrip().endswith("true")
                         acc.setdefault(coarse, []).append(float(r["Counter_Value"]))
             if False not in acc:
+                if c == "SQ_INSTS_VALU":     # an extra: the traffic figure stands without it
+                    tot[c] = None
+                    continue
                 return None, f"no scan_units_kernel rows in the {c} pass"
             tot[c] = sum(sum(v) / len(v) for v in acc.values())     # list scan + coarse scan, KiB
         except Exception as e:     # noqa: BLE001 - profiling is an extra
+            if c == "SQ_INSTS_VALU":
+                tot[c] = None
+                continue
             return None, f"{c} pass failed: {e!r}"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+    measure_traffic.valu_insts = tot["SQ_INSTS_VALU"]      # wave-instructions, list + coarse scan
     return (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024, \
         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this script in this run (pipeline 1: list " \
         "scan + coarse scan launches summed; FETCH x2 per the gfx950 correction)"
+
+
+VALU_RATE_PER_SIMD = 0.52e9      # wave-instructions/s/SIMD of the scan's VOP3/VOP3P mix, measured:
+                                 # profiles/r02_valu_issue_rate_microbench.txt (4.0-4.6 cycles each)
+
+
+def valu_roofline(scan_ms, iso_stages):
+    """The bound the scan kernel actually runs against (profiles/r02_scan_forms.md): VALU issue.
+    floor = SQ_INSTS_VALU of the list + coarse scan (PMC child run of this script, in this run) /
+    (1024 SIMDs x the measured issue rate of the kernel's instruction mix)."""
+    n = getattr(measure_traffic, "valu_insts", None)
+    if not n:
+        return None
+    floor_ms = n / (1024 * VALU_RATE_PER_SIMD) * 1e3
+    iso = iso_stages["scan"] + iso_stages["coarse_scan"]
+    return {"wave_instructions_per_launch": n, "issue_rate_per_simd": VALU_RATE_PER_SIMD,
+            "floor_ms": floor_ms, "frac_isolated": floor_ms / iso if iso > 0 else None,
+            "frac_timed_region": floor_ms / scan_ms if scan_ms > 0 else None,
+            "note": "fraction of the VALU issue ceiling: list scan + coarse scan, one batch in flight "
+                    "(isolated) / the fused launch of the timed region"}
 
 
 def main():
@@ -683,14 +710,19 @@ def main():
     # -- recall against brute force (torch matmul on the GPU: measurement plumbing)
     rs = min(args.recall_sample, args.nq)
     truth_s = None
+    truth = None
     if ivf.data.dtype == np.float32 and args.d <= 128:
         # exact ground truth on the f32 matrix cores (brute.hip: numpy's knn_brute distances
         # bit for bit); qn and IVF.data are normalised for the angular metric
-        tg = time.perf_counter()
-        truth = dev.knn_brute(qn[:rs], args.k)
-        truth_s = time.perf_counter() - tg
-        recall = float(np.mean([len(set(truth[i]) & set(got[i])) / args.k for i in range(rs)]))
-    else:
+        try:
+            tg = time.perf_counter()
+            truth = dev.knn_brute(qn[:rs], args.k)
+            truth_s = time.perf_counter() - tg
+            recall = float(np.mean([len(set(truth[i]) & set(got[i])) / args.k for i in range(rs)]))
+        except Exception as e:      # noqa: BLE001 - e.g. a candidate list overflow: fall back below
+            log(f"[bench] tk_index_knn_brute failed ({e!r}); recall by torch matmul + topk")
+            truth = None
+    if truth is None and isinstance(ivf.data, np.ndarray):
         data_t = torch.from_numpy(ivf.data).to(device)
         sims = q_dev[:rs] @ data_t.T
         if not ang:   # squared euclidean: smallest |x|^2 - 2 q.x
@@ -698,6 +730,8 @@ def main():
         truth = sims.topk(args.k, dim=1).indices.cpu().numpy()
         recall = float(np.mean([len(set(truth[i]) & set(got[i])) / args.k for i in range(rs)]))
         del data_t, sims
+    elif truth is None:
+        recall = None
 
     # -- CPU baseline: the oracle (a C port of the reference path), one thread, a
     #    bounded sample of the same batch; also a full-size parity check of the ids
@@ -791,7 +825,7 @@ def main():
                                 "scan_units2_kernel<AVX,signed> (one launch: list scan of a batch + coarse scan "
                                 "of a later one)"),
                      "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
-                     "launches_timed": n_prof},
+                     "launches_timed": n_prof, "valu": valu_roofline(scan_ms, iso_stages)},
         "raw_in_ids_out": raw_leg,
         "roofline_hbm_scale": hbm_leg,
         "stage_ms": stages,

@@ -1,0 +1,81 @@
+"""The documented limits of the C ABI fail loudly and leave the index usable:
+heap size, queries per sharded batch, fast-mode dimension, assignment k, lane-kernel heap sizes."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from test_hip_parity import ivf_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    g = golden("g6_ivf_an100.npz")
+    return g, ivf_from_fixture(None, g)
+
+
+def test_heap_larger_than_lds_is_refused_and_index_survives(small):
+    from tinyknn_amd import _lib
+    g, ivf = small
+    dev = ivf.device_index()
+    with pytest.raises((_lib.TinyKnnHipError, AssertionError)):
+        dev.query_batch(g["qn"], g["qpq"], 10, 5, pass_1=5461)       # R * 12 + 16 > 64 KiB
+    np.testing.assert_array_equal(dev.query_batch(g["qn"], g["qpq"], 10, 5), g["ids_p5"])
+
+
+@pytest.mark.parametrize("pass_1", [232, 233, 574, 575, 1500])
+def test_heap_sizes_around_the_lane_kernel_limits(small, oracle, pass_1):
+    """pass_1 = 574 is the largest heap of the lane-per-query kernel, 232 with the duplicate test;
+    one more switches to the wave-per-query kernel — same ids either side."""
+    from test_oracle_golden import load_oracle_index
+    g, ivf = small
+    ox = load_oracle_index(oracle, g)
+    got = ivf.device_index().query_batch(g["qn"], g["qpq"], 10, 5, pass_1=pass_1)
+    np.testing.assert_array_equal(got, ox.query_batch(g["qn"], 10, 5, pass_1))
+    gb = golden("g6_ivf_an100b2.npz")                               # repeating labels
+    ivfb = ivf_from_fixture(None, gb)
+    oxb = load_oracle_index(oracle, gb)
+    got = ivfb.device_index().query_batch(gb["qn"], gb["qpq"], 10, 5, pass_1=pass_1)
+    np.testing.assert_array_equal(got, oxb.query_batch(gb["qn"], 10, 5, pass_1))
+
+
+def test_sharded_batch_larger_than_32768_is_refused(small):
+    import torch
+    from tinyknn_amd import _lib
+    from tinyknn_amd.multi_gpu import _HipShardEngine, shard_lists
+    g, ivf = small
+    owner = shard_lists(g["list_sizes"], 1)
+    e = _HipShardEngine(ivf, owner, 0, 1, 1)
+    nq = 32769
+    qn = torch.zeros((nq, ivf.data.shape[1]), dtype=torch.float32, device="cuda")
+    qp = torch.zeros((nq, ivf.pq.centers.shape[1]), dtype=torch.float32, device="cuda")
+    send = torch.zeros(16 * 1024, dtype=torch.uint8, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(AssertionError, match="32768"):      # argument errors: the reference layer's convention
+        e.scan(0, qn, qp, 10, 5, None, 1024, send, flag)
+    e.dev.close()
+
+
+def test_fast_mode_refuses_angular_beyond_128_dims():
+    from tinyknn_amd import IVF, FastPQ, _lib
+    rng = np.random.RandomState(0)
+    X = rng.randn(2000, 160).astype(np.float32)
+    ivf = IVF("angular", 8, FastPQ(2, use_kmeans=False, rotate_dim=None))
+    ivf.fit(X).build(X, n_probes=1)
+    qs = rng.randn(5, 160).astype(np.float32)
+    exact = ivf.query_batch(qs, 5, n_probes=3)                      # the exact path has no such limit
+    assert exact.shape == (5, 5)
+    with pytest.raises((_lib.TinyKnnHipError, AssertionError)):
+        ivf.query_batch(qs, 5, n_probes=3, fast=True)
+
+
+def test_assign_lists_refuses_k_above_two():
+    from tinyknn_amd import _lib
+    X = np.zeros((100, 16), dtype=np.float32)
+    Y = np.eye(16, dtype=np.float32)[:8]
+    yn = np.einsum("ij,ij->i", Y, Y)
+    out = np.zeros((100, 3), dtype=np.int64)
+    rc = _lib.lib().tk_assign_lists(_lib.ptr(X, _lib._f32p), 100, 16, 0, Y.ctypes.data, 0, yn.ctypes.data,
+                                    8, 3, _lib.ptr(out, _lib._i64p))
+    assert rc < 0 and b"k must be 1 or 2" in _lib.lib().tk_last_error()
