@@ -24,9 +24,9 @@ def test_heap_larger_than_lds_is_refused_and_index_survives(small):
     np.testing.assert_array_equal(dev.query_batch(g["qn"], g["qpq"], 10, 5), g["ids_p5"])
 
 
-@pytest.mark.parametrize("pass_1", [232, 233, 574, 575, 1500])
+@pytest.mark.parametrize("pass_1", [149, 150, 232, 574, 575, 1500])
 def test_heap_sizes_around_the_lane_kernel_limits(small, oracle, pass_1):
-    """pass_1 = 574 is the largest heap of the lane-per-query kernel, 232 with the duplicate test;
+    """pass_1 = 574 is the largest heap of the lane-per-query kernel, 149 with the duplicate test;
     one more switches to the wave-per-query kernel — same ids either side."""
     from test_oracle_golden import load_oracle_index
     g, ivf = small

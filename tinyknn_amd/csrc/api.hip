@@ -1139,7 +1139,8 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                      p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                      w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
-    } else if (packed_ok && ix->have_ids32 && ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R_DEDUPE) {
+    } else if (packed_ok && ix->have_ids32 && ix->heap_mode == 0 && tk_lanes_dedupe_fits(p.R, p.S) &&
+               ix->total_ids < (1ll << 31)) {
         // repeating labels that fit int32: one query per lane with the duplicate test
         if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
                                         slot_loff, p.S, ix->ids.as<int64_t>(),
@@ -1227,7 +1228,8 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
                              ix->list_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                              w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(),
                              w.u_pair_f0.as<int>(), w.dist.as<uint4>(), p.cap,
-                             w.mins.as<uint8_t>(), p.cap_min, 1, ix->order, 768, st);
+                             w.mins.as<uint8_t>(), p.cap_min, 1, ix->order,
+                             getenv("TINYKNN_SCAN_BLOCKS_ISO") ? atoi(getenv("TINYKNN_SCAN_BLOCKS_ISO")) : 768, st);
     else
         tk_launch_scan_probes(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), b.nq,
                               w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), p.S,

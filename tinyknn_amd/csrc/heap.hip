@@ -350,7 +350,7 @@ __global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq
 // a SLOT, LAB[slot][lane] holds the slot's 32-bit label, `insert` first scans LAB for
 // the candidate's label (the reference's duplicate test, _fast_pq.pyx:284-287) and a
 // new entry inherits the slot of the root it evicts.  labels32 = the ids as int32.
-template <bool SIGNED, bool DEDUPE>
+template <bool SIGNED, bool DEDUPE, bool PRED>
 __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
@@ -374,21 +374,26 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const unsigned long long d_t0 = TK_TICK();
     // the replay is a chain of dependent LDS round trips on 157 waves; when it shares SIMDs
     // with other batches' VALU-bound scan waves, let the arbiter issue its instructions first
-    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
-    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    if ((prio & 0xff) >= 3) __builtin_amdgcn_s_setprio(3);
+    else if ((prio & 0xff) == 2) __builtin_amdgcn_s_setprio(2);
+    else if ((prio & 0xff) == 1) __builtin_amdgcn_s_setprio(1);
     // LDS: H[R+2][64] heap columns (+2 sentinel rows) | DEDUPE: LAB[ceil(R/4)][64][4]
-    //      labels by slot, CNT[256][64] label-hash counters | ST[nbuf][16][64] staged blocks
+    //      labels by slot, TB[64][64] x 4 hash set of the labels | ST[16][64] staged blocks | slot table
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
     unsigned char *smem = smem_wg + (size_t)(threadIdx.x >> 6) * wave_lds;
     uint32_t *H = (uint32_t *)smem;
     const int R4 = (R + 3) >> 2;
     uint32_t *LAB = (uint32_t *)(smem + (size_t)(R + 2) * 256);
-    uint32_t *CNT = (uint32_t *)(smem + (size_t)(R + 2) * 256 + (size_t)R4 * 1024);  // 4 x uint8 per dword
+    // DEDUPE: TB[64 buckets][64 lanes] x 4 labels: the labels in the heap as a two-choice hash set
+    uint4 *TB = (uint4 *)(smem + (size_t)(R + 2) * 256 + (size_t)R4 * 1024);
     uint4 *ST = (uint4 *)(smem + (size_t)(R + 2) * 256 +
-                          (DEDUPE ? (size_t)R4 * 1024 + 256 * 64 : 0));
+                          (DEDUPE ? (size_t)R4 * 1024 + 65536 : 0));
+    // DEDUPE: slot table of the lane's query, SE[s][lane] = first flat chunk past slot s,
+    // SB[s][lane] = label offset of slot s - 16 * its first flat chunk (label of row r of flat
+    // chunk c in slot s = labels32[SB[s] + 16 c + r])
+    int *SE = (int *)(ST + 16 * 64);
+    int *SB = SE + (size_t)S * 64;
 #define TK_LAB(slot) LAB[(((slot) >> 2) * 64 + lane) * 4 + ((slot) & 3)]
-#define TK_HASH(label) (((uint32_t)(label) * 0x9E3779B1u) >> 24)
     // a workgroup = blockDim.x / 64 independent query-waves, each with its own LDS region
     const int lane = threadIdx.x & 63;
     const int64_t q = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64 + lane;
@@ -407,8 +412,13 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     if (DEDUPE) {
         for (int g = 0; g < R4; g++)                                     // every label -1
             ((uint4 *)LAB)[g * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        for (int b = 0; b < 64; b++) CNT[b * 64 + lane] = 0;
+        for (int b = 0; b < 64; b++) TB[b * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
+    // DEDUPE: labels that found both their buckets full wait in a four-entry stash (registers);
+    // only a lane whose stash is full too falls back to scanning LAB — with 64 lanes x ~1000
+    // inserts per wave even a 1e-4 event per insert would otherwise put every wave on the scan
+    uint32_t sh0 = ~0u, sh1 = ~0u, sh2 = ~0u, sh3 = ~0u;
+    bool tb_ovf = false;
     H[R * 64 + lane] = H[(R + 1) * 64 + lane] = lowest;   // sentinel rows: never taken
     // the top three levels (nodes 0..6) live in registers; nodes >= R are sentinels
 #define TK_FRESH(j) (R > (j) ? (DEDUPE ? (fresh_val | (uint32_t)(j)) : fresh) : lowest)
@@ -427,12 +437,14 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     }
     max_nseg = __builtin_amdgcn_readfirstlane(max_nseg);
 
-    // slot cursor (monotonic): flat chunks [s_begin, s_end) belong to slot s with n rows
-    int s = 0, s_begin = 0, s_end = 0;
-    int64_t s_loff = 0;   // DEDUPE: label offset of the current slot
-    if (total > 0) {
-        s_end = prefix[1];
-        if (DEDUPE) s_loff = slot_label_off[qs * S];
+    // DEDUPE: slot cursor (monotonic) over the LDS slot table
+    int s = 0;
+    if (DEDUPE) {
+        for (int t = 0; t < S; t++) {
+            const int e0 = prefix[t], e1 = prefix[t + 1];
+            SE[t * 64 + lane] = valid ? e1 : 0x7fffffff;
+            SB[t * 64 + lane] = (int)(slot_label_off[qs * S + t] - 16 * (int64_t)e0);
+        }
     }
 
     // Segment g + 1 (16 blocks per lane, each lane from its own row, + its 16 block minima) is
@@ -448,25 +460,50 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const int last_blk = (int)(cap > 0 ? cap - 1 : 0);
     const int last_m = (int)(cap_min / 16) - 1;
     uint4 nx[16];
-    uint4 mins_nx = make_uint4(0, 0, 0, 0);
-#define TK_FETCH_SEGMENT(g_)                                                      \
+    uint4 mins_nx = make_uint4(0, 0, 0, 0), mins_n2 = make_uint4(0, 0, 0, 0);
+    uint32_t pf = 0xffffu;          // PRED: blocks of the pending segment that were fetched
+#define TK_MINS_ROW(g_) mrow[(g_) < last_m ? (g_) : (last_m > 0 ? last_m : 0)]
+#define TK_FETCH_BLOCKS(g_, mask_)                                                \
     {                                                                             \
-        _Pragma("unroll") for (int k = 0; k < 16; k++) {                          \
-            int blk_ = 16 * (g_) + k;                                             \
-            blk_ = blk_ < last_blk ? blk_ : last_blk;                             \
-            nx[k] = drow[blk_];                                                   \
-        }                                                                         \
-        const int mg_ = (g_) < last_m ? (g_) : (last_m > 0 ? last_m : 0);         \
-        mins_nx = mrow[mg_];                                                      \
+        _Pragma("unroll") for (int k = 0; k < 16; k++)                            \
+            if (!PRED || ((mask_) & (1u << k))) {                                 \
+                int blk_ = 16 * (g_) + k;                                         \
+                blk_ = blk_ < last_blk ? blk_ : last_blk;                         \
+                nx[k] = drow[blk_];                                               \
+            }                                                                     \
     }
+    auto seg_mask = [&](int g_) {         // blocks of segment g_ that exist in this lane's row
+        int km = total - 16 * g_;
+        km = km < 0 ? 0 : (km > 16 ? 16 : km);
+        return km >= 16 ? 0xffffu : ((1u << km) - 1u);
+    };
 #pragma unroll
     for (int k = 0; k < 16; k++) nx[k] = make_uint4(0, 0, 0, 0);
-    if (max_nseg > 0) TK_FETCH_SEGMENT(0)
+    if (max_nseg > 0) {
+        mins_nx = TK_MINS_ROW(0);
+        if (PRED && max_nseg > 1) mins_n2 = TK_MINS_ROW(1);
+        if (PRED) pf = mask_lt16<SIGNED>(mins_nx, bound) & seg_mask(0);
+        TK_FETCH_BLOCKS(0, pf)
+    }
     for (int g = 0; g < max_nseg; g++) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) ST[k * 64 + lane] = nx[k];
+        for (int k = 0; k < 16; k++)
+            if (!PRED || (pf & (1u << k))) ST[k * 64 + lane] = nx[k];
         const uint4 mins_cur = mins_nx;
-        if (g + 1 < max_nseg) TK_FETCH_SEGMENT(g + 1)
+        // PRED: only the blocks of the next segment whose minimum is below the bound known NOW
+        // are fetched (the bound only decreases: a superset of the blocks that will be entered);
+        // that needs the minima one segment earlier than the blocks
+        if (PRED) {
+            mins_nx = mins_n2;
+            if (g + 2 < max_nseg) mins_n2 = TK_MINS_ROW(g + 2);
+            if (g + 1 < max_nseg) {
+                pf = mask_lt16<SIGNED>(mins_nx, bound) & seg_mask(g + 1);
+                TK_FETCH_BLOCKS(g + 1, pf)
+            }
+        } else if (g + 1 < max_nseg) {
+            mins_nx = TK_MINS_ROW(g + 1);
+            TK_FETCH_BLOCKS(g + 1, 0xffffu)
+        }
         const int buf = 0;
         int kmax = total - 16 * g;
         kmax = kmax < 0 ? 0 : (kmax > 16 ? 16 : kmax);
@@ -478,7 +515,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
         uint4 dd = make_uint4(0, 0, 0, 0);
         int cur = 0;
         uint32_t lab_next = 0;        // DEDUPE: label of the lowest pending row, fetched ahead
-        int64_t lab_base = 0;         //         first label of the current block
+        int lab_base = 0;             //         labels32 index of row 0 of the current block
         for (;;) {
             // next block of this segment with a byte below the live bound
             const unsigned long long d_ts = TK_TICK();
@@ -493,14 +530,9 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                 // with distinct labels no slot cursor at all, is needed here
                 bits = mask_lt16<SIGNED>(dd, bound);          // cmp_mask, _fast_pq_256.pyx:81-90
                 if (DEDUPE && bits) {
-                    while (cur >= s_end) {   // next probed list (empty lists are stepped over)
-                        s++;
-                        s_begin = s_end;
-                        s_end = prefix[s + 1];
-                        s_loff = slot_label_off[qs * S + s];
-                    }
-                    lab_base = s_loff + 16 * (int64_t)(cur - s_begin);
-                    lab_next = (uint32_t)labels32[lab_base + __builtin_ctz(bits)];
+                    while (cur >= SE[s * 64 + lane]) s++;   // next probed list (empty ones stepped over)
+                    lab_base = SB[s * 64 + lane] + 16 * cur;
+                    lab_next = (uint32_t)labels32[(int64_t)lab_base + __builtin_ctz(bits)];
                 }
             }
             const unsigned long long d_ti = TK_TICK();
@@ -516,30 +548,61 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                 bool dup = false;
                 if (DEDUPE) {
                     const uint32_t label = lab_next;
-                    if (bits) lab_next = (uint32_t)labels32[lab_base + __builtin_ctz(bits)];
-                    // `if i == indices[j]: return` over every slot, _fast_pq.pyx:284-287.  A
-                    // counter per label hash tells most candidates apart without the scan
-                    // (a heap never holds more than R <= 232 labels: no uint8 overflow).
-                    const uint32_t hb = TK_HASH(label);
-                    low = h0 & 0x00ffffffu;            // the evicted root's slot
-                    const uint32_t cw = CNT[(hb >> 2) * 64 + lane];
-                    const uint32_t gone = TK_LAB(low); // label leaving with the root
-                    if ((cw >> (8 * (hb & 3))) & 0xffu) {
+                    if (bits) lab_next = (uint32_t)labels32[(int64_t)lab_base + __builtin_ctz(bits)];
+                    // `if i == indices[j]: return` over every slot, _fast_pq.pyx:284-287, answered by
+                    // a hash set of the labels in the heap instead of a scan of all R slots (with
+                    // any cheaper pre-filter some lane of 64 passes it in every round, and the
+                    // scan then runs for the whole wave: it was 1.0 of the kernel's 2.2 ms,
+                    // profiles/r02_replay_phases.md).  Two candidate buckets of four labels per
+                    // label, the emptier one takes it; a label that finds both full is only kept in
+                    // LAB and switches its lane to the full scan (exactness never depends on the
+                    // set: LAB always holds every slot's label).
+                    const uint32_t hh = label * 0x9E3779B1u;
+                    const int b1 = (int)(hh >> 26);
+                    int b2 = (int)((hh >> 18) & 63u);
+                    b2 = b2 == b1 ? (b1 ^ 1) : b2;
+                    const uint4 x1 = TB[b1 * 64 + lane], x2 = TB[b2 * 64 + lane];
+                    dup = (x1.x == label) | (x1.y == label) | (x1.z == label) | (x1.w == label) |
+                          (x2.x == label) | (x2.y == label) | (x2.z == label) | (x2.w == label) |
+                          (sh0 == label) | (sh1 == label) | (sh2 == label) | (sh3 == label);
+                    if (tb_ovf && !(prio & 0x100)) {
 #pragma unroll 4
                         for (int g = 0; g < R4; g++) {
                             const uint4 lv = ((const uint4 *)LAB)[g * 64 + lane];
                             dup |= (lv.x == label) | (lv.y == label) | (lv.z == label) | (lv.w == label);
                         }
                     }
+                    low = h0 & 0x00ffffffu;            // the evicted root's slot
+                    const uint32_t gone = TK_LAB(low); // label leaving with the root
                     if (!dup) {
-                        // lane-private counters, 4 per dword: ds_add_u32 without return
-                        if (gone != 0xffffffffu) {
-                            const uint32_t hg = TK_HASH(gone);
-                            __hip_atomic_fetch_add(&CNT[(hg >> 2) * 64 + lane], 0u - (1u << (8 * (hg & 3))),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (gone != 0xffffffffu) {     // out of its bucket (if it ever got into one)
+                            const uint32_t gh = gone * 0x9E3779B1u;
+                            const int g1 = (int)(gh >> 26);
+                            int g2 = (int)((gh >> 18) & 63u);
+                            g2 = g2 == g1 ? (g1 ^ 1) : g2;
+                            const uint4 y1 = TB[g1 * 64 + lane], y2 = TB[g2 * 64 + lane];
+                            const int p1 = y1.x == gone ? 0 : y1.y == gone ? 1 : y1.z == gone ? 2 : y1.w == gone ? 3 : -1;
+                            const int p2 = y2.x == gone ? 0 : y2.y == gone ? 1 : y2.z == gone ? 2 : y2.w == gone ? 3 : -1;
+                            if (p1 >= 0) ((uint32_t *)TB)[(g1 * 64 + lane) * 4 + p1] = 0xffffffffu;
+                            else if (p2 >= 0) ((uint32_t *)TB)[(g2 * 64 + lane) * 4 + p2] = 0xffffffffu;
+                            else {
+                                sh0 = sh0 == gone ? ~0u : sh0; sh1 = sh1 == gone ? ~0u : sh1;
+                                sh2 = sh2 == gone ? ~0u : sh2; sh3 = sh3 == gone ? ~0u : sh3;
+                            }
                         }
-                        __hip_atomic_fetch_add(&CNT[(hb >> 2) * 64 + lane], 1u << (8 * (hb & 3)),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        // x1 / x2 were read before that removal: an entry it freed still looks taken,
+                        // which can only cost an unnecessary overflow, never a wrong placement
+                        const int e1 = (x1.x == ~0u) + (x1.y == ~0u) + (x1.z == ~0u) + (x1.w == ~0u);
+                        const int e2 = (x2.x == ~0u) + (x2.y == ~0u) + (x2.z == ~0u) + (x2.w == ~0u);
+                        const bool first = e1 >= e2;
+                        const uint4 xs = first ? x1 : x2;
+                        const int pe = xs.x == ~0u ? 0 : xs.y == ~0u ? 1 : xs.z == ~0u ? 2 : xs.w == ~0u ? 3 : -1;
+                        if (pe >= 0) ((uint32_t *)TB)[((first ? b1 : b2) * 64 + lane) * 4 + pe] = label;
+                        else if (sh0 == ~0u) sh0 = label;
+                        else if (sh1 == ~0u) sh1 = label;
+                        else if (sh2 == ~0u) sh2 = label;
+                        else if (sh3 == ~0u) sh3 = label;
+                        else tb_ovf = true;
                         TK_LAB(low) = label;
                     }
                 }
@@ -600,7 +663,8 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
             d_ins += TK_TICK() - d_ti;
         }
     }
-#undef TK_FETCH_SEGMENT
+#undef TK_FETCH_BLOCKS
+#undef TK_MINS_ROW
     TK_DBG(if (dbg && lane == 0) {
         unsigned long long *o = dbg + (size_t)blockIdx.x * 8;
         o[0] = TK_TICK() - d_t0; o[1] = d_search; o[2] = d_ins; o[3] = d_lds;
@@ -823,7 +887,18 @@ void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, co
 }
 
 #undef TK_LAB
-#undef TK_HASH
+
+// LDS of one query-wave of the lane kernel without the staged segment: heap columns, and with
+// the duplicate test the label slots, the label-hash counters and the slot table
+static size_t tk_lanes_fixed_lds(int R, int S, int dedupe)
+{
+    return (size_t)(R + 2) * 256 + (dedupe ? (size_t)((R + 3) / 4) * 1024 + 65536 + (size_t)S * 512 : 0);
+}
+
+int tk_lanes_dedupe_fits(int R, int S)
+{
+    return R <= TK_LANES_MAX_R_DEDUPE && tk_lanes_fixed_lds(R, S, 1) + 16384 <= 160 * 1024;
+}
 
 // phase timers of the lane kernel (debug tooling, scripts/replay_timers.py; the kernel carries
 // the timer code only when the library is built with -DTK_REPLAY_TIMERS): while armed, every
@@ -868,17 +943,20 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     if (nq == 0 || R == 0) return 0;
     const int dedupe = labels32 != nullptr;
     // heap columns (+ label slots) + 16 staged blocks per lane
-    const size_t fixed = (size_t)(R + 2) * 256 +
-                         (dedupe ? (size_t)((R + 3) / 4) * 1024 + 256 * 64 : 0);
+    const size_t fixed = tk_lanes_fixed_lds(R, S, dedupe);
     // one staged segment (16 blocks x 64 lanes x 16 B); the next one waits in registers
     const int nbuf = 1;
     size_t lds = fixed + 16384;
     static bool attr_set = false;
     if (!attr_set) {
-        const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false>,
-                             (const void *)heap_replay_lanes_kernel<false, false>,
-                             (const void *)heap_replay_lanes_kernel<true, true>,
-                             (const void *)heap_replay_lanes_kernel<false, true>};
+        const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false, false>,
+                             (const void *)heap_replay_lanes_kernel<false, false, false>,
+                             (const void *)heap_replay_lanes_kernel<true, true, false>,
+                             (const void *)heap_replay_lanes_kernel<false, true, false>,
+                             (const void *)heap_replay_lanes_kernel<true, false, true>,
+                             (const void *)heap_replay_lanes_kernel<false, false, true>,
+                             (const void *)heap_replay_lanes_kernel<true, true, true>,
+                             (const void *)heap_replay_lanes_kernel<false, true, true>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
@@ -917,19 +995,27 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     if (prio < 0) {
         const char *e = getenv("TINYKNN_REPLAY_PRIO");
         prio = e ? atoi(e) : 3;
+        if (getenv("TINYKNN_DEBUG_NOSCAN")) prio |= 0x100;      // wrong results: timing only
     }
     unsigned long long *dbg = nullptr;
     if (g_replay_dbg && nq >= g_replay_dbg_min_nq && grid.x <= TK_REPLAY_DBG_WG) {
         dbg = g_replay_dbg;
         g_replay_dbg_wgs = (int)grid.x;
     }
-#define TK_LAUNCH(S_, D_)                                                                       \
-    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
+    static int pred = -1;       // fetch only blocks whose minimum passes (A/B: TINYKNN_REPLAY_PRED)
+    if (pred < 0) {
+        const char *e = getenv("TINYKNN_REPLAY_PRED");
+        pred = e ? atoi(e) : 0;
+    }
+#define TK_LAUNCH2(S_, D_, P_)                                                                  \
+    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, P_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, nbuf, mins, cap_min, labels32, dbg, prio, wave_lds)
-    if (signd) { if (dedupe) TK_LAUNCH(true, true); else TK_LAUNCH(true, false); }
-    else { if (dedupe) TK_LAUNCH(false, true); else TK_LAUNCH(false, false); }
+#define TK_LAUNCH(S_, D_) { if (pred) TK_LAUNCH2(S_, D_, true); else TK_LAUNCH2(S_, D_, false); }
+    if (signd) { if (dedupe) TK_LAUNCH(true, true) else TK_LAUNCH(true, false) }
+    else { if (dedupe) TK_LAUNCH(false, true) else TK_LAUNCH(false, false) }
 #undef TK_LAUNCH
+#undef TK_LAUNCH2
     return 0;
 }
 

@@ -105,9 +105,11 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 // skip (nq bytes or NULL): queries to leave untouched.  mins: (nq, cap_min) per-block
 // minima written by the scan kernels, cap_min a multiple of 16.
 #define TK_LANES_MAX_R 574
-// with labels32 (labels may repeat: duplicate test on 32-bit label slots + uint8
-// label-hash counters) the LDS budget is (2R+2)*256 + 16 KiB + 16 KiB and R <= 255
-#define TK_LANES_MAX_R_DEDUPE 232
+// with labels32 (labels may repeat: duplicate test on 32-bit label slots + a two-choice hash
+// set of the labels in the heap, 64 KiB) the LDS budget is (2R+2)*256 + 64 KiB + 16 KiB + the
+// slot table
+#define TK_LANES_MAX_R_DEDUPE 149
+int tk_lanes_dedupe_fits(int R, int S);     // ... and the slot table of S probed lists fits too
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
