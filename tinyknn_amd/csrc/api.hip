@@ -1123,7 +1123,9 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     // (a list may then be scanned twice) re-run with the duplicate test.  Repeating labels
     // (build n_probes >= 2): the packed wave kernel with the duplicate test for everybody.
     const bool packed_ok = ix->heap_mode != 1 && p.cap * 16 <= 0xffffff;
-    if (packed_ok && ix->ids_unique) {
+    static const int dbg_skip = getenv("TINYKNN_DEBUG_SKIP") ? atoi(getenv("TINYKNN_DEBUG_SKIP")) : 0;
+    if (dbg_skip & 1) {             // timing experiments only (wrong results): no main replay
+    } else if (packed_ok && ix->ids_unique) {
         const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
         if (!lanes)
             tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
@@ -1160,6 +1162,7 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     }
     TRY(pf.mark(st));
     // 4. strip sentinels, exact rescoring                   ivf.py:154-163
+    if (!(dbg_skip & 2))
     tk_launch_rescore(q_dev, 0, ix->d, ix->data.p, ix->data_is_f64, ix->N,
                       w.heap_idx.as<int64_t>(), p.R, nq, k, 1, out_dev, nullptr, st);
     TRY(pf.mark(st));
