@@ -513,8 +513,8 @@ def main():
         if args.n_clusters == dflt.n_clusters: args.n_clusters = 10000
         args.metric = "euclidean"
         args.cpu_sample = min(args.cpu_sample, 300)
-        args.py_cpu_sample = min(args.py_cpu_sample, 50)
-        args.shard = "none"
+        args.py_cpu_sample = min(args.py_cpu_sample, 50)     # (N > 1: every rank generates and builds the
+        #  same index from the seed, then keeps the codes of the lists it owns: tk_index_shard_resident)
 
     import torch
     import torch.distributed as dist

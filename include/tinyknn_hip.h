@@ -399,6 +399,9 @@ int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int k, int64_t 
 int tk_index_set_lists_shard(tk_index *ix, const int64_t *list_sizes, const int32_t *owner,
                              int rank, int world, const uint64_t *codes_owned,
                              const int64_t *ids);
+/* a complete unsharded index (host upload or tk_index_build_dev) -> this rank's shard, in place:
+ * the codes of the lists with owner[l] == rank are compacted on the device, the rest is dropped */
+int tk_index_shard_resident(tk_index *ix, const int32_t *owner, int rank, int world);
 int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
                               int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                               int64_t *probes_home_dev, void *stream);

@@ -16,15 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, owner=None,
-                   coarse="home"):
+                   coarse="home", engines=None, sizes=None):
     """-> (ids (nq, k), overflow flags (world,), capacity).  coarse="home": every simulated rank
     runs the coarse stage of its home queries only and the probe lists are gathered by hand;
     "replicated": every rank derives all probe lists itself."""
     import torch
     from tinyknn_amd.multi_gpu import _HipShardEngine, shard_capacity, shard_lists
     L = ivf.active_centers.shape[0]
-    sizes = np.array([0 if isinstance(t, np.ndarray) else t.size
-                      for t in ivf.pq_transformed_points[:L]], dtype=np.int64)
+    if sizes is None:
+        sizes = np.array([0 if isinstance(t, np.ndarray) else t.size
+                          for t in ivf.pq_transformed_points[:L]], dtype=np.int64)
     if owner is None:
         owner = shard_lists(sizes, world)
     nq = len(qn)
@@ -33,7 +34,8 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
     qh = -(-nq // world)
     qn_t = torch.from_numpy(np.ascontiguousarray(qn, dtype=np.float32)).cuda()
     qp_t = torch.from_numpy(np.ascontiguousarray(qp)).cuda()
-    engines = [_HipShardEngine(ivf, owner, r, world, 1) for r in range(world)]
+    if engines is None:
+        engines = [_HipShardEngine(ivf, owner, r, world, 1) for r in range(world)]
     sends = [torch.full((world, capacity * 16), 0xAB, dtype=torch.uint8, device="cuda")
              for _ in range(world)]
     flags = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(world)]
@@ -162,3 +164,43 @@ def test_sharded_two_processes_one_gpu():
     for r in range(2):
         for p in (1, 5, 10):
             np.testing.assert_array_equal(ret[r][p], g[f"ids_p{p}"])
+
+
+def test_resident_index_sharded_in_place(oracle):
+    """IVF.build_resident on every simulated rank (same seed: same vectors, lists and codes),
+    each rank's index sharded where it lies (tk_index_shard_resident): ids of the unsharded
+    resident index and of the oracle over its exported lists."""
+    from tinyknn_amd import IVF, FastPQ
+    from tinyknn_amd.multi_gpu import _HipShardEngine, shard_lists
+    from test_resident_build_gpu import oracle_from_resident, synth_rows
+    n, d, nq, seed, world = 30011, 128, 257, 9, 3
+    cent = np.random.RandomState(4).randn(20, d).astype(np.float32)
+    proto = IVF("euclidean", 40, FastPQ(2))
+    proto.fit(synth_rows(5000, d, seed, cent, 0.8))
+
+    def build():
+        ivf = IVF("euclidean", 40, FastPQ(2))
+        ivf.all_centers, ivf.pq = proto.all_centers, proto.pq
+        return ivf.build_resident(n, d, seed, cent, 0.8)
+
+    whole = build()
+    ox, _ = oracle_from_resident(oracle, whole)
+    qs = synth_rows(nq, d, seed + 1, cent, 0.8)
+    qn, qp = whole._prepare(qs.copy())
+    owner = shard_lists(whole.list_sizes, world)
+    ranks = [build() for _ in range(world)]
+    engines = [_HipShardEngine(ranks[r], owner, r, world, 1, resident=True) for r in range(world)]
+    for n_probes in (1, 6):
+        want = whole.device_index().query_batch(qn, qp, 10, n_probes)
+        np.testing.assert_array_equal(want, ox.query_batch(qn, 10, n_probes))
+        ids, flags, _ = simulate_world(whole, world, qn, qp, 10, n_probes, owner=owner,
+                                       engines=engines, sizes=whole.list_sizes)
+        assert not flags.any()
+        np.testing.assert_array_equal(ids, want)
+        engines = [_HipShardEngine.__new__(_HipShardEngine) for _ in range(world)]   # closed by simulate_world
+        for r, e in enumerate(engines):
+            ranks[r] = build()
+            e.dev = ranks[r].device_index()
+            e.dev.shard_resident(owner, r, world)
+            e.dev.set_pipeline(1)
+            e.device = "cuda"

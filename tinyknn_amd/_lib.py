@@ -63,6 +63,7 @@ SIGNATURES = {
     "tk_index_set_centers": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _u64p, C.c_int64]),
     "tk_index_set_lists": (C.c_int, [C.c_void_p, _i64p, _u64p, _i64p]),
     "tk_index_set_lists_shard": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int, C.c_int, _u64p, _i64p]),
+    "tk_index_shard_resident": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int]),
     "tk_index_shard_coarse_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p]),

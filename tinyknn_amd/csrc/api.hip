@@ -1164,7 +1164,8 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     // 4. strip sentinels, exact rescoring                   ivf.py:154-163
     if (!(dbg_skip & 2))
     tk_launch_rescore(q_dev, 0, ix->d, ix->data.p, ix->data_is_f64, ix->N,
-                      w.heap_idx.as<int64_t>(), p.R, nq, k, 1, out_dev, nullptr, st);
+                      w.heap_idx.as<int64_t>(), p.R, nq, k, 1 | ((dbg_skip & 4) ? 0x100 : 0) | ((dbg_skip & 8) ? 0x200 : 0),
+                      out_dev, nullptr, st);
     TRY(pf.mark(st));
     return TK_OK;
 }
@@ -1893,6 +1894,45 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
     ix->max_list_chunks = (int)maxc;
     ix->have_centers = ix->have_lists = ix->have_data = true;
     if (n_active_out) *n_active_out = L;
+    return TK_OK;
+}
+
+// A complete unsharded index (tk_index_build_dev, or the host upload) becomes this rank's shard
+// of a list-sharded index IN PLACE: the codes of the lists with owner[l] == rank are compacted
+// into the rank's own array, everything else (centres, ids, vectors) stays replicated.
+extern "C" int tk_index_shard_resident(tk_index *ix, const int32_t *owner, int rank, int world)
+{
+    ARGCHECK(ix && ix->have_lists && !ix->sharded, "a complete unsharded index");
+    ARGCHECK(owner && world >= 1 && rank >= 0 && rank < world, "owner / rank / world");
+    TRY(flush_pending(ix));
+    HIPCHECK(hipDeviceSynchronize());
+    const int64_t L = ix->n_lists;
+    std::vector<int64_t> sizes((size_t)L), coff((size_t)L + 1, 0), loff((size_t)L + 1, 0);
+    HIPCHECK(hipMemcpy(sizes.data(), ix->list_n.p, (size_t)L * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < L; i++) {
+        ARGCHECK(owner[i] >= 0 && owner[i] < world, "owner out of range");
+        const int64_t c = (sizes[(size_t)i] + 15) / 16;
+        coff[(size_t)i + 1] = coff[(size_t)i] + c;
+        loff[(size_t)i + 1] = loff[(size_t)i] + (owner[i] == rank ? c : 0);
+    }
+    const int P = ix->M / 2;
+    TRY(ix->owner.ensure((size_t)L * 4));
+    TRY(ix->local_chunk_off.ensure((size_t)(L + 1) * 8));
+    HIPCHECK(hipMemcpy(ix->owner.p, owner, (size_t)L * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ix->local_chunk_off.p, loff.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice));
+    DevBuf mine;
+    const size_t bytes = (size_t)tk_tiled_uint4s(loff[(size_t)L], P) * 16;
+    TRY(mine.ensure(bytes > 0 ? bytes : 16));
+    HIPCHECK(hipMemset(mine.p, 0, bytes > 0 ? bytes : 16));
+    tk_launch_compact_tiled(ix->codes.as<uint4>(), mine.as<uint4>(), P, ix->list_chunk_off.as<int64_t>(),
+                            ix->local_chunk_off.as<int64_t>(), (int)L, loff[(size_t)L], 0);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    ix->codes.release();
+    ix->codes = mine;            // (DevBuf is a plain pointer + capacity)
+    ix->sharded = true;
+    ix->rank = rank;
+    ix->world = world;
     return TK_OK;
 }
 

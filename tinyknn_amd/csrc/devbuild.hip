@@ -188,3 +188,32 @@ void tk_launch_gather_rows(const float *X, int d, const int64_t *rows, int64_t n
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, s, X, d, rows,
                        n, out);
 }
+
+// chunks of the lists a rank owns, copied from the whole index's tiled code array into the
+// rank's own (compact) tiled array: local chunk cl of list l = global chunk coff[l] + cl - loff[l]
+__global__ void compact_tiled_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int P,
+                                     const int64_t *__restrict__ global_off,
+                                     const int64_t *__restrict__ local_off, int n_lists,
+                                     int64_t local_chunks)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= local_chunks * P) return;
+    const int64_t cl = i / P;
+    const int p = (int)(i - cl * P);
+    int lo = 0, hi = n_lists;   // local_off[lo] <= cl < local_off[hi]; empty (foreign) lists are skipped
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (local_off[mid] <= cl) lo = mid; else hi = mid;
+    }
+    const int64_t cg = global_off[lo] + (cl - local_off[lo]);
+    dst[((cl >> 3) * P + p) * 8 + (cl & 7)] = src[((cg >> 3) * P + p) * 8 + (cg & 7)];
+}
+
+void tk_launch_compact_tiled(const uint4 *src, uint4 *dst, int P, const int64_t *global_off,
+                             const int64_t *local_off, int n_lists, int64_t local_chunks, hipStream_t s)
+{
+    const int64_t items = local_chunks * P;
+    if (items <= 0) return;
+    hipLaunchKernelGGL(compact_tiled_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, src, dst,
+                       P, global_off, local_off, n_lists, local_chunks);
+}

@@ -93,6 +93,8 @@ __global__ __launch_bounds__(128) void rescore_kernel(const TX *__restrict__ q, 
     for (int t = tid; t < nc; t += blockDim.x) {
         int64_t id = cs[t];
         if (id < 0) id += n_rows;  // numpy fancy indexing with a negative index
+        if (strip & 0x100) id = 0;            // timing experiment (wrong results): one row for every lane
+        else if (strip & 0x200) id = blockIdx.x * 128 + t;    // ... consecutive rows
         ds[t] = sqdist_row<T, TY>(rows + id * (int64_t)d, xs, d);
     }
     __syncthreads();

@@ -216,6 +216,14 @@ class DeviceIndex:
         self.code_bytes = int(((self.list_sizes + 15) // 16).sum()) * (self.dq // self.dpb) * 8
         return self.n_lists
 
+    def shard_resident(self, owner, rank, world):
+        """This complete index becomes rank `rank`'s shard of a list-sharded index, in place
+        (tk_index_shard_resident): only the codes of the lists it owns stay in HBM."""
+        own = np.ascontiguousarray(owner, dtype=np.int32)
+        assert own.shape == (self.n_lists,)
+        _lib.check(_lib.lib().tk_index_shard_resident(self._h, _lib.ptr(own, _lib._i32p), int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
     def export_lists(self, codes=True, ids=True):
         """(list_sizes, packed codes (chunks, M) uint64 or None, ids or None) back on the host
         in the reference's formats (tk_index_export_lists)."""

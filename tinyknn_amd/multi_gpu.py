@@ -130,9 +130,14 @@ def shard_positions(probes, chunks, owner, world, capacity):
 class _HipShardEngine:
     """scan / finish on the MI355X (torch tensors carry the device buffers)."""
 
-    def __init__(self, ivf, owner, rank, world, depth):
+    def __init__(self, ivf, owner, rank, world, depth, resident=False):
         from .ivf import DeviceIndex
-        self.dev = DeviceIndex(ivf, owner=owner, rank=rank, world=world)
+        if resident:
+            # the index was built in HBM (IVF.build_resident): shard it where it lies
+            self.dev = ivf.device_index()
+            self.dev.shard_resident(owner, rank, world)
+        else:
+            self.dev = DeviceIndex(ivf, owner=owner, rank=rank, world=world)
         self.dev.set_pipeline(depth)
         self.device = "cuda"
 
@@ -183,6 +188,9 @@ class ListShardedIndex:
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         self.backend = dist.get_backend(group) if on else None
+        resident = getattr(ivf, "pq_transformed_points", 0) is None     # IVF.build_resident
+        if list_sizes is None and resident:
+            list_sizes = ivf.list_sizes
         if list_sizes is None:
             list_sizes = [0 if isinstance(t, np.ndarray) else t.size
                           for t in ivf.pq_transformed_points[:ivf.active_centers.shape[0]]]
@@ -192,7 +200,7 @@ class ListShardedIndex:
         assert coarse in ("home", "replicated")
         self.coarse = coarse
         self.engine = engine if engine is not None else _HipShardEngine(
-            ivf, self.owner, self.rank, self.world, depth)
+            ivf, self.owner, self.rank, self.world, depth, resident=resident)
         self.device = self.engine.device
         self.capacity = {}          # (nq, n_probes) -> uint4 per region, grows on overflow
         self._bufs = {}
