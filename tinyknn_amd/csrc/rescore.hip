@@ -13,6 +13,8 @@
 // candidate row and carries the lane-accumulators.  The k best are returned in ascending distance (ties:
 // lower candidate position first) — the order numpy's argpartition yields on the
 // fixture host for these sizes; a rank-by-counting pass in LDS does the ordering.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 // squared distance of row y to the query xs in numpy's einsum order, computed in T
@@ -110,6 +112,125 @@ __global__ __launch_bounds__(128) void rescore_kernel(const TX *__restrict__ q, 
     if (tid == 0 && out_count) out_count[qi] = k;
 }
 
+// sqdist_row<float, float> for a row held in LDS as 16-byte pieces (explicit 128-bit reads: with
+// an odd piece stride the 64 lanes' reads are conflict-free; 32-bit reads of the same layout
+// would collide four ways).  Same operations in the same order.
+__device__ __forceinline__ float sqdist_row_lds(const float4 *__restrict__ y4, const float *xs, int d)
+{
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; d - i >= 16; i += 16) {
+        const float4 a = y4[(i >> 2)], b = y4[(i >> 2) + 1], c = y4[(i >> 2) + 2], e = y4[(i >> 2) + 3];
+        const float yv[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+        float df[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) df[t] = yv[t] - xs[i + t];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            float ab3 = df[12 + l] * df[12 + l] + acc[l];
+            float ab2 = df[8 + l] * df[8 + l] + ab3;
+            float ab1 = df[4 + l] * df[4 + l] + ab2;
+            acc[l] = df[l] * df[l] + ab1;
+        }
+    }
+    for (; i < d; i += 4) {          // d % 4 == 0: whole vectors only
+        const float4 a = y4[i >> 2];
+        const float yv[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const float df = yv[l] - xs[i + l];
+            acc[l] = df * df + acc[l];
+        }
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+// The same for float32 vectors and queries with d % 4 == 0, rows staged through LDS: in the
+// kernel above a lane walks its own row, so every load instruction of a wave touches 64
+// different lines — 2775 line visits per query at R = 111, d = 100 — and that address traffic
+// is what this kernel costs the scan kernels it runs beside (profiles/r02_scan_grid.md).  Here
+// the wave reads 64 candidate rows as one stream of 16-byte pieces, consecutive lanes =
+// consecutive pieces of a row (4 lines per 400-byte row), drops them into a tile whose row
+// stride is an odd number of 16-byte pieces (conflict-free ds_read_b128), and each lane then
+// runs the identical summation (sqdist_row: numpy's order) on its row from LDS.
+// LDS: cand[R] (int64) | dist[R] | x[d] | tile[64 + 1 spare][stride]
+template <int TILE>
+__global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restrict__ q, int d,
+                                                            const float *__restrict__ rows,
+                                                            int64_t n_rows,
+                                                            const int64_t *__restrict__ cand, int R,
+                                                            int k, int strip, int64_t *__restrict__ out,
+                                                            int *__restrict__ out_count, int stride4)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int64_t *cs = (int64_t *)smem;
+    float *ds = (float *)(smem + (((size_t)R * 8 + 15) & ~(size_t)15));
+    float *xs = ds + ((R + 3) & ~3);
+    float4 *tile = (float4 *)(xs + ((d + 3) & ~3));      // 16-byte aligned
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.x;
+    const int64_t *c = cand + qi * R;
+    for (int t = tid; t < d; t += 64) xs[t] = q[qi * d + t];
+    // ordered compaction of the candidate ids (ivf.py:154-155 drops -1)
+    int nc = 0;
+    for (int t0 = 0; t0 < R; t0 += 64) {
+        const int t = t0 + tid;
+        const int64_t id = t < R ? c[t] : -1;
+        const bool keep = t < R && (!strip || id != -1);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        const int before = __builtin_popcountll(m & ((1ull << tid) - 1ull));
+        if (keep) cs[nc + before] = id;
+        nc += __builtin_popcountll(m);
+    }
+    __syncthreads();
+    int64_t *o = out + qi * k;
+    if (nc <= k) {  // ivf.py:158-159 / fast_pq.py:307-308: heap order, no rescoring
+        for (int t = tid; t < k; t += 64) o[t] = t < nc ? cs[t] : -1;
+        if (tid == 0 && out_count) out_count[qi] = nc;
+        return;
+    }
+    const int d4 = d >> 2;
+    // lanes_per_row = the power of two >= d4 (16, 32 or 64): a load instruction covers
+    // 64 / lanes_per_row whole rows, lane (rr, pc) fetches piece pc of its row
+    const int lpr_log = d4 <= 16 ? 4 : (d4 <= 32 ? 5 : 6);
+    const int rr = tid >> lpr_log, pc = tid & ((1 << lpr_log) - 1), rpi = 64 >> lpr_log;
+    for (int t0 = 0; t0 < nc; t0 += TILE) {
+        const int nt = nc - t0 < TILE ? nc - t0 : TILE;
+        if (pc < d4)
+            for (int r0 = rr; r0 < nt; r0 += 16 * rpi) {
+                // sixteen loads in flight per lane before the first LDS store waits for one
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int r = r0 + u * rpi;
+                    int64_t id = cs[t0 + (r < nt ? r : nt - 1)];
+                    if (id < 0) id += n_rows;  // numpy fancy indexing with a negative index
+                    v[u] = ((const float4 *)(rows + id * (int64_t)d))[pc];
+                }
+                // unconditional stores (rows past the tile go to a spare row): a branch here
+                // lets the compiler sink each load next to its store, one exposed latency apiece
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int r = r0 + u * rpi;
+                    tile[(r < nt ? r : TILE) * stride4 + pc] = v[u];
+                }
+            }
+        __syncthreads();
+        if (tid < nt) ds[t0 + tid] = sqdist_row_lds(tile + tid * stride4, xs, d);
+        __syncthreads();
+    }
+    for (int t = tid; t < nc; t += 64) {
+        const float dv = ds[t];
+        int rank = 0;
+        for (int u = 0; u < nc; u++) {
+            const float du = ds[u];
+            rank += (du < dv) || (du == dv && u < t);
+        }
+        if (rank < k) o[rank] = cs[t];
+    }
+    if (tid == 0 && out_count) out_count[qi] = k;
+}
+
 void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
                        int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
                        int64_t *out, int *out_count, hipStream_t s)
@@ -118,6 +239,32 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
     const bool dbl = q_is_f64 || rows_is_f64;   // numpy promotes `Y - x` to float64
     size_t lds = (size_t)R * 8 + ((size_t)R + d) * (dbl ? 8 : 4) + 16;
     dim3 grid((unsigned)nq), block(128);
+    // A/B: TINYKNN_RESCORE_STAGED=1 / 2 stages the rows through LDS in tiles of 64 / 32 rows.
+    // Measured (profiles/r02_scan_grid.md): alone the 32-row form is the fastest (0.118 ms per
+    // 10 000 queries against 0.135), and it takes address traffic off the scan kernels it runs
+    // beside (scan launch 0.612 -> 0.58-0.60 ms), but next to them its own workgroups (15-29 KB
+    // of LDS each) are placed late: 0.45-0.57 ms on its stream against 0.29, and the step gets
+    // longer (0.68-0.70 ms against 0.656).  Default: off.
+    static int staged = -1;
+    if (staged < 0) {
+        const char *e = getenv("TINYKNN_RESCORE_STAGED");
+        staged = e ? atoi(e) : 0;
+    }
+    if (!dbl && staged && d % 4 == 0 && d <= 256 && !(strip & 0x300)) {
+        const int stride4 = (d / 4) | 1;                      // odd number of 16-byte pieces
+        const int tile_rows = staged == 2 ? 32 : 64;
+        const size_t slds = (((size_t)R * 8 + 15) & ~(size_t)15) +
+                            (size_t)(((R + 3) & ~3) + ((d + 3) & ~3)) * 4 + (size_t)(tile_rows + 1) * stride4 * 16;
+        if (slds <= 64 * 1024) {
+            if (tile_rows == 32)
+                hipLaunchKernelGGL(rescore_staged_kernel<32>, grid, dim3(64), slds, s, (const float *)q, d,
+                                   (const float *)rows, n_rows, cand, R, k, strip, out, out_count, stride4);
+            else
+                hipLaunchKernelGGL(rescore_staged_kernel<64>, grid, dim3(64), slds, s, (const float *)q, d,
+                                   (const float *)rows, n_rows, cand, R, k, strip, out, out_count, stride4);
+            return;
+        }
+    }
     if (!dbl)
         hipLaunchKernelGGL((rescore_kernel<float, float, float>), grid, block, lds, s,
                            (const float *)q, d, (const float *)rows, n_rows, cand, R, k, strip, out,
