@@ -17,6 +17,14 @@
 
 #include "kernels.h"
 
+// (tried: nontemporal loads of the candidate rows, so that they would not evict the scan
+// kernels' code and table lines from L2 — 2.5x slower alone, 0.135 -> 0.332 ms per 10 000
+// queries, and the scan beside it 0.61 -> 0.79 ms: a lane fetches its row in 25 pieces of 16 B
+// and an uncached piece is a memory transaction of its own.  -DTK_NT=1 rebuilds that.)
+#ifndef TK_NT
+#define TK_NT 0
+#endif
+
 // squared distance of row y to the query xs in numpy's einsum order, computed in T
 // (float when both operands are float32, else double as numpy promotes): L = 16 /
 // sizeof(T) lane-accumulators, groups of 4 vectors folded 3,2,1,0, zero tail.
@@ -31,7 +39,7 @@ __device__ __forceinline__ T sqdist_row(const TY *__restrict__ y, const T *xs, i
     for (; d - i >= 4 * L; i += 4 * L) {
         T df[4 * L];
 #pragma unroll
-        for (int t = 0; t < 4 * L; t++) df[t] = (T)y[i + t] - xs[i + t];
+        for (int t = 0; t < 4 * L; t++) df[t] = (T)(TK_NT ? __builtin_nontemporal_load(y + i + t) : y[i + t]) - xs[i + t];
 #pragma unroll
         for (int l = 0; l < L; l++) {
             T ab3 = df[3 * L + l] * df[3 * L + l] + acc[l];
