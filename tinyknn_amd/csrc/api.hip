@@ -101,7 +101,7 @@ struct DevBuf {
 struct Scratch {
     std::mutex mu;
     DevBuf ref, tiled, tables, out, hidx, hval, labels, slots_i, slots_l, q, rows, cand, pos,
-        centers, shift, scale, tabs8;
+        centers, shift, scale, tabs8, mins;
 };
 static Scratch &scratch()
 {
@@ -187,12 +187,14 @@ extern "C" int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t 
     int64_t sl[1] = {labels ? 0 : -1};
     HIPCHECK(hipMemcpyAsync(S.slots_i.p, si, sizeof si, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.slots_l.p, sl, sizeof sl, hipMemcpyHostToDevice, st));
+    const int64_t cap_min = (chunks + 15) / 16 * 16;
+    TRY(S.mins.ensure((size_t)cap_min));
     tk_launch_scan_flat(S.tiled.as<uint4>(), chunks, M, S.tables.as<uint4>(), 1, S.out.as<uint4>(),
-                        chunks, nullptr, 0, signd, order, st);
+                        chunks, S.mins.as<uint8_t>(), cap_min, signd, order, st);
     tk_launch_heap_replay(S.out.as<uint4>(), chunks, 1, S.slots_i.as<int>(),
                           S.slots_i.as<int>() + 2, S.slots_l.as<int64_t>(), 1,
                           S.labels.as<int64_t>(), S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R,
-                          signd, 1, nullptr, st);
+                          signd, 1, nullptr, st, S.mins.as<uint8_t>(), cap_min);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(indices, S.hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(vals, S.hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
@@ -323,7 +325,7 @@ struct tk_codes {
     int M = 0;
     // scratch of the calls on this array
     DevBuf tables, out, hidx, hval, labels, slots_i, slots_l, pair_off, unit_prefix, pair_q,
-        pair_f0, chunk_off;
+        pair_f0, chunk_off, mins;
 };
 
 extern "C" tk_codes *tk_codes_upload(const uint64_t *data, int64_t chunks, int M)
@@ -362,7 +364,7 @@ extern "C" void tk_codes_free(tk_codes *c)
     if (!c) return;
     DevBuf *b[] = {&c->tiled, &c->tables, &c->out, &c->hidx, &c->hval, &c->labels, &c->slots_i,
                    &c->slots_l, &c->pair_off, &c->unit_prefix, &c->pair_q, &c->pair_f0,
-                   &c->chunk_off};
+                   &c->chunk_off, &c->mins};
     for (DevBuf *x : b) x->release();
     delete c;
 }
@@ -450,12 +452,15 @@ extern "C" int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, in
     int64_t sl[1] = {labels ? 0 : -1};
     HIPCHECK(hipMemcpyAsync(c->slots_i.p, si, sizeof si, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(c->slots_l.p, sl, sizeof sl, hipMemcpyHostToDevice, st));
+    // the scan also writes each block's minimum: the replay walks 1024 blocks per step on them
+    const int64_t cap_min = (chunks + 15) / 16 * 16;
+    TRY(c->mins.ensure((size_t)cap_min));
     tk_launch_scan_flat(c->tiled.as<uint4>(), chunks, c->M, c->tables.as<uint4>(), 1,
-                        c->out.as<uint4>(), chunks, nullptr, 0, signd, order, st);
+                        c->out.as<uint4>(), chunks, c->mins.as<uint8_t>(), cap_min, signd, order, st);
     tk_launch_heap_replay(c->out.as<uint4>(), chunks, 1, c->slots_i.as<int>(),
                           c->slots_i.as<int>() + 2, c->slots_l.as<int64_t>(), 1,
                           c->labels.as<int64_t>(), c->hidx.as<int64_t>(), c->hval.as<int32_t>(), R,
-                          signd, 1, nullptr, st);
+                          signd, 1, nullptr, st, c->mins.as<uint8_t>(), cap_min);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(indices, c->hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(vals, c->hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_kernel(
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
-    const unsigned char *__restrict__ only_flagged, int64_t nq)
+    const unsigned char *__restrict__ only_flagged, int64_t nq,
+    const uint8_t *__restrict__ mins, int64_t cap_min)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6;
@@ -191,9 +192,30 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_kernel(
         const int64_t n = slot_n[qs * S + s];
         const int64_t loff = slot_label_off[qs * S + s];
         const int64_t *lab = loff < 0 ? nullptr : labels + loff;
-        for (int base = 0; base < nchunks; base += 64) {
+        // 64 blocks per step — or, with the scan's per-block minima and a heap whose bound can
+        // only fall, 1024: lane j looks at the 16 minima of blocks [sbase + 16 j, +16) and only
+        // groups that can hold a hit are entered, 16 blocks at a time (one long list against a
+        // small heap, the flat DistanceTable.top: 977 steps of 1 KiB become 61 of 1 KiB of
+        // minima plus the few groups that matter)
+        const bool by_mins = mins != nullptr && !no_skip && (c0 & 15) == 0;
+        const int width = by_mins ? 16 : 64;
+        for (int sbase = 0; sbase < nchunks; sbase += by_mins ? 1024 : 64) {
+          uint64_t groups = 1;
+          if (by_mins) {
+              const int gb = sbase + 16 * lane;
+              bool gv = false;
+              if (gb < nchunks) {
+                  const uint4 m16 = *(const uint4 *)(mins + q * cap_min + c0 + gb);
+                  gv = any_lt16<SIGNED>(m16, bound);
+              }
+              groups = __builtin_amdgcn_ballot_w64(gv);
+          }
+          while (groups) {
+            const int gj = __builtin_ctzll(groups);
+            groups &= groups - 1;
+            const int base = by_mins ? sbase + 16 * gj : sbase;
             const int b = base + lane;
-            const bool have = b < nchunks;
+            const bool have = lane < width && b < nchunks;
             uint4 dd = never;
             if (have) dd = drow[c0 + b];
             bool vote = have && (no_skip || any_lt16<SIGNED>(dd, bound));
@@ -233,6 +255,7 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_kernel(
                     mask &= __builtin_amdgcn_ballot_w64(vote);
                 }
             }
+          }
         }
     }
     for (int t = lane; t < R; t += 64) {
@@ -245,7 +268,7 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
                            const int *slot_n, const int64_t *slot_label_off, int S,
                            const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                            int signd, int slots_uniform, const unsigned char *only_flagged,
-                           hipStream_t s)
+                           hipStream_t s, const uint8_t *mins, int64_t cap_min)
 {
     if (nq == 0 || R == 0) return;
     const size_t wstride = ((size_t)R * 12 + 15) & ~(size_t)15;
@@ -256,11 +279,11 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
     if (signd)
         hipLaunchKernelGGL(heap_replay_kernel<true>, grid, block, lds, s, dist, cap, slot_prefix,
                            slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform,
-                           only_flagged, nq);
+                           only_flagged, nq, mins, cap_min);
     else
         hipLaunchKernelGGL(heap_replay_kernel<false>, grid, block, lds, s, dist, cap, slot_prefix,
                            slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform,
-                           only_flagged, nq);
+                           only_flagged, nq, mins, cap_min);
 }
 
 // ---------------------------------------------------------------------------

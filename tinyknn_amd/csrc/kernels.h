@@ -96,7 +96,9 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
                            const int *slot_n, const int64_t *slot_label_off, int S,
                            const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                            int signd, int slots_uniform, const unsigned char *only_flagged,
-                           hipStream_t s);
+                           hipStream_t s, const uint8_t *mins = nullptr, int64_t cap_min = 0);
+// mins (optional): the scan's per-block minima, (nq, cap_min) bytes, cap_min a multiple of 16:
+// slots that start at a multiple of 16 blocks are then walked 1024 blocks per step
 
 // Lane-per-query form of the same replay: 64 queries per wave.  Preconditions
 // (checked by the caller): heaps start fresh (-1 / 127|255), no label can repeat
