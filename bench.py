@@ -490,7 +490,7 @@ def main():
                          "implies --n 100000000 --d 128 --n-clusters 10000 --metric euclidean unless given")
     ap.add_argument("--shard", choices=["auto", "none", "lists"], default="auto",
                     help="list-sharded leg after the replica measurement (auto: when N > 1)")
-    ap.add_argument("--shard-depth", type=int, default=3,
+    ap.add_argument("--shard-depth", type=int, default=4,
                     help="list-sharded leg: batches in flight (each on its own stream)")
     ap.add_argument("--shard-coarse", choices=["home", "replicated"], default="home",
                     help="list-sharded leg: coarse stage of the home queries + probe all-gather, or of all "
