@@ -35,35 +35,51 @@ __global__ __launch_bounds__(1024) void shard_positions_kernel(
     const int64_t n_e = q1 > q0 ? (q1 - q0) * S : 0;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int64_t base = 0; base < n_e; base += 1024) {
-        const int64_t e = base + threadIdx.x;
-        int c = 0;
-        bool mine = false;
-        int64_t qi = 0;
-        int s = 0;
-        if (e < n_e) {
-            qi = q0 + e / S;
-            s = (int)(e % S);
-            int64_t cl = probes[qi * S + s];
-            if (cl < 0) cl += n_lists;
-            mine = owner[cl] == own;
-            if (mine) c = slot_prefix[qi * (S + 1) + s + 1] - slot_prefix[qi * (S + 1) + s];
+    // 8 consecutive entries per thread: a serial prefix inside the thread, one block-wide
+    // scan of the 1024 thread sums per 8192 entries (at W = 1 a stream is nq * S = 10^5
+    // entries long: 98 block scans of 1024 became 13)
+    constexpr int PER = 8;
+    for (int64_t base = 0; base < n_e; base += 1024 * PER) {
+        int c[PER];
+        bool mine[PER];
+        int tot = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int64_t e = base + (int64_t)threadIdx.x * PER + u;
+            c[u] = 0;
+            mine[u] = false;
+            if (e < n_e) {
+                const int64_t qi = q0 + e / S;
+                const int sl = (int)(e % S);
+                int64_t cl = probes[qi * S + sl];
+                if (cl < 0) cl += n_lists;
+                mine[u] = owner[cl] == own;
+                if (mine[u]) c[u] = slot_prefix[qi * (S + 1) + sl + 1] - slot_prefix[qi * (S + 1) + sl];
+            }
+            tot += c[u];
         }
-        s_v[threadIdx.x] = c;
+        s_v[threadIdx.x] = tot;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+        for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan of the thread sums
             int v = threadIdx.x >= (unsigned)o ? s_v[threadIdx.x - o] : 0;
             __syncthreads();
             s_v[threadIdx.x] += v;
             __syncthreads();
         }
-        if (e < n_e) {
-            const int64_t pos = carry + s_v[threadIdx.x] - c;
-            const bool fits = pos + c <= C;
-            const int where = fits ? (int)((int64_t)peer * C + pos) : -1;
-            if (sender) spos[qi * S + s] = mine ? where : -1;
-            else if (mine) rpos[(qi - q0) * S + s] = where;
-            if (mine && !fits) atomicOr(flag, 1);
+        int64_t run = carry + s_v[threadIdx.x] - tot;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int64_t e = base + (int64_t)threadIdx.x * PER + u;
+            if (e < n_e) {
+                const int64_t qi = q0 + e / S;
+                const int sl = (int)(e % S);
+                const bool fits = run + c[u] <= C;
+                const int where = fits ? (int)((int64_t)peer * C + run) : -1;
+                if (sender) spos[qi * S + sl] = mine[u] ? where : -1;
+                else if (mine[u]) rpos[(qi - q0) * S + sl] = where;
+                if (mine[u] && !fits) atomicOr(flag, 1);
+            }
+            run += c[u];
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry += s_v[1023];
