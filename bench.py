@@ -231,18 +231,24 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
                         args.n_probes, want.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     want = want.cpu().numpy()
-    idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse)
+    co = max(1, min(args.shard_coalesce, 32768 // args.nq))
+    idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co)
     got = idx.query_prepared(qn_t, qp_t, args.k, args.n_probes)     # also settles the capacity
     same = int((got == want).all(axis=1).sum())
-    for _ in range(max(1, args.warmup)):
+    if co > 1:      # the coalesced batch: settles its capacity, and its rows must repeat `want`
+        gotc = idx.query_prepared(torch.cat([qn_t] * co), torch.cat([qp_t] * co), args.k, args.n_probes)
+        same = min(same, *[int((gotc[j * args.nq:(j + 1) * args.nq] == want).all(axis=1).sum()) for j in range(co)])
+    for _ in range(max(co, args.warmup)):
         idx.submit(qn_t, qp_t, args.k, args.n_probes)
     idx.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    g = None
     for _ in range(args.steps):
-        g = idx.submit(qn_t, qp_t, args.k, args.n_probes)
+        r = idx.submit(qn_t, qp_t, args.k, args.n_probes)
+        g = g if r is None else r
     idx.join()
     torch.cuda.synchronize()
     if world > 1:
@@ -252,13 +258,14 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
-    cap = idx.capacity[(args.nq, args.n_probes)]
+    cap = idx.capacity[(args.nq * co, args.n_probes)] if (args.nq * co, args.n_probes) in idx.capacity \
+        else idx.capacity[(args.nq, args.n_probes)]
     load = np.bincount(idx.owner, weights=(idx.list_sizes + 15) // 16, minlength=world)
     return {"queries_per_s": args.nq * args.steps / el, "ms_per_step": el / args.steps * 1e3,
             "scaling": "strong (one shared batch of %d queries per step)" % args.nq,
             "identical_rows_vs_replica": same, "rows": args.nq,
-            "overflow_in_timed_steps": bool(g.cpu().numpy()[:, -1].any()),
-            "exchange": {"all_to_all_bytes_per_rank_per_step": int(world * cap * 16),
+            "overflow_in_timed_steps": bool(g is not None and g.cpu().numpy()[:, -1].any()),
+            "exchange": {"all_to_all_bytes_per_rank_per_step": int(world * cap * 16 // co),
                          "region_capacity_uint4": int(cap),
                          "probe_all_gather_bytes_per_rank_per_step":
                              int(-(-args.nq // world) * min(args.n_probes, len(idx.list_sizes)) * 8)
@@ -267,7 +274,8 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
             "coarse_stage": args.shard_coarse + (" (tables for all queries, coarse scan/replay/rescoring of the "
                                                  "rank's nq/W home queries, probe lists all-gathered)"
                                                  if args.shard_coarse == "home" else " on every rank"),
-            "code_chunks_per_rank": [int(x) for x in load], "batches_in_flight": args.shard_depth}
+            "code_chunks_per_rank": [int(x) for x in load], "batches_in_flight": args.shard_depth,
+            "steps_coalesced_per_exchange": co}
 
 
 def raw_stream_leg(args, dev, qs, out_dev, device, world):
@@ -492,6 +500,8 @@ def main():
                     help="list-sharded leg after the replica measurement (auto: when N > 1)")
     ap.add_argument("--shard-depth", type=int, default=4,
                     help="list-sharded leg: batches in flight (each on its own stream)")
+    ap.add_argument("--shard-coalesce", type=int, default=3,
+                    help="list-sharded leg: consecutive steps answered as ONE sharded batch (<= 32768 queries)")
     ap.add_argument("--shard-coarse", choices=["home", "replicated"], default="home",
                     help="list-sharded leg: coarse stage of the home queries + probe all-gather, or of all "
                          "queries on every rank")

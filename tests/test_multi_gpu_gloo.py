@@ -144,3 +144,52 @@ def test_shard_bounds():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _coalesce_worker(rank, world, port, tag, nq, k, n_probes, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import golden
+        from test_oracle_golden import load_oracle_index
+        from shard_cpu_engine import OracleShardEngine
+        from oracle import oracle as O
+        from tinyknn_amd.multi_gpu import ListShardedIndex, shard_lists
+        g = golden(f"g6_ivf_{tag}.npz")
+        ox = load_oracle_index(O, g)
+        owner = shard_lists(g["list_sizes"], world)
+        eng = OracleShardEngine(O, ox, owner, rank, world)
+        idx = ListShardedIndex(None, engine=eng, owner=owner, list_sizes=g["list_sizes"], coalesce=2)
+        qn = torch.from_numpy(np.ascontiguousarray(g["qn"][:nq]))
+        qp = torch.from_numpy(np.ascontiguousarray(ox.pq_query(g["qn"][:nq])))
+        first = idx.submit(qn, qp, k, n_probes)             # waits for a second batch
+        out = idx.submit(qn.flip(0).contiguous(), qp.flip(0).contiguous(), k, n_probes)
+        third = idx.submit(qn, qp, k, n_probes)             # flushed alone by join()
+        idx.join()
+        qh = -(-2 * nq // world)
+        ret[rank] = (first is None, third is None, out[:, :-1].reshape(world * qh, k)[:2 * nq].numpy().copy(),
+                     bool(out[:, -1].any()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_list_sharded_coalesced_submits_gloo():
+    """Two consecutive submits answered as ONE sharded batch (coalesce=2): rows of both, in
+    order; an odd batch left over is flushed by join()."""
+    import torch.multiprocessing as mp
+    from conftest import golden
+    tag, k, n_probes, nq, world = "an100", 10, 5, 11, 2
+    port = 35500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_coalesce_worker, args=(world, port, tag, nq, k, n_probes, ret), nprocs=world, join=True)
+    exp = golden(f"g6_ivf_{tag}.npz")[f"ids_p{n_probes}"][:nq]
+    for r in range(world):
+        first_none, third_none, rows, overflow = ret[r]
+        assert first_none and third_none and not overflow
+        np.testing.assert_array_equal(rows[:nq], exp)
+        np.testing.assert_array_equal(rows[nq:], exp[::-1])
