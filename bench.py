@@ -231,7 +231,8 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
                         args.n_probes, want.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     want = want.cpu().numpy()
-    co = max(1, min(args.shard_coalesce, 32768 // args.nq))
+    co = args.shard_coalesce if args.shard_coalesce > 0 else max(3, world)    # auto: a rank's home share = one batch
+    co = max(1, min(co, 131072 // args.nq))
     idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co)
     got = idx.query_prepared(qn_t, qp_t, args.k, args.n_probes)     # also settles the capacity
     same = int((got == want).all(axis=1).sum())
@@ -500,8 +501,9 @@ def main():
                     help="list-sharded leg after the replica measurement (auto: when N > 1)")
     ap.add_argument("--shard-depth", type=int, default=4,
                     help="list-sharded leg: batches in flight (each on its own stream)")
-    ap.add_argument("--shard-coalesce", type=int, default=3,
-                    help="list-sharded leg: consecutive steps answered as ONE sharded batch (<= 32768 queries)")
+    ap.add_argument("--shard-coalesce", type=int, default=0,
+                    help="list-sharded leg: consecutive steps answered as ONE sharded batch (<= 131072 queries); "
+                         "0 = max(3, N): a rank's home share is then a whole batch")
     ap.add_argument("--shard-coarse", choices=["home", "replicated"], default="home",
                     help="list-sharded leg: coarse stage of the home queries + probe all-gather, or of all "
                          "queries on every rank")

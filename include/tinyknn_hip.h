@@ -395,7 +395,7 @@ int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int k, int64_t 
  *                              (ceil(nq/world), k), rows past nq and missing ids = -1;
  *   all-gather of the id rows  (by the caller).
  * All calls enqueue on `stream` and use workspace `slot` (< pipeline depth), so that
- * several batches can be in flight on different streams.  nq <= 32768 per batch. */
+ * several batches can be in flight on different streams.  nq <= 131072 per batch. */
 int tk_index_set_lists_shard(tk_index *ix, const int64_t *list_sizes, const int32_t *owner,
                              int rank, int world, const uint64_t *codes_owned,
                              const int64_t *ids);

@@ -40,19 +40,19 @@ def test_heap_sizes_around_the_lane_kernel_limits(small, oracle, pass_1):
     np.testing.assert_array_equal(got, oxb.query_batch(gb["qn"], 10, 5, pass_1))
 
 
-def test_sharded_batch_larger_than_32768_is_refused(small):
+def test_sharded_batch_larger_than_131072_is_refused(small):
     import torch
     from tinyknn_amd import _lib
     from tinyknn_amd.multi_gpu import _HipShardEngine, shard_lists
     g, ivf = small
     owner = shard_lists(g["list_sizes"], 1)
     e = _HipShardEngine(ivf, owner, 0, 1, 1)
-    nq = 32769
+    nq = 131073
     qn = torch.zeros((nq, ivf.data.shape[1]), dtype=torch.float32, device="cuda")
     qp = torch.zeros((nq, ivf.pq.centers.shape[1]), dtype=torch.float32, device="cuda")
     send = torch.zeros(16 * 1024, dtype=torch.uint8, device="cuda")
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    with pytest.raises(AssertionError, match="32768"):      # argument errors: the reference layer's convention
+    with pytest.raises(AssertionError, match="131072"):      # argument errors: the reference layer's convention
         e.scan(0, qn, qp, 10, 5, None, 1024, send, flag)
     e.dev.close()
 

@@ -902,6 +902,9 @@ static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
 }
 
 static const int64_t MAX_SUB = 32768;  // gridDim.y limit of the scan kernels is 65535
+// a sharded batch only runs the list-major kernels (no gridDim.y); what bounds it is int32 unit
+// counts and the 16 GB of distance rows per rank, both checked in shard_args
+static const int64_t MAX_SHARD_BATCH = 131072;
 
 // Queries per sub-batch: the distance buffer is nq * cap * 17 bytes (16 int8 + 1 minimum
 // per chunk, cap = n_probes * longest list); one workspace keeps it under 12 GB (env
@@ -1548,7 +1551,7 @@ static int shard_args(tk_index *ix, int slot, int64_t nq, int64_t capacity, cons
 {
     ARGCHECK(ix->sharded, "not a list-sharded index (tk_index_set_lists_shard)");
     ARGCHECK(slot >= 0 && slot < ix->depth, "slot must be < the pipeline depth");
-    ARGCHECK(nq >= 1 && nq <= MAX_SUB, "1 <= nq <= 32768 per sharded batch");
+    ARGCHECK(nq >= 1 && nq <= MAX_SHARD_BATCH, "1 <= nq <= 131072 per sharded batch");
     ARGCHECK(capacity >= 1 && capacity * ix->world < (1ll << 31), "capacity");
     qh = (nq + ix->world - 1) / ix->world;
     ARGCHECK((double)nq * p.S / 4 * ix->max_list_chunks + (double)ix->total_chunks < 2.0e9,

@@ -307,7 +307,7 @@ class ListShardedIndex:
         t = self.torch
         qs = np.array(qs, dtype=np.float32, order="C", copy=True)
         out = np.empty((len(qs), k), dtype=np.int64)
-        for lo in range(0, len(qs), 32768):
+        for lo in range(0, len(qs), 32768):       # (a sharded batch may hold up to 131072 queries)
             qn, qp = self.ivf._prepare(qs[lo:lo + 32768])
             out[lo:lo + len(qn)] = self.query_prepared(
                 t.from_numpy(np.ascontiguousarray(qn)).to(self.device),
