@@ -98,6 +98,8 @@ int64_t tk_knn_brute1(const void *x, int x_is_f64, const void *Y, int y_is_f64, 
  * A TransformedData (fast_pq.py:30,184) kept in HBM so that repeated
  * estimate_distances / top calls on the same data (examples/example.py:60-66 runs
  * 1000 of them) do not re-send the codes over PCIe. */
+/* (a tk_codes handle carries the scratch of the calls made on it: one caller at a time per
+ * handle; the host-buffer entry points above share one mutex-guarded scratch) */
 typedef struct tk_codes tk_codes;
 tk_codes *tk_codes_upload(const uint64_t *data, int64_t chunks, int M);
 void tk_codes_free(tk_codes *c);

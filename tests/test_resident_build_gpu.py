@@ -117,3 +117,37 @@ def test_resident_build_rotated_vs_oracle(oracle):
             np.testing.assert_array_equal(dev.query_batch(qn, qp, 10, n_probes), ox.query_batch(qn, 10, n_probes))
     dev.set_pipeline(1)
     np.testing.assert_array_equal(ivf.query_batch(qs, 10, n_probes=4), ox.query_batch(qn, 10, 4))
+
+
+@pytest.mark.parametrize("n,n_clusters", [(500, 64), (100, 7), (1600, 3)])
+def test_resident_build_small_and_sparse(oracle, n, n_clusters):
+    """More centres than some lists can fill (inactive centres are dropped as ivf.py:91 does),
+    lists of one row, N below one slab: same active centres and memberships as the host build,
+    same answers as the oracle over the exported index."""
+    from tinyknn_amd import IVF, FastPQ
+    d, seed = 100, 21
+    cent = np.random.RandomState(7).randn(5, d).astype(np.float32) * 3
+    X = synth_rows(n, d, seed, cent, 0.5)
+    host = IVF("euclidean", n_clusters, FastPQ(2))
+    host.fit(np.concatenate([X, synth_rows(max(0, 400 - n), d, seed + 5, cent, 0.5)]))
+    # centres nobody is nearest to: far away from all the data
+    host.all_centers = np.concatenate([host.all_centers, np.full((5, d), 1e3, host.all_centers.dtype)])
+    host.n_clusters += 5
+    host.pq_transformed_points = [None] * host.n_clusters
+    host.ids = [None] * host.n_clusters
+    host.build(X, n_probes=1, device=True)
+    res = IVF("euclidean", host.n_clusters, FastPQ(2))
+    res.all_centers, res.pq = host.all_centers, host.pq
+    res.build_resident(n, d, seed, cent, 0.5)
+    assert len(res.active_centers) == len(host.active_centers) < host.n_clusters
+    np.testing.assert_array_equal(res.active_centers, host.active_centers)
+    sizes, codes, ids = res.device_index().export_lists()
+    ioff = np.concatenate([[0], np.cumsum(sizes)])
+    for i in range(len(sizes)):
+        np.testing.assert_array_equal(ids[ioff[i]:ioff[i + 1]], np.sort(np.asarray(host.ids[i], np.int64)))
+    ox, _ = oracle_from_resident(oracle, res)
+    qs = synth_rows(50, d, seed + 1, cent, 0.5)
+    qn, qp = res._prepare(qs.copy())
+    for n_probes in (1, 3, 100):
+        np.testing.assert_array_equal(res.device_index().query_batch(qn, qp, 10, n_probes),
+                                      ox.query_batch(qn, 10, n_probes))
