@@ -181,7 +181,9 @@ int tk_index_query_batch(tk_index *ix, const float *q, const void *q_pq, int q_p
 
 /* Same with device-resident inputs/outputs, enqueued on `stream`, no sync.  Large
  * batches are processed in sub-batches whose distance buffers stay under 12 GB (TINYKNN_WORKSPACE_GB).
- * An index handle is not thread-safe: one caller at a time per tk_index. */
+ * An index handle serves one caller at a time: its entry points take a per-handle lock, so
+ * calls from several threads are serialised (the reference's kernels are nogil and re-entrant
+ * on distinct buffers; use one handle per thread for concurrency). */
 int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_dev,
                              int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                              int64_t *out_ids_dev, void *stream);

@@ -79,3 +79,29 @@ def test_assign_lists_refuses_k_above_two():
     rc = _lib.lib().tk_assign_lists(_lib.ptr(X, _lib._f32p), 100, 16, 0, Y.ctypes.data, 0, yn.ctypes.data,
                                     8, 3, _lib.ptr(out, _lib._i64p))
     assert rc < 0 and b"k must be 1 or 2" in _lib.lib().tk_last_error()
+
+
+def test_one_handle_from_several_threads_is_serialised(small):
+    """The reference's entry points are nogil and re-entrant; a tk_index handle is not — its entry
+    points take a per-handle lock, so concurrent callers are serialised instead of corrupting
+    the pipeline state (ctypes releases the GIL during the calls)."""
+    import threading
+    g, ivf = small
+    dev = ivf.device_index()
+    errors = []
+
+    def worker(n_probes):
+        try:
+            for _ in range(15):
+                out, dbg = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, debug=True)
+                np.testing.assert_array_equal(out, g[f"ids_p{n_probes}"])
+                np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(p,)) for p in (1, 2, 5, 10, 5, 2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors[:2]

@@ -581,11 +581,19 @@ struct Work {
     }
 };
 
+#define IXLOCK(ix_)                                               \
+    std::unique_lock<std::recursive_mutex> ixlock_;               \
+    if (ix_) ixlock_ = std::unique_lock<std::recursive_mutex>((ix_)->mu)
+
 struct Pending;
 static int flush_pending(struct tk_index *ix);
 static int batch_epilogue(const struct Pending &b, hipStream_t st);
 
 struct tk_index {
+    // one caller at a time: every entry point takes this lock (the reference's kernels are
+    // nogil and re-entrant on distinct buffers; calls on one handle from several threads are
+    // serialised here instead of corrupting the pipeline state)
+    std::recursive_mutex mu;
     // FastPQ
     DevBuf pq_centers;
     int dq = 0, dpb = 0, M = 0, f_order = 0, order = TK_ORDER_AVX;
@@ -668,6 +676,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
 extern "C" int tk_index_set_pq(tk_index *ix, const float *centers, int dq, int dpb, int f_order,
                                double sqrt_n_blocks, int order)
 {
+    IXLOCK(ix);
     ARGCHECK(ix, "null index");
     ARGCHECK(dpb >= 1 && dpb <= 32 && dq % dpb == 0, "dq/dpb");
     ARGCHECK((dq / dpb) % 2 == 0, "number of blocks must be even");
@@ -699,6 +708,7 @@ static int upload_tiled(DevBuf &dst, DevBuf &stage, const uint64_t *codes, int64
 extern "C" int tk_index_set_centers(tk_index *ix, const float *active_centers, int64_t n_lists,
                                     int d, const uint64_t *center_codes, int64_t center_chunks)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_pq, "set_pq first");
     ARGCHECK(n_lists >= 1 && d >= 1, "sizes");
     ARGCHECK(center_chunks == (n_lists + 15) / 16, "center_chunks must be ceil(n_lists/16)");
@@ -805,6 +815,7 @@ static int set_lists_impl(tk_index *ix, const int64_t *list_sizes, const uint64_
 extern "C" int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const uint64_t *codes,
                                   const int64_t *ids)
 {
+    IXLOCK(ix);
     return set_lists_impl(ix, list_sizes, codes, ids, nullptr, 0, 1);
 }
 
@@ -812,6 +823,7 @@ extern "C" int tk_index_set_lists_shard(tk_index *ix, const int64_t *list_sizes,
                                         const int32_t *owner, int rank, int world,
                                         const uint64_t *codes_owned, const int64_t *ids)
 {
+    IXLOCK(ix);
     ARGCHECK(owner, "owner");
     ARGCHECK(world >= 1 && rank >= 0 && rank < world, "rank/world");
     return set_lists_impl(ix, list_sizes, codes_owned, ids, owner, rank, world);
@@ -820,6 +832,7 @@ extern "C" int tk_index_set_lists_shard(tk_index *ix, const int64_t *list_sizes,
 extern "C" int tk_index_set_data(tk_index *ix, const void *data, int data_is_f64, int64_t N,
                                  int d)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_centers, "set_centers first");
     ARGCHECK(d == ix->d, "data dimension differs from the centres'");
     ARGCHECK(N >= 1, "N");
@@ -931,6 +944,7 @@ static int64_t sub_batch(const Plan &p)
 
 extern "C" int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, int pass_1)
 {
+    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     TRY(flush_pending(ix));
@@ -1457,6 +1471,7 @@ extern "C" int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const 
                                         int q_pq_is_f64, int64_t nq, int k, int n_probes,
                                         int pass_1, int64_t *out_ids_dev, void *stream)
 {
+    IXLOCK(ix);
     return query_batch_dev_impl(ix, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1,
                                 out_ids_dev, nullptr, nullptr, stream);
 }
@@ -1466,6 +1481,7 @@ extern "C" int tk_index_query_batch_dev_ex(tk_index *ix, const float *q_dev, con
                                            int pass_1, int64_t *out_ids_dev,
                                            int64_t *out_ids_pinned, void *done_event, void *stream)
 {
+    IXLOCK(ix);
     return query_batch_dev_impl(ix, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1,
                                 out_ids_dev, out_ids_pinned, (hipEvent_t)done_event, stream);
 }
@@ -1474,6 +1490,7 @@ void tk_index_host_out_by_kernel(tk_index *ix, bool on) { ix->host_out_kernel = 
 
 extern "C" int64_t tk_index_max_sub_batch(tk_index *ix, int k, int n_probes, int pass_1)
 {
+    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     return sub_batch(p);
@@ -1485,6 +1502,7 @@ extern "C" int64_t tk_index_max_sub_batch(tk_index *ix, int k, int n_probes, int
 // = the stream the batch is enqueued on.
 extern "C" void *tk_index_input_stream(tk_index *ix)
 {
+    IXLOCK(ix);
     if (!ix || ix->depth <= 1) return nullptr;
     if (!ix->front_stream &&
         hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking) != hipSuccess)
@@ -1496,6 +1514,7 @@ extern "C" int tk_index_pending(tk_index *ix) { return ix ? (int)ix->pending.siz
 
 extern "C" int tk_index_info(tk_index *ix, int64_t *info8)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && info8, "null index / buffer");
     ARGCHECK(ix->have_pq && ix->have_centers, "set_pq and set_centers first");
     info8[0] = ix->d; info8[1] = ix->dq; info8[2] = ix->M; info8[3] = ix->n_lists;
@@ -1568,6 +1587,7 @@ extern "C" int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_
                                          int n_probes, int pass_1, int64_t *probes_home_dev,
                                          void *stream)
 {
+    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     int64_t qh = 0;
@@ -1600,6 +1620,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
                                        int n_probes, int pass_1, const int64_t *probes_all_dev,
                                        int64_t capacity, void *send_dev, int *flag_dev, void *stream)
 {
+    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     int64_t qh = 0;
@@ -1646,6 +1667,7 @@ extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_
                                          const void *recv_dev, int64_t *out_ids_home_dev,
                                          void *stream)
 {
+    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     int64_t qh = 0;
@@ -1683,6 +1705,7 @@ static int upload_rotation(tk_index *ix, const double *R, int d_pad)
 
 extern "C" float *tk_index_alloc_data(tk_index *ix, int64_t N, int d)
 {
+    IXLOCK(ix);
     if (!ix || !ix->have_pq || N < 1 || d < 1) {
         fail(TK_ERR_ARG, "bad argument: tk_index_alloc_data (set_pq first, N >= 1, d >= 1)");
         return nullptr;
@@ -1708,6 +1731,7 @@ static int synth_centres(DevBuf &buf, const float *centres, int n_centres, int d
 extern "C" int tk_index_synth_data(tk_index *ix, int64_t row0, int64_t n, uint64_t seed,
                                    const float *centres, int n_centres, float sigma)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->data.p && ix->N > 0, "tk_index_alloc_data first");
     ARGCHECK(row0 >= 0 && n >= 0 && row0 + n <= ix->N, "row range");
     const float *cd = nullptr;
@@ -1759,6 +1783,7 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
                                   const float *search_centers, const float *ynorm2, int64_t C,
                                   const double *R, int d_pad, int64_t *n_active_out)
 {
+    IXLOCK(ix);
     if (!search_centers) search_centers = all_centers;
     ARGCHECK(ix && ix->have_pq && ix->data.p && ix->N > 0, "set_pq and tk_index_alloc_data first");
     ARGCHECK(all_centers && ynorm2 && C >= 1 && C < (1ll << 31), "centres");
@@ -1910,6 +1935,7 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
 // into the rank's own array, everything else (centres, ids, vectors) stays replicated.
 extern "C" int tk_index_shard_resident(tk_index *ix, const int32_t *owner, int rank, int world)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_lists && !ix->sharded, "a complete unsharded index");
     ARGCHECK(owner && world >= 1 && rank >= 0 && rank < world, "owner / rank / world");
     TRY(flush_pending(ix));
@@ -1948,6 +1974,7 @@ extern "C" int tk_index_shard_resident(tk_index *ix, const int32_t *owner, int r
 // (n_lists,), codes (total chunks, M) uint64 Quick-ADC layout, ids (sum sizes,) — any NULL
 extern "C" int tk_index_export_lists(tk_index *ix, int64_t *list_sizes, uint64_t *codes, int64_t *ids)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_lists && !ix->sharded, "an unsharded index with lists");
     if (list_sizes)
         HIPCHECK(hipMemcpy(list_sizes, ix->list_n.p, (size_t)ix->n_lists * 8, hipMemcpyDeviceToHost));
@@ -1968,6 +1995,7 @@ extern "C" int tk_index_export_lists(tk_index *ix, int64_t *list_sizes, uint64_t
 // active_centers (n_lists, d) float32, center_codes (ceil(n_lists/16), M) uint64 — any NULL
 extern "C" int tk_index_export_centers(tk_index *ix, float *active_centers, uint64_t *center_codes)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_centers, "an index with centres");
     if (active_centers)
         HIPCHECK(hipMemcpy(active_centers, ix->active_centers.p, (size_t)ix->n_lists * ix->d * 4,
@@ -1987,6 +2015,7 @@ extern "C" int tk_index_export_centers(tk_index *ix, float *active_centers, uint
 // rows of IVF.data by id (float32 vectors), e.g. the candidates a checker wants to rescore
 extern "C" int tk_index_read_rows(tk_index *ix, const int64_t *rows, int64_t n, float *out)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_data && !ix->data_is_f64, "an index with float32 vectors");
     ARGCHECK(n >= 0 && (n == 0 || (rows && out)), "buffers");
     for (int64_t i = 0; i < n; i++) ARGCHECK(rows[i] >= 0 && rows[i] < ix->N, "row id out of range");
@@ -2012,6 +2041,7 @@ extern "C" int tk_index_read_rows(tk_index *ix, const int64_t *rows, int64_t n, 
 // device front end ("fast mode")
 extern "C" int tk_index_set_rotation(tk_index *ix, const double *R, int d_pad)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_pq && ix->have_centers, "set_pq and set_centers first");
     if (!R) {
         ix->rot_t.release();
@@ -2025,6 +2055,7 @@ extern "C" int tk_index_set_rotation(tk_index *ix, const double *R, int d_pad)
 extern "C" int tk_index_prepare_dev(tk_index *ix, const float *q_raw_dev, int64_t nq, int angular,
                                     float *qn_dev, void *q_pq_dev, void *stream)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_pq && ix->have_centers, "set_pq and set_centers first");
     ARGCHECK(nq >= 0 && q_raw_dev && qn_dev && q_pq_dev, "buffers");
     ARGCHECK(!angular || ix->d <= 128, "device normalisation needs d <= 128");
@@ -2043,6 +2074,7 @@ extern "C" int tk_index_prepare_dev(tk_index *ix, const float *q_raw_dev, int64_
 extern "C" int tk_index_query_batch_raw(tk_index *ix, const float *q_raw, int64_t nq, int angular,
                                         int k, int n_probes, int pass_1, int64_t *out_ids)
 {
+    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     ARGCHECK(nq >= 0 && q_raw && out_ids, "buffers");
@@ -2073,6 +2105,7 @@ extern "C" int tk_index_query_batch_raw(tk_index *ix, const float *q_raw, int64_
 // exact k nearest vectors of IVF.data: the ground truth of recall (brute.hip)
 extern "C" int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int k, int64_t *out_ids)
 {
+    IXLOCK(ix);
     ARGCHECK(ix && ix->have_data, "set_data first");
     ARGCHECK(!ix->data_is_f64, "float32 vectors only");
     ARGCHECK(ix->d <= 128, "d <= 128");
@@ -2110,6 +2143,7 @@ extern "C" int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int 
 
 extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
 {
+    IXLOCK(ix);
     ARGCHECK(ix, "null index");
     ARGCHECK(depth >= 1 && depth <= 8, "depth must be in 1..8");
     TRY(flush_pending(ix));
@@ -2129,6 +2163,7 @@ extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
 
 extern "C" int tk_index_join(tk_index *ix, void *stream)
 {
+    IXLOCK(ix);
     ARGCHECK(ix, "null index");
     TRY(flush_pending(ix));
     if (ix->depth > 1)
@@ -2142,6 +2177,7 @@ extern "C" int tk_index_query_batch(tk_index *ix, const float *q, const void *q_
                                     int64_t *out_ids, int64_t *out_probes, int64_t *out_heap_idx,
                                     int32_t *out_heap_val)
 {
+    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     ARGCHECK(nq >= 0, "nq");
@@ -2176,6 +2212,7 @@ extern "C" int tk_index_query_batch(tk_index *ix, const float *q, const void *q_
 
 extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
 {
+    IXLOCK(ix);
     ARGCHECK(ix, "null index");
     ARGCHECK(mode >= 0 && mode <= 2, "mode");
     TRY(flush_pending(ix));
@@ -2192,6 +2229,7 @@ extern "C" int tk_set_scan_form(int form)
 
 extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
 {
+    IXLOCK(ix);
     ARGCHECK(ix, "null index");
     ARGCHECK(mode >= 0 && mode <= 2, "mode");
     TRY(flush_pending(ix));
@@ -2201,6 +2239,7 @@ extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
 
 extern "C" int tk_index_set_profiling(tk_index *ix, int on)
 {
+    IXLOCK(ix);
     ARGCHECK(ix, "null index");
     ix->profiling = on < 0 ? 0 : on;
     ix->prof_seen = 0;
@@ -2210,6 +2249,7 @@ extern "C" int tk_index_set_profiling(tk_index *ix, int on)
 
 extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches)
 {
+    IXLOCK(ix);
     ARGCHECK(ix, "null index");
     for (int i = 0; i < 7; i++) ms7[i] = 0;
     *scan_bytes = 0;
