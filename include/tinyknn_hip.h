@@ -351,6 +351,9 @@ tk_stream *tk_stream_create(tk_index *ix, int64_t max_nq, int k, int n_probes, i
 int64_t tk_stream_submit(tk_stream *s, const float *q_raw, int64_t nq, int64_t *out_ids);
 int64_t tk_stream_submit_prepared(tk_stream *s, const float *qn, const void *q_pq, int64_t nq,
                                   int64_t *out_ids);
+/* n_probes / pass_1 of the submits that follow (drains the session first; its staging buffers
+ * are kept, so that a sweep over n_probes does not re-allocate page-locked memory) */
+int tk_stream_set_probes(tk_stream *s, int n_probes, int pass_1);
 int tk_stream_wait(tk_stream *s, int64_t ticket);
 int tk_stream_drain(tk_stream *s);
 double tk_stream_prepare_seconds(tk_stream *s);

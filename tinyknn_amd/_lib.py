@@ -112,6 +112,7 @@ SIGNATURES = {
     "tk_stream_submit_prepared": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                               C.c_void_p]),
     "tk_stream_wait": (C.c_int, [C.c_void_p, C.c_int64]),
+    "tk_stream_set_probes": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "tk_stream_drain": (C.c_int, [C.c_void_p]),
     "tk_stream_prepare_seconds": (C.c_double, [C.c_void_p]),
     "tk_stream_destroy": (None, [C.c_void_p]),

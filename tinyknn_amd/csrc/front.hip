@@ -570,6 +570,24 @@ extern "C" int tk_stream_drain(tk_stream *s)
     return r;
 }
 
+// n_probes / pass_1 of the submits that follow (drains first; the page-locked staging and the
+// device buffers of the session do not depend on them, only the index's workspaces do)
+extern "C" int tk_stream_set_probes(tk_stream *s, int n_probes, int pass_1)
+{
+    if (!s || n_probes < 1) return tk_fail(TK_ERR_ARG, "bad argument: tk_stream_set_probes");
+    int r = tk_stream_drain(s);
+    if (r != TK_OK) return r;
+    if (n_probes == s->n_probes && pass_1 == s->pass_1) return TK_OK;
+    r = tk_index_reserve(s->ix, s->max_nq, s->k, n_probes, pass_1);
+    if (r != TK_OK) return r;
+    if (s->max_nq > tk_index_max_sub_batch(s->ix, s->k, n_probes, pass_1))
+        return tk_fail(TK_ERR_ARG, "bad argument: max_nq exceeds one sub-batch of this index at these "
+                                   "n_probes (tk_index_max_sub_batch)");
+    s->n_probes = n_probes;
+    s->pass_1 = pass_1;
+    return TK_OK;
+}
+
 extern "C" double tk_stream_prepare_seconds(tk_stream *s) { return s ? s->prep_s : 0.0; }
 
 extern "C" void tk_stream_destroy(tk_stream *s)

@@ -54,6 +54,9 @@ class QueryStream:
         self._keep[t % 64] = (qn, q_pq, out)
         return t
 
+    def set_probes(self, n_probes, pass_1=None):
+        _lib.check(_lib.lib().tk_stream_set_probes(self._s, int(n_probes), int(pass_1 or 0)))
+
     def wait(self, ticket):
         _lib.check(_lib.lib().tk_stream_wait(self._s, int(ticket)))
 
@@ -277,15 +280,20 @@ class DeviceIndex:
     CHUNK = 10000       # queries per sub-batch of the chunked host API
 
     def _cached_stream(self, nq, k, n_probes, pass_1):
-        key = (int(k), int(n_probes), int(pass_1 or 0))
+        """One session per k: its page-locked staging does not depend on n_probes, so a sweep
+        over n_probes only re-sizes the index's workspaces (tk_stream_set_probes)."""
+        key = int(k)
         chunk = min(self.CHUNK, self.max_sub_batch(k, n_probes, pass_1))
         want = min(int(nq), chunk)
         st = self._streams.get(key)
-        if st is None or st.max_nq < want:
-            if st is not None:
-                st.close()
+        if st is not None and (st.max_nq < want or st.max_nq > chunk):
+            st.close()
+            st = None
+        if st is None:
             cap = min(chunk, max(64, 1 << (want - 1).bit_length()))
             st = self._streams[key] = QueryStream(self, cap, k, n_probes, pass_1)
+        else:
+            st.set_probes(n_probes, pass_1)
         return st
 
     def query_raw(self, qs, k, n_probes, pass_1=None):
