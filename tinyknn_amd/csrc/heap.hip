@@ -373,7 +373,7 @@ __global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq
 // a SLOT, LAB[slot][lane] holds the slot's 32-bit label, `insert` first scans LAB for
 // the candidate's label (the reference's duplicate test, _fast_pq.pyx:284-287) and a
 // new entry inherits the slot of the root it evicts.  labels32 = the ids as int32.
-template <bool SIGNED, bool DEDUPE, bool PRED>
+template <bool SIGNED, bool DEDUPE, bool PRED, int LW>
 __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
@@ -406,21 +406,25 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     unsigned char *smem = smem_wg + (size_t)(threadIdx.x >> 6) * wave_lds;
     uint32_t *H = (uint32_t *)smem;
     const int R4 = (R + 3) >> 2;
-    uint32_t *LAB = (uint32_t *)(smem + (size_t)(R + 2) * 256);
+    // LW = queries per wave: 64, or 32 (lanes 32..63 idle) where the per-lane columns of the
+    // duplicate test would otherwise leave room for only ONE workgroup per CU
+    constexpr size_t CB = (size_t)LW * 4;      // bytes of one row of dword columns
+    uint32_t *LAB = (uint32_t *)(smem + (size_t)(R + 2) * CB);
     // DEDUPE: TB[64 buckets][64 lanes] x 4 labels: the labels in the heap as a two-choice hash set
-    uint4 *TB = (uint4 *)(smem + (size_t)(R + 2) * 256 + (size_t)R4 * 1024);
-    uint4 *ST = (uint4 *)(smem + (size_t)(R + 2) * 256 +
-                          (DEDUPE ? (size_t)R4 * 1024 + 65536 : 0));
+    uint4 *TB = (uint4 *)(smem + (size_t)(R + 2) * CB + (size_t)R4 * CB * 4);
+    uint4 *ST = (uint4 *)(smem + (size_t)(R + 2) * CB +
+                          (DEDUPE ? (size_t)R4 * CB * 4 + (size_t)64 * CB * 4 : 0));
     // DEDUPE: slot table of the lane's query, SE[s][lane] = first flat chunk past slot s,
     // SB[s][lane] = label offset of slot s - 16 * its first flat chunk (label of row r of flat
     // chunk c in slot s = labels32[SB[s] + 16 c + r])
-    int *SE = (int *)(ST + 16 * 64);
-    int *SB = SE + (size_t)S * 64;
-#define TK_LAB(slot) LAB[(((slot) >> 2) * 64 + lane) * 4 + ((slot) & 3)]
+    int *SE = (int *)(ST + 16 * LW);
+    int *SB = SE + (size_t)S * LW;
+#define TK_LAB(slot) LAB[(((slot) >> 2) * LW + lane) * 4 + ((slot) & 3)]
     // a workgroup = blockDim.x / 64 independent query-waves, each with its own LDS region
     const int lane = threadIdx.x & 63;
-    const int64_t q = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64 + lane;
+    const int64_t q = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LW + lane;
     // `skip`: queries whose probe list may repeat a list (left to the wave kernel)
+    if (LW < 64 && lane >= LW) return;   // idle half-wave: no barrier follows, ballots see exec only
     const bool valid = q < nq && !(skip && skip[q]);
     const int64_t qc = q < nq ? q : nq - 1;
     const int64_t qs = slots_uniform ? 0 : qc;
@@ -431,18 +435,18 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint32_t fresh = fresh_val | 0x00ffffffu;
     const uint32_t lowest = SIGNED ? 0x80000000u : 0u;    // a value no entry is below
     for (int j = 0; j < R; j++)
-        H[j * 64 + lane] = DEDUPE ? (fresh_val | (uint32_t)j) : fresh;   // node j owns slot j
+        H[j * LW + lane] = DEDUPE ? (fresh_val | (uint32_t)j) : fresh;   // node j owns slot j
     if (DEDUPE) {
         for (int g = 0; g < R4; g++)                                     // every label -1
-            ((uint4 *)LAB)[g * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        for (int b = 0; b < 64; b++) TB[b * 64 + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            ((uint4 *)LAB)[g * LW + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int b = 0; b < 64; b++) TB[b * LW + lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
     // DEDUPE: labels that found both their buckets full wait in a four-entry stash (registers);
     // only a lane whose stash is full too falls back to scanning LAB — with 64 lanes x ~1000
     // inserts per wave even a 1e-4 event per insert would otherwise put every wave on the scan
     uint32_t sh0 = ~0u, sh1 = ~0u, sh2 = ~0u, sh3 = ~0u;
     bool tb_ovf = false;
-    H[R * 64 + lane] = H[(R + 1) * 64 + lane] = lowest;   // sentinel rows: never taken
+    H[R * LW + lane] = H[(R + 1) * LW + lane] = lowest;   // sentinel rows: never taken
     // the top three levels (nodes 0..6) live in registers; nodes >= R are sentinels
 #define TK_FRESH(j) (R > (j) ? (DEDUPE ? (fresh_val | (uint32_t)(j)) : fresh) : lowest)
     uint32_t h0 = TK_FRESH(0), h1 = TK_FRESH(1), h2 = TK_FRESH(2), h3 = TK_FRESH(3),
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint4 *mrow = (const uint4 *)(mins + qc * cap_min);   // per-block minima, 16 per uint4
     int nseg = (total + 15) >> 4;
     int max_nseg = nseg;
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = LW / 2; o > 0; o >>= 1) {
         int other = __shfl_xor(max_nseg, o, 64);
         max_nseg = other > max_nseg ? other : max_nseg;
     }
@@ -465,8 +469,8 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     if (DEDUPE) {
         for (int t = 0; t < S; t++) {
             const int e0 = prefix[t], e1 = prefix[t + 1];
-            SE[t * 64 + lane] = valid ? e1 : 0x7fffffff;
-            SB[t * 64 + lane] = (int)(slot_label_off[qs * S + t] - 16 * (int64_t)e0);
+            SE[t * LW + lane] = valid ? e1 : 0x7fffffff;
+            SB[t * LW + lane] = (int)(slot_label_off[qs * S + t] - 16 * (int64_t)e0);
         }
     }
 
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     for (int g = 0; g < max_nseg; g++) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            if (!PRED || (pf & (1u << k))) ST[k * 64 + lane] = nx[k];
+            if (!PRED || (pf & (1u << k))) ST[k * LW + lane] = nx[k];
         const uint4 mins_cur = mins_nx;
         // PRED: only the blocks of the next segment whose minimum is below the bound known NOW
         // are fetched (the bound only decreases: a superset of the blocks that will be entered);
@@ -546,15 +550,15 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                 TK_DBG(if (dbg) d_sit++;)
                 const int k = __builtin_ctz(hit);
                 hit &= hit - 1;
-                dd = ST[(buf * 16 + k) * 64 + lane];
+                dd = ST[(buf * 16 + k) * LW + lane];
                 cur = 16 * g + k;
                 // `pos < n` (:111): the rows that pad a list's last chunk were set to the largest
                 // value by pad_fix_kernel and can never be below a bound — no row count, and
                 // with distinct labels no slot cursor at all, is needed here
                 bits = mask_lt16<SIGNED>(dd, bound);          // cmp_mask, _fast_pq_256.pyx:81-90
                 if (DEDUPE && bits) {
-                    while (cur >= SE[s * 64 + lane]) s++;   // next probed list (empty ones stepped over)
-                    lab_base = SB[s * 64 + lane] + 16 * cur;
+                    while (cur >= SE[s * LW + lane]) s++;   // next probed list (empty ones stepped over)
+                    lab_base = SB[s * LW + lane] + 16 * cur;
                     lab_next = (uint32_t)labels32[(int64_t)lab_base + __builtin_ctz(bits)];
                 }
             }
@@ -584,14 +588,14 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                     const int b1 = (int)(hh >> 26);
                     int b2 = (int)((hh >> 18) & 63u);
                     b2 = b2 == b1 ? (b1 ^ 1) : b2;
-                    const uint4 x1 = TB[b1 * 64 + lane], x2 = TB[b2 * 64 + lane];
+                    const uint4 x1 = TB[b1 * LW + lane], x2 = TB[b2 * LW + lane];
                     dup = (x1.x == label) | (x1.y == label) | (x1.z == label) | (x1.w == label) |
                           (x2.x == label) | (x2.y == label) | (x2.z == label) | (x2.w == label) |
                           (sh0 == label) | (sh1 == label) | (sh2 == label) | (sh3 == label);
                     if (tb_ovf && !(prio & 0x100)) {
 #pragma unroll 4
                         for (int g = 0; g < R4; g++) {
-                            const uint4 lv = ((const uint4 *)LAB)[g * 64 + lane];
+                            const uint4 lv = ((const uint4 *)LAB)[g * LW + lane];
                             dup |= (lv.x == label) | (lv.y == label) | (lv.z == label) | (lv.w == label);
                         }
                     }
@@ -603,11 +607,11 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                             const int g1 = (int)(gh >> 26);
                             int g2 = (int)((gh >> 18) & 63u);
                             g2 = g2 == g1 ? (g1 ^ 1) : g2;
-                            const uint4 y1 = TB[g1 * 64 + lane], y2 = TB[g2 * 64 + lane];
+                            const uint4 y1 = TB[g1 * LW + lane], y2 = TB[g2 * LW + lane];
                             const int p1 = y1.x == gone ? 0 : y1.y == gone ? 1 : y1.z == gone ? 2 : y1.w == gone ? 3 : -1;
                             const int p2 = y2.x == gone ? 0 : y2.y == gone ? 1 : y2.z == gone ? 2 : y2.w == gone ? 3 : -1;
-                            if (p1 >= 0) ((uint32_t *)TB)[(g1 * 64 + lane) * 4 + p1] = 0xffffffffu;
-                            else if (p2 >= 0) ((uint32_t *)TB)[(g2 * 64 + lane) * 4 + p2] = 0xffffffffu;
+                            if (p1 >= 0) ((uint32_t *)TB)[(g1 * LW + lane) * 4 + p1] = 0xffffffffu;
+                            else if (p2 >= 0) ((uint32_t *)TB)[(g2 * LW + lane) * 4 + p2] = 0xffffffffu;
                             else {
                                 sh0 = sh0 == gone ? ~0u : sh0; sh1 = sh1 == gone ? ~0u : sh1;
                                 sh2 = sh2 == gone ? ~0u : sh2; sh3 = sh3 == gone ? ~0u : sh3;
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                         const bool first = e1 >= e2;
                         const uint4 xs = first ? x1 : x2;
                         const int pe = xs.x == ~0u ? 0 : xs.y == ~0u ? 1 : xs.z == ~0u ? 2 : xs.w == ~0u ? 3 : -1;
-                        if (pe >= 0) ((uint32_t *)TB)[((first ? b1 : b2) * 64 + lane) * 4 + pe] = label;
+                        if (pe >= 0) ((uint32_t *)TB)[((first ? b1 : b2) * LW + lane) * 4 + pe] = label;
                         else if (sh0 == ~0u) sh0 = label;
                         else if (sh1 == ~0u) sh1 = label;
                         else if (sh2 == ~0u) sh2 = label;
@@ -657,8 +661,8 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                                 TK_DBG(if (dbg) d_ldsit++;)
                                 const int l = 2 * j + 1;
                                 const int lc = l < R ? l : R;
-                                const uint32_t el = H[lc * 64 + lane];
-                                const uint32_t er = H[(lc + 1) * 64 + lane];
+                                const uint32_t el = H[lc * LW + lane];
+                                const uint32_t er = H[(lc + 1) * LW + lane];
                                 const int vl = entry_val<SIGNED>(el), vr = entry_val<SIGNED>(er);
                                 const bool cl = vl > v;                 // vals[l] > nxt_val
                                 const int nvv = cl ? vl : v;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                                     h5 = j == 5 ? ne : h5; h6 = j == 6 ? ne : h6;
                                     first = false;
                                 } else {
-                                    H[j * 64 + lane] = ne;              // entry itself when nxt == j
+                                    H[j * LW + lane] = ne;              // entry itself when nxt == j
                                 }
                                 go = nxt != j;
                                 j = nxt;
@@ -697,18 +701,18 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
 #undef TK_TICK
 #undef TK_DBG
     // registers back to their heap rows
-    if (R > 0) H[0 * 64 + lane] = h0;
-    if (R > 1) H[1 * 64 + lane] = h1;
-    if (R > 2) H[2 * 64 + lane] = h2;
-    if (R > 3) H[3 * 64 + lane] = h3;
-    if (R > 4) H[4 * 64 + lane] = h4;
-    if (R > 5) H[5 * 64 + lane] = h5;
-    if (R > 6) H[6 * 64 + lane] = h6;
+    if (R > 0) H[0 * LW + lane] = h0;
+    if (R > 1) H[1 * LW + lane] = h1;
+    if (R > 2) H[2 * LW + lane] = h2;
+    if (R > 3) H[3 * LW + lane] = h3;
+    if (R > 4) H[4 * LW + lane] = h4;
+    if (R > 5) H[5 * LW + lane] = h5;
+    if (R > 6) H[6 * LW + lane] = h6;
     if (!valid) return;
     // ---- resolve flat positions (or slots) to labels
     const int64_t *loffs = slot_label_off + qs * S;
     for (int j = 0; j < R; j++) {
-        const uint32_t e = H[j * 64 + lane];
+        const uint32_t e = H[j * LW + lane];
         const uint32_t pos = e & 0x00ffffffu;
         int64_t label = -1;
         if (DEDUPE) {
@@ -965,21 +969,34 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
 {
     if (nq == 0 || R == 0) return 0;
     const int dedupe = labels32 != nullptr;
-    // heap columns (+ label slots) + 16 staged blocks per lane
-    const size_t fixed = tk_lanes_fixed_lds(R, S, dedupe);
-    // one staged segment (16 blocks x 64 lanes x 16 B); the next one waits in registers
+    // Queries per wave.  With the duplicate test a 64-query wave needs 140+ KB of LDS at
+    // R = 111: one workgroup per CU, and the two replay kernels of the pipelined mode (2 x 157
+    // workgroups on 256 CUs) then wait for each other's CUs — 1.6 ms alone became 2.9 ms in the
+    // pipeline.  Half-filled waves (32 queries, lanes 32..63 exit at once) halve every per-lane
+    // column: two workgroups per CU.  A/B: TINYKNN_REPLAY_LANES=64.
+    static int lanes_dedupe = -1;
+    if (lanes_dedupe < 0) {
+        const char *e = getenv("TINYKNN_REPLAY_LANES");
+        lanes_dedupe = (e && atoi(e) == 64) ? 64 : 32;
+    }
+    const int LWr = dedupe ? lanes_dedupe : 64;
+    // heap columns (+ label slots) + 16 staged blocks per lane, scaled to the columns in use
+    const size_t fixed = tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64;
+    // one staged segment (16 blocks x LW lanes x 16 B); the next one waits in registers
     const int nbuf = 1;
-    size_t lds = fixed + 16384;
+    size_t lds = fixed + (size_t)16384 * LWr / 64;
     static bool attr_set = false;
     if (!attr_set) {
-        const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false, false>,
-                             (const void *)heap_replay_lanes_kernel<false, false, false>,
-                             (const void *)heap_replay_lanes_kernel<true, true, false>,
-                             (const void *)heap_replay_lanes_kernel<false, true, false>,
-                             (const void *)heap_replay_lanes_kernel<true, false, true>,
-                             (const void *)heap_replay_lanes_kernel<false, false, true>,
-                             (const void *)heap_replay_lanes_kernel<true, true, true>,
-                             (const void *)heap_replay_lanes_kernel<false, true, true>};
+        const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false, false, 64>,
+                             (const void *)heap_replay_lanes_kernel<false, false, false, 64>,
+                             (const void *)heap_replay_lanes_kernel<true, true, false, 64>,
+                             (const void *)heap_replay_lanes_kernel<false, true, false, 64>,
+                             (const void *)heap_replay_lanes_kernel<true, false, true, 64>,
+                             (const void *)heap_replay_lanes_kernel<false, false, true, 64>,
+                             (const void *)heap_replay_lanes_kernel<true, true, true, 64>,
+                             (const void *)heap_replay_lanes_kernel<false, true, true, 64>,
+                             (const void *)heap_replay_lanes_kernel<true, true, false, 32>,
+                             (const void *)heap_replay_lanes_kernel<false, true, false, 32>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
@@ -1011,7 +1028,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     int waves = slots_uniform ? 1 : wpw;
     while (waves > 1 && lds * waves > 160 * 1024) waves--;
     const int wave_lds = (int)lds;
-    const int64_t n_waves = (nq + 63) / 64;
+    const int64_t n_waves = (nq + LWr - 1) / LWr;
     dim3 grid((unsigned)((n_waves + waves - 1) / waves));
     const size_t lds_wg = lds * waves;
     static int prio = -1;       // s_setprio of the replay waves (A/B: TINYKNN_REPLAY_PRIO)
@@ -1030,14 +1047,20 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
         const char *e = getenv("TINYKNN_REPLAY_PRED");
         pred = e ? atoi(e) : 0;
     }
-#define TK_LAUNCH2(S_, D_, P_)                                                                  \
-    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, P_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
+#define TK_LAUNCH3(S_, D_, P_, L_)                                                              \
+    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, P_, L_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, nbuf, mins, cap_min, labels32, dbg, prio, wave_lds)
+    if (dedupe && LWr == 32) {
+        if (signd) TK_LAUNCH3(true, true, false, 32); else TK_LAUNCH3(false, true, false, 32);
+        return 0;
+    }
+#define TK_LAUNCH2(S_, D_, P_) TK_LAUNCH3(S_, D_, P_, 64)
 #define TK_LAUNCH(S_, D_) { if (pred) TK_LAUNCH2(S_, D_, true); else TK_LAUNCH2(S_, D_, false); }
     if (signd) { if (dedupe) TK_LAUNCH(true, true) else TK_LAUNCH(true, false) }
     else { if (dedupe) TK_LAUNCH(false, true) else TK_LAUNCH(false, false) }
 #undef TK_LAUNCH
+#undef TK_LAUNCH3
 #undef TK_LAUNCH2
     return 0;
 }
