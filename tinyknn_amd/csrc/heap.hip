@@ -979,7 +979,12 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
         const char *e = getenv("TINYKNN_REPLAY_LANES");
         lanes_dedupe = (e && atoi(e) == 64) ? 64 : 32;
     }
-    const int LWr = dedupe ? lanes_dedupe : 64;
+    static int lanes_plain = -1;      // distinct labels: 64 (A/B: TINYKNN_REPLAY_LANES_PLAIN=32)
+    if (lanes_plain < 0) {
+        const char *e = getenv("TINYKNN_REPLAY_LANES_PLAIN");
+        lanes_plain = (e && atoi(e) == 32) ? 32 : 64;
+    }
+    const int LWr = dedupe ? lanes_dedupe : lanes_plain;
     // heap columns (+ label slots) + 16 staged blocks per lane, scaled to the columns in use
     const size_t fixed = tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64;
     // one staged segment (16 blocks x LW lanes x 16 B); the next one waits in registers
@@ -996,7 +1001,9 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                              (const void *)heap_replay_lanes_kernel<true, true, true, 64>,
                              (const void *)heap_replay_lanes_kernel<false, true, true, 64>,
                              (const void *)heap_replay_lanes_kernel<true, true, false, 32>,
-                             (const void *)heap_replay_lanes_kernel<false, true, false, 32>};
+                             (const void *)heap_replay_lanes_kernel<false, true, false, 32>,
+                             (const void *)heap_replay_lanes_kernel<true, false, false, 32>,
+                             (const void *)heap_replay_lanes_kernel<false, false, false, 32>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
@@ -1051,8 +1058,9 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, P_, L_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, nbuf, mins, cap_min, labels32, dbg, prio, wave_lds)
-    if (dedupe && LWr == 32) {
-        if (signd) TK_LAUNCH3(true, true, false, 32); else TK_LAUNCH3(false, true, false, 32);
+    if (LWr == 32) {
+        if (dedupe) { if (signd) TK_LAUNCH3(true, true, false, 32); else TK_LAUNCH3(false, true, false, 32); }
+        else { if (signd) TK_LAUNCH3(true, false, false, 32); else TK_LAUNCH3(false, false, false, 32); }
         return 0;
     }
 #define TK_LAUNCH2(S_, D_, P_) TK_LAUNCH3(S_, D_, P_, 64)
