@@ -1275,15 +1275,19 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
 // while its share of the work is drawn by others — measured per 10 000 queries: 768 -> 0.705 ms,
 // 640 -> 0.703, 576 -> 0.682, 512 -> 0.657, 448 -> 0.678, 384 -> 0.743 (profiles/r02_scan_grid.md).
 // A/B: TINYKNN_SCAN_BLOCKS.
-static int scan_blocks_pipelined()
+// Long launches (100M x 128: 15 M units, 3 ms) amortise that wait and prefer more resident
+// waves: 512 -> 4.15 ms per batch, 576 -> 3.95, 640 -> 3.89, 704 -> 3.84, 768 -> 4.03
+// (profiles/r02_scan_grid.md), so the grid is 704 above ~6 M estimated units.
+static int scan_blocks_pipelined(double est_units)
 {
-    static int n = 0;
-    if (n == 0) {
+    static int forced = -1;
+    if (forced < 0) {
         const char *e = getenv("TINYKNN_SCAN_BLOCKS");
-        n = e ? atoi(e) : 512;
-        n = n < 64 ? 512 : n;
+        forced = e ? atoi(e) : 0;
+        forced = forced < 64 ? 0 : forced;
     }
-    return n;
+    if (forced) return forced;
+    return est_units > 6.0e6 ? 704 : 512;
 }
 
 // depth > 1: the launch on the caller's stream that carries the list scan of `prev` (may be
@@ -1318,7 +1322,9 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         memset(&none, 0, sizeof none);
         tk_launch_scan_units2(fuse_prev ? list_job(ix, *prev->w, prev->p) : none,
                               fuse_cur ? coarse_job(ix, *cur->w, cur->p) : none, M, ix->order,
-                              scan_blocks_pipelined(), st);
+                              scan_blocks_pipelined(fuse_prev ? (double)prev->nq * prev->p.S / 4.0 *
+                                                    ((double)ix->total_chunks / (double)ix->n_lists) : 0.0),
+                              st);
     }
     if (prev) {
         // heap replay + rescoring of the previous batch on its stream
