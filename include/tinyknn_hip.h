@@ -162,6 +162,16 @@ int tk_index_set_lists(tk_index *ix, const int64_t *list_sizes, const uint64_t *
  * caller's X was (ivf.py:77-79 keeps X's dtype)  */
 int tk_index_set_data(tk_index *ix, const void *data, int data_is_f64, int64_t N, int d);
 
+/* _FastDistanceTable.top(transformed_data, data, k) (fast_pq.py:284-312) for a batch of queries
+ * against the rows the index holds as its centres — tk_index_set_pq + tk_index_set_centers(rows,
+ * packed codes) is all this call needs: per query a heap of rescore = min(2k + 10, n) PQ
+ * estimates over ALL rows, then the exact float32 distances of those candidates (knn_brute1,
+ * utils.py:89-92), the k best in ascending order.  (The coarse stage of IVF.query, ivf.py:131,
+ * is this call on the coded centres.)  q: (nq, d) float32 rows as distance_table takes them,
+ * q_pq: their padded / rotated form; out_ids: (nq, k) int64, -1 beyond n. */
+int tk_index_top_centers(tk_index *ix, const float *q, const void *q_pq, int q_pq_is_f64, int64_t nq,
+                         int k, int64_t *out_ids);
+
 /* Largest batch the workspace is currently sized for grows on demand; this call
  * pre-sizes it (so that tk_index_query_batch_dev never allocates, e.g. under
  * stream capture). */

@@ -83,6 +83,7 @@ SIGNATURES = {
     "tk_index_export_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_export_centers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_read_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f32p]),
+    "tk_index_top_centers": (C.c_int, [C.c_void_p, _f32p, C.c_void_p, C.c_int, C.c_int64, C.c_int, _i64p]),
     "tk_index_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]),
     "tk_index_reserve": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "tk_index_query_batch": (C.c_int, [C.c_void_p, _f32p, C.c_void_p, C.c_int, C.c_int64, C.c_int,

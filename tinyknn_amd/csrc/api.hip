@@ -2147,6 +2147,71 @@ extern "C" int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int 
     return TK_OK;
 }
 
+// _FastDistanceTable.top (fast_pq.py:284-312) for a BATCH of queries against the coded rows the
+// index holds as its "centres" (tk_index_set_pq + tk_index_set_centers(rows, packed codes) are
+// all it needs): per query a heap of rescore = min(2k + 10, n) PQ estimates over all rows, then
+// the exact distances of those candidates, k best in ascending order — the coarse stage of
+// IVF.query (ivf.py:131) is exactly this call, so the same three kernels run.  Host buffers;
+// queries are processed in chunks whose distance rows fit one workspace.
+extern "C" int tk_index_top_centers(tk_index *ix, const float *q, const void *q_pq, int q_pq_is_f64,
+                                    int64_t nq, int k, int64_t *out_ids)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix && ix->have_pq && ix->have_centers, "set_pq and set_centers first");
+    ARGCHECK(nq >= 0 && k >= 1 && (nq == 0 || (q && q_pq && out_ids)), "buffers / sizes");
+    if (nq == 0) return TK_OK;
+    TRY(flush_pending(ix));
+    Plan p;
+    const int64_t kc = k < ix->n_lists ? k : ix->n_lists;                        // fast_pq.py:263
+    const int64_t rescore = 2 * kc + 10 < ix->n_lists ? 2 * kc + 10 : ix->n_lists;   // :264-265
+    ARGCHECK(rescore * 12 + 16 <= 64 * 1024, "heap larger than 64 KiB of LDS");
+    p.kc = (int)kc; p.rescore = (int)rescore; p.R = (int)rescore; p.S = 1;
+    p.cap = 1; p.cap_min = 16;
+    p.ccap_min = (ix->center_chunks + 15) / 16 * 16;
+    int64_t chunk = (int64_t)(workspace_bytes() / ((double)ix->center_chunks * 17.0));
+    chunk = chunk < 16 ? 16 : (chunk > MAX_SUB ? MAX_SUB : chunk);
+    chunk = chunk < nq ? chunk : nq;
+    Work &w = ix->works[0];
+    const int M = ix->M;
+    const size_t esz = q_pq_is_f64 ? 8 : 4;
+    TRY(w.tables.ensure((size_t)chunk * M * 16));
+    TRY(w.shift.ensure((size_t)chunk * 8));
+    TRY(w.scale.ensure((size_t)chunk * 8));
+    TRY(w.cdist.ensure((size_t)chunk * ix->center_chunks * 16));
+    TRY(w.cmins.ensure((size_t)chunk * p.ccap_min));
+    TRY(w.cheap_idx.ensure((size_t)chunk * p.rescore * 8));
+    TRY(w.cheap_val.ensure((size_t)chunk * p.rescore * 4));
+    TRY(w.probes.ensure((size_t)chunk * p.kc * 8));
+    TRY(w.c_pair_off.ensure(8));
+    TRY(w.c_unit_prefix.ensure(tk_unit_prefix_ints(1) * 4));
+    TRY(w.c_pair_q.ensure(((size_t)chunk + 4) * 4));
+    TRY(w.c_pair_f0.ensure(((size_t)chunk + 4) * 4));
+    TRY(ix->q.ensure((size_t)chunk * ix->d * 4));
+    TRY(ix->qpq.ensure((size_t)chunk * ix->dq * esz));
+    for (int64_t o = 0; o < nq; o += chunk) {
+        const int64_t m = nq - o < chunk ? nq - o : chunk;
+        HIPCHECK(hipMemcpy(ix->q.p, q + o * ix->d, (size_t)m * ix->d * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(ix->qpq.p, (const char *)q_pq + (size_t)o * ix->dq * esz, (size_t)m * ix->dq * esz,
+                           hipMemcpyHostToDevice));
+        Prof pf;
+        TRY(stage_tables(ix, w, ix->qpq.p, q_pq_is_f64, m, nullptr, pf));
+        launch_coarse_scan(ix, w, m, p, nullptr);
+        TRY(coarse_replay_probes(ix, w, ix->q.as<float>(), m, p, w.probes.as<int64_t>(), nullptr, pf));
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipDeviceSynchronize());
+        if (p.kc == k) {
+            HIPCHECK(hipMemcpy(out_ids + o * k, w.probes.p, (size_t)m * k * 8, hipMemcpyDeviceToHost));
+        } else {    // fewer rows than k: rows of kc ids into rows of k, padded with -1
+            std::vector<int64_t> tmp((size_t)m * p.kc);
+            HIPCHECK(hipMemcpy(tmp.data(), w.probes.p, tmp.size() * 8, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < m; i++)
+                for (int t = 0; t < k; t++)
+                    out_ids[(o + i) * k + t] = t < p.kc ? tmp[(size_t)i * p.kc + t] : -1;
+        }
+    }
+    return TK_OK;
+}
+
 extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
 {
     IXLOCK(ix);

@@ -227,6 +227,62 @@ def estimate_batch(pq, transformed_data, qs, signed=True):
     return out.view(np.int8 if signed else np.uint8)[:, :true_n]
 
 
+class FlatTop:
+    """`pq.distance_table(q).top(transformed_data, data, k)` (fast_pq.py:284-312) for a BATCH of
+    queries: the codes and the float32 rows go to HBM once, a call runs tables, one list-major
+    scan of all rows for all queries, the exact lane-per-query heap replay and the exact
+    rescoring on the device (tk_index_top_centers) — row i of the result equals the reference's
+    per-query call.  float32 rows and queries (the per-query API covers float64)."""
+
+    def __init__(self, pq, transformed_data, data):
+        true_n, packed = transformed_data
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        assert len(data) == true_n
+        self.pq, self.n, self.d = pq, true_n, data.shape[1]
+        L = _lib.lib()
+        self._h = L.tk_index_create()
+        if not self._h:
+            raise _lib.TinyKnnHipError(L.tk_last_error().decode() or "tk_index_create failed")
+        c32 = np.ascontiguousarray(pq.centers, dtype=np.float32)
+        order = _lib.ORDER_AVX if avx else _lib.ORDER_SSE
+        _lib.check(L.tk_index_set_pq(self._h, _lib.ptr(c32, _lib._f32p), c32.shape[1], pq.dims_per_block,
+                                     int(not pq.centers.flags.c_contiguous), float(pq.sqrt_n_blocks), order))
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        _lib.check(L.tk_index_set_centers(self._h, _lib.ptr(data, _lib._f32p), true_n, self.d,
+                                          _lib.ptr(packed, _lib._u64p), packed.shape[0]))
+
+    def top(self, qs, k=1):
+        """(nq, d) float32 queries -> (nq, min(k, n)) int64 row ids."""
+        qs = np.ascontiguousarray(qs, dtype=np.float32)
+        assert qs.ndim == 2 and qs.shape[1] == self.d
+        k = min(int(k), self.n)
+        from . import _front
+        R = self.pq.R
+        if len(qs) and _front.bind() and (R is None or (min(R.shape) >= 2 and R.dtype == np.float64)):
+            # pad1 / q @ R.T row by row through numpy's own BLAS on a thread pool (exact)
+            pad = (-self.d) % (dpad * self.pq.dims_per_block)
+            _, qp = _front.prepare(qs.copy(), False, R, pad)
+        else:
+            qp = np.stack([self.pq._pq_query(q) for q in qs]) if len(qs) else np.zeros((0, 1), np.float32)
+        qp = np.ascontiguousarray(qp)
+        out = np.full((len(qs), k), -1, dtype=np.int64)
+        _lib.check(_lib.lib().tk_index_top_centers(
+            self._h, _lib.ptr(qs, _lib._f32p), qp.ctypes.data, int(qp.dtype != np.float32), len(qs), k,
+            _lib.ptr(out, _lib._i64p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().tk_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _FastDistanceTable:
     """reference: fast_pq.py:255-312"""
 
