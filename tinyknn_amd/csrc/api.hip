@@ -1145,7 +1145,13 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     // (a list may then be scanned twice) re-run with the duplicate test.  Repeating labels
     // (build n_probes >= 2): the packed wave kernel with the duplicate test for everybody.
     const bool packed_ok = ix->heap_mode != 1 && p.cap * 16 <= 0xffffff;
+    // timing experiments (profiles/r02_scan_grid.md) skip stages and give WRONG results: only a
+    // library built with -DTK_TIMING_EXPERIMENTS reads the switch
+#ifdef TK_TIMING_EXPERIMENTS
     static const int dbg_skip = getenv("TINYKNN_DEBUG_SKIP") ? atoi(getenv("TINYKNN_DEBUG_SKIP")) : 0;
+#else
+    constexpr int dbg_skip = 0;
+#endif
     if (dbg_skip & 1) {             // timing experiments only (wrong results): no main replay
     } else if (packed_ok && ix->ids_unique) {
         const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;

@@ -1042,7 +1042,9 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     if (prio < 0) {
         const char *e = getenv("TINYKNN_REPLAY_PRIO");
         prio = e ? atoi(e) : 3;
+#ifdef TK_TIMING_EXPERIMENTS
         if (getenv("TINYKNN_DEBUG_NOSCAN")) prio |= 0x100;      // wrong results: timing only
+#endif
     }
     unsigned long long *dbg = nullptr;
     if (g_replay_dbg && nq >= g_replay_dbg_min_nq && grid.x <= TK_REPLAY_DBG_WG) {
