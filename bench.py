@@ -507,6 +507,8 @@ def main():
     ap.add_argument("--shard-coarse", choices=["home", "replicated"], default="home",
                     help="list-sharded leg: coarse stage of the home queries + probe all-gather, or of all "
                          "queries on every rank")
+    ap.add_argument("--caller-stream", choices=["null", "own"], default="null",
+                    help="stream of the timed region (A/B: the NULL stream, or a stream of its own)")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the >= 1 GiB streaming scan leg")
     ap.add_argument("--traffic", choices=["auto", "none"], default="auto",
                     help="auto: HBM bytes of the scan launch from rocprofv3 --pmc child runs of this "
@@ -571,6 +573,10 @@ def main():
     q_dev = torch.from_numpy(qn).to(device)
     qp_dev = torch.from_numpy(np.ascontiguousarray(qp)).to(device)
     out_dev = torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)
+    own_stream = None
+    if args.caller_stream == "own":       # A/B: a non-NULL, non-blocking stream carries the scan chain
+        own_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(own_stream)
     stream = torch.cuda.current_stream().cuda_stream
     dev.set_pipeline(args.pipeline)
     dev.reserve(args.nq, args.k, args.n_probes)

@@ -1449,7 +1449,16 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         }
         while ((int)ix->lat_streams.size() < ix->depth) {
             hipStream_t st;
-            HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            // A/B: TINYKNN_REPLAY_CUS=n confines the replay + rescoring streams to the first n
+            // bits of the CU mask (so that the rest of the chip scans undisturbed)
+            static const int cus = getenv("TINYKNN_REPLAY_CUS") ? atoi(getenv("TINYKNN_REPLAY_CUS")) : 0;
+            if (cus > 0 && cus < 256) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < cus; i++) mask[i >> 5] |= 1u << (i & 31);
+                HIPCHECK(hipExtStreamCreateWithCUMask(&st, 8, mask));
+            } else {
+                HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            }
             ix->lat_streams.push_back(st);
         }
         if (!ix->front_stream)
