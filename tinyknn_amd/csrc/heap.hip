@@ -14,7 +14,7 @@
 // included, with the compiled reference):
 //
 //   heap_replay_lanes_kernel   one query per LANE (64 per wave), packed 32-bit entries
-//                              in LDS columns, LDS-DMA staged distance blocks, block
+//                              in LDS columns, register-prefetched distance blocks, block
 //                              minima, top heap levels in registers; fresh heaps only;
 //                              with DEDUPE also labels that can repeat.  The batch path.
 //   heap_replay_packed_kernel  one query per WAVE on the same packed entries (heaps too
@@ -299,12 +299,15 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 //   * heap entry = one dword (value8 << 24 | flat position24) in LDS, laid out
 //     [slot j][lane]: a lane only touches its own column and bank = lane % 32, so
 //     the divergent sift-down addresses are conflict-free by construction;
-//   * the distance rows are staged 16 blocks per lane at a time by LDS-DMA
-//     (global_load_lds_dwordx4: each lane's 16 bytes from its own row land in
-//     ST[k][lane]), double-buffered, so that no lane ever waits on a dependent
-//     global load; inside a segment lanes are decoupled: each walks to its next
-//     block with a byte below its bound, then all lanes with a pending candidate
-//     perform one insert together; a bound is refreshed when its block is done;
+//   * the distance rows are staged 16 blocks per lane at a time: the next segment is
+//     fetched into registers while the current one is replayed and dropped into
+//     ST[k][lane] at the switch, so that no lane ever waits on a dependent global
+//     load; inside a segment lanes are decoupled: each walks to its next block with
+//     a byte below its bound, then all lanes with a pending candidate perform one
+//     insert together; a bound is refreshed when its block is done;
+//   * pad_fix_kernel has set the rows that pad a list's last chunk to the largest
+//     value beforehand (`pos < n`, _fast_pq_256.pyx:111), so there is no row mask
+//     and, with distinct labels, no slot cursor in the loop;
 //   * the scan kernel also wrote each block's minimum (1 byte per block): a lane
 //     tests 16 minima at once and touches only blocks that can contain a hit;
 //   * the top three heap levels (nodes 0..6) are kept in registers;
