@@ -721,9 +721,17 @@ def main():
             dst.copy_(src)
         torch.cuda.synchronize()
         copy_gbps = 5 * 2 * src.numel() * 4 / (time.perf_counter() - tc0) / 1e9
+        # ... and a read-only kernel over 1 GiB (the flat scan's access pattern): the streaming-read
+        # ceiling the HBM-scale scan leg is up against (profiles/r02_read_bw_microbench.txt)
         del src, dst
+        import ctypes
+        rb = ctypes.c_double(0.0)
+        _lib.check(_lib.lib().tk_measure_read_bandwidth(1 << 30, 10, ctypes.byref(rb)))
+        read_gbps = rb.value
     except Exception:
-        copy_gbps = None
+        copy_gbps = read_gbps = None
+    if hbm_leg and "GBps" in hbm_leg and read_gbps:
+        hbm_leg["frac_of_measured_read_only_kernel"] = hbm_leg["GBps"] / read_gbps
 
     # -- recall against brute force (torch matmul on the GPU: measurement plumbing)
     rs = min(args.recall_sample, args.nq)
@@ -837,7 +845,7 @@ def main():
                      "achieved_is": "ALGORITHMIC GB/s (one code byte per (query, code) pair); the fabric "
                                     "carries `traffic` bytes per launch: four queries share each fetched "
                                     "code byte and the code set sits in L2/Infinity Cache",
-                     "device_copy_GBps_measured": copy_gbps,
+                     "device_copy_GBps_measured": copy_gbps, "device_read_GBps_measured": read_gbps,
                      "kernel": ("scan_probes_kernel<AVX,signed>" if args.scan_mode == 1 else
                                 "scan_units_kernel<AVX,signed>" if args.pipeline == 1 else
                                 "scan_units2_kernel<AVX,signed> (one launch: list scan of a batch + coarse scan "

@@ -249,6 +249,10 @@ int tk_set_scan_form(int form);
 int tk_index_set_profiling(tk_index *ix, int on);
 int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches);
 
+/* measurement plumbing (bench.py): GB/s of a kernel that only reads `bytes` of HBM, every byte
+ * once with the flat scan's access pattern — the streaming-read ceiling of the box */
+int tk_measure_read_bandwidth(int64_t bytes, int reps, double *gbps);
+
 /* ---- device-resident build ----------------------------------------
  * IVF.build(X, n_probes = 1) (ivf.py:77-102) for float32 vectors that are produced IN HBM
  * and never visit the host — how the 100M x 128 configuration is assembled ("per-GPU

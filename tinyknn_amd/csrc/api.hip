@@ -1711,6 +1711,39 @@ extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_
     return TK_OK;
 }
 
+// GB/s of a kernel that only reads `bytes` of HBM (measurement plumbing for bench.py)
+extern "C" int tk_measure_read_bandwidth(int64_t bytes, int reps, double *gbps)
+{
+    TRY(require_gpu());
+    ARGCHECK(bytes >= (1 << 20) && reps >= 1 && gbps, "bytes >= 1 MiB, reps >= 1");
+    DevBuf buf, out;
+    int rc = buf.ensure((size_t)bytes);
+    if (rc == TK_OK) rc = out.ensure(16);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (rc == TK_OK) {
+        hipError_t e = hipMemset(buf.p, 1, (size_t)bytes);
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) {
+            tk_launch_read_only(buf.p, bytes / 16, out.as<uint32_t>(), nullptr);
+            e = hipDeviceSynchronize();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+        for (int r = 0; r < reps && e == hipSuccess; r++) tk_launch_read_only(buf.p, bytes / 16, out.as<uint32_t>(), nullptr);
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && ms > 0) *gbps = (double)bytes * reps / (ms * 1e-3) / 1e9;
+        else rc = fail(TK_ERR_HIP, e == hipSuccess ? "zero elapsed time" : hipGetErrorString(e));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    buf.release();
+    out.release();
+    return rc;
+}
+
 // ---------------------------------------------------------------------------
 // device-resident build (devbuild.hip): IVF.build for vectors that live in HBM
 static int upload_rotation(tk_index *ix, const double *R, int d_pad)

@@ -217,3 +217,24 @@ void tk_launch_compact_tiled(const uint4 *src, uint4 *dst, int P, const int64_t 
     hipLaunchKernelGGL(compact_tiled_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, src, dst,
                        P, global_off, local_off, n_lists, local_chunks);
 }
+
+// ---------------------------------------------------------------------------
+// measurement plumbing: a kernel that only READS `n` uint4 (every byte once, 16 B per lane and
+// load, a wave 1 KiB contiguous — the access pattern of the flat scan), for the streaming-read
+// ceiling bench.py prints beside the HBM-scale scan leg
+__global__ __launch_bounds__(256) void read_only_kernel(const uint4 *__restrict__ src, int64_t n,
+                                                        uint32_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;      // never true for the test pattern: keeps the loads
+}
+
+void tk_launch_read_only(const void *src, int64_t n_uint4, uint32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(read_only_kernel, dim3(65536), dim3(256), 0, s, (const uint4 *)src, n_uint4, out);
+}

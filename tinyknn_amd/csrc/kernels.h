@@ -211,6 +211,7 @@ void tk_launch_pack_lists(const uint8_t *labels, int M, const int *rows_sorted, 
                           const int64_t *chunk_off, const int64_t *list_n, int n_lists,
                           const uint8_t *zero_code, uint4 *tiled, int64_t total_chunks, hipStream_t s);
 void tk_launch_gather_rows(const float *X, int d, const int64_t *rows, int64_t n, float *out, hipStream_t s);
+void tk_launch_read_only(const void *src, int64_t n_uint4, uint32_t *out, hipStream_t s);
 void tk_launch_compact_tiled(const uint4 *src, uint4 *dst, int P, const int64_t *global_off,
                              const int64_t *local_off, int n_lists, int64_t local_chunks, hipStream_t s);
 
