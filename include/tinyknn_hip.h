@@ -254,7 +254,7 @@ int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *bat
 int tk_measure_read_bandwidth(int64_t bytes, int reps, double *gbps);
 
 /* ---- device-resident build ----------------------------------------
- * IVF.build(X, n_probes = 1) (ivf.py:77-102) for float32 vectors that are produced IN HBM
+ * IVF.build(X, n_probes = 1 or 2) (ivf.py:77-102) for float32 vectors that are produced IN HBM
  * and never visit the host — how the 100M x 128 configuration is assembled ("per-GPU
  * generation on device (seeded per shard), codes produced by the build's encoder").
  * tk_index_alloc_data: after tk_index_set_pq; the index allocates its (N, d) float32
@@ -264,7 +264,9 @@ int tk_measure_read_bandwidth(int64_t bytes, int reps, double *gbps);
  *   how the rows are split over calls or ranks; centres: host (n_centres, d) float32 or NULL
  *   (noise only).  tk_synth_rows: the same generator into a host buffer (queries, samples).
  * tk_index_build_dev: normalise != 0 divides every row by its norm first (ivf.py:78-79);
- *   nearest of the C centres per row (knn_brute(data, all_centers, 1), ivf.py:85:
+ *   the n_probes <= 2 nearest of the C centres per row (knn_brute(data, all_centers, n_probes),
+ *   ivf.py:85; with 2 every row sits in two lists, column-0 members of a list before its column-1
+ *   members as group_data_by_indices appends them, and the replay runs its duplicate test):
  *   search_centers (C, d) float32 = all_centers after knn_brute's own normalisation for the
  *   angular metric (utils.py:75; NULL: all_centers themselves), ynorm2 its einsum norms),
  *   active centres = the rows of all_centers that own a vector, in id order (ivf.py:91), PQ codes of
@@ -283,8 +285,8 @@ int tk_index_synth_data(tk_index *ix, int64_t row0, int64_t n, uint64_t seed, co
 int tk_synth_rows(float *out, int64_t row0, int64_t n, int d, uint64_t seed, const float *centres,
                   int n_centres, float sigma);
 int tk_index_build_dev(tk_index *ix, int normalise, const float *all_centers,
-                       const float *search_centers, const float *ynorm2, int64_t C, const double *R,
-                       int d_pad, int64_t *n_active_out);
+                       const float *search_centers, const float *ynorm2, int64_t C, int n_probes,
+                       const double *R, int d_pad, int64_t *n_active_out);
 int tk_index_export_lists(tk_index *ix, int64_t *list_sizes, uint64_t *codes, int64_t *ids);
 int tk_index_export_centers(tk_index *ix, float *active_centers, uint64_t *center_codes);
 int tk_index_read_rows(tk_index *ix, const int64_t *rows, int64_t n, float *out);

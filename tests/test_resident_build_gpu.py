@@ -151,3 +151,49 @@ def test_resident_build_small_and_sparse(oracle, n, n_clusters):
     for n_probes in (1, 3, 100):
         np.testing.assert_array_equal(res.device_index().query_batch(qn, qp, 10, n_probes),
                                       ox.query_batch(qn, 10, n_probes))
+
+
+@pytest.mark.parametrize("metric", ["angular", "euclidean"])
+def test_resident_build_two_lists_per_row(oracle, metric):
+    """IVF.build(n_probes=2), the reference's default: every row in its two nearest lists, a
+    list's column-0 members before its column-1 members (utils.py:131-150), labels repeat and
+    the replay runs its duplicate test.  Same memberships and codes as the host build; same
+    answers as the oracle over the exported lists."""
+    from tinyknn_amd import IVF, FastPQ
+    unpack = oracle.unpack
+    n, d, nq, seed = 20000, 100, 250, 31
+    cent = np.random.RandomState(3).randn(30, d).astype(np.float32)
+    X = synth_rows(n, d, seed, cent, 0.7)
+    host = IVF(metric, 48, FastPQ(2))
+    host.fit(X[:6000])
+    host.build(X, n_probes=2, device=True)
+    res = IVF(metric, 48, FastPQ(2))
+    res.all_centers, res.pq = host.all_centers, host.pq
+    res.build_resident(n, d, seed, cent, 0.7, n_probes=2)
+    np.testing.assert_array_equal(res.active_centers, host.active_centers)
+    dev = res.device_index()
+    sizes, codes, ids = dev.export_lists()
+    assert sizes.sum() == 2 * n
+    chunks = (sizes + 15) // 16
+    coff = np.concatenate([[0], np.cumsum(chunks)])
+    ioff = np.concatenate([[0], np.cumsum(sizes)])
+    for i in range(len(sizes)):
+        hi = np.asarray(host.ids[i], dtype=np.int64)
+        mine = ids[ioff[i]:ioff[i + 1]]
+        np.testing.assert_array_equal(np.sort(mine), np.sort(hi))
+        # two ascending runs: the list's column-0 members, then its column-1 members
+        brk = np.flatnonzero(np.diff(mine) < 0)
+        assert len(brk) <= 1
+        hl = unpack(host.pq_transformed_points[i].packed)[:len(hi)]
+        ml = unpack(codes[coff[i]:coff[i + 1]])[:len(hi)]
+        np.testing.assert_array_equal(ml[np.argsort(mine, kind="stable")], hl[np.argsort(hi, kind="stable")])
+    ox, _ = oracle_from_resident(oracle, res)
+    qs = synth_rows(nq, d, seed + 1, cent, 0.7)
+    qn, qp = res._prepare(qs.copy())
+    for n_probes in (1, 5, 12):
+        got, dbg = dev.query_batch(qn, qp, 10, n_probes, debug=True)
+        np.testing.assert_array_equal(got, ox.query_batch(qn, 10, n_probes))
+        for i in range(0, nq, 41):
+            _, want = ox.query(qn[i], 10, n_probes, debug=True)
+            np.testing.assert_array_equal(dbg["heap_idx"][i], want["heap_idx"])
+            np.testing.assert_array_equal(dbg["heap_val"][i], want["heap_val"])

@@ -79,8 +79,8 @@ SIGNATURES = {
                                       C.c_float]),
     "tk_synth_rows": (C.c_int, [_f32p, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_void_p, C.c_int,
                                 C.c_float]),
-    "tk_index_build_dev": (C.c_int, [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_int64, C.c_void_p,
-                                     C.c_int, _i64p]),
+    "tk_index_build_dev": (C.c_int, [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_int64, C.c_int,
+                                     C.c_void_p, C.c_int, _i64p]),
     "tk_index_export_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_export_centers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_read_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f32p]),

@@ -1835,13 +1835,15 @@ static int encode_rows_dev(tk_index *ix, const float *x, int64_t m, DevBuf &rows
 
 extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_centers,
                                   const float *search_centers, const float *ynorm2, int64_t C,
-                                  const double *R, int d_pad, int64_t *n_active_out)
+                                  int n_probes, const double *R, int d_pad, int64_t *n_active_out)
 {
     IXLOCK(ix);
     if (!search_centers) search_centers = all_centers;
+    ARGCHECK(n_probes >= 1 && n_probes <= 2 && n_probes <= C, "n_probes must be 1 or 2 (numpy's dumb_select range)");
+    const int kp = n_probes;
     ARGCHECK(ix && ix->have_pq && ix->data.p && ix->N > 0, "set_pq and tk_index_alloc_data first");
     ARGCHECK(all_centers && ynorm2 && C >= 1 && C < (1ll << 31), "centres");
-    ARGCHECK(ix->N < (1ll << 31), "N < 2^31");
+    ARGCHECK(ix->N * kp < (1ll << 31), "N * n_probes < 2^31");
     ARGCHECK(ix->d <= 384 && (!normalise || ix->d <= 128), "d <= 384 (128 with normalisation)");
     ARGCHECK(16 % ix->dpb == 0, "dims_per_block must divide 16 for the device encoder");
     ARGCHECK(R ? (d_pad >= ix->d && d_pad <= 16384) : ix->dq >= ix->d, "rotation / padding");
@@ -1867,16 +1869,17 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
         HIPCHECK(hipMemcpy(yt.p, ytv.data(), ytv.size() * 4, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(yn.p, ynorm2, (size_t)C * 4, hipMemcpyHostToDevice));
     }
-    TRY(near.ensure((size_t)slab * 8));
-    TRY(keys.ensure((size_t)N * 4));
-    TRY(rows.ensure((size_t)N * 4));
+    const int64_t T = N * kp;           // (list, row) pairs: every row sits in kp lists
+    TRY(near.ensure((size_t)slab * kp * 8));
+    TRY(keys.ensure((size_t)T * 4));
+    TRY(rows.ensure((size_t)T * 4));
     TRY(count.ensure((size_t)C * 4));
     HIPCHECK(hipMemset(count.p, 0, (size_t)C * 4));
     for (int64_t o = 0; o < N; o += slab) {
         const int64_t m = N - o < slab ? N - o : slab;
         if (normalise) tk_launch_normalise_rows(X + o * d, m, d, X + o * d, 0);
-        tk_launch_assign(X + o * d, m, d, yt.p, yn.p, 0, (int)C, 1, near.as<int64_t>(), 0);
-        tk_launch_keys_count(near.as<int64_t>(), m, o, keys.as<int>(), rows.as<int>(), count.as<int>(), 0);
+        tk_launch_assign(X + o * d, m, d, yt.p, yn.p, 0, (int)C, kp, near.as<int64_t>(), 0);
+        tk_launch_keys_count(near.as<int64_t>(), m, kp, o, N, keys.as<int>(), rows.as<int>(), count.as<int>(), 0);
         HIPCHECK(hipGetLastError());
     }
     HIPCHECK(hipDeviceSynchronize());
@@ -1903,17 +1906,18 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
     ARGCHECK(maxc < (1ll << 26), "list too long");
     TRY(remap.ensure((size_t)C * 4));
     HIPCHECK(hipMemcpy(remap.p, rm.data(), (size_t)C * 4, hipMemcpyHostToDevice));
-    tk_launch_remap_keys(keys.as<int>(), N, remap.as<int>(), 0);
-    // ---- 3. rows grouped by list: stable sort of (list, row)
+    tk_launch_remap_keys(keys.as<int>(), T, remap.as<int>(), 0);
+    // ---- 3. rows grouped by list: stable sort of (list, row); with two lists per row the
+    //         column-0 pairs precede the column-1 pairs of every list (utils.py:131-150)
     int bits = 1;
     while ((1ll << bits) < L) bits++;
-    TRY(keys2.ensure((size_t)N * 4));
-    TRY(rows2.ensure((size_t)N * 4));
+    TRY(keys2.ensure((size_t)T * 4));
+    TRY(rows2.ensure((size_t)T * 4));
     size_t tmp_bytes = 0;
-    if (tk_sort_pairs(nullptr, &tmp_bytes, keys.as<int>(), keys2.as<int>(), rows.as<int>(), rows2.as<int>(), N, bits, 0))
+    if (tk_sort_pairs(nullptr, &tmp_bytes, keys.as<int>(), keys2.as<int>(), rows.as<int>(), rows2.as<int>(), T, bits, 0))
         return fail(TK_ERR_HIP, "radix sort: size query failed");
     TRY(tmp.ensure(tmp_bytes > 0 ? tmp_bytes : 16));
-    if (tk_sort_pairs(tmp.p, &tmp_bytes, keys.as<int>(), keys2.as<int>(), rows.as<int>(), rows2.as<int>(), N, bits, 0))
+    if (tk_sort_pairs(tmp.p, &tmp_bytes, keys.as<int>(), keys2.as<int>(), rows.as<int>(), rows2.as<int>(), T, bits, 0))
         return fail(TK_ERR_HIP, "radix sort failed");
     HIPCHECK(hipDeviceSynchronize());
     keys.release(); rows.release(); keys2.release(); tmp.release(); near.release();
@@ -1960,7 +1964,7 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
     TRY(ix->list_chunk_off.ensure((size_t)(L + 1) * 8));
     TRY(ix->ids_off.ensure((size_t)(L + 1) * 8));
     TRY(ix->list_n.ensure((size_t)L * 8));
-    TRY(ix->ids.ensure((size_t)N * 8));
+    TRY(ix->ids.ensure((size_t)T * 8));
     HIPCHECK(hipMemcpy(ix->list_chunk_off.p, coff.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ix->ids_off.p, ioff.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ix->list_n.p, sizes.data(), (size_t)L * 8, hipMemcpyHostToDevice));
@@ -1970,14 +1974,19 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
     tk_launch_pack_lists(labels.as<uint8_t>(), M, rows2.as<int>(), ix->ids_off.as<int64_t>(),
                          ix->list_chunk_off.as<int64_t>(), ix->list_n.as<int64_t>(), (int)L, zero_code,
                          ix->codes.as<uint4>(), coff[(size_t)L], 0);
-    tk_launch_widen_ids(rows2.as<int>(), N, ix->ids.as<int64_t>(), 0);
+    tk_launch_widen_ids(rows2.as<int>(), T, ix->ids.as<int64_t>(), 0);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipDeviceSynchronize());
-    ix->ids_unique = true;          // every row sits in exactly one list
+    ix->ids_unique = kp == 1;       // one list per row: no label can repeat
     ix->have_ids32 = false;
+    if (kp > 1) {                   // the lane replay's duplicate test reads the labels as int32
+        TRY(ix->ids32.ensure((size_t)T * 4));
+        HIPCHECK(hipMemcpyAsync(ix->ids32.p, rows2.p, (size_t)T * 4, hipMemcpyDeviceToDevice, 0));
+        ix->have_ids32 = true;
+    }
+    HIPCHECK(hipDeviceSynchronize());
     ix->sharded = false; ix->rank = 0; ix->world = 1;
     ix->total_chunks = coff[(size_t)L];
-    ix->total_ids = N;
+    ix->total_ids = T;
     ix->max_list_chunks = (int)maxc;
     ix->have_centers = ix->have_lists = ix->have_data = true;
     if (n_active_out) *n_active_out = L;

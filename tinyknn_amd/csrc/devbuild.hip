@@ -64,24 +64,30 @@ void tk_launch_synth_rows(float *X, int64_t row0, int64_t n, int d, uint64_t see
 }
 
 // ---------------------------------------------------------------------------
-// nearest (n,) int64 of a slab -> sort keys / values + the per-centre histogram
-__global__ void keys_count_kernel(const int64_t *__restrict__ nearest, int64_t n, int64_t row0,
-                                  int *__restrict__ keys, int *__restrict__ rows, int *__restrict__ count)
+// nearest (n, kp) int64 of a slab -> sort keys / values + the per-centre histogram.  Column j of
+// the rows goes to block j of the pair arrays (block stride N): group_data_by_indices
+// (utils.py:131-150) appends a list's column-0 members first, then its column-1 members, and a
+// stable sort of the pairs by list keeps exactly that order.
+__global__ void keys_count_kernel(const int64_t *__restrict__ nearest, int64_t n, int kp, int64_t row0,
+                                  int64_t N, int *__restrict__ keys, int *__restrict__ rows,
+                                  int *__restrict__ count)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n * kp) return;
+    const int64_t r = i / kp;
+    const int j = (int)(i - r * kp);
     const int k = (int)nearest[i];
-    keys[row0 + i] = k;
-    rows[row0 + i] = (int)(row0 + i);
+    keys[(int64_t)j * N + row0 + r] = k;
+    rows[(int64_t)j * N + row0 + r] = (int)(row0 + r);
     atomicAdd(&count[k], 1);
 }
 
-void tk_launch_keys_count(const int64_t *nearest, int64_t n, int64_t row0, int *keys, int *rows, int *count,
-                          hipStream_t s)
+void tk_launch_keys_count(const int64_t *nearest, int64_t n, int kp, int64_t row0, int64_t N, int *keys,
+                          int *rows, int *count, hipStream_t s)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(keys_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nearest, n,
-                       row0, keys, rows, count);
+    hipLaunchKernelGGL(keys_count_kernel, dim3((unsigned)((n * kp + 255) / 256)), dim3(256), 0, s, nearest, n,
+                       kp, row0, N, keys, rows, count);
 }
 
 // centre id -> active-list id (ivf.py:91: active_centers = all_centers[np.unique(nearest)])

@@ -201,8 +201,8 @@ void tk_launch_prepare_queries(const float *X, int64_t n, int d, const double *R
 // ---- device-resident build + seeded generator (devbuild.hip) ----
 void tk_launch_synth_rows(float *X, int64_t row0, int64_t n, int d, uint64_t seed, const float *centres,
                           int n_centres, float sigma, hipStream_t s);
-void tk_launch_keys_count(const int64_t *nearest, int64_t n, int64_t row0, int *keys, int *rows, int *count,
-                          hipStream_t s);
+void tk_launch_keys_count(const int64_t *nearest, int64_t n, int kp, int64_t row0, int64_t N, int *keys,
+                          int *rows, int *count, hipStream_t s);
 void tk_launch_remap_keys(int *keys, int64_t n, const int *remap, hipStream_t s);
 int tk_sort_pairs(void *tmp, size_t *tmp_bytes, const int *keys_in, int *keys_out, const int *vals_in,
                   int *vals_out, int64_t n, int bits, hipStream_t s);

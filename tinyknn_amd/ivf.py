@@ -201,8 +201,8 @@ class DeviceIndex:
             self._h, int(row0), int(n), int(seed), None if c is None else c.ctypes.data,
             0 if c is None else len(c), float(sigma)))
 
-    def build_dev(self, all_centers):
-        """IVF.build(n_probes=1) on the resident vectors (tk_index_build_dev) -> n_active."""
+    def build_dev(self, all_centers, n_probes=1):
+        """IVF.build(n_probes=1 or 2) on the resident vectors (tk_index_build_dev) -> n_active."""
         A = np.ascontiguousarray(all_centers, dtype=np.float32)
         Y = A
         if self.angular:
@@ -212,7 +212,7 @@ class DeviceIndex:
         R = self._R
         _lib.check(_lib.lib().tk_index_build_dev(
             self._h, int(self.angular), _lib.ptr(A, _lib._f32p), _lib.ptr(Y, _lib._f32p),
-            _lib.ptr(ynorm2, _lib._f32p), len(Y),
+            _lib.ptr(ynorm2, _lib._f32p), len(Y), int(n_probes),
             None if R is None else R.ctypes.data, 0 if R is None else R.shape[1], C.byref(n_active)))
         self.n_lists = int(n_active.value)
         self.list_sizes = self.export_lists(codes=False, ids=False)[0]
@@ -643,8 +643,8 @@ class IVF:
         ivf.data = z["data"] if data is None else data
         return ivf
 
-    def build_resident(self, N, d, seed, centres=None, sigma=1.0, verbose=False):
-        """IVF.build(X, n_probes=1) (ivf.py:53-104) for N synthetic float32 vectors that are
+    def build_resident(self, N, d, seed, centres=None, sigma=1.0, verbose=False, n_probes=1):
+        """IVF.build(X, n_probes=1 or 2) (ivf.py:53-104) for N synthetic float32 vectors that are
         generated IN HBM (seeded, devbuild.hip) and never visit the host — the way the
         100M x 128 configuration is assembled.  Needs all_centers and a
         fitted pq (fit()).  Everything runs on the device: nearest centre per row, PQ codes,
@@ -660,7 +660,7 @@ class IVF:
             dev = DeviceIndex.resident(self, N, d)
             dev.synth_data(seed, centres, sigma)
         with timer(verbose, "Building lists on the device..."):
-            L = dev.build_dev(self.all_centers)
+            L = dev.build_dev(self.all_centers, n_probes)
         self.active_centers, cc = dev.export_centers()
         self.pq_transformed_centers = TransformedData(L, cc)
         self.list_sizes = dev.list_sizes
