@@ -436,6 +436,43 @@ int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_
                               int n_probes, int pass_1, int64_t capacity, const void *recv_dev,
                               int64_t *out_ids_home_dev, void *stream);
 
+/* Filtered exchange — the same batch with a fraction of the bytes on
+ * the links.  Every insert of a 16-code block is below the bound captured at the block's start
+ * (_fast_pq_256.pyx:73,111-123), so the bound never increases from block to block: a distance
+ * that is not below B1, the bound after the query's FIRST probed list, can never enter the
+ * heap.  After tk_index_shard_scan_dev (whose buffer then stays on the rank: `scan_dev`):
+ *   tk_index_shard_bound_dev   bound_dev[nq] bytes: B1 (order key = distance byte ^ 0x80) of
+ *                              the queries whose first probed list this rank owns — replayed
+ *                              from the fresh heap over that list — and 255 elsewhere;
+ *   all-reduce(MIN, uint8)     -> B1 of every query on every rank (by the caller);
+ *   tk_index_shard_filter_dev  the blocks that travel — all of a query's first list, of the
+ *                              later lists those whose minimum is below B1 — as records of 5
+ *                              int32 {row * cap + block (in the home rank's distance rows), 16
+ *                              distance bytes}, grouped by home rank in records_dev (room for
+ *                              world * capacity records); counts_dev: 3 * world int32,
+ *                              [0, world) = records per home rank, [2 world, 3 world) = all
+ *                              blocks this rank scored per home rank (what the dense exchange
+ *                              carries), the middle third is scratch;
+ *   all-to-all of the counts, then of the records with those splits (by the caller);
+ *   tk_index_shard_finish_filtered_dev
+ *                              home rows filled with the largest value — a block that did not
+ *                              travel then behaves like the real one: no byte of it is below
+ *                              any bound — received blocks dropped in, replay, rescoring as
+ *                              tk_index_shard_finish_dev; *flag_dev |= 2 on a record that does
+ *                              not belong to this rank's rows (never written).
+ * Same slot, nq, k, n_probes, pass_1 and capacity as the scan call; the probe lists handed to
+ * it must still be alive.  Results are identical to the dense exchange. */
+int tk_index_shard_bound_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
+                             int64_t capacity, const void *scan_dev, uint8_t *bound_dev,
+                             void *stream);
+int tk_index_shard_filter_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
+                              int64_t capacity, const void *scan_dev, const uint8_t *bound_dev,
+                              int32_t *counts_dev, int32_t *records_dev, void *stream);
+int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq,
+                                       int k, int n_probes, int pass_1, const int32_t *records_dev,
+                                       int64_t n_records, int64_t *out_ids_home_dev, int *flag_dev,
+                                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

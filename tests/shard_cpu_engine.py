@@ -3,7 +3,9 @@ built on the oracle).  `scan` scores the segments this rank owns with the oracle
 estimate_pq and packs them exactly where shard_positions_kernel would; `finish` checks
 every received segment of the home queries against a local recomputation and answers them
 with the oracle's full query — so a misplaced, missing or foreign byte in the exchange
-fails the test."""
+fails the test.  Filtered exchange: `bound` replays the first probed list with the oracle's
+query_pq from a fresh heap, `filter` packs the blocks below the reduced bound, and
+`finish_filtered` checks that exactly the blocks the rule names arrived, byte for byte."""
 import numpy as np
 
 from tinyknn_amd.multi_gpu import shard_positions
@@ -49,6 +51,7 @@ class OracleShardEngine:
 
     def scan(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None):
         qn = qn.numpy()
+        self.last_capacity = capacity
         probes, tables = self._front(qn, k, n_probes, pass_1)
         if probes_all is not None:
             # the gathered probe lists must be what every rank would have derived itself
@@ -85,3 +88,97 @@ class OracleShardEngine:
                 got = buf[src[i, s], pos[i, s] * 16: pos[i, s] * 16 + len(seg)]
                 np.testing.assert_array_equal(got, seg)
             out[i - self.rank * qh] = self.ox.query_batch(qn[i:i + 1], k, n_probes, pass_1)[0]
+
+    # ---- filtered exchange: same three calls as the HIP engine
+    def _heap_size(self, k, n_probes, pass_1):
+        return int(pass_1) if pass_1 else (n_probes + 1) * k + 1        # ivf.py:135-136
+
+    def bound(self, slot, qn, k, n_probes, pass_1, capacity, scan_buf, bound):
+        qn = qn.numpy()
+        probes, tables = self._front(qn, k, n_probes, pass_1)
+        out = bound.numpy()
+        out[:] = 255
+        off = self.ox.list_chunk_off
+        for i in range(len(qn)):
+            l = probes[i, 0]
+            if self.owner[l] != self.rank:
+                continue
+            idx = np.zeros(self._heap_size(k, n_probes, pass_1), dtype=np.int64)
+            val = np.zeros(len(idx), dtype=np.int32)
+            self.O.init_heap(idx, val, True)
+            codes = np.ascontiguousarray(self.ox.codes[off[l]:off[l + 1]])
+            if len(codes):
+                self.O.query_pq(codes, int(self.ox.list_n[l]), tables[i], idx, val, True)
+            out[i] = (int(val[0]) & 0xff) ^ 0x80
+
+    def _passing(self, seg, slot, b):
+        """chunk indices of a segment that travel under bound key b"""
+        m = seg.view(np.int8).reshape(-1, 16).min(axis=1).astype(np.int64) + 128
+        return np.arange(len(m)) if slot == 0 else np.flatnonzero(m < int(b))
+
+    def filter(self, slot, qn, k, n_probes, pass_1, capacity, scan_buf, bound, counts, records):
+        qn = qn.numpy()
+        probes, tables = self._front(qn, k, n_probes, pass_1)
+        src, pos = shard_positions(probes, self.chunks, self.owner, self.world, capacity)
+        buf = scan_buf.numpy().reshape(self.world, capacity * 16)
+        b = bound.numpy()
+        qh = -(-len(qn) // self.world)
+        cap = probes.shape[1] * int(self.chunks.max())                  # Plan.cap (api.hip make_plan)
+        prefix = np.concatenate([np.zeros((len(qn), 1), np.int64),
+                                 np.cumsum(self.chunks[probes], axis=1)], axis=1)
+        per_home = [[] for _ in range(self.world)]
+        dense = np.zeros(self.world, dtype=np.int64)
+        for i in range(len(qn)):
+            h = i // qh
+            for s in range(probes.shape[1]):
+                if src[i, s] != self.rank or pos[i, s] < 0:
+                    continue
+                n = int(self.chunks[probes[i, s]])
+                seg = buf[h, pos[i, s] * 16:(pos[i, s] + n) * 16]
+                dense[h] += n
+                for c in self._passing(seg, s, b[i]):
+                    rec = np.empty(5, dtype=np.int32)
+                    rec[0] = (i - h * qh) * cap + prefix[i, s] + c
+                    rec[1:] = seg[16 * c:16 * c + 16].view(np.int32)
+                    per_home[h].append(rec)
+        cnt = counts.numpy()
+        cnt[:] = 0
+        cnt[:self.world] = [len(x) for x in per_home]
+        cnt[2 * self.world:] = dense
+        flat = [r for x in per_home for r in x]
+        if flat:
+            records.numpy()[:len(flat)] = np.array(flat)
+
+    def finish_filtered(self, slot, qn, k, n_probes, pass_1, records, n_records, out_home, flag):
+        qn = qn.numpy()
+        probes, tables = self._front(qn, k, n_probes, pass_1)
+        qh = -(-len(qn) // self.world)
+        cap = probes.shape[1] * int(self.chunks.max())
+        _, pos = shard_positions(probes, self.chunks, self.owner, self.world, self.last_capacity)
+        rec = records.numpy()[:n_records]
+        got = {int(r[0]): r[1:].tobytes() for r in rec}
+        assert len(got) == n_records, "a block arrived twice"
+        out = out_home.numpy().reshape(qh, k)
+        out[:] = -1
+        want = 0
+        # the bound every rank must have used: after the first list, from a fresh heap
+        for i in range(self.rank * qh, min(len(qn), (self.rank + 1) * qh)):
+            idx = np.zeros(self._heap_size(k, n_probes, pass_1), dtype=np.int64)
+            val = np.zeros(len(idx), dtype=np.int32)
+            self.O.init_heap(idx, val, True)
+            l0 = probes[i, 0]
+            off = self.ox.list_chunk_off
+            codes = np.ascontiguousarray(self.ox.codes[off[l0]:off[l0 + 1]])
+            if len(codes):
+                self.O.query_pq(codes, int(self.ox.list_n[l0]), tables[i], idx, val, True)
+            b = (int(val[0]) & 0xff) ^ 0x80
+            f0 = 0
+            for s in range(probes.shape[1]):
+                seg = self._segment(probes[i, s], tables[i])
+                for c in (self._passing(seg, s, b) if pos[i, s] >= 0 else []):   # overflowed: repeated
+                    key = (i - self.rank * qh) * cap + f0 + int(c)
+                    assert got.get(key) == seg[16 * c:16 * c + 16].tobytes(), (i, s, c)
+                    want += 1
+                f0 += int(self.chunks[probes[i, s]])
+            out[i - self.rank * qh] = self.ox.query_batch(qn[i:i + 1], k, n_probes, pass_1)[0]
+        assert want == n_records, "blocks that should not have travelled"

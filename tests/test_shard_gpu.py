@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, owner=None,
-                   coarse="home", engines=None, sizes=None):
+                   coarse="home", engines=None, sizes=None, exchange="dense", stats=None):
     """-> (ids (nq, k), overflow flags (world,), capacity).  coarse="home": every simulated rank
     runs the coarse stage of its home queries only and the probe lists are gathered by hand;
     "replicated": every rank derives all probe lists itself."""
@@ -49,11 +49,37 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
     for r, e in enumerate(engines):
         e.scan(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], probes_all=p_all)
     homes = []
-    for h, e in enumerate(engines):
-        recv = torch.stack([sends[s][h] for s in range(world)]).contiguous()   # all-to-all
-        out = torch.zeros(qh * k, dtype=torch.int64, device="cuda")
-        e.finish(0, qn_t, k, n_probes, pass_1, capacity, recv, out)
-        homes.append(out.view(qh, k))
+    if exchange == "filtered":
+        bounds = [torch.zeros(nq, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        for r, e in enumerate(engines):
+            e.bound(0, qn_t, k, n_probes, pass_1, capacity, sends[r].view(-1), bounds[r])
+        b_all = torch.stack(bounds).min(dim=0).values.contiguous()             # all-reduce(MIN)
+        assert (torch.stack(bounds) != 255).sum(dim=0).le(1).all()             # one owner per query
+        counts, recs = [], []
+        for r, e in enumerate(engines):
+            c = torch.full((3 * world,), -5, dtype=torch.int32, device="cuda")
+            rec = torch.full((world * capacity, 5), -9, dtype=torch.int32, device="cuda")
+            e.filter(0, qn_t, k, n_probes, pass_1, capacity, sends[r].view(-1), b_all, c, rec)
+            counts.append(c.cpu().numpy())
+            recs.append(rec)
+        if stats is not None:
+            stats["records"] = int(sum(c[:world].sum() for c in counts))
+            stats["dense_blocks"] = int(sum(c[2 * world:].sum() for c in counts))
+        for h, e in enumerate(engines):
+            parts = []
+            for s_ in range(world):                                             # all-to-all (splits)
+                o = int(counts[s_][:h].sum())
+                parts.append(recs[s_][o:o + int(counts[s_][h])])
+            rrec = torch.cat(parts).contiguous()
+            out = torch.zeros(qh * k, dtype=torch.int64, device="cuda")
+            e.finish_filtered(0, qn_t, k, n_probes, pass_1, rrec, rrec.shape[0], out, flags[h])
+            homes.append(out.view(qh, k))
+    else:
+        for h, e in enumerate(engines):
+            recv = torch.stack([sends[s][h] for s in range(world)]).contiguous()   # all-to-all
+            out = torch.zeros(qh * k, dtype=torch.int64, device="cuda")
+            e.finish(0, qn_t, k, n_probes, pass_1, capacity, recv, out)
+            homes.append(out.view(qh, k))
     torch.cuda.synchronize()
     ids = torch.cat(homes).cpu().numpy()
     assert (ids[nq:] == -1).all()
@@ -71,6 +97,21 @@ def test_sharded_golden(tag, world, coarse):
     for n_probes in g["probes_list"]:
         n_probes = int(n_probes)
         ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, coarse=coarse)
+        assert not flags.any()
+        np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+
+
+@pytest.mark.parametrize("tag", G6_TAGS)
+@pytest.mark.parametrize("world,coarse", [(1, "home"), (3, "home"), (2, "replicated")])
+def test_sharded_filtered_golden(tag, world, coarse):
+    """Filtered exchange (bound after the first list, blocks below it as records): the golden ids."""
+    from test_hip_parity import ivf_from_fixture
+    g = golden(f"g6_ivf_{tag}.npz")
+    ivf = ivf_from_fixture(None, g)
+    for n_probes in g["probes_list"]:
+        n_probes = int(n_probes)
+        ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, coarse=coarse,
+                                       exchange="filtered")
         assert not flags.any()
         np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
 
@@ -124,6 +165,56 @@ def test_sharded_vs_unsharded_larger(oracle, build_probes, world, coarse):
         np.testing.assert_array_equal(ids[:60], ox.query_batch(qn[:60], 10, n_probes))
 
 
+@pytest.mark.parametrize("build_probes,world", [(1, 4), (2, 3), (1, 8)])
+def test_sharded_filtered_vs_unsharded_larger(oracle, build_probes, world):
+    """The 60k x 100 index through the filtered exchange: ids of the unsharded pipeline for
+    distinct and repeating labels, pass_1 heaps too; and the exchange is the smaller the longer
+    the lists are against the heap (here ~250 rows per list)."""
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(10)
+    n, d, nq = 60000, 100, 1003
+    cent = np.random.randn(300, d)
+    X = (cent[np.random.randint(300, size=n)] + 0.7 * np.random.randn(n, d)).astype(np.float32)
+    qs = (cent[np.random.randint(300, size=nq)] + 0.7 * np.random.randn(nq, d)).astype(np.float32)
+    ivf = IVF("angular", 244, FastPQ(2))
+    ivf.fit(X[:20000]).build(X, n_probes=build_probes)
+    qn, qp = ivf._prepare(qs.copy())
+    for n_probes, pass_1 in ((1, None), (10, None), (30, None), (10, 40), (5, 700)):
+        want = ivf.device_index().query_batch(qn, qp, 10, n_probes, pass_1)
+        st = {}
+        ids, flags, cap = simulate_world(ivf, world, qn, qp, 10, n_probes, pass_1=pass_1,
+                                         exchange="filtered", stats=st)
+        assert not flags.any(), f"default capacity {cap} overflowed"
+        np.testing.assert_array_equal(ids, want)
+        assert 0 < st["records"] <= st["dense_blocks"]
+        if n_probes == 10 and pass_1 == 40:
+            assert 20 * st["records"] < 16 * st["dense_blocks"] * 0.6, st
+
+
+def test_filtered_public_class_world1():
+    """ListShardedIndex(exchange="filtered") without a process group, pipelined submit too."""
+    import torch
+    from test_hip_parity import ivf_from_fixture
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+    g = golden("g6_ivf_an100.npz")
+    ivf = ivf_from_fixture(None, g)
+    idx = ListShardedIndex(ivf, exchange="filtered", depth=2, coalesce=2)
+    np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=5), g["ids_p5"])
+    assert 0 < idx.bytes_sent and idx.bytes_dense > 0
+    qn, qp = ivf._prepare(np.array(g["qs"], dtype=np.float32))
+    qn_t, qp_t = torch.from_numpy(qn).cuda(), torch.from_numpy(np.ascontiguousarray(qp)).cuda()
+    outs = [idx.submit(qn_t, qp_t, 10, 10) for _ in range(4)]
+    idx.join()
+    torch.cuda.synchronize()
+    nq, qh = len(qn), 2 * len(qn)
+    for o in outs[1::2]:
+        got = o.cpu().numpy()
+        assert not got[:, -1].any()
+        both = got[:, :-1].reshape(qh, 10)
+        np.testing.assert_array_equal(both[:nq], g["ids_p10"])
+        np.testing.assert_array_equal(both[nq:], g["ids_p10"])
+
+
 def test_sharded_world1_public_class():
     """ListShardedIndex without a process group: the all-to-all is a copy."""
     from test_hip_parity import ivf_from_fixture
@@ -137,7 +228,7 @@ def test_sharded_world1_public_class():
     assert idx.capacity[(len(g["qs"]), 10)] > 2
 
 
-def _gloo_gpu_worker(rank, world, port, ret):
+def _gloo_gpu_worker(rank, world, port, ret, exchange):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -148,18 +239,19 @@ def _gloo_gpu_worker(rank, world, port, ret):
         from tinyknn_amd.multi_gpu import ListShardedIndex
         g = golden("g6_ivf_an100b2.npz")
         ivf = ivf_from_fixture(None, g)
-        idx = ListShardedIndex(ivf, depth=2)
+        idx = ListShardedIndex(ivf, depth=2, exchange=exchange)
         ret[rank] = {p: idx.query_batch(g["qs"], 10, n_probes=p) for p in (1, 5, 10)}
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_two_processes_one_gpu():
+@pytest.mark.parametrize("exchange", ["dense", "filtered"])
+def test_sharded_two_processes_one_gpu(exchange):
     import torch.multiprocessing as mp
-    port = 33500 + os.getpid() % 2000
+    port = 33500 + (os.getpid() + len(exchange)) % 2000
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_gloo_gpu_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_gloo_gpu_worker, args=(2, port, ret, exchange), nprocs=2, join=True)
     g = golden("g6_ivf_an100b2.npz")
     for r in range(2):
         for p in (1, 5, 10):

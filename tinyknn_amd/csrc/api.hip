@@ -559,7 +559,10 @@ struct Work {
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
-        c_pair_f0, spos, rpos;
+        c_pair_f0, spos, rpos, smins, pair_cnt;
+    // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
+    const int64_t *shard_probes = nullptr;
+    int64_t shard_nq = 0, shard_capacity = 0;
     // pipelined mode (depth > 1): hand-offs between the caller's stream and a latency stream
     hipEvent_t tables_done = nullptr, coarse_scanned = nullptr, front_done = nullptr,
                scanned = nullptr, done = nullptr;
@@ -570,7 +573,7 @@ struct Work {
                        &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
-                       &spos, &rpos};
+                       &spos, &rpos, &smins, &pair_cnt};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -1650,6 +1653,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     Work &w = ix->works[(size_t)slot];
     hipStream_t st = (hipStream_t)stream;
     TRY(reserve_shard(ix, w, nq, qh, p));
+    TRY(w.smins.ensure((size_t)ix->world * capacity + 16));
     Prof pf;
     const int *owner = ix->owner.as<int>();
     const int64_t *probes = probes_all_dev;
@@ -1678,7 +1682,96 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
                          ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                          w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
-                         (uint4 *)send_dev, 0, nullptr, 0, 1, ix->order, 768, st);
+                         (uint4 *)send_dev, 0, w.smins.as<uint8_t>(), 0, 1, ix->order, 768, st);
+    w.shard_probes = probes;
+    w.shard_nq = nq;
+    w.shard_capacity = capacity;
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+// ---- filtered exchange: bound -> [min all-reduce] -> filter ->
+// [all-to-all of the counts and of the records] -> finish_filtered.  `scan_dev` is the buffer
+// tk_index_shard_scan_dev of the same slot filled (it stays on the rank), with the same nq,
+// k, n_probes, pass_1 and capacity; the probe lists handed to that call must still be alive.
+static int filtered_args(tk_index *ix, Work &w, int64_t nq, int64_t capacity)
+{
+    ARGCHECK(w.shard_probes && w.shard_nq == nq && w.shard_capacity == capacity,
+             "tk_index_shard_scan_dev of this slot (same nq and capacity) comes first");
+    return TK_OK;
+}
+
+extern "C" int tk_index_shard_bound_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
+                                        int pass_1, int64_t capacity, const void *scan_dev,
+                                        uint8_t *bound_dev, void *stream)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, capacity, p, qh));
+    ARGCHECK(scan_dev && bound_dev, "scan/bound buffers");
+    Work &w = ix->works[(size_t)slot];
+    TRY(filtered_args(ix, w, nq, capacity));
+    tk_launch_shard_first_bound(w.shard_probes, w.slot_prefix.as<int>(), w.slot_n.as<int>(), p.S, nq,
+                                ix->n_lists, ix->owner.as<int>(), ix->rank, w.spos.as<int>(),
+                                (const uint4 *)scan_dev, w.smins.as<uint8_t>(), p.R, bound_dev,
+                                (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+extern "C" int tk_index_shard_filter_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
+                                         int pass_1, int64_t capacity, const void *scan_dev,
+                                         const uint8_t *bound_dev, int32_t *counts_dev,
+                                         int32_t *records_dev, void *stream)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, capacity, p, qh));
+    ARGCHECK(scan_dev && bound_dev && counts_dev && records_dev, "scan/bound/counts/records buffers");
+    Work &w = ix->works[(size_t)slot];
+    TRY(filtered_args(ix, w, nq, capacity));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(w.pair_cnt.ensure((size_t)nq * p.S * 4));
+    HIPCHECK(hipMemsetAsync(counts_dev, 0, (size_t)ix->world * 3 * 4, st));
+    tk_launch_shard_filter(w.shard_probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
+                           ix->owner.as<int>(), ix->rank, ix->world, qh, p.cap, w.spos.as<int>(),
+                           (const uint4 *)scan_dev, w.smins.as<uint8_t>(), bound_dev,
+                           w.pair_cnt.as<int>(), counts_dev, records_dev, st);
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+extern "C" int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_dev,
+                                                  int64_t nq, int k, int n_probes, int pass_1,
+                                                  const int32_t *records_dev, int64_t n_records,
+                                                  int64_t *out_ids_home_dev, int *flag_dev,
+                                                  void *stream)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, 1, p, qh));
+    ARGCHECK(out_ids_home_dev && flag_dev && n_records >= 0 && (records_dev || n_records == 0),
+             "records/out/flag buffers");
+    Work &w = ix->works[(size_t)slot];
+    ARGCHECK(w.shard_probes && w.shard_nq == nq, "tk_index_shard_scan_dev of this slot comes first");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t q0 = (int64_t)ix->rank * qh;
+    int64_t nqh = nq - q0;
+    nqh = nqh < 0 ? 0 : (nqh > qh ? qh : nqh);
+    HIPCHECK(hipMemsetAsync(out_ids_home_dev, 0xff, (size_t)qh * k * 8, st));   // -1 rows
+    if (nqh > 0) {
+        tk_launch_shard_expand(records_dev, n_records, w.slot_prefix.as<int>() + q0 * (p.S + 1), p.S,
+                               nqh, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(), p.cap_min,
+                               flag_dev, st);
+        Prof pf;
+        TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf));
+    }
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }

@@ -177,6 +177,21 @@ void tk_launch_shard_pairs_fill(const int64_t *probes, int S, int64_t nq, int64_
 void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_prefix, int S,
                             int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,
                             int64_t min_stride, int signd, hipStream_t s);
+// filtered exchange: bound after the first probed list (order key = byte ^ 0x80,
+// 255 where this rank does not own the query's first list), blocks below it as 5-int records
+// grouped by destination (counts: 3 * W ints, zeroed by the caller), rows rebuilt at home
+void tk_launch_shard_first_bound(const int64_t *probes, const int *slot_prefix, const int *slot_n,
+                                 int S, int64_t nq, int64_t n_lists, const int *owner, int me,
+                                 const int *spos, const uint4 *scan, const uint8_t *smins, int R,
+                                 uint8_t *bound, hipStream_t s);
+void tk_launch_shard_filter(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
+                            int64_t n_lists, const int *owner, int me, int W, int64_t qh,
+                            int64_t cap, const int *spos, const uint4 *scan, const uint8_t *smins,
+                            const uint8_t *bound, int *pair_cnt, int *counts, int *rec,
+                            hipStream_t s);
+void tk_launch_shard_expand(const int *rec, int64_t n_rec, const int *slot_prefix, int S,
+                            int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,
+                            int64_t min_stride, int *bad, hipStream_t s);
 
 // ---- offline build path (build.hip) ----
 // labels (n, M) uint8 = FastPQ.transform's per-block nearest centroid; data: (n, dq) padded

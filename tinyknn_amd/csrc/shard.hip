@@ -172,3 +172,213 @@ void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_
         hipLaunchKernelGGL(shard_unpack_kernel<false>, dim3(grid), dim3(64), 0, s, recv, rpos,
                            slot_prefix, S, dist, cap, mins, min_stride);
 }
+
+// ---------------------------------------------------------------------------
+// Filtered exchange.  Every insert of a block is below the bound
+// captured at the block's start (_fast_pq_256.pyx:73,111-123), so the bound never increases
+// from one block to the next; a distance that is not below B1 — the bound after the query's
+// FIRST probed list — can therefore never enter the heap, whatever comes before it.  The
+// owner of a query's first list replays that list from the fresh heap (B1), B1 is min-reduced
+// over the ranks (1 byte per query), and of the later lists only the 16-distance blocks whose
+// minimum is below B1 travel, as (destination, 16 bytes) records.  The home rank drops them
+// into distance rows pre-filled with the largest value (what pad rows carry, `pos < n`), where
+// a missing block behaves exactly like the real one: no byte of it is below any bound.
+//
+// Signed tables: the order key of a distance byte is byte ^ 0x80 (unsigned compare).
+__device__ __forceinline__ uint32_t key8(uint32_t b) { return (b ^ 0x80u) & 0xffu; }
+
+// B1 by value multiset: insert() (_fast_pq.pyx:274-307) replaces the root — the maximum of a
+// valid max-heap — and sifts down, so the VALUES of the heap after an insert are the old ones
+// minus the maximum plus the new one, whatever the layout; labels of one list are distinct and
+// the heap starts empty, so the duplicate test never fires here.  One query per lane, the
+// multiset as 256 counters in the lane's LDS column.
+__global__ __launch_bounds__(64) void shard_first_bound_kernel(
+    const int64_t *__restrict__ probes, const int *__restrict__ slot_prefix,
+    const int *__restrict__ slot_n, int S, int64_t nq, int64_t n_lists,
+    const int *__restrict__ owner, int me, const int *__restrict__ spos,
+    const uint4 *__restrict__ scan, const uint8_t *__restrict__ smins, int R,
+    uint8_t *__restrict__ bound)
+{
+    __shared__ uint16_t hist[256 * 64];
+    const int lane = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x * 64 + lane;
+    if (q >= nq) return;
+    int64_t cl = probes[q * S];
+    if (cl < 0) cl += n_lists;
+    const int p = spos[q * S];
+    uint32_t res = 255;
+    if (owner[cl] == me && p >= 0) {
+        for (int b = 0; b < 255; b++) hist[b * 64 + lane] = 0;
+        hist[255 * 64 + lane] = (uint16_t)R;           // init_heap: R entries of 127
+        int mx = 255;
+        const int nch = slot_prefix[q * (S + 1) + 1] - slot_prefix[q * (S + 1)];
+        int n = slot_n[q * S];
+        n = n < 0 ? 0 : n;
+        for (int c = 0; c < nch; c++) {
+            const uint32_t bnd = (uint32_t)mx;         // bound at block start
+            if (key8(smins[(int64_t)p + c]) >= bnd) continue;
+            const uint4 v = scan[(int64_t)p + c];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t kv = key8(w[j] >> (8 * t));
+                    if (kv < bnd && 16 * c + 4 * j + t < n) {
+                        hist[mx * 64 + lane]--;
+                        hist[kv * 64 + lane]++;
+                        if ((int)kv > mx) mx = (int)kv;
+                        else
+                            while (hist[mx * 64 + lane] == 0) mx--;
+                    }
+                }
+        }
+        res = (uint32_t)mx;
+    }
+    bound[q] = (uint8_t)res;
+}
+
+void tk_launch_shard_first_bound(const int64_t *probes, const int *slot_prefix, const int *slot_n,
+                                 int S, int64_t nq, int64_t n_lists, const int *owner, int me,
+                                 const int *spos, const uint4 *scan, const uint8_t *smins, int R,
+                                 uint8_t *bound, hipStream_t s)
+{
+    if (nq == 0 || S == 0) return;
+    hipLaunchKernelGGL(shard_first_bound_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s,
+                       probes, slot_prefix, slot_n, S, nq, n_lists, owner, me, spos, scan, smins, R,
+                       bound);
+}
+
+// One wave per (query, slot) this rank owns.  PACK = false: blocks that pass -> pair_cnt and
+// the per-destination totals counts[0..W) (and all owned blocks per destination
+// in counts[2W..3W), for the books).  PACK = true: the records, destination by
+// destination (region h starts at counts[0] + .. + counts[h-1]; cursors in counts[W..2W)),
+// in any order inside a region — the header says where a block belongs.
+template <bool PACK>
+__global__ __launch_bounds__(256) void shard_filter_kernel(
+    const int64_t *__restrict__ probes, const int *__restrict__ slot_prefix, int S, int64_t nq,
+    int64_t n_lists, const int *__restrict__ owner, int me, int W, int64_t qh, int64_t cap,
+    const int *__restrict__ spos, const uint4 *__restrict__ scan,
+    const uint8_t *__restrict__ smins, const uint8_t *__restrict__ bound,
+    int *__restrict__ pair_cnt, int *__restrict__ counts, int *__restrict__ rec)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nq * S) return;
+    const int64_t q = i / S;
+    const int sl = (int)(i - q * S);
+    int64_t cl = probes[i];
+    if (cl < 0) cl += n_lists;
+    const int p = spos[i];
+    if (owner[cl] != me || p < 0) {
+        if (!PACK && lane == 0) pair_cnt[i] = 0;
+        return;
+    }
+    const int f0 = slot_prefix[q * (S + 1) + sl];
+    const int nch = slot_prefix[q * (S + 1) + sl + 1] - f0;
+    const uint32_t b = sl == 0 ? 256u : (uint32_t)bound[q];     // the first list travels whole
+    const int h = (int)(q / qh);
+    if (!PACK) {
+        int cnt = 0;
+        for (int c = lane; c < nch; c += 64) cnt += key8(smins[(int64_t)p + c]) < b;
+        for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) {
+            pair_cnt[i] = cnt;
+            if (cnt) atomicAdd(&counts[h], cnt);
+            atomicAdd(&counts[2 * W + h], nch);        // what the dense exchange carries
+        }
+        return;
+    }
+    const int tot = pair_cnt[i];
+    if (tot == 0) return;
+    int base = 0;
+    if (lane == 0) {
+        for (int r = 0; r < h; r++) base += counts[r];
+        base += atomicAdd(&counts[W + h], tot);
+    }
+    base = __shfl(base, 0);
+    const int hdr0 = (int)((q - (int64_t)h * qh) * cap + f0);
+    for (int c0 = 0; c0 < nch; c0 += 64) {
+        const int c = c0 + lane;
+        const bool pass = c < nch && key8(smins[(int64_t)p + c]) < b;
+        const uint64_t m = __ballot(pass);
+        if (pass) {
+            const int at = base + __popcll(m & ((1ull << lane) - 1));
+            const uint4 v = scan[(int64_t)p + c];
+            int *r = rec + (int64_t)at * 5;
+            r[0] = hdr0 + c;
+            r[1] = (int)v.x; r[2] = (int)v.y; r[3] = (int)v.z; r[4] = (int)v.w;
+        }
+        base += __popcll(m);
+    }
+}
+
+void tk_launch_shard_filter(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
+                            int64_t n_lists, const int *owner, int me, int W, int64_t qh,
+                            int64_t cap, const int *spos, const uint4 *scan, const uint8_t *smins,
+                            const uint8_t *bound, int *pair_cnt, int *counts, int *rec,
+                            hipStream_t s)
+{
+    if (nq == 0 || S == 0) return;
+    const unsigned grid = (unsigned)((nq * S + 3) / 4);
+    hipLaunchKernelGGL(shard_filter_kernel<false>, dim3(grid), dim3(256), 0, s, probes, slot_prefix,
+                       S, nq, n_lists, owner, me, W, qh, cap, spos, scan, smins, bound, pair_cnt,
+                       counts, rec);
+    hipLaunchKernelGGL(shard_filter_kernel<true>, dim3(grid), dim3(256), 0, s, probes, slot_prefix,
+                       S, nq, n_lists, owner, me, W, qh, cap, spos, scan, smins, bound, pair_cnt,
+                       counts, rec);
+}
+
+// Home side: rows of the home queries filled with the largest value, then the received blocks
+// dropped where their headers say, with the block minimum the scan would have written.
+__global__ __launch_bounds__(256) void shard_fill_rows_kernel(
+    const int *__restrict__ slot_prefix, int S, uint4 *__restrict__ dist, int64_t cap,
+    uint8_t *__restrict__ mins, int64_t min_stride)
+{
+    const int64_t qi = blockIdx.x;
+    const int len = slot_prefix[qi * (S + 1) + S];
+    const uint4 f = make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu);
+    for (int c = threadIdx.x; c < len; c += 256) dist[qi * cap + c] = f;
+    int64_t ml = ((int64_t)len + 15) / 16 * 16;
+    if (ml > min_stride) ml = min_stride;
+    for (int c = threadIdx.x; c < ml; c += 256) mins[qi * min_stride + c] = 0x7f;
+}
+
+__global__ __launch_bounds__(256) void shard_scatter_kernel(
+    const int *__restrict__ rec, int64_t n_rec, int64_t rows, uint4 *__restrict__ dist,
+    int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride, int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rec) return;
+    const int *r = rec + i * 5;
+    const int64_t hdr = r[0];
+    if (hdr < 0 || hdr >= rows * cap) {            // a record that is not ours: never write it
+        atomicOr(bad, 2);
+        return;
+    }
+    const uint4 v = make_uint4((uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3], (uint32_t)r[4]);
+    dist[hdr] = v;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int m = 127;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int x = (int)(int8_t)((w[j] >> (8 * t)) & 0xffu);
+            m = x < m ? x : m;
+        }
+    const int64_t qi = hdr / cap;
+    mins[qi * min_stride + (hdr - qi * cap)] = (uint8_t)m;
+}
+
+void tk_launch_shard_expand(const int *rec, int64_t n_rec, const int *slot_prefix, int S,
+                            int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,
+                            int64_t min_stride, int *bad, hipStream_t s)
+{
+    if (nq_home == 0 || S == 0) return;
+    hipLaunchKernelGGL(shard_fill_rows_kernel, dim3((unsigned)nq_home), dim3(256), 0, s,
+                       slot_prefix, S, dist, cap, mins, min_stride);
+    if (n_rec > 0)
+        hipLaunchKernelGGL(shard_scatter_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0,
+                           s, rec, n_rec, nq_home, dist, cap, mins, min_stride, bad);
+}

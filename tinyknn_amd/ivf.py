@@ -403,6 +403,27 @@ class DeviceIndex:
             self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0),
             int(capacity), recv_ptr, out_ptr, stream))
 
+    def shard_bound_dev(self, slot, nq, k, n_probes, pass_1, capacity, scan_ptr, bound_ptr, stream=0):
+        """Bound after the first probed list, for the queries whose first list this rank owns
+        (tk_index_shard_bound_dev); the caller min-reduces the bytes over the ranks."""
+        _lib.check(_lib.lib().tk_index_shard_bound_dev(
+            self._h, int(slot), nq, int(k), int(n_probes), int(pass_1 or 0), int(capacity),
+            scan_ptr, bound_ptr, stream))
+
+    def shard_filter_dev(self, slot, nq, k, n_probes, pass_1, capacity, scan_ptr, bound_ptr,
+                         counts_ptr, records_ptr, stream=0):
+        """Blocks below the bound as records grouped by home rank (tk_index_shard_filter_dev)."""
+        _lib.check(_lib.lib().tk_index_shard_filter_dev(
+            self._h, int(slot), nq, int(k), int(n_probes), int(pass_1 or 0), int(capacity),
+            scan_ptr, bound_ptr, counts_ptr, records_ptr, stream))
+
+    def shard_finish_filtered_dev(self, slot, qn_ptr, nq, k, n_probes, pass_1, records_ptr,
+                                  n_records, out_ptr, flag_ptr, stream=0):
+        """Received records -> rows, replay, rescoring (tk_index_shard_finish_filtered_dev)."""
+        _lib.check(_lib.lib().tk_index_shard_finish_filtered_dev(
+            self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0), records_ptr,
+            int(n_records), out_ptr, flag_ptr, stream))
+
     def reserve(self, nq, k, n_probes, pass_1=None):
         _lib.check(_lib.lib().tk_index_reserve(self._h, nq, int(k), int(n_probes), int(pass_1 or 0)))
 

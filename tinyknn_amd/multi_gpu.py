@@ -161,6 +161,27 @@ class _HipShardEngine:
         self.dev.shard_finish_dev(slot, qn.data_ptr(), qn.shape[0], k, n_probes, pass_1, capacity,
                                   recv.data_ptr(), out_home.data_ptr(), stream=st)
 
+    # filtered exchange (tk_index_shard_bound_dev / _filter_dev / _finish_filtered_dev)
+    def bound(self, slot, qn, k, n_probes, pass_1, capacity, scan_buf, bound):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_bound_dev(slot, qn.shape[0], k, n_probes, pass_1, capacity,
+                                 scan_buf.data_ptr(), bound.data_ptr(), stream=st)
+
+    def filter(self, slot, qn, k, n_probes, pass_1, capacity, scan_buf, bound, counts, records):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_filter_dev(slot, qn.shape[0], k, n_probes, pass_1, capacity,
+                                  scan_buf.data_ptr(), bound.data_ptr(), counts.data_ptr(),
+                                  records.data_ptr(), stream=st)
+
+    def finish_filtered(self, slot, qn, k, n_probes, pass_1, records, n_records, out_home, flag):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_finish_filtered_dev(slot, qn.data_ptr(), qn.shape[0], k, n_probes, pass_1,
+                                           records.data_ptr(), n_records, out_home.data_ptr(),
+                                           flag.data_ptr(), stream=st)
+
 
 class ListShardedIndex:
     """One rank of an IVF index whose inverted lists are sharded by cluster id.
@@ -175,11 +196,19 @@ class ListShardedIndex:
     not divided by the world size).  Results are identical to the unsharded index (and to the
     reference) by construction: the home rank replays the same distance rows in the same order.
 
+    `exchange="filtered"`: the bound never increases from one 16-code block to the
+    next, so after the query's FIRST probed list — replayed by its owner, the bound min-reduced
+    over the ranks, 1 byte per query — only the blocks of the later lists with a distance below
+    that bound can matter; they travel as (destination, 16 bytes) records with the splits the
+    ranks exchange first, and the home rank replays rows in which every other block holds the
+    largest value.  Same ids; a fraction of the bytes (bytes_sent / bytes_dense count them);
+    one host synchronisation per batch for the split sizes.
+
     `engine`: object with coarse/scan/finish (default: the HIP engine); tests inject a CPU one.
     """
 
     def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None,
-                 coarse="home", coalesce=1):
+                 coarse="home", coalesce=1, exchange="dense"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -199,6 +228,9 @@ class ListShardedIndex:
         self.depth = depth
         assert coarse in ("home", "replicated")
         self.coarse = coarse
+        assert exchange in ("dense", "filtered")
+        self.exchange = exchange
+        self.bytes_sent = self.bytes_dense = 0      # filtered exchange: records vs whole segments
         # submit() answers `coalesce` consecutive batches as ONE sharded batch: the latency-bound
         # stages (two heap replays of the home queries, three collectives) cost the same for
         # 1250 as for 3750 home queries, so what bounds a rank is batches per second, not queries
@@ -210,6 +242,7 @@ class ListShardedIndex:
         self.capacity = {}          # (nq, n_probes) -> uint4 per region, grows on overflow
         self._bufs = {}
         self._pbufs = {}
+        self._fbufs = {}
         self._calls = 0
         self._streams = ([torch.cuda.Stream() for _ in range(depth)]
                          if self.device == "cuda" and depth > 1 else None)
@@ -235,6 +268,58 @@ class ListShardedIndex:
             o = self.torch.empty(out.shape, dtype=out.dtype)
             self.dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
             out.copy_(o)
+
+    def _all_reduce_min(self, t_):
+        if self.world == 1:
+            return
+        if self.backend == "nccl" or self.device == "cpu":
+            self.dist.all_reduce(t_, op=self.dist.ReduceOp.MIN, group=self.group)
+        else:
+            h = t_.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN, group=self.group)
+            t_.copy_(h)
+
+    def _all_to_all_rows(self, recv, send, rsplit, ssplit):
+        """Variable splits along dim 0."""
+        if self.world == 1:
+            recv.copy_(send)
+        elif self.backend == "nccl" or self.device == "cpu":
+            self.dist.all_to_all_single(recv, send, rsplit, ssplit, group=self.group)
+        else:
+            r = self.torch.empty(recv.shape, dtype=recv.dtype)
+            self.dist.all_to_all_single(r, send.cpu(), rsplit, ssplit, group=self.group)
+            recv.copy_(r)
+
+    def _filtered_buffers(self, slot, nq, capacity):
+        key = (nq, capacity)
+        if self._fbufs.get(slot, (None,))[0] != key:
+            t, W = self.torch, self.world
+            mk = lambda n, dt: t.empty(n, dtype=dt, device=self.device)
+            self._fbufs[slot] = (key, dict(
+                bound=mk(nq, t.uint8), counts=mk(3 * W, t.int32), rcounts=mk(W, t.int32),
+                rec=mk((W * capacity, 5), t.int32), rrec=mk((1024, 5), t.int32)))
+        return self._fbufs[slot][1]
+
+    def _exchange_filtered(self, slot, qn, k, n_probes, pass_1, capacity, b):
+        """send buffer (stays here) -> records of the home queries in f["rrec"][:n]."""
+        W = self.world
+        f = self._filtered_buffers(slot, qn.shape[0], capacity)
+        self.engine.bound(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"])
+        self._all_reduce_min(f["bound"])
+        self.engine.filter(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"],
+                           f["counts"], f["rec"])
+        self._all_to_all(f["rcounts"], f["counts"][:W])
+        cnt = f["counts"].cpu().tolist()                # the one host synchronisation
+        ssplit = cnt[:W]
+        self.bytes_dense += 16 * sum(cnt[2 * W:])
+        rsplit = f["rcounts"].cpu().tolist()
+        n_s, n_r = sum(ssplit), sum(rsplit)
+        if f["rrec"].shape[0] < n_r:
+            f["rrec"] = self.torch.empty((int(1.25 * n_r) + 1024, 5), dtype=self.torch.int32,
+                                         device=self.device)
+        self._all_to_all_rows(f["rrec"][:n_r], f["rec"][:n_s], rsplit, ssplit)
+        self.bytes_sent += 20 * n_s + qn.shape[0] + 4 * W
+        return f["rrec"], n_r
 
     def _buffers(self, slot, nq, k, capacity):
         key = (slot, nq, k, capacity)
@@ -274,8 +359,13 @@ class ListShardedIndex:
                              probes_all=p_all)
         else:
             self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"])
-        self._all_to_all(b["recv"], b["send"])
-        self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, b["recv"], b["home"][:qh * k])
+        if self.exchange == "filtered":
+            rrec, n_r = self._exchange_filtered(slot, qn, k, n_probes, pass_1, capacity, b)
+            self.engine.finish_filtered(slot, qn, k, n_probes, pass_1, rrec, n_r,
+                                        b["home"][:qh * k], b["flag"])
+        else:
+            self._all_to_all(b["recv"], b["send"])
+            self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, b["recv"], b["home"][:qh * k])
         b["home"][qh * k:] = b["flag"]
         self._all_gather(b["all"], b["home"])
         return b["all"].view(self.world, qh * k + 1)
@@ -295,6 +385,8 @@ class ListShardedIndex:
             cap = self._capacity(nq, n_probes)
             g = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
             g = g.cpu().numpy()
+            if (g[:, -1] & 2).any():
+                raise RuntimeError("filtered exchange: a record outside the home rank's rows")
             if not g[:, -1].any():
                 return g[:, :-1].reshape(self.world * qh, k)[:nq]
             worst = qh * min(n_probes, len(self.list_sizes)) * int((self.list_sizes.max() + 15) // 16)
