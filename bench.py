@@ -233,18 +233,38 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     want = want.cpu().numpy()
     co = args.shard_coalesce if args.shard_coalesce > 0 else max(3, world)    # auto: a rank's home share = one batch
     co = max(1, min(co, 131072 // args.nq))
+    kinds = ["dense", "filtered"] if args.shard_exchange == "both" else [args.shard_exchange]
+    res = None
     idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co)
+    for kind in kinds:
+        idx.exchange = kind        # same shard of the index, same buffers; only the exchange differs
+        r = _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind)
+        if res is None:
+            res = r
+        else:
+            res["filtered_exchange"] = {k_: r[k_] for k_ in ("queries_per_s", "ms_per_step",
+                                                             "identical_rows_vs_replica", "exchange")}
+    return res
+
+
+def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind):
+    import torch
+    import torch.distributed as dist
     got = idx.query_prepared(qn_t, qp_t, args.k, args.n_probes)     # also settles the capacity
     same = int((got == want).all(axis=1).sum())
     if co > 1:      # the coalesced batch: settles its capacity, and its rows must repeat `want`
         gotc = idx.query_prepared(torch.cat([qn_t] * co), torch.cat([qp_t] * co), args.k, args.n_probes)
         same = min(same, *[int((gotc[j * args.nq:(j + 1) * args.nq] == want).all(axis=1).sum()) for j in range(co)])
-    for _ in range(max(co, args.warmup)):
+    # every workspace slot must have seen a batch of the timed size before the clock starts: a slot
+    # that grows inside the timed region pays hipMalloc/hipFree of gigabytes there (seen as a 4x
+    # slower leg whenever the untimed calls above had left slot 0 at the single-batch size)
+    for _ in range(-(-max(args.warmup, args.shard_depth * co) // co) * co):
         idx.submit(qn_t, qp_t, args.k, args.n_probes)
     idx.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    idx.bytes_sent = idx.bytes_dense = 0
     t0 = time.perf_counter()
     g = None
     for _ in range(args.steps):
@@ -262,11 +282,20 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     cap = idx.capacity[(args.nq * co, args.n_probes)] if (args.nq * co, args.n_probes) in idx.capacity \
         else idx.capacity[(args.nq, args.n_probes)]
     load = np.bincount(idx.owner, weights=(idx.list_sizes + 15) // 16, minlength=world)
+    filt = {}
+    if kind == "filtered":
+        # measured in the timed steps, this rank: records (20 B per block that travels) + bounds +
+        # counts, against the blocks of whole segments (16 B each, what the dense form needs at least)
+        filt = {"kind": "filtered (bound after the first probed list; blocks below it as 20-byte records)",
+                "record_bytes_per_rank_per_step": int(idx.bytes_sent // args.steps),
+                "whole_segment_bytes_per_rank_per_step": int(idx.bytes_dense // args.steps),
+                "bytes_ratio": round(idx.bytes_sent / max(1, idx.bytes_dense), 4),
+                "host_syncs_per_exchange": 1}
     return {"queries_per_s": args.nq * args.steps / el, "ms_per_step": el / args.steps * 1e3,
             "scaling": "strong (one shared batch of %d queries per step)" % args.nq,
             "identical_rows_vs_replica": same, "rows": args.nq,
             "overflow_in_timed_steps": bool(g is not None and g.cpu().numpy()[:, -1].any()),
-            "exchange": {"all_to_all_bytes_per_rank_per_step": int(world * cap * 16 // co),
+            "exchange": {**filt, "all_to_all_bytes_per_rank_per_step": int(world * cap * 16 // co),
                          "region_capacity_uint4": int(cap),
                          "probe_all_gather_bytes_per_rank_per_step":
                              int(-(-args.nq // world) * min(args.n_probes, len(idx.list_sizes)) * 8)
@@ -504,6 +533,10 @@ def main():
     ap.add_argument("--shard-coalesce", type=int, default=0,
                     help="list-sharded leg: consecutive steps answered as ONE sharded batch (<= 131072 queries); "
                          "0 = max(3, N): a rank's home share is then a whole batch")
+    ap.add_argument("--shard-exchange", choices=["dense", "filtered", "both"], default="dense",
+                    help="list-sharded leg: whole distance segments at fixed positions (no host "
+                         "synchronisation), or SURVEY 8e's filtered records; both: dense is reported, the "
+                         "filtered run beside it")
     ap.add_argument("--shard-coarse", choices=["home", "replicated"], default="home",
                     help="list-sharded leg: coarse stage of the home queries + probe all-gather, or of all "
                          "queries on every rank")

@@ -559,7 +559,7 @@ struct Work {
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
-        c_pair_f0, spos, rpos, smins, pair_cnt;
+        c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally;
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -573,7 +573,7 @@ struct Work {
                        &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
-                       &spos, &rpos, &smins, &pair_cnt};
+                       &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -1735,12 +1735,24 @@ extern "C" int tk_index_shard_filter_dev(tk_index *ix, int slot, int64_t nq, int
     Work &w = ix->works[(size_t)slot];
     TRY(filtered_args(ix, w, nq, capacity));
     hipStream_t st = (hipStream_t)stream;
-    TRY(w.pair_cnt.ensure((size_t)nq * p.S * 4));
+    const int64_t np1 = nq * p.S + 1;
+    ARGCHECK(np1 < (1ll << 31), "too many (query, list) pairs");
+    TRY(w.pair_cnt.ensure((size_t)np1 * 4));
+    TRY(w.pair_off.ensure((size_t)np1 * 4));
+    size_t tmp_bytes = 0;
+    ARGCHECK(tk_scan_exclusive(nullptr, &tmp_bytes, w.pair_cnt.as<int>(), w.pair_off.as<int>(), np1,
+                               st) == 0, "hipcub scan (size query) failed");
+    TRY(w.scan_tmp.ensure(tmp_bytes + 16));
+    TRY(w.tally.ensure((size_t)ix->world * 256 * 4));
+    HIPCHECK(hipMemsetAsync(w.tally.p, 0, (size_t)ix->world * 256 * 4, st));
     HIPCHECK(hipMemsetAsync(counts_dev, 0, (size_t)ix->world * 3 * 4, st));
-    tk_launch_shard_filter(w.shard_probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
-                           ix->owner.as<int>(), ix->rank, ix->world, qh, p.cap, w.spos.as<int>(),
-                           (const uint4 *)scan_dev, w.smins.as<uint8_t>(), bound_dev,
-                           w.pair_cnt.as<int>(), counts_dev, records_dev, st);
+    HIPCHECK(hipMemsetAsync(w.pair_cnt.as<int>() + (np1 - 1), 0, 4, st));
+    if (tk_launch_shard_filter(w.shard_probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
+                               ix->owner.as<int>(), ix->rank, ix->world, qh, p.cap,
+                               w.spos.as<int>(), (const uint4 *)scan_dev, w.smins.as<uint8_t>(),
+                               bound_dev, w.pair_cnt.as<int>(), w.pair_off.as<int>(), w.scan_tmp.p,
+                               tmp_bytes, w.tally.as<int>(), counts_dev, records_dev, st))
+        return fail(TK_ERR_HIP, "hipcub scan failed");
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }

@@ -184,11 +184,14 @@ void tk_launch_shard_first_bound(const int64_t *probes, const int *slot_prefix, 
                                  int S, int64_t nq, int64_t n_lists, const int *owner, int me,
                                  const int *spos, const uint4 *scan, const uint8_t *smins, int R,
                                  uint8_t *bound, hipStream_t s);
-void tk_launch_shard_filter(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
-                            int64_t n_lists, const int *owner, int me, int W, int64_t qh,
-                            int64_t cap, const int *spos, const uint4 *scan, const uint8_t *smins,
-                            const uint8_t *bound, int *pair_cnt, int *counts, int *rec,
-                            hipStream_t s);
+// pair_cnt / pair_off: nq * S + 1 ints (pair_cnt's last entry zeroed by the caller); tmp: room
+// for tk_scan_exclusive over that many; tally: 256 * W ints, zeroed by the caller
+int tk_scan_exclusive(void *tmp, size_t *tmp_bytes, const int *in, int *out, int64_t n, hipStream_t s);
+int tk_launch_shard_filter(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
+                           int64_t n_lists, const int *owner, int me, int W, int64_t qh,
+                           int64_t cap, const int *spos, const uint4 *scan, const uint8_t *smins,
+                           const uint8_t *bound, int *pair_cnt, int *pair_off, void *tmp,
+                           size_t tmp_bytes, int *tally, int *counts, int *rec, hipStream_t s);
 void tk_launch_shard_expand(const int *rec, int64_t n_rec, const int *slot_prefix, int S,
                             int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,
                             int64_t min_stride, int *bad, hipStream_t s);

@@ -190,52 +190,82 @@ __device__ __forceinline__ uint32_t key8(uint32_t b) { return (b ^ 0x80u) & 0xff
 // B1 by value multiset: insert() (_fast_pq.pyx:274-307) replaces the root — the maximum of a
 // valid max-heap — and sifts down, so the VALUES of the heap after an insert are the old ones
 // minus the maximum plus the new one, whatever the layout; labels of one list are distinct and
-// the heap starts empty, so the duplicate test never fires here.  One query per lane, the
-// multiset as 256 counters in the lane's LDS column.
-__global__ __launch_bounds__(64) void shard_first_bound_kernel(
+// the heap starts empty, so the duplicate test never fires here.  One query per wave: the 64
+// lanes fetch 64 blocks' minima and — where a minimum is below the bound so far — distances at
+// once (coalesced, no dependent loads), park them in LDS, and the wave walks them in order
+// with uniform state: 16 lanes test a block's distances, the passing ones enter the multiset —
+// 256 counters in LDS, the count of the current maximum in a register: an insert below the
+// maximum is one ds_add and a decrement.
+__global__ __launch_bounds__(256) void shard_first_bound_kernel(
     const int64_t *__restrict__ probes, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, int S, int64_t nq, int64_t n_lists,
     const int *__restrict__ owner, int me, const int *__restrict__ spos,
     const uint4 *__restrict__ scan, const uint8_t *__restrict__ smins, int R,
     uint8_t *__restrict__ bound)
 {
-    __shared__ uint16_t hist[256 * 64];
-    const int lane = threadIdx.x;
-    const int64_t q = (int64_t)blockIdx.x * 64 + lane;
+    __shared__ uint32_t s_hist[4][256];
+    __shared__ uint4 s_blk[4][64];
+    __shared__ uint32_t s_key[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wv;
     if (q >= nq) return;
     int64_t cl = probes[q * S];
     if (cl < 0) cl += n_lists;
     const int p = spos[q * S];
-    uint32_t res = 255;
-    if (owner[cl] == me && p >= 0) {
-        for (int b = 0; b < 255; b++) hist[b * 64 + lane] = 0;
-        hist[255 * 64 + lane] = (uint16_t)R;           // init_heap: R entries of 127
-        int mx = 255;
-        const int nch = slot_prefix[q * (S + 1) + 1] - slot_prefix[q * (S + 1)];
-        int n = slot_n[q * S];
-        n = n < 0 ? 0 : n;
-        for (int c = 0; c < nch; c++) {
-            const uint32_t bnd = (uint32_t)mx;         // bound at block start
-            if (key8(smins[(int64_t)p + c]) >= bnd) continue;
-            const uint4 v = scan[(int64_t)p + c];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const uint32_t kv = key8(w[j] >> (8 * t));
-                    if (kv < bnd && 16 * c + 4 * j + t < n) {
-                        hist[mx * 64 + lane]--;
-                        hist[kv * 64 + lane]++;
-                        if ((int)kv > mx) mx = (int)kv;
-                        else
-                            while (hist[mx * 64 + lane] == 0) mx--;
-                    }
-                }
-        }
-        res = (uint32_t)mx;
+    if (owner[cl] != me || p < 0) {
+        if (lane == 0) bound[q] = 255;
+        return;
     }
-    bound[q] = (uint8_t)res;
+    uint32_t *hist = s_hist[wv];
+    for (int b = lane; b < 256; b += 64) hist[b] = b == 255 ? (uint32_t)R : 0u;   // init_heap: R x 127
+    const int nch = slot_prefix[q * (S + 1) + 1] - slot_prefix[q * (S + 1)];
+    int n = slot_n[q * S];
+    n = n < 0 ? 0 : n;
+    int mx = 255;                                      // wave-uniform: the bound so far ...
+    uint32_t cm = (uint32_t)R;                         // ... and how many heap entries hold it
+    for (int c0 = 0; c0 < nch; c0 += 64) {
+        const int c = c0 + lane;
+        const uint32_t mk = c < nch ? key8(smins[(int64_t)p + c]) : 255u;
+        s_key[wv][lane] = mk;
+        if (mk < (uint32_t)mx) s_blk[wv][lane] = scan[(int64_t)p + c];
+        // (same wave: LDS traffic is ordered, no barrier needed between the lanes' stores and
+        //  lane 0's loads — but the compiler must not reorder them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // wave-uniform walk over the parked blocks: lanes 0..15 test the 16 distances of a block
+        // at once, the passing ones are inserted in row order with uniform (scalar) state
+        const int lim = nch - c0 < 64 ? nch - c0 : 64;
+        for (int j = 0; j < lim; j++) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_key[wv][j]);
+            if (kj >= (uint32_t)mx) continue;
+            const uint32_t wsel = reinterpret_cast<const uint32_t *>(&s_blk[wv][j])[(lane >> 2) & 3];
+            const uint32_t kv = key8(wsel >> (8 * (lane & 3)));
+            // bound at block start = mx: every lane that passes is inserted without re-check
+            uint64_t mask = __ballot(lane < 16 && kv < (uint32_t)mx && 16 * (c0 + j) + lane < n);
+            while (mask) {
+                const int e = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int kve = __builtin_amdgcn_readlane((int)kv, e);
+                if (kve < mx) {
+                    if (lane == 0) atomicAdd(&hist[kve], 1u);
+                    if (--cm == 0) {
+                        if (lane == 0) hist[mx] = 0;
+                        do {
+                            mx--;
+                            cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)hist[mx]);
+                        } while (cm == 0);
+                    }
+                } else if (kve > mx) {                 // the maximum leaves, kve is the new one
+                    if (lane == 0) hist[mx] = cm - 1;
+                    mx = kve;
+                    cm = 1;
+                }                                      // kve == mx: one out, one in
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) bound[q] = (uint8_t)mx;
 }
 
 void tk_launch_shard_first_bound(const int64_t *probes, const int *slot_prefix, const int *slot_n,
@@ -244,89 +274,123 @@ void tk_launch_shard_first_bound(const int64_t *probes, const int *slot_prefix, 
                                  uint8_t *bound, hipStream_t s)
 {
     if (nq == 0 || S == 0) return;
-    hipLaunchKernelGGL(shard_first_bound_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s,
+    hipLaunchKernelGGL(shard_first_bound_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s,
                        probes, slot_prefix, slot_n, S, nq, n_lists, owner, me, spos, scan, smins, R,
                        bound);
 }
 
-// One wave per (query, slot) this rank owns.  PACK = false: blocks that pass -> pair_cnt and
-// the per-destination totals counts[0..W) (and all owned blocks per destination
-// in counts[2W..3W), for the books).  PACK = true: the records, destination by
-// destination (region h starts at counts[0] + .. + counts[h-1]; cursors in counts[W..2W)),
-// in any order inside a region — the header says where a block belongs.
+// One wave per (query, slot) this rank owns.  PACK = false: blocks that pass -> pair_cnt
+// (0 for pairs of other ranks), all owned blocks -> dense[256][W] partial sums (for the books;
+// spread over 256 addresses: one counter per home rank serialised 75 000 atomics at W = 1).  The pairs
+// are in (query, slot) order and a home rank's queries are consecutive, so an exclusive
+// prefix sum of pair_cnt (tk_scan_exclusive) IS the layout of the records: region h starts at
+// pair_off[h * qh * S].  PACK = true: the records at their pair's offset, in block order.
 template <bool PACK>
 __global__ __launch_bounds__(256) void shard_filter_kernel(
     const int64_t *__restrict__ probes, const int *__restrict__ slot_prefix, int S, int64_t nq,
     int64_t n_lists, const int *__restrict__ owner, int me, int W, int64_t qh, int64_t cap,
     const int *__restrict__ spos, const uint4 *__restrict__ scan,
     const uint8_t *__restrict__ smins, const uint8_t *__restrict__ bound,
-    int *__restrict__ pair_cnt, int *__restrict__ counts, int *__restrict__ rec)
+    int *__restrict__ pair_cnt, const int *__restrict__ pair_off, int *__restrict__ dense,
+    int *__restrict__ rec)
 {
+    __shared__ int s_dense[4];
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= nq * S) return;
-    const int64_t q = i / S;
-    const int sl = (int)(i - q * S);
-    int64_t cl = probes[i];
-    if (cl < 0) cl += n_lists;
-    const int p = spos[i];
-    if (owner[cl] != me || p < 0) {
-        if (!PACK && lane == 0) pair_cnt[i] = 0;
-        return;
+    int mine = 0;                                      // owned blocks of this wave's pair
+    if (i < nq * S) {
+        const int64_t q = i / S;
+        const int sl = (int)(i - q * S);
+        int64_t cl = probes[i];
+        if (cl < 0) cl += n_lists;
+        const int p = spos[i];
+        if (owner[cl] != me || p < 0) {
+            if (!PACK && lane == 0) pair_cnt[i] = 0;
+        } else {
+            const int f0 = slot_prefix[q * (S + 1) + sl];
+            const int nch = slot_prefix[q * (S + 1) + sl + 1] - f0;
+            const uint32_t b = sl == 0 ? 256u : (uint32_t)bound[q];     // the first list travels whole
+            const int h = (int)(q / qh);
+            if (!PACK) {
+                int cnt = 0;
+                for (int c = lane; c < nch; c += 64) cnt += key8(smins[(int64_t)p + c]) < b;
+                for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
+                if (lane == 0) pair_cnt[i] = cnt;
+                mine = nch;
+            } else if (pair_cnt[i] > 0) {
+                int base = pair_off[i];
+                const int hdr0 = (int)((q - (int64_t)h * qh) * cap + f0);
+                for (int c0 = 0; c0 < nch; c0 += 64) {
+                    const int c = c0 + lane;
+                    const bool pass = c < nch && key8(smins[(int64_t)p + c]) < b;
+                    const uint64_t m = __ballot(pass);
+                    if (pass) {
+                        const int at = base + __popcll(m & ((1ull << lane) - 1));
+                        const uint4 v = scan[(int64_t)p + c];
+                        int *r = rec + (int64_t)at * 5;
+                        r[0] = hdr0 + c;
+                        r[1] = (int)v.x; r[2] = (int)v.y; r[3] = (int)v.z; r[4] = (int)v.w;
+                    }
+                    base += __popcll(m);
+                }
+            }
+        }
     }
-    const int f0 = slot_prefix[q * (S + 1) + sl];
-    const int nch = slot_prefix[q * (S + 1) + sl + 1] - f0;
-    const uint32_t b = sl == 0 ? 256u : (uint32_t)bound[q];     // the first list travels whole
-    const int h = (int)(q / qh);
     if (!PACK) {
-        int cnt = 0;
-        for (int c = lane; c < nch; c += 64) cnt += key8(smins[(int64_t)p + c]) < b;
-        for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (lane == 0) {
-            pair_cnt[i] = cnt;
-            if (cnt) atomicAdd(&counts[h], cnt);
-            atomicAdd(&counts[2 * W + h], nch);        // what the dense exchange carries
+        // the four pairs of a workgroup are consecutive: almost always one home rank
+        if (lane == 0) s_dense[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int64_t i0 = (int64_t)blockIdx.x * 4;
+            int acc = 0, hprev = -1;
+            for (int t = 0; t < 4 && i0 + t < nq * S; t++) {
+                const int h = (int)((i0 + t) / S / qh);
+                if (h != hprev && acc) { atomicAdd(&dense[(blockIdx.x & 255) * W + hprev], acc); acc = 0; }
+                hprev = h;
+                acc += s_dense[t];
+            }
+            if (acc) atomicAdd(&dense[(blockIdx.x & 255) * W + hprev], acc);
         }
-        return;
-    }
-    const int tot = pair_cnt[i];
-    if (tot == 0) return;
-    int base = 0;
-    if (lane == 0) {
-        for (int r = 0; r < h; r++) base += counts[r];
-        base += atomicAdd(&counts[W + h], tot);
-    }
-    base = __shfl(base, 0);
-    const int hdr0 = (int)((q - (int64_t)h * qh) * cap + f0);
-    for (int c0 = 0; c0 < nch; c0 += 64) {
-        const int c = c0 + lane;
-        const bool pass = c < nch && key8(smins[(int64_t)p + c]) < b;
-        const uint64_t m = __ballot(pass);
-        if (pass) {
-            const int at = base + __popcll(m & ((1ull << lane) - 1));
-            const uint4 v = scan[(int64_t)p + c];
-            int *r = rec + (int64_t)at * 5;
-            r[0] = hdr0 + c;
-            r[1] = (int)v.x; r[2] = (int)v.y; r[3] = (int)v.z; r[4] = (int)v.w;
-        }
-        base += __popcll(m);
     }
 }
 
-void tk_launch_shard_filter(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
-                            int64_t n_lists, const int *owner, int me, int W, int64_t qh,
-                            int64_t cap, const int *spos, const uint4 *scan, const uint8_t *smins,
-                            const uint8_t *bound, int *pair_cnt, int *counts, int *rec,
-                            hipStream_t s)
+// counts[h] = records for home rank h, from the prefix sums (pair_off has nq * S + 1 entries)
+__global__ void shard_counts_kernel(const int *__restrict__ pair_off, int S, int64_t nq, int W,
+                                    int64_t qh, const int *__restrict__ tally,
+                                    int *__restrict__ counts)
 {
-    if (nq == 0 || S == 0) return;
+    const int h = threadIdx.x + blockIdx.x * blockDim.x;
+    if (h >= W) return;
+    int64_t a = (int64_t)h * qh, b = a + qh;
+    a = a > nq ? nq : a;
+    b = b > nq ? nq : b;
+    counts[h] = pair_off[b * S] - pair_off[a * S];
+    int t = 0;
+    for (int r = 0; r < 256; r++) t += tally[r * W + h];
+    counts[2 * W + h] = t;
+}
+
+int tk_scan_exclusive(void *tmp, size_t *tmp_bytes, const int *in, int *out, int64_t n, hipStream_t s);
+
+int tk_launch_shard_filter(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
+                           int64_t n_lists, const int *owner, int me, int W, int64_t qh,
+                           int64_t cap, const int *spos, const uint4 *scan, const uint8_t *smins,
+                           const uint8_t *bound, int *pair_cnt, int *pair_off, void *tmp,
+                           size_t tmp_bytes, int *tally, int *counts, int *rec, hipStream_t s)
+{
+    if (nq == 0 || S == 0) return 0;
     const unsigned grid = (unsigned)((nq * S + 3) / 4);
     hipLaunchKernelGGL(shard_filter_kernel<false>, dim3(grid), dim3(256), 0, s, probes, slot_prefix,
                        S, nq, n_lists, owner, me, W, qh, cap, spos, scan, smins, bound, pair_cnt,
-                       counts, rec);
+                       (const int *)nullptr, tally, rec);
+    // pair_cnt has one more entry (zero, set by the caller) so that pair_off[nq * S] = total
+    if (tk_scan_exclusive(tmp, &tmp_bytes, pair_cnt, pair_off, nq * S + 1, s)) return -1;
+    hipLaunchKernelGGL(shard_counts_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, s, pair_off,
+                       S, nq, W, qh, tally, counts);
     hipLaunchKernelGGL(shard_filter_kernel<true>, dim3(grid), dim3(256), 0, s, probes, slot_prefix,
                        S, nq, n_lists, owner, me, W, qh, cap, spos, scan, smins, bound, pair_cnt,
-                       counts, rec);
+                       (const int *)pair_off, tally, rec);
+    return 0;
 }
 
 // Home side: rows of the home queries filled with the largest value, then the received blocks

@@ -247,6 +247,7 @@ class ListShardedIndex:
         self._streams = ([torch.cuda.Stream() for _ in range(depth)]
                          if self.device == "cuda" and depth > 1 else None)
         self._pending = []
+        self._deferred = None
 
     # -- collectives (RCCL on device tensors; any other backend is staged through the host)
     def _all_to_all(self, recv, send):
@@ -300,8 +301,8 @@ class ListShardedIndex:
                 rec=mk((W * capacity, 5), t.int32), rrec=mk((1024, 5), t.int32)))
         return self._fbufs[slot][1]
 
-    def _exchange_filtered(self, slot, qn, k, n_probes, pass_1, capacity, b):
-        """send buffer (stays here) -> records of the home queries in f["rrec"][:n]."""
+    def _filtered_front(self, slot, qn, k, n_probes, pass_1, capacity, b):
+        """bound -> min all-reduce -> filter -> all-to-all of the counts (all enqueued)."""
         W = self.world
         f = self._filtered_buffers(slot, qn.shape[0], capacity)
         self.engine.bound(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"])
@@ -309,7 +310,12 @@ class ListShardedIndex:
         self.engine.filter(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"],
                            f["counts"], f["rec"])
         self._all_to_all(f["rcounts"], f["counts"][:W])
-        cnt = f["counts"].cpu().tolist()                # the one host synchronisation
+        return f
+
+    def _filtered_back(self, qn, f):
+        """the one host synchronisation (split sizes), then the records -> f["rrec"][:n]."""
+        W = self.world
+        cnt = f["counts"].cpu().tolist()
         ssplit = cnt[:W]
         self.bytes_dense += 16 * sum(cnt[2 * W:])
         rsplit = f["rcounts"].cpu().tolist()
@@ -345,6 +351,11 @@ class ListShardedIndex:
     def _enqueue(self, qn, qp, k, n_probes, pass_1, capacity):
         """One batch on the current stream; returns the gathered (world, qh*k+1) tensor
         (last column: the rank's overflow flag)."""
+        return self._enqueue_back(self._enqueue_front(qn, qp, k, n_probes, pass_1, capacity))
+
+    def _enqueue_front(self, qn, qp, k, n_probes, pass_1, capacity):
+        """Everything that needs no host decision.  Dense exchange: the whole batch.  Filtered:
+        up to the exchange of the record counts; _enqueue_back reads them and does the rest."""
         nq = qn.shape[0]
         slot = self._calls % self.depth
         self._calls += 1
@@ -359,16 +370,30 @@ class ListShardedIndex:
                              probes_all=p_all)
         else:
             self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"])
+        st = dict(slot=slot, qn=qn, k=k, n_probes=n_probes, pass_1=pass_1, capacity=capacity, b=b,
+                  out=b["all"].view(self.world, qh * k + 1), f=None)
         if self.exchange == "filtered":
-            rrec, n_r = self._exchange_filtered(slot, qn, k, n_probes, pass_1, capacity, b)
-            self.engine.finish_filtered(slot, qn, k, n_probes, pass_1, rrec, n_r,
-                                        b["home"][:qh * k], b["flag"])
+            st["f"] = self._filtered_front(slot, qn, k, n_probes, pass_1, capacity, b)
         else:
             self._all_to_all(b["recv"], b["send"])
             self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, b["recv"], b["home"][:qh * k])
+            self._gather_ids(b, qh, k)
+        return st
+
+    def _gather_ids(self, b, qh, k):
         b["home"][qh * k:] = b["flag"]
         self._all_gather(b["all"], b["home"])
-        return b["all"].view(self.world, qh * k + 1)
+
+    def _enqueue_back(self, st):
+        if st["f"] is not None:
+            b, qn, k = st["b"], st["qn"], st["k"]
+            qh = -(-qn.shape[0] // self.world)
+            rrec, n_r = self._filtered_back(qn, st["f"])
+            self.engine.finish_filtered(st["slot"], qn, k, st["n_probes"], st["pass_1"], rrec, n_r,
+                                        b["home"][:qh * k], b["flag"])
+            self._gather_ids(b, qh, k)
+            st["f"] = None
+        return st["out"]
 
     def _capacity(self, nq, n_probes):
         key = (nq, n_probes)
@@ -381,6 +406,7 @@ class ListShardedIndex:
         Synchronous; repeats the batch with a larger capacity if a region overflowed."""
         nq = qn.shape[0]
         qh = -(-nq // self.world)
+        self._finish_deferred()
         while True:
             cap = self._capacity(nq, n_probes)
             g = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
@@ -433,16 +459,30 @@ class ListShardedIndex:
         t = self.torch
         cap = self._capacity(qn.shape[0], n_probes)
         if self._streams is None:
-            g = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
-        else:
-            st = self._streams[self._calls % self.depth]
-            st.wait_stream(t.cuda.current_stream())
-            with t.cuda.stream(st):
-                g = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
-        return g
+            return self._enqueue(qn, qp, k, n_probes, pass_1, cap)
+        st = self._streams[self._calls % self.depth]
+        st.wait_stream(t.cuda.current_stream())
+        with t.cuda.stream(st):
+            state = self._enqueue_front(qn, qp, k, n_probes, pass_1, cap)
+        # filtered exchange: the host must read this batch's record counts before it can enqueue
+        # the second half — it does so only after the NEXT batch's first half is in the queue
+        # (same order on every rank), so that the device is never idle while the host waits
+        self._finish_deferred()
+        self._deferred = (st, state)
+        if state["f"] is None:
+            self._deferred = None
+        return state["out"]
+
+    def _finish_deferred(self):
+        if self._deferred is not None:
+            st, state = self._deferred
+            self._deferred = None
+            with self.torch.cuda.stream(st):
+                self._enqueue_back(state)
 
     def join(self):
         self._flush()
+        self._finish_deferred()
         if self._streams is not None:
             cur = self.torch.cuda.current_stream()
             for st in self._streams:
