@@ -233,9 +233,18 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     want = want.cpu().numpy()
     co = args.shard_coalesce if args.shard_coalesce > 0 else max(3, world)    # auto: a rank's home share = one batch
     co = max(1, min(co, 131072 // args.nq))
-    kinds = ["dense", "filtered"] if args.shard_exchange == "both" else [args.shard_exchange]
-    res = None
     idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co)
+    if args.shard_exchange == "auto":
+        # the filter drops what is not below the bound after the first list: worth a host
+        # synchronisation per exchange only where a list holds many heaps' worth of rows
+        # (measured at W = 1: 0.36 of the bytes at 1 100-row lists, -15 % queries/s;
+        #  0.21 of the bytes — 0.10 of what the fixed regions carry — at 10 000-row lists, +7 %)
+        sz = idx.list_sizes.astype(np.float64)
+        heap = (args.n_probes + 1) * args.k + 1
+        kinds = ["filtered" if (sz * sz).sum() / max(sz.sum(), 1.0) >= 32 * heap else "dense"]
+    else:
+        kinds = ["dense", "filtered"] if args.shard_exchange == "both" else [args.shard_exchange]
+    res = None
     for kind in kinds:
         idx.exchange = kind        # same shard of the index, same buffers; only the exchange differs
         r = _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind)
@@ -282,7 +291,7 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
     cap = idx.capacity[(args.nq * co, args.n_probes)] if (args.nq * co, args.n_probes) in idx.capacity \
         else idx.capacity[(args.nq, args.n_probes)]
     load = np.bincount(idx.owner, weights=(idx.list_sizes + 15) // 16, minlength=world)
-    filt = {}
+    filt = {"kind": "dense (whole segments at fixed positions, no host synchronisation)"}
     if kind == "filtered":
         # measured in the timed steps, this rank: records (20 B per block that travels) + bounds +
         # counts, against the blocks of whole segments (16 B each, what the dense form needs at least)
@@ -533,10 +542,11 @@ def main():
     ap.add_argument("--shard-coalesce", type=int, default=0,
                     help="list-sharded leg: consecutive steps answered as ONE sharded batch (<= 131072 queries); "
                          "0 = max(3, N): a rank's home share is then a whole batch")
-    ap.add_argument("--shard-exchange", choices=["dense", "filtered", "both"], default="dense",
+    ap.add_argument("--shard-exchange", choices=["auto", "dense", "filtered", "both"], default="auto",
                     help="list-sharded leg: whole distance segments at fixed positions (no host "
                          "synchronisation), or SURVEY 8e's filtered records; both: dense is reported, the "
-                         "filtered run beside it")
+                         "filtered run beside it; auto: filtered where the lists are long against the heap "
+                         "(size-weighted mean list >= 32 heap sizes: the 100M workload), dense otherwise")
     ap.add_argument("--shard-coarse", choices=["home", "replicated"], default="home",
                     help="list-sharded leg: coarse stage of the home queries + probe all-gather, or of all "
                          "queries on every rank")
