@@ -436,6 +436,11 @@ int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_
                               int n_probes, int pass_1, int64_t capacity, const void *recv_dev,
                               int64_t *out_ids_home_dev, void *stream);
 
+/* Longest (source -> home) stream of the slot's last tk_index_shard_scan_dev in uint4, fitted or
+ * not: max-reduce it over the ranks and size `capacity` by it (the regions of the dense exchange
+ * travel whole).  Synchronises with the device. */
+int tk_index_shard_usage(tk_index *ix, int slot, int64_t *max_stream_uint4);
+
 /* Filtered exchange — the same batch with a fraction of the bytes on
  * the links.  Every insert of a 16-code block is below the bound captured at the block's start
  * (_fast_pq_256.pyx:73,111-123), so the bound never increases from block to block: a distance

@@ -59,6 +59,8 @@ class OracleShardEngine:
             got[got < 0] += self.ox.n_lists
             np.testing.assert_array_equal(got, probes)
         src, pos = shard_positions(probes, self.chunks, self.owner, self.world, capacity)
+        _, free = shard_positions(probes, self.chunks, self.owner, self.world, 10 ** 12)
+        self.last_usage = int((free + self.chunks[probes]).max()) if probes.size else 0
         buf = send.numpy().reshape(self.world, capacity * 16)
         buf[:] = 0xAB                               # stale bytes must never be consumed
         qh = -(-len(qn) // self.world)
@@ -88,6 +90,10 @@ class OracleShardEngine:
                 got = buf[src[i, s], pos[i, s] * 16: pos[i, s] * 16 + len(seg)]
                 np.testing.assert_array_equal(got, seg)
             out[i - self.rank * qh] = self.ox.query_batch(qn[i:i + 1], k, n_probes, pass_1)[0]
+
+    def usage(self, slot):
+        """longest stream of the last scan, fitted or not (tk_index_shard_usage)"""
+        return self.last_usage
 
     # ---- filtered exchange (SURVEY §8e): same three calls as the HIP engine
     def _heap_size(self, k, n_probes, pass_1):

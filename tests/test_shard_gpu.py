@@ -81,6 +81,8 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
             e.finish(0, qn_t, k, n_probes, pass_1, capacity, recv, out)
             homes.append(out.view(qh, k))
     torch.cuda.synchronize()
+    if stats is not None:
+        stats["usage"] = max(e.usage(0) for e in engines)
     ids = torch.cat(homes).cpu().numpy()
     assert (ids[nq:] == -1).all()
     for e in engines:
@@ -124,7 +126,8 @@ def test_sharded_overflow_is_flagged_and_harmless():
     g = golden("g6_ivf_an100.npz")
     ivf = ivf_from_fixture(None, g)
     world, n_probes = 2, 5
-    ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, capacity=4)
+    st = {}
+    ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, capacity=4, stats=st)
     assert flags.any()
     owner = shard_lists(g["list_sizes"], world)
     chunks = (g["list_sizes"] + 15) // 16
@@ -132,6 +135,7 @@ def test_sharded_overflow_is_flagged_and_harmless():
     probes[probes < 0] += len(chunks)
     src, pos = shard_positions(probes, chunks, owner, world, 10 ** 9)
     exact = int((pos + chunks[probes]).max())
+    assert st["usage"] == exact          # tk_index_shard_usage: the longest stream, fitted or not
     ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, capacity=exact)
     assert not flags.any()
     np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
@@ -223,9 +227,15 @@ def test_sharded_world1_public_class():
     ivf = ivf_from_fixture(None, g)
     idx = ListShardedIndex(ivf)
     np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=5), g["ids_p5"])
-    idx.capacity[(len(g["qs"]), 10)] = 2           # overflow -> repeated with more room
+    idx.capacity[(len(g["qs"]), 10)] = 2           # overflow -> repeated with room for the longest stream
     np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=10), g["ids_p10"])
-    assert idx.capacity[(len(g["qs"]), 10)] > 2
+    cap = idx.capacity[(len(g["qs"]), 10)]
+    assert cap > 2
+    np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=10), g["ids_p10"])
+    assert idx.capacity[(len(g["qs"]), 10)] == cap                         # settled
+    idx.capacity[(len(g["qs"]), 5)] = 10 ** 6      # far too roomy -> trimmed to 1.25 x the longest stream
+    np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=5), g["ids_p5"])
+    assert idx.capacity[(len(g["qs"]), 5)] < 10 ** 6 // 2
 
 
 def _gloo_gpu_worker(rank, world, port, ret, exchange):

@@ -73,6 +73,7 @@ SIGNATURES = {
     "tk_index_shard_finish_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                             C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                             C.c_void_p]),
+    "tk_index_shard_usage": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "tk_index_shard_bound_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_shard_filter_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,

@@ -559,7 +559,7 @@ struct Work {
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
-        c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally;
+        c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage;
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -573,7 +573,7 @@ struct Work {
                        &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
-                       &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally};
+                       &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -1654,6 +1654,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     hipStream_t st = (hipStream_t)stream;
     TRY(reserve_shard(ix, w, nq, qh, p));
     TRY(w.smins.ensure((size_t)ix->world * capacity + 16));
+    TRY(w.usage.ensure((size_t)ix->world * 2 * 8));
     Prof pf;
     const int *owner = ix->owner.as<int>();
     const int64_t *probes = probes_all_dev;
@@ -1670,7 +1671,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     }
     tk_launch_shard_positions(probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
                               owner, ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
-                              w.rpos.as<int>(), flag_dev, st);
+                              w.rpos.as<int>(), flag_dev, w.usage.as<long long>(), st);
     tk_launch_pairs_scan(w.u_count.as<int>(), ix->local_chunk_off.as<int64_t>(), ix->n_lists,
                          w.u_pair_off.as<int>(), w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
                          w.u_pair_q.as<int>(), st);
@@ -1687,6 +1688,25 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     w.shard_nq = nq;
     w.shard_capacity = capacity;
     HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+// Longest (source -> home) stream of the slot's last tk_index_shard_scan_dev, in uint4, whether
+// it fitted the regions or not: what a caller sizes `capacity` by (max-reduce it over the ranks).
+// Synchronises with the device.
+extern "C" int tk_index_shard_usage(tk_index *ix, int slot, int64_t *max_stream_uint4)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix && ix->sharded && max_stream_uint4, "sharded index and an output pointer");
+    ARGCHECK(slot >= 0 && slot < ix->depth, "slot must be < the pipeline depth");
+    Work &w = ix->works[(size_t)slot];
+    ARGCHECK(w.shard_probes && w.usage.p, "tk_index_shard_scan_dev of this slot comes first");
+    std::vector<long long> u((size_t)ix->world * 2);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(u.data(), w.usage.p, u.size() * 8, hipMemcpyDeviceToHost));
+    long long m = 0;
+    for (long long x : u) m = x > m ? x : m;
+    *max_stream_uint4 = m;
     return TK_OK;
 }
 

@@ -169,7 +169,8 @@ void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_l
 // home rank of query i = i / qh.  spos: (nq, S), rpos: (qh, S); *flag |= 1 on overflow.
 void tk_launch_shard_positions(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
                                int64_t n_lists, const int *owner, int me, int W, int64_t qh,
-                               int64_t C, int *spos, int *rpos, int *flag, hipStream_t s);
+                               int64_t C, int *spos, int *rpos, int *flag, long long *usage,
+                               hipStream_t s);   // usage: 2 * W stream lengths (uint4) or NULL
 void tk_launch_shard_pairs_fill(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
                                 const int *owner, int me, const int *spos, const int *pair_off,
                                 int *cursor, int *pair_q, int *pair_f0, hipStream_t s);

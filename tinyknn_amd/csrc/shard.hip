@@ -21,7 +21,8 @@
 __global__ __launch_bounds__(1024) void shard_positions_kernel(
     const int64_t *__restrict__ probes, const int *__restrict__ slot_prefix, int S, int64_t nq,
     int64_t n_lists, const int *__restrict__ owner, int me, int W, int64_t qh, int64_t C,
-    int *__restrict__ spos, int *__restrict__ rpos, int *__restrict__ flag)
+    int *__restrict__ spos, int *__restrict__ rpos, int *__restrict__ flag,
+    long long *__restrict__ usage)
 {
     __shared__ int s_v[1024];
     __shared__ int64_t carry;
@@ -85,15 +86,18 @@ __global__ __launch_bounds__(1024) void shard_positions_kernel(
         if (threadIdx.x == 1023) carry += s_v[1023];
         __syncthreads();
     }
+    // length of this stream in uint4, fitting or not: what the caller sizes the regions by
+    if (threadIdx.x == 0 && usage) usage[blockIdx.x] = carry;
 }
 
 void tk_launch_shard_positions(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
                                int64_t n_lists, const int *owner, int me, int W, int64_t qh,
-                               int64_t C, int *spos, int *rpos, int *flag, hipStream_t s)
+                               int64_t C, int *spos, int *rpos, int *flag, long long *usage,
+                               hipStream_t s)
 {
     if (nq == 0 || S == 0) return;
     hipLaunchKernelGGL(shard_positions_kernel, dim3(2 * W), dim3(1024), 0, s, probes, slot_prefix,
-                       S, nq, n_lists, owner, me, W, qh, C, spos, rpos, flag);
+                       S, nq, n_lists, owner, me, W, qh, C, spos, rpos, flag, usage);
 }
 
 // (query, slot) records of the lists this rank owns, grouped by list, for the list-major

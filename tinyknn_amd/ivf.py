@@ -403,6 +403,13 @@ class DeviceIndex:
             self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0),
             int(capacity), recv_ptr, out_ptr, stream))
 
+    def shard_usage(self, slot):
+        """Longest stream (uint4) of the slot's last shard_scan_dev (tk_index_shard_usage; syncs)."""
+        import ctypes
+        v = ctypes.c_int64(0)
+        _lib.check(_lib.lib().tk_index_shard_usage(self._h, int(slot), ctypes.byref(v)))
+        return int(v.value)
+
     def shard_bound_dev(self, slot, nq, k, n_probes, pass_1, capacity, scan_ptr, bound_ptr, stream=0):
         """Bound after the first probed list, for the queries whose first list this rank owns
         (tk_index_shard_bound_dev); the caller min-reduces the bytes over the ranks."""

@@ -161,6 +161,9 @@ class _HipShardEngine:
         self.dev.shard_finish_dev(slot, qn.data_ptr(), qn.shape[0], k, n_probes, pass_1, capacity,
                                   recv.data_ptr(), out_home.data_ptr(), stream=st)
 
+    def usage(self, slot):
+        return self.dev.shard_usage(slot)
+
     # filtered exchange (tk_index_shard_bound_dev / _filter_dev / _finish_filtered_dev)
     def bound(self, slot, qn, k, n_probes, pass_1, capacity, scan_buf, bound):
         import torch
@@ -208,7 +211,7 @@ class ListShardedIndex:
     """
 
     def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None,
-                 coarse="home", coalesce=1, exchange="dense"):
+                 coarse="home", coalesce=1, exchange="dense", calibrate=True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -230,6 +233,7 @@ class ListShardedIndex:
         self.coarse = coarse
         assert exchange in ("dense", "filtered")
         self.exchange = exchange
+        self.calibrate = calibrate
         self.bytes_sent = self.bytes_dense = 0      # filtered exchange: records vs whole segments
         # submit() answers `coalesce` consecutive batches as ONE sharded batch: the latency-bound
         # stages (two heap replays of the home queries, three collectives) cost the same for
@@ -401,23 +405,43 @@ class ListShardedIndex:
             self.capacity[key] = shard_capacity(self.list_sizes, self.owner, self.world, nq, n_probes)
         return self.capacity[key]
 
+    def _usage(self, slot):
+        """Longest (source -> home) stream of the slot's last batch over all ranks, in uint4
+        (None if the engine does not report it)."""
+        if not hasattr(self.engine, "usage"):
+            return None
+        u = int(self.engine.usage(slot))
+        if self.world > 1:
+            t_ = self.torch.tensor([u], dtype=self.torch.int64,
+                                   device=self.device if self.backend == "nccl" else "cpu")
+            self.dist.all_reduce(t_, op=self.dist.ReduceOp.MAX, group=self.group)
+            u = int(t_.item())
+        return u
+
     def query_prepared(self, qn, qp, k, n_probes=1, pass_1=None):
         """qn / qp: tensors on the engine's device (normalised queries, table-build queries).
-        Synchronous; repeats the batch with a larger capacity if a region overflowed."""
+        Synchronous; repeats the batch with a larger capacity if a region overflowed, and
+        trims the capacity to 1.25 x the longest stream seen (the regions of the dense exchange
+        travel whole: the a-priori estimate carries ~2x the bytes the segments need)."""
         nq = qn.shape[0]
         qh = -(-nq // self.world)
         self._finish_deferred()
         while True:
             cap = self._capacity(nq, n_probes)
+            slot = self._calls % self.depth
             g = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
             g = g.cpu().numpy()
             if (g[:, -1] & 2).any():
                 raise RuntimeError("filtered exchange: a record outside the home rank's rows")
+            need = self._usage(slot)
             if not g[:, -1].any():
+                if need is not None and self.calibrate and int(1.25 * need) + 64 < 0.8 * cap:
+                    self.capacity[(nq, n_probes)] = int(1.25 * need) + 64
                 return g[:, :-1].reshape(self.world * qh, k)[:nq]
             worst = qh * min(n_probes, len(self.list_sizes)) * int((self.list_sizes.max() + 15) // 16)
             assert cap < worst, "overflow at the worst-case capacity"
-            self.capacity[(nq, n_probes)] = min(2 * cap, worst)
+            grow = 2 * cap if need is None else max(int(1.25 * need) + 64, cap + 1)
+            self.capacity[(nq, n_probes)] = min(grow, worst)
 
     def query_batch(self, qs, k, n_probes=1, pass_1=None):
         """Every rank passes the same (nq, d) batch and receives all (nq, k) ids
