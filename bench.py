@@ -235,13 +235,8 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     co = max(1, min(co, 131072 // args.nq))
     idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co)
     if args.shard_exchange == "auto":
-        # the filter drops what is not below the bound after the first list: worth a host
-        # synchronisation per exchange only where a list holds many heaps' worth of rows
-        # (measured at W = 1: 0.36 of the bytes at 1 100-row lists, -15 % queries/s;
-        #  0.21 of the bytes — 0.10 of what the fixed regions carry — at 10 000-row lists, +7 %)
-        sz = idx.list_sizes.astype(np.float64)
-        heap = (args.n_probes + 1) * args.k + 1
-        kinds = ["filtered" if (sz * sz).sum() / max(sz.sum(), 1.0) >= 32 * heap else "dense"]
+        idx.exchange = "auto"          # ListShardedIndex._exchange_kind: filtered where lists are long
+        kinds = [idx._exchange_kind(args.k, args.n_probes, None)]
     else:
         kinds = ["dense", "filtered"] if args.shard_exchange == "both" else [args.shard_exchange]
     res = None
