@@ -559,7 +559,7 @@ struct Work {
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
-        c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage;
+        c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage, pos_lens, pos_off;
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -573,7 +573,7 @@ struct Work {
                        &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
-                       &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage};
+                       &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage, &pos_lens, &pos_off};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -1669,9 +1669,23 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf));
         probes = w.probes.as<int64_t>();
     }
-    tk_launch_shard_positions(probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists,
-                              owner, ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
-                              w.rpos.as<int>(), flag_dev, w.usage.as<long long>(), st);
+    {
+        const int64_t n1 = nq * p.S + (int64_t)ix->world * qh * p.S + 1;
+        ARGCHECK(n1 < (1ll << 31), "too many (query, list) entries for one sharded batch");
+        TRY(w.pos_lens.ensure((size_t)n1 * 8));
+        TRY(w.pos_off.ensure((size_t)n1 * 8));
+        size_t tmp_bytes = 0;
+        ARGCHECK(tk_scan_exclusive64(nullptr, &tmp_bytes, w.pos_lens.as<long long>(),
+                                     w.pos_off.as<long long>(), n1, st) == 0,
+                 "hipcub scan (size query) failed");
+        TRY(w.scan_tmp.ensure(tmp_bytes + 16));
+        if (tk_launch_shard_positions(probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists, owner,
+                                      ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
+                                      w.rpos.as<int>(), flag_dev, w.usage.as<long long>(),
+                                      w.pos_lens.as<long long>(), w.pos_off.as<long long>(),
+                                      w.scan_tmp.p, tmp_bytes, st))
+            return fail(TK_ERR_HIP, "hipcub scan failed");
+    }
     tk_launch_pairs_scan(w.u_count.as<int>(), ix->local_chunk_off.as<int64_t>(), ix->n_lists,
                          w.u_pair_off.as<int>(), w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
                          w.u_pair_q.as<int>(), st);

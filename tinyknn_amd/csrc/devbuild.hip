@@ -123,6 +123,15 @@ int tk_scan_exclusive(void *tmp, size_t *tmp_bytes, const int *in, int *out, int
     return e == hipSuccess ? 0 : -1;
 }
 
+int tk_scan_exclusive64(void *tmp, size_t *tmp_bytes, const long long *in, long long *out, int64_t n,
+                        hipStream_t s)
+{
+    size_t bytes = *tmp_bytes;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, s);
+    *tmp_bytes = bytes;
+    return e == hipSuccess ? 0 : -1;
+}
+
 __global__ void widen_ids_kernel(const int *__restrict__ rows, int64_t n, int64_t *__restrict__ ids)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

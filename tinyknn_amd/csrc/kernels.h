@@ -167,10 +167,15 @@ void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_l
 // ---- list-sharded index (shard.hip) ----
 // positions of the (query, slot) segments in the all-to-all buffers: W regions of C uint4;
 // home rank of query i = i / qh.  spos: (nq, S), rpos: (qh, S); *flag |= 1 on overflow.
-void tk_launch_shard_positions(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
-                               int64_t n_lists, const int *owner, int me, int W, int64_t qh,
-                               int64_t C, int *spos, int *rpos, int *flag, long long *usage,
-                               hipStream_t s);   // usage: 2 * W stream lengths (uint4) or NULL
+// lens / P: nq*S + W*qh*S + 1 int64 each; tmp: room for tk_scan_exclusive64 over that many;
+// usage: 2 * W stream lengths (uint4) or NULL.  Returns -1 if the prefix sum could not run.
+int tk_scan_exclusive64(void *tmp, size_t *tmp_bytes, const long long *in, long long *out, int64_t n,
+                        hipStream_t s);
+int tk_launch_shard_positions(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
+                              int64_t n_lists, const int *owner, int me, int W, int64_t qh,
+                              int64_t C, int *spos, int *rpos, int *flag, long long *usage,
+                              long long *lens, long long *P, void *tmp, size_t tmp_bytes,
+                              hipStream_t s);
 void tk_launch_shard_pairs_fill(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
                                 const int *owner, int me, const int *spos, const int *pair_off,
                                 int *cursor, int *pair_q, int *pair_f0, hipStream_t s);

@@ -14,90 +14,121 @@
 // C raises `flag`; the caller then repeats the batch with a larger C.
 #include "kernels.h"
 
-// blockIdx.x < W: sender role, stream me -> peer.   spos (nq*S): position in the send
-//                 buffer of every slot I own (region = peer), -1 otherwise.
-// blockIdx.x >= W: receiver role, stream peer -> me.   rpos (qh*S): position in the
-//                 receive buffer of the slots of MY queries that peer owns (region = peer).
-__global__ __launch_bounds__(1024) void shard_positions_kernel(
-    const int64_t *__restrict__ probes, const int *__restrict__ slot_prefix, int S, int64_t nq,
-    int64_t n_lists, const int *__restrict__ owner, int me, int W, int64_t qh, int64_t C,
-    int *__restrict__ spos, int *__restrict__ rpos, int *__restrict__ flag,
-    long long *__restrict__ usage)
+// Entry i < nq*S: sender role — (query i/S, slot i%S), owned if the list is mine.
+// Entry nq*S + p*qh*S + e: receiver role — entry e of MY home queries, owned if peer p has it.
+// One exclusive prefix sum over the owned lengths of all entries (tk_scan_exclusive) gives every
+// stream's running offset: a stream's entries are consecutive, so offset = P[i] - P[first entry
+// of the stream].  (Round 1 walked each stream with ONE workgroup: 0.5 ms for the 300 000
+// entries of a 30 000-query batch at W = 1, a fifth of the batch.)
+__device__ __forceinline__ bool shard_entry(int64_t i, const int64_t *__restrict__ probes,
+                                            const int *__restrict__ slot_prefix, int S, int64_t nq,
+                                            int64_t n_lists, const int *__restrict__ owner, int me,
+                                            int64_t qh, int64_t &qi, int &sl, int &len)
 {
-    __shared__ int s_v[1024];
-    __shared__ int64_t carry;
-    const bool sender = (int)blockIdx.x < W;
-    const int peer = sender ? (int)blockIdx.x : (int)blockIdx.x - W;
-    const int home = sender ? peer : me;
-    const int own = sender ? me : peer;
-    const int64_t q0 = (int64_t)home * qh;
-    int64_t q1 = q0 + qh;
-    if (q1 > nq) q1 = nq;
-    const int64_t n_e = q1 > q0 ? (q1 - q0) * S : 0;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    // 8 consecutive entries per thread: a serial prefix inside the thread, one block-wide
-    // scan of the 1024 thread sums per 8192 entries (at W = 1 a stream is nq * S = 10^5
-    // entries long: 98 block scans of 1024 became 13)
-    constexpr int PER = 8;
-    for (int64_t base = 0; base < n_e; base += 1024 * PER) {
-        int c[PER];
-        bool mine[PER];
-        int tot = 0;
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int64_t e = base + (int64_t)threadIdx.x * PER + u;
-            c[u] = 0;
-            mine[u] = false;
-            if (e < n_e) {
-                const int64_t qi = q0 + e / S;
-                const int sl = (int)(e % S);
-                int64_t cl = probes[qi * S + sl];
-                if (cl < 0) cl += n_lists;
-                mine[u] = owner[cl] == own;
-                if (mine[u]) c[u] = slot_prefix[qi * (S + 1) + sl + 1] - slot_prefix[qi * (S + 1) + sl];
-            }
-            tot += c[u];
-        }
-        s_v[threadIdx.x] = tot;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan of the thread sums
-            int v = threadIdx.x >= (unsigned)o ? s_v[threadIdx.x - o] : 0;
-            __syncthreads();
-            s_v[threadIdx.x] += v;
-            __syncthreads();
-        }
-        int64_t run = carry + s_v[threadIdx.x] - tot;
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int64_t e = base + (int64_t)threadIdx.x * PER + u;
-            if (e < n_e) {
-                const int64_t qi = q0 + e / S;
-                const int sl = (int)(e % S);
-                const bool fits = run + c[u] <= C;
-                const int where = fits ? (int)((int64_t)peer * C + run) : -1;
-                if (sender) spos[qi * S + sl] = mine[u] ? where : -1;
-                else if (mine[u]) rpos[(qi - q0) * S + sl] = where;
-                if (mine[u] && !fits) atomicOr(flag, 1);
-            }
-            run += c[u];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += s_v[1023];
-        __syncthreads();
+    const int64_t n_s = nq * S;
+    int own;
+    if (i < n_s) {
+        qi = i / S;
+        sl = (int)(i - qi * S);
+        own = me;
+    } else {
+        const int64_t j = i - n_s;
+        own = (int)(j / (qh * S));
+        const int64_t e = j - (int64_t)own * qh * S;
+        qi = (int64_t)me * qh + e / S;
+        sl = (int)(e % S);
     }
-    // length of this stream in uint4, fitting or not: what the caller sizes the regions by
-    if (threadIdx.x == 0 && usage) usage[blockIdx.x] = carry;
+    len = 0;
+    if (qi >= nq) return false;
+    int64_t cl = probes[qi * S + sl];
+    if (cl < 0) cl += n_lists;
+    if (owner[cl] != own) return false;
+    len = slot_prefix[qi * (S + 1) + sl + 1] - slot_prefix[qi * (S + 1) + sl];
+    return true;
 }
 
-void tk_launch_shard_positions(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
-                               int64_t n_lists, const int *owner, int me, int W, int64_t qh,
-                               int64_t C, int *spos, int *rpos, int *flag, long long *usage,
-                               hipStream_t s)
+__global__ void shard_lens_kernel(const int64_t *__restrict__ probes,
+                                  const int *__restrict__ slot_prefix, int S, int64_t nq,
+                                  int64_t n_lists, const int *__restrict__ owner, int me, int W,
+                                  int64_t qh, long long *__restrict__ lens)
 {
-    if (nq == 0 || S == 0) return;
-    hipLaunchKernelGGL(shard_positions_kernel, dim3(2 * W), dim3(1024), 0, s, probes, slot_prefix,
-                       S, nq, n_lists, owner, me, W, qh, C, spos, rpos, flag, usage);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_tot = nq * S + (int64_t)W * qh * S;
+    if (i > n_tot) return;
+    int64_t qi;
+    int sl, len = 0;
+    if (i < n_tot) shard_entry(i, probes, slot_prefix, S, nq, n_lists, owner, me, qh, qi, sl, len);
+    lens[i] = len;                                     // entry n_tot: 0, so that P[n_tot] = total
+}
+
+// spos (nq*S): position in the send buffer of every slot I own (region = home rank), -1
+// otherwise.  rpos (qh*S): position in the receive buffer of the slots of MY queries
+// (region = owner).  usage[0..W): lengths of my send streams, [W..2W): of my receive streams.
+__global__ void shard_place_kernel(const int64_t *__restrict__ probes,
+                                   const int *__restrict__ slot_prefix, int S, int64_t nq,
+                                   int64_t n_lists, const int *__restrict__ owner, int me, int W,
+                                   int64_t qh, int64_t C, const long long *__restrict__ P,
+                                   int *__restrict__ spos, int *__restrict__ rpos,
+                                   int *__restrict__ flag, long long *__restrict__ usage)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_s = nq * S, seg = qh * S, n_tot = n_s + (int64_t)W * seg;
+    if (i < 2 * W && usage) {
+        int64_t a, b;
+        if (i < W) {
+            a = i * seg;
+            b = a + seg;
+            a = a > n_s ? n_s : a;
+            b = b > n_s ? n_s : b;
+        } else {
+            a = n_s + (i - W) * seg;
+            b = a + seg;
+        }
+        usage[i] = P[b] - P[a];
+    }
+    if (i >= n_tot) return;
+    int64_t qi;
+    int sl, len;
+    const bool mine = shard_entry(i, probes, slot_prefix, S, nq, n_lists, owner, me, qh, qi, sl, len);
+    if (i < n_s) {
+        int where = -1;
+        if (mine) {
+            const int64_t h = qi / qh;
+            int64_t a = h * seg;
+            a = a > n_s ? n_s : a;
+            const int64_t run = P[i] - P[a];
+            if (run + len <= C) where = (int)(h * C + run);
+            else atomicOr(flag, 1);
+        }
+        spos[i] = where;
+    } else if (mine) {
+        const int64_t peer = (i - n_s) / seg;
+        const int64_t run = P[i] - P[n_s + peer * seg];
+        if (run + len <= C) rpos[(qi - (int64_t)me * qh) * S + sl] = (int)(peer * C + run);
+        else {
+            rpos[(qi - (int64_t)me * qh) * S + sl] = -1;
+            atomicOr(flag, 1);
+        }
+    }
+}
+
+// lens / P: nq*S + W*qh*S + 1 int64 each (a batch may score more than 2^31 blocks in
+// total); tmp: room for tk_scan_exclusive64 over that many
+int tk_launch_shard_positions(const int64_t *probes, const int *slot_prefix, int S, int64_t nq,
+                              int64_t n_lists, const int *owner, int me, int W, int64_t qh,
+                              int64_t C, int *spos, int *rpos, int *flag, long long *usage,
+                              long long *lens, long long *P, void *tmp, size_t tmp_bytes,
+                              hipStream_t s)
+{
+    if (nq == 0 || S == 0) return 0;
+    const int64_t n1 = nq * S + (int64_t)W * qh * S + 1;
+    const unsigned grid = (unsigned)((n1 + 255) / 256);
+    hipLaunchKernelGGL(shard_lens_kernel, dim3(grid), dim3(256), 0, s, probes, slot_prefix, S, nq,
+                       n_lists, owner, me, W, qh, lens);
+    if (tk_scan_exclusive64(tmp, &tmp_bytes, lens, P, n1, s)) return -1;
+    hipLaunchKernelGGL(shard_place_kernel, dim3(grid), dim3(256), 0, s, probes, slot_prefix, S, nq,
+                       n_lists, owner, me, W, qh, C, P, spos, rpos, flag, usage);
+    return 0;
 }
 
 // (query, slot) records of the lists this rank owns, grouped by list, for the list-major
