@@ -11,7 +11,15 @@ qs = bench.synth_queries(cent, 10000, 110)
 qn, qp = ivf._prepare(qs.copy())
 want = ivf.device_index().query_batch(qn, qp, 10, 10)
 for W in (8, 4):
-    t = time.time()
-    ids, flags, cap = simulate_world(ivf, W, qn, qp, 10, 10)
-    print(f"W={W}: capacity {cap} uint4 per region ({W * cap * 16 / 1e6:.1f} MB all-to-all per rank), overflow flags {flags.tolist()}, "
-          f"identical rows {int((ids == want).all(axis=1).sum())}/10000, {time.time() - t:.1f}s")
+    for ex in ("dense", "filtered"):
+        t = time.time()
+        st = {}
+        ids, flags, cap = simulate_world(ivf, W, qn, qp, 10, 10, exchange=ex, stats=st)
+        extra = ""
+        if ex == "filtered":
+            extra = (f", records {st['records']} x 20 B = {st['records'] * 20 / W / 1e6:.2f} MB per rank against "
+                     f"{st['dense_blocks'] * 16 / W / 1e6:.2f} MB of whole segments")
+        print(f"W={W} {ex}: capacity {cap} uint4 per region ({W * cap * 16 / 1e6:.1f} MB all-to-all per rank a priori, "
+              f"longest stream {st['usage']} uint4 -> {W * int(1.25 * st['usage']) * 16 / 1e6:.1f} MB trimmed), "
+              f"overflow flags {flags.tolist()}, identical rows {int((ids == want).all(axis=1).sum())}/10000{extra}, "
+              f"{time.time() - t:.1f}s")
