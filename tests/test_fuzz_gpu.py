@@ -69,3 +69,40 @@ def test_random_index_all_modes(oracle, seed):
         dv.all_centers, dv.pq = ivf.all_centers, ivf.pq
         dv.build(X, n_probes=c["build_probes"], device=True)
         np.testing.assert_array_equal(dv.query_batch(qs, c["k"], c["n_probes"]), want, err_msg=f"{c} device build")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TINYKNN_FUZZ_SEEDS", "32"))))
+def test_random_index_sharded_both_exchanges(oracle, seed):
+    """(TINYKNN_FUZZ_SEEDS=400: green after the filtered exchange went in.)
+    The same awkward shapes over 1-4 simulated ranks: dense and filtered exchange (lists shorter
+    than the heap — the bound stays at its rail and everything travels —, empty lists, probe
+    lists that wrap, repeated labels, one query) against the oracle."""
+    from tinyknn_amd import IVF, FastPQ
+    from test_hip_parity import _oracle_index
+    from test_shard_gpu import simulate_world
+    c = _case(500 + seed)
+    rng = np.random.RandomState(2000 + seed)
+    cent = rng.randn(max(c["n_clusters"], 3), c["d"]) * c["spread"]
+    X = (cent[rng.randint(len(cent), size=c["n"])] + 0.5 * rng.randn(c["n"], c["d"])).astype(np.float32)
+    qs = (cent[rng.randint(len(cent), size=c["nq"])] + 0.5 * rng.randn(c["nq"], c["d"])).astype(np.float32)
+    ivf = IVF(c["metric"], c["n_clusters"], FastPQ(2))
+    try:
+        ivf.fit(X).build(X, n_probes=c["build_probes"])
+    except AssertionError:
+        pytest.skip("the host build rejects this shape exactly as the reference does")
+    if len(ivf.active_centers) != c["n_clusters"]:
+        pytest.skip("inactive centres: the reference's grouping asserts on them")
+    ox = _oracle_index(oracle, ivf)
+    qn, qp = ivf._prepare(qs.copy())
+    want = ox.query_batch(qn, c["k"], c["n_probes"])
+    world = int(rng.choice([1, 2, 3, 4]))
+    worst = c["nq"] * min(c["n_probes"], c["n_clusters"]) * (c["n"] // 16 + 2)
+    for ex in ("dense", "filtered"):
+        st = {}
+        ids, flags, _ = simulate_world(ivf, world, qn, qp, c["k"], c["n_probes"], capacity=worst,
+                                       exchange=ex, stats=st,
+                                       coarse=str(rng.choice(["home", "replicated"])))
+        assert not flags.any()
+        np.testing.assert_array_equal(ids, want, err_msg=f"{c} world={world} {ex}")
+        if ex == "filtered":
+            assert st["records"] <= st["dense_blocks"]
