@@ -163,20 +163,22 @@ void tk_launch_shard_pairs_fill(const int64_t *probes, int S, int64_t nq, int64_
 
 // Received segments -> the home queries' distance rows (the layout the replay kernels
 // read) + the per-chunk minima the scan kernels would have written.
-// One 64-lane workgroup per (home query, slot).
+// One wave per (home query, slot), four to a workgroup (one-wave workgroups were bound by
+// the dispatch rate: 300 000 of them for a 30 000-query exchange took 0.39 ms).
 template <bool SIGNED>
-__global__ __launch_bounds__(64) void shard_unpack_kernel(
+__global__ __launch_bounds__(256) void shard_unpack_kernel(
     const uint4 *__restrict__ recv, const int *__restrict__ rpos,
-    const int *__restrict__ slot_prefix, int S, uint4 *__restrict__ dist, int64_t cap,
-    uint8_t *__restrict__ mins, int64_t min_stride)
+    const int *__restrict__ slot_prefix, int S, int64_t n_pairs, uint4 *__restrict__ dist,
+    int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride)
 {
-    const int64_t b = blockIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_pairs) return;
     const int64_t qi = b / S;
     const int s = (int)(b - qi * S);
     const int f0 = slot_prefix[qi * (S + 1) + s];
     const int n = slot_prefix[qi * (S + 1) + s + 1] - f0;
     const int p = rpos[b];
-    for (int c = threadIdx.x; c < n; c += 64) {
+    for (int c = threadIdx.x & 63; c < n; c += 64) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (p >= 0) v = recv[(int64_t)p + c];
         dist[qi * cap + f0 + c] = v;
@@ -199,13 +201,14 @@ void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_
                             int64_t min_stride, int signd, hipStream_t s)
 {
     if (nq_home == 0 || S == 0) return;
-    const unsigned grid = (unsigned)(nq_home * S);
+    const int64_t n_pairs = nq_home * S;
+    const unsigned grid = (unsigned)((n_pairs + 3) / 4);
     if (signd)
-        hipLaunchKernelGGL(shard_unpack_kernel<true>, dim3(grid), dim3(64), 0, s, recv, rpos,
-                           slot_prefix, S, dist, cap, mins, min_stride);
+        hipLaunchKernelGGL(shard_unpack_kernel<true>, dim3(grid), dim3(256), 0, s, recv, rpos,
+                           slot_prefix, S, n_pairs, dist, cap, mins, min_stride);
     else
-        hipLaunchKernelGGL(shard_unpack_kernel<false>, dim3(grid), dim3(64), 0, s, recv, rpos,
-                           slot_prefix, S, dist, cap, mins, min_stride);
+        hipLaunchKernelGGL(shard_unpack_kernel<false>, dim3(grid), dim3(256), 0, s, recv, rpos,
+                           slot_prefix, S, n_pairs, dist, cap, mins, min_stride);
 }
 
 // ---------------------------------------------------------------------------
