@@ -219,3 +219,37 @@ def test_list_sharded_coalesced_submits_gloo():
         assert first_none and third_none and not overflow
         np.testing.assert_array_equal(rows[:nq], exp)
         np.testing.assert_array_equal(rows[nq:], exp[::-1])
+
+
+def _mismatch_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tinyknn_amd.multi_gpu import ListShardedIndex
+        sizes = np.array([40, 17, 99, 3 + rank])        # rank 1 built a different index
+
+        class Eng:
+            device = "cpu"
+
+        try:
+            ListShardedIndex(object(), engine=Eng(), list_sizes=sizes)
+            ret[rank] = "accepted"
+        except RuntimeError as e:
+            ret[rank] = str(e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_list_sharded_index_rejects_different_indexes():
+    """Positions in the exchange are computed from replicated state, not transmitted: ranks whose
+    indexes differ (an unseeded fit per rank) must be told at construction, on every rank."""
+    import torch.multiprocessing as mp
+    port = 37500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mismatch_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert "different indexes" in ret[r]

@@ -15,6 +15,18 @@ from .fast_pq import FastPQ, avx, dpad
 from .utils import group_data_by_indices, knn_brute, timer
 
 
+def synth_rows(n, d, seed, centres=None, sigma=1.0, row0=0):
+    """Rows [row0, row0 + n) of the seeded device generator (devbuild.hip synth_rows_kernel:
+    a pure function of (seed, row)), copied to the host — the vectors IVF.build_resident
+    generates in HBM, e.g. to fit centres on a sample or to draw queries."""
+    out = np.zeros((n, d), dtype=np.float32)
+    c = None if centres is None else np.ascontiguousarray(centres, dtype=np.float32)
+    _lib.check(_lib.lib().tk_synth_rows(_lib.ptr(out, _lib._f32p), int(row0), int(n), int(d), int(seed),
+                                        None if c is None else c.ctypes.data,
+                                        0 if c is None else len(c), float(sigma)))
+    return out
+
+
 class QueryStream:
     """Streaming session on a DeviceIndex (C ABI: tk_stream_*): raw float32 queries on the
     host in, ids on the host out, batch after batch; the exact host preparation

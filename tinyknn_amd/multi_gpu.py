@@ -229,6 +229,7 @@ class ListShardedIndex:
         self.list_sizes = np.array(list_sizes, dtype=np.int64)
         self.owner = shard_lists(self.list_sizes, self.world) if owner is None else owner
         self.depth = depth
+        self._check_same_index(ivf)
         assert coarse in ("home", "replicated")
         self.coarse = coarse
         assert exchange in ("dense", "filtered", "auto")
@@ -254,6 +255,27 @@ class ListShardedIndex:
                          if self.device == "cuda" and depth > 1 else None)
         self._pending = []
         self._deferred = None
+
+    def _check_same_index(self, ivf):
+        """Every rank must hold the SAME index (same centres, same lists): positions in the
+        exchange are computed, not transmitted.  An index fitted per rank from an unseeded RNG
+        differs silently — compare a checksum once, at construction."""
+        if self.world == 1:
+            return
+        import zlib
+        crc = zlib.crc32(np.ascontiguousarray(self.list_sizes).tobytes())
+        ac = getattr(ivf, "active_centers", None)
+        if ac is not None:
+            crc = zlib.crc32(np.ascontiguousarray(ac).tobytes(), crc)
+        t = self.torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        lo = t.tensor([crc], dtype=t.int64, device=dev)
+        hi = lo.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.group)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
+        if int(lo.item()) != int(hi.item()):
+            raise RuntimeError("ListShardedIndex: the ranks hold different indexes (list sizes or centres "
+                               "differ) — build every rank's index from the same data and the same seed")
 
     # -- collectives (RCCL on device tensors; any other backend is staged through the host)
     def _all_to_all(self, recv, send):
