@@ -253,3 +253,20 @@ def test_list_sharded_index_rejects_different_indexes():
     mp.spawn(_mismatch_worker, args=(2, port, ret), nprocs=2, join=True)
     for r in range(2):
         assert "different indexes" in ret[r]
+
+
+def test_exchange_auto_rule():
+    """exchange="auto": filtered where the size-weighted mean list holds >= 32 heaps' worth of rows
+    (replicated values only: every rank takes the same branch)."""
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+
+    class Eng:
+        device = "cpu"
+
+    short = ListShardedIndex(object(), engine=Eng(), list_sizes=np.full(1087, 1100), exchange="auto")
+    assert short._exchange_kind(10, 10, None) == "dense"            # heap 111: 1100 < 32 * 111
+    assert short._exchange_kind(1, 1, None) == "filtered"           # heap 3
+    long_ = ListShardedIndex(object(), engine=Eng(), list_sizes=np.full(10000, 10000), exchange="auto")
+    assert long_._exchange_kind(10, 10, None) == "filtered"
+    assert long_._exchange_kind(10, 10, 5000) == "dense"            # pass_1 = 5000 rows per heap
+    assert ListShardedIndex(object(), engine=Eng(), list_sizes=[5], exchange="dense")._exchange_kind(1, 1, None) == "dense"
