@@ -96,3 +96,38 @@ def test_filtered_rows_replay_identically(oracle, tag, n_probes):
     # and everything travels — correct, only not smaller)
     assert total > dropped
     print(f"{tag} n_probes={n_probes}: {dropped}/{total} blocks of the later lists need not travel")
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_filtered_rows_random_streams(oracle, seed):
+    """The same two statements on random distance streams with the shapes the fixtures lack: lists
+    much longer than the heap, heavy ties (narrow value range), labels that repeat across lists
+    (the duplicate test fires), values at both int8 rails, lists shorter than the heap, R = 1."""
+    O = oracle
+    rng = np.random.RandomState(seed)
+    R = int(rng.choice([1, 3, 30, 111, 300]))
+    n_lists = int(rng.choice([2, 5, 10]))
+    spread = float(rng.choice([2.0, 12.0, 60.0]))
+    pool = int(rng.choice([500, 5000, 10 ** 6]))          # small pool: labels repeat across lists
+    rows = []
+    for _ in range(n_lists):
+        n = int(rng.choice([1, 15, 16, 17, 200, 1500, 4000]))
+        d = np.clip(np.round(rng.randn(-(-n // 16) * 16) * spread + rng.randint(-40, 40)), -128, 127).astype(np.int8)
+        lab = rng.choice(pool, size=n, replace=pool < n) if pool >= n else rng.randint(0, pool, size=n)
+        if pool >= n:
+            lab = rng.choice(pool, size=n, replace=False)      # distinct inside one list, as in an IVF list
+        rows.append((d, n, lab.astype(np.int64)))
+    idx, val = _replay(O, rows, R)
+    _, v1 = _replay(O, rows, R, stop_after=0)
+    b1 = int(np.uint8(int(v1[0]) & 0xff).view(np.int8))
+    if len(set(rows[0][2].tolist())) == len(rows[0][2]):
+        assert _bound_by_multiset(rows[0][0], rows[0][1], R) == b1 + 128
+    filt = [rows[0]]
+    for d, n, lab in rows[1:]:
+        d = d.copy()
+        m = d.reshape(-1, 16).min(axis=1)
+        d.reshape(-1, 16)[m >= b1] = 127
+        filt.append((d, n, lab))
+    idx2, val2 = _replay(O, filt, R)
+    np.testing.assert_array_equal(idx2, idx)
+    np.testing.assert_array_equal(val2, val)

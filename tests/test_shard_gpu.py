@@ -55,6 +55,8 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
             e.bound(0, qn_t, k, n_probes, pass_1, capacity, sends[r].view(-1), bounds[r])
         b_all = torch.stack(bounds).min(dim=0).values.contiguous()             # all-reduce(MIN)
         assert (torch.stack(bounds) != 255).sum(dim=0).le(1).all()             # one owner per query
+        if stats is not None:
+            stats["bound"] = b_all.cpu().numpy()
         counts, recs = [], []
         for r, e in enumerate(engines):
             c = torch.full((3 * world,), -5, dtype=torch.int32, device="cuda")
@@ -183,6 +185,8 @@ def test_sharded_filtered_vs_unsharded_larger(oracle, build_probes, world):
     ivf = IVF("angular", 244, FastPQ(2))
     ivf.fit(X[:20000]).build(X, n_probes=build_probes)
     qn, qp = ivf._prepare(qs.copy())
+    from test_hip_parity import _oracle_index
+    ox = _oracle_index(oracle, ivf)
     for n_probes, pass_1 in ((1, None), (10, None), (30, None), (10, 40), (5, 700)):
         want = ivf.device_index().query_batch(qn, qp, 10, n_probes, pass_1)
         st = {}
@@ -191,6 +195,18 @@ def test_sharded_filtered_vs_unsharded_larger(oracle, build_probes, world):
         assert not flags.any(), f"default capacity {cap} overflowed"
         np.testing.assert_array_equal(ids, want)
         assert 0 < st["records"] <= st["dense_blocks"]
+        # the reduced bound IS the oracle's bound after the first probed list (fresh heap, query_pq)
+        R = pass_1 if pass_1 else (n_probes + 1) * 10 + 1
+        off = ox.list_chunk_off
+        for i in range(0, nq, 29):
+            _, dbg = ox.query(qn[i], 10, n_probes, pass_1, debug=True)
+            l0 = int(dbg["probes"][0]) % ox.n_lists
+            hidx, hval = np.zeros(R, np.int64), np.zeros(R, np.int32)
+            oracle.init_heap(hidx, hval, True)
+            codes = np.ascontiguousarray(ox.codes[off[l0]:off[l0 + 1]])
+            if len(codes):
+                oracle.query_pq(codes, int(ox.list_n[l0]), oracle.transform_tables(dbg["table"]), hidx, hval, True)
+            assert int(st["bound"][i]) == ((int(hval[0]) & 0xff) ^ 0x80), (i, n_probes, pass_1)
         if n_probes == 10 and pass_1 == 40:
             assert 20 * st["records"] < 16 * st["dense_blocks"] * 0.6, st
 
