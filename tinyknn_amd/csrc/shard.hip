@@ -243,7 +243,6 @@ __global__ __launch_bounds__(256) void shard_first_bound_kernel(
 {
     __shared__ uint32_t s_hist[4][256];
     __shared__ uint4 s_blk[4][64];
-    __shared__ uint32_t s_key[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 4 + wv;
     if (q >= nq) return;
@@ -264,7 +263,6 @@ __global__ __launch_bounds__(256) void shard_first_bound_kernel(
     for (int c0 = 0; c0 < nch; c0 += 64) {
         const int c = c0 + lane;
         const uint32_t mk = c < nch ? key8(smins[(int64_t)p + c]) : 255u;
-        s_key[wv][lane] = mk;
         if (mk < (uint32_t)mx) s_blk[wv][lane] = scan[(int64_t)p + c];
         // (same wave: LDS traffic is ordered, no barrier needed between the lanes' stores and
         //  lane 0's loads — but the compiler must not reorder them)
@@ -272,9 +270,13 @@ __global__ __launch_bounds__(256) void shard_first_bound_kernel(
         __builtin_amdgcn_wave_barrier();
         // wave-uniform walk over the parked blocks: lanes 0..15 test the 16 distances of a block
         // at once, the passing ones are inserted in row order with uniform (scalar) state
-        const int lim = nch - c0 < 64 ? nch - c0 : 64;
-        for (int j = 0; j < lim; j++) {
-            const uint32_t kj = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_key[wv][j]);
+        // (only the blocks whose minimum is below the bound at the start of this round of 64 —
+        //  the bound only falls from block to block, so the others cannot pass later either)
+        uint64_t cand = __ballot(mk < (uint32_t)mx);
+        while (cand) {
+            const int j = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mk, j);
             if (kj >= (uint32_t)mx) continue;
             const uint32_t wsel = reinterpret_cast<const uint32_t *>(&s_blk[wv][j])[(lane >> 2) & 3];
             const uint32_t kv = key8(wsel >> (8 * (lane & 3)));
@@ -351,25 +353,43 @@ __global__ __launch_bounds__(256) void shard_filter_kernel(
             const int h = (int)(q / qh);
             if (!PACK) {
                 int cnt = 0;
-                for (int c = lane; c < nch; c += 64) cnt += key8(smins[(int64_t)p + c]) < b;
+                int c = lane;
+                const uint8_t *mp = smins + (int64_t)p;
+                for (; c + 192 < nch; c += 256) {      // four loads in flight
+                    const uint32_t m0 = mp[c], m1 = mp[c + 64], m2 = mp[c + 128], m3 = mp[c + 192];
+                    cnt += (key8(m0) < b) + (key8(m1) < b) + (key8(m2) < b) + (key8(m3) < b);
+                }
+                for (; c < nch; c += 64) cnt += key8(mp[c]) < b;
                 for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
                 if (lane == 0) pair_cnt[i] = cnt;
                 mine = nch;
             } else if (pair_cnt[i] > 0) {
                 int base = pair_off[i];
                 const int hdr0 = (int)((q - (int64_t)h * qh) * cap + f0);
-                for (int c0 = 0; c0 < nch; c0 += 64) {
-                    const int c = c0 + lane;
-                    const bool pass = c < nch && key8(smins[(int64_t)p + c]) < b;
-                    const uint64_t m = __ballot(pass);
-                    if (pass) {
-                        const int at = base + __popcll(m & ((1ull << lane) - 1));
-                        const uint4 v = scan[(int64_t)p + c];
-                        int *r = rec + (int64_t)at * 5;
-                        r[0] = hdr0 + c;
-                        r[1] = (int)v.x; r[2] = (int)v.y; r[3] = (int)v.z; r[4] = (int)v.w;
+                const uint8_t *mp = smins + (int64_t)p;
+                const uint4 *sp = scan + (int64_t)p;
+                for (int c0 = 0; c0 < nch; c0 += 256) {    // four rounds of 64 with their loads in flight
+                    bool pass[4];
+                    uint4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int c = c0 + 64 * u + lane;
+                        pass[u] = c < nch && key8(mp[c < nch ? c : 0]) < b;
                     }
-                    base += __popcll(m);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (pass[u]) v[u] = sp[c0 + 64 * u + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint64_t m = __ballot(pass[u]);
+                        if (pass[u]) {
+                            const int at = base + __popcll(m & ((1ull << lane) - 1));
+                            int *r = rec + (int64_t)at * 5;
+                            r[0] = hdr0 + c0 + 64 * u + lane;
+                            r[1] = (int)v[u].x; r[2] = (int)v[u].y; r[3] = (int)v[u].z; r[4] = (int)v[u].w;
+                        }
+                        base += __popcll(m);
+                    }
                 }
             }
         }
