@@ -160,14 +160,34 @@ def build_index_c5(args, device):
     from tinyknn_amd import IVF, FastPQ
     t0 = time.time()
     cent = np.random.RandomState(args.seed).randn(3000, args.d).astype(np.float32)
-    ns = min(args.n, 1_000_000)
-    sample = synth_rows_host(ns, args.d, args.seed, cent, 0.7)   # rows 0..ns: a uniform sample of the clusters
     ivf = IVF("euclidean", args.n_clusters, FastPQ(2))
-    ivf.all_centers = quick_kmeans(sample, args.n_clusters, 6, args.seed, device).astype(np.float32)
-    ivf.pq.fit(sample[:30000])
-    del sample
-    torch.cuda.empty_cache()
-    log(f"[bench] c5 fit done in {time.time() - t0:.1f}s")
+    # The FIT (k-means on the GPU: atomics; ortho_group / k-means of FastPQ.fit: numpy's global RNG)
+    # is not bit-reproducible from run to run, and a list-sharded index needs every rank to hold
+    # the SAME centres and codebook: rank 0 fits first (main() orders the ranks) and leaves the
+    # fitted parameters in the cache directory; the other ranks load them.  The BUILD from those
+    # parameters is deterministic (seeded generator, stable sort) and runs on every rank.
+    fit_cache = os.path.join(args.cache_dir, f"tinyknn_bench_c5fit_n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}.npz")
+    if os.path.exists(fit_cache):
+        z = np.load(fit_cache)
+        ivf.all_centers = z["all_centers"]
+        ivf.pq.centers = z["pq_centers"]
+        ivf.pq.sqrt_n_blocks = float(z["sqrt_n_blocks"])
+        ivf.pq.R = z["R"] if "R" in z else None
+        log(f"[bench] c5 fit loaded from {fit_cache}")
+    else:
+        ns = min(args.n, 1_000_000)
+        sample = synth_rows_host(ns, args.d, args.seed, cent, 0.7)   # rows 0..ns: a uniform sample of the clusters
+        ivf.all_centers = quick_kmeans(sample, args.n_clusters, 6, args.seed, device).astype(np.float32)
+        ivf.pq.fit(sample[:30000])
+        del sample
+        torch.cuda.empty_cache()
+        try:
+            extra = {} if ivf.pq.R is None else {"R": ivf.pq.R}
+            np.savez(fit_cache, all_centers=ivf.all_centers, pq_centers=ivf.pq.centers,
+                     sqrt_n_blocks=ivf.pq.sqrt_n_blocks, **extra)
+        except OSError as e:
+            log(f"[bench] could not cache the c5 fit: {e}")
+        log(f"[bench] c5 fit done in {time.time() - t0:.1f}s")
     ivf.build_resident(args.n, args.d, args.seed, cent, 0.7)
     sz = ivf.list_sizes
     log(f"[bench] c5 index built on the device in {time.time() - t0:.1f}s: {len(sz)} lists of "
