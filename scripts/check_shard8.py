@@ -23,3 +23,13 @@ for W in (8, 4):
               f"longest stream {st['usage']} uint4 -> {W * int(1.25 * st['usage']) * 16 / 1e6:.1f} MB trimmed), "
               f"overflow flags {flags.tolist()}, identical rows {int((ids == want).all(axis=1).sum())}/10000{extra}, "
               f"{time.time() - t:.1f}s")
+
+# the exchange size bench.py --gpus 8 uses (8 steps coalesced: 80 000 queries per exchange)
+qn8, qp8 = np.concatenate([qn] * 8), np.concatenate([qp] * 8)
+for ex in ("dense", "filtered"):
+    t = time.time()
+    st = {}
+    ids, flags, cap = simulate_world(ivf, 8, qn8, qp8, 10, 10, exchange=ex, stats=st)
+    same = min(int((ids[j * 10000:(j + 1) * 10000] == want).all(axis=1).sum()) for j in range(8))
+    print(f"W=8 {ex}, 80000 queries per exchange: capacity {cap} uint4, longest stream {st['usage']}, overflow flags "
+          f"{flags.tolist()}, identical rows per step >= {same}/10000, {time.time() - t:.1f}s")
