@@ -448,7 +448,10 @@ int tk_index_shard_usage(tk_index *ix, int slot, int64_t *max_stream_uint4);
  * heap.  After tk_index_shard_scan_dev (whose buffer then stays on the rank: `scan_dev`):
  *   tk_index_shard_bound_dev   bound_dev[nq] bytes: B1 (order key = distance byte ^ 0x80) of
  *                              the queries whose first probed list this rank owns — replayed
- *                              from the fresh heap over that list — and 255 elsewhere;
+ *                              from the fresh heap over that list — and 255 elsewhere
+ *                              (computed from the heap's VALUES alone, which is exact as long
+ *                              as the ids inside one list are distinct: a row joins a list
+ *                              once, ivf.py:85-102, utils.py:131-150);
  *   all-reduce(MIN, uint8)     -> B1 of every query on every rank (by the caller);
  *   tk_index_shard_filter_dev  the blocks that travel — all of a query's first list, of the
  *                              later lists those whose minimum is below B1 — as records of 5
