@@ -95,6 +95,17 @@ static PwProgram pw_program(int n)
     return P;
 }
 
+// Everything a query needs lives in its own wave and its own LDS region, and LDS operations of
+// one wave complete in issue order: a wave-level fence (for the compiler) is all the
+// synchronisation the stages need — with __syncthreads() the four waves of a workgroup waited
+// for each other seven times per query.
+#define TK_WAVE_SYNC()                                              \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+    } while (0)
+
 // One wave per query, blockDim.x / 64 queries per workgroup.  Per-wave LDS:
 //   dists[16M] T | acc[64][8] T | node_val[128] T (leaf sums, then inner nodes)
 template <typename T, bool SIGNED>
@@ -113,14 +124,32 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
     T *acc = dists + cnt;                 // [leaf][8]
     T *node_val = acc + 64 * 8;
     const int64_t qraw = (int64_t)blockIdx.x * waves + wave;
-    const bool valid = qraw < nq;
-    const int64_t qi = valid ? qraw : nq - 1;   // surplus waves recompute the last query
+    if (qraw >= nq) return;                     // (no workgroup barrier below)
+    const int64_t qi = qraw;
     const T *q = qs + qi * dq;
     constexpr int MAXDPB = 32;
     T diff[MAXDPB];
 
+    const float rcpM = 1.0f / (float)M;
+    if (SIGNED && dpb == 2 && M <= 256) {
+        // FastPQ(2), the configuration every BASELINE index uses: the 13 rounds of a query were
+        // 13 dependent trips to L2 (centre pair + query pair per entry); unrolled, four rounds'
+        // loads are in flight.  Same operations: einsum_selfdot over the two differences.
+#pragma unroll 4
+        for (int e = lane; e < cnt; e += 64) {
+            const int i = (int)(((float)e + 0.5f) * rcpM);
+            const int m = e - i * M;
+            const float2 c2 = *reinterpret_cast<const float2 *>(centers + (int64_t)i * dq + 2 * m);
+            T d2[2];
+            d2[0] = (T)c2.x - q[2 * m];
+            d2[1] = (T)c2.y - q[2 * m + 1];
+            dists[f_order ? (m * 16 + i) : e] = einsum_selfdot<T>(d2, 2);
+        }
+    } else
     for (int e = lane; e < cnt; e += 64) {
-        const int i = e / M, m = e - i * M;
+        // e / M without the integer division (exact for e < 2^16: |error| << 0.5 / M)
+        const int i = M <= 256 ? (int)(((float)e + 0.5f) * rcpM) : e / M;
+        const int m = e - i * M;
         T v;
         if (SIGNED) {
             for (int k = 0; k < dpb; k++)
@@ -137,7 +166,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
         }
         dists[f_order ? (m * 16 + i) : e] = v;
     }
-    __syncthreads();
+    TK_WAVE_SYNC();
     T shift;
     if (SIGNED) {
         // numpy's pairwise mean, the 8 accumulators of every <=128-element leaf in
@@ -154,7 +183,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
             }
             acc[L * 8 + j] = r;
         }
-        __syncthreads();
+        TK_WAVE_SYNC();
         for (int L = lane; L < nleaf; L += 64) {
             const int off = pw.leaf_off[L], n = pw.leaf_n[L];
             T res;
@@ -168,12 +197,12 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
             }
             node_val[L] = res;
         }
-        __syncthreads();
+        TK_WAVE_SYNC();
         for (int lv = 1; lv <= pw.nlevels; lv++) {
             const int t = pw.level_start[lv - 1] + lane;
             if (t < pw.level_start[lv])
                 node_val[pw.op_dst[t]] = node_val[pw.op_a[t]] + node_val[pw.op_b[t]];
-            __syncthreads();
+            TK_WAVE_SYNC();
         }
         const T mean = node_val[pw.root] / (T)cnt;   // _mean
         shift = mean * (T)0.6931471806;              // fast_pq.py:214
@@ -201,12 +230,20 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
         scale = 128.0 / ((double)mx * aux0);           // :216
     else
         scale = 255.0 / (((double)mx * aux0) * aux1);  // :248
-    __syncthreads();
-    if (!valid) return;
-    for (int e = lane; e < cnt; e += 64) {
-        const int i = e / M, m = e - i * M;
-        double v = rint((double)dists[f_order ? (m * 16 + i) : e] * scale);
-        tables[qi * (int64_t)cnt + m * 16 + i] = (uint8_t)(int32_t)v;  // :217-221
+    TK_WAVE_SYNC();
+    // in OUTPUT order (entry o = m * 16 + i), four bytes per lane: one coalesced dword store
+    // instead of four byte stores 16 bytes apart
+    uint32_t *out4 = reinterpret_cast<uint32_t *>(tables + qi * (int64_t)cnt);
+    for (int o4 = lane; o4 < cnt / 4; o4 += 64) {
+        uint32_t pack = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int o = 4 * o4 + b;
+            const int m = o >> 4, i = o & 15;
+            const double v = rint((double)dists[f_order ? o : (i * M + m)] * scale);
+            pack |= (uint32_t)(uint8_t)(int32_t)v << (8 * b);  // :217-221
+        }
+        out4[o4] = pack;
     }
     if (lane == 0) {
         shift_out[qi] = shift;
