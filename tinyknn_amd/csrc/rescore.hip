@@ -251,7 +251,9 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
     if (nq == 0 || k == 0) return;
     const bool dbl = q_is_f64 || rows_is_f64;   // numpy promotes `Y - x` to float64
     size_t lds = (size_t)R * 8 + ((size_t)R + d) * (dbl ? 8 : 4) + 16;
-    dim3 grid((unsigned)nq), block(128);
+    // one wave is enough for the coarse stage's 2 * n_probes + 10 candidates: the second wave of
+    // a 128-thread workgroup only waited at the barriers and took a wave slot beside the scan
+    dim3 grid((unsigned)nq), block(R <= 64 ? 64 : 128);
     // A/B: TINYKNN_RESCORE_STAGED=1 / 2 stages the rows through LDS in tiles of 64 / 32 rows.
     // Measured (profiles/r02_scan_grid.md): alone the 32-row form is the fastest (0.118 ms per
     // 10 000 queries against 0.135), and it takes address traffic off the scan kernels it runs
