@@ -637,6 +637,7 @@ struct tk_index {
     uint64_t calls = 0;
     std::vector<hipStream_t> lat_streams;    // `depth` of them (pipelined mode)
     hipEvent_t ev_in = nullptr;              // caller's stream -> a batch's stream
+    hipEvent_t ev_front_in = nullptr;        // front stream (input copies) -> the table build's stream
     std::vector<struct Pending *> pending;   // calls whose list scan is still to be enqueued (<= 2)
     hipStream_t front_stream = nullptr;      // coarse replays + descriptors of all batches, in order
     // profiling: one set of 8 events per recorded batch, read back on demand
@@ -672,6 +673,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
     for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
     if (ix->front_stream) (void)hipStreamDestroy(ix->front_stream);
     if (ix->ev_in) (void)hipEventDestroy(ix->ev_in);
+    if (ix->ev_front_in) (void)hipEventDestroy(ix->ev_front_in);
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -1301,6 +1303,12 @@ static int scan_blocks_pipelined(double est_units)
 
 // depth > 1: the launch on the caller's stream that carries the list scan of `prev` (may be
 // NULL) and the coarse scan of `cur` (may be NULL), and what follows each on its stream
+static bool tables_on_replay_stream()
+{
+    static const bool on = getenv("TINYKNN_TABLES_STREAM") && atoi(getenv("TINYKNN_TABLES_STREAM")) == 1;
+    return on;
+}
+
 static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
 {
     const int M = ix->M;
@@ -1308,7 +1316,8 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
     // what the launch waits for lives on the front stream, in order: ..., front_done(c-3),
     // tables_done(c-1), ... — the later event covers the earlier one, and every hand-over
     // between streams is a barrier packet the command processor spends microseconds on
-    static const bool merge = !(getenv("TINYKNN_MERGE_EVENTS") && getenv("TINYKNN_MERGE_EVENTS")[0] == '0');
+    static const bool merge = !(getenv("TINYKNN_MERGE_EVENTS") && getenv("TINYKNN_MERGE_EVENTS")[0] == '0') &&
+                              !tables_on_replay_stream();     // (the events are then on different streams)
     if (cur) {
         HIPCHECK(hipStreamWaitEvent(st, cur->w->tables_done, 0));
         cur->coarse_launched = true;
@@ -1476,14 +1485,25 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         // the table build of this call goes to the front stream now (after the caller's work
         // so far — its inputs — and once the workspace is free); its coarse scan rides in the
         // NEXT call's launch, its list scan in the launch three calls later
+        // A/B (TINYKNN_TABLES_STREAM=1): the table build on the batch's REPLAY stream instead.
+        // The front stream carries, per batch, the tables of call c and the coarse replay /
+        // rescoring / descriptors of call c-1 — within a tenth of the scan launch it must keep
+        // ahead of; the replay streams are a third busy, and a table build has a whole call's
+        // time before its coarse scan is launched.
+        hipStream_t stt = tables_on_replay_stream() ? b.sl : b.sf;
         HIPCHECK(hipEventRecord(ix->ev_in, caller));
-        HIPCHECK(hipStreamWaitEvent(b.sf, ix->ev_in, 0));
-        if (w.busy) HIPCHECK(hipStreamWaitEvent(b.sf, w.done, 0));
+        HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
+        if (stt != b.sf) {      // input copies arrive on the front stream (tk_index_input_stream)
+            if (!ix->ev_front_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_front_in, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(ix->ev_front_in, b.sf));
+            HIPCHECK(hipStreamWaitEvent(stt, ix->ev_front_in, 0));
+        }
+        if (w.busy) HIPCHECK(hipStreamWaitEvent(stt, w.done, 0));
         TRY(reserve(ix, w, sub, k, p));
         TRY(prof_begin(ix, w, b.nq, p, b.sl, b.pf));
         b.units = use_units(ix, b.nq, p);
-        TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, b.sf, b.pf));
-        HIPCHECK(hipEventRecord(w.tables_done, b.sf));
+        TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, stt, b.pf));
+        HIPCHECK(hipEventRecord(w.tables_done, stt));
         // this call's launch: list scan of call c-3 + coarse scan of call c-1
         TRY(pipeline_advance(ix, false));
         ix->pending.push_back(new Pending(b));
