@@ -1303,11 +1303,13 @@ static int scan_blocks_pipelined(double est_units)
 
 // depth > 1: the launch on the caller's stream that carries the list scan of `prev` (may be
 // NULL) and the coarse scan of `cur` (may be NULL), and what follows each on its stream
-static bool tables_on_replay_stream()
+// 0: front stream (default); 1: the batch's own replay stream; 2: the other replay stream
+static int tables_stream_mode()
 {
-    static const bool on = getenv("TINYKNN_TABLES_STREAM") && atoi(getenv("TINYKNN_TABLES_STREAM")) == 1;
-    return on;
+    static const int m = getenv("TINYKNN_TABLES_STREAM") ? atoi(getenv("TINYKNN_TABLES_STREAM")) : 0;
+    return m;
 }
+static bool tables_on_replay_stream() { return tables_stream_mode() != 0; }
 
 static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
 {
@@ -1490,7 +1492,9 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         // rescoring / descriptors of call c-1 — within a tenth of the scan launch it must keep
         // ahead of; the replay streams are a third busy, and a table build has a whole call's
         // time before its coarse scan is launched.
-        hipStream_t stt = tables_on_replay_stream() ? b.sl : b.sf;
+        hipStream_t stt = b.sf;
+        if (tables_stream_mode() == 1) stt = b.sl;
+        else if (tables_stream_mode() == 2) stt = ix->lat_streams[ix->calls % (uint64_t)ix->depth];   // (calls is already c + 1)
         HIPCHECK(hipEventRecord(ix->ev_in, caller));
         HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
         if (stt != b.sf) {      // input copies arrive on the front stream (tk_index_input_stream)
