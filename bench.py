@@ -87,14 +87,30 @@ def quick_kmeans(X, k, iters, seed, device):
     return C.cpu().numpy().astype(np.float64)
 
 
-def build_index(args, device):
+def load_real(args):
+    """examples/bench.py:67-70: load the .npy, np.random.seed(10), shuffle, the last n_queries rows
+    are the queries (unless --query-file holds them).  GloVe-100 / SIFT-1M run unchanged when the
+    files are provided (there is no network here to fetch them)."""
+    data = np.load(args.data_file)
+    np.random.seed(10)
+    np.random.shuffle(data)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    if args.query_file:
+        return data, np.ascontiguousarray(np.load(args.query_file), dtype=np.float32)
+    return data[:-args.nq], data[-args.nq:]
+
+
+def build_index(args, device, X=None):
     """Fit + build with the product's host code; cached on local disk because the
     driver runs N = 1, 2, 4, 8 back to back on one box."""
     from tinyknn_amd import IVF, FastPQ
     from tinyknn_amd.fast_pq import TransformedData
-    tag = f"n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}_b{args.build_probes}_{args.metric}_{args.data}_c32"
+    src = args.data if X is None else os.path.basename(args.data_file)
+    tag = f"n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}_b{args.build_probes}_{args.metric}_{src}_c32"
     cache = os.path.join(args.cache_dir, f"tinyknn_bench_{tag}.npz")
-    X, cent = synth(args.n, 0, args.d, args.seed, kind=args.data)
+    cent = None
+    if X is None:
+        X, cent = synth(args.n, 0, args.d, args.seed, kind=args.data)
     ang = args.metric == "angular"
     ivf = IVF(args.metric, args.n_clusters, FastPQ(2))
     if os.path.exists(cache):
@@ -253,7 +269,8 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     want = want.cpu().numpy()
     co = args.shard_coalesce if args.shard_coalesce > 0 else max(3, world)    # auto: a rank's home share = one batch
     co = max(1, min(co, 131072 // args.nq))
-    idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co)
+    idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co,
+                           force_collectives=args.force_collectives)
     if args.shard_exchange == "auto":
         idx.exchange = "auto"          # ListShardedIndex._exchange_kind: filtered where lists are long
         kinds = [idx._exchange_kind(args.k, args.n_probes, None)]
@@ -282,27 +299,43 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
     # every workspace slot must have seen a batch of the timed size before the clock starts: a slot
     # that grows inside the timed region pays hipMalloc/hipFree of gigabytes there (seen as a 4x
     # slower leg whenever the untimed calls above had left slot 0 at the single-batch size)
-    for _ in range(-(-max(args.warmup, args.shard_depth * co) // co) * co):
-        idx.submit(qn_t, qp_t, args.k, args.n_probes)
-    idx.join()
-    torch.cuda.synchronize()
+    def run(n):
+        """n submits + join; join() raises if a batch in flight overflowed its exchange regions
+        (it has grown them): the run is then repeated — never timed with invalid rows."""
+        for attempt in range(4):
+            try:
+                for _ in range(n):
+                    idx.submit(qn_t, qp_t, args.k, args.n_probes)
+                idx.join()
+                torch.cuda.synchronize()
+                return attempt
+            except RuntimeError as e:
+                if "overflowed" not in str(e):
+                    raise
+                log(f"[bench] rank {rank}: {e}")
+        raise RuntimeError("list-sharded leg: exchange regions overflowed four times in a row")
+
+    run(-(-max(args.warmup, args.shard_depth * co) // co) * co)
     if world > 1:
         dist.barrier()
+    # windows of --steps steps (each drained: the exchange is a collective, every rank joins);
+    # ms_per_step = the median window, as in the replica region
+    n_win = args.windows if args.windows > 0 else max(3, min(9, -(-300 // args.steps)))
+    wins, repeats = [], 0
     idx.bytes_sent = idx.bytes_dense = 0
-    t0 = time.perf_counter()
-    g = None
-    for _ in range(args.steps):
-        r = idx.submit(qn_t, qp_t, args.k, args.n_probes)
-        g = g if r is None else r
-    idx.join()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+    for w in range(n_win):
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        repeats += run(args.steps)
+        if world > 1:
+            dist.barrier()
+        wins.append(time.perf_counter() - t0)
+    t = torch.tensor(wins, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
+    wins = sorted(t.tolist())
+    el = wins[len(wins) // 2]
     cap = idx.capacity[(args.nq * co, args.n_probes)] if (args.nq * co, args.n_probes) in idx.capacity \
         else idx.capacity[(args.nq, args.n_probes)]
     load = np.bincount(idx.owner, weights=(idx.list_sizes + 15) // 16, minlength=world)
@@ -311,14 +344,14 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
         # measured in the timed steps, this rank: records (20 B per block that travels) + bounds +
         # counts, against the blocks of whole segments (16 B each, what the dense form needs at least)
         filt = {"kind": "filtered (bound after the first probed list; blocks below it as 20-byte records)",
-                "record_bytes_per_rank_per_step": int(idx.bytes_sent // args.steps),
-                "whole_segment_bytes_per_rank_per_step": int(idx.bytes_dense // args.steps),
+                "record_bytes_per_rank_per_step": int(idx.bytes_sent // (args.steps * n_win)),
+                "whole_segment_bytes_per_rank_per_step": int(idx.bytes_dense // (args.steps * n_win)),
                 "bytes_ratio": round(idx.bytes_sent / max(1, idx.bytes_dense), 4),
                 "host_syncs_per_exchange": 1}
     return {"queries_per_s": args.nq * args.steps / el, "ms_per_step": el / args.steps * 1e3,
             "scaling": "strong (one shared batch of %d queries per step)" % args.nq,
             "identical_rows_vs_replica": same, "rows": args.nq,
-            "overflow_in_timed_steps": bool(g is not None and g.cpu().numpy()[:, -1].any()),
+            "windows_ms": [w_ * 1e3 for w_ in wins], "windows_repeated_after_overflow": repeats,
             "exchange": {**filt, "all_to_all_bytes_per_rank_per_step": int(world * cap * 16 // co),
                          "region_capacity_uint4": int(cap),
                          "probe_all_gather_bytes_per_rank_per_step":
@@ -577,6 +610,22 @@ def main():
                     help="stop after the timed region + the isolated stages (profiler runs)")
     ap.add_argument("--shard-limit", type=float, default=240.0,
                     help="seconds after which a stuck list-sharded leg is abandoned")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 with --shard lists: a one-rank nccl process group, the sharded leg's "
+                         "exchanges through RCCL instead of device copies (rehearsal of the N > 1 code path)")
+    ap.add_argument("--batches", type=int, default=4,
+                    help="distinct query batches rotated through the timed loop")
+    ap.add_argument("--warmup-seconds", type=float, default=0.5,
+                    help="warm up for at least this long, whatever --warmup says")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="windows of --steps steps in the timed region (0: ~600 steps in all, 3..15 windows); "
+                         "ms_per_step is the median window")
+    ap.add_argument("--data-file", default=None,
+                    help=".npy of float vectors (GloVe-100, SIFT-1M ...): the protocol of examples/bench.py:67-70 "
+                         "(seed 10, shuffle, last --nq rows are the queries) instead of the synthetic stand-in")
+    ap.add_argument("--query-file", default=None, help=".npy of queries for --data-file (else its last --nq rows)")
+    ap.add_argument("--a", type=float, default=1.0,
+                    help="--data-file: n_clusters = int(a * sqrt(n)) unless --n-clusters is given (examples/bench.py:73)")
     args = ap.parse_args()
     if args.workload == "c5":
         dflt = ap.parse_args([])
@@ -603,6 +652,11 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.backend)
+    elif args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group(args.backend, rank=0, world_size=1,
+                                **({"device_id": device} if args.backend == "nccl" else {}))
 
     from tinyknn_amd import _lib
     _lib.check(_lib.lib().tk_set_device(dev_id))
@@ -610,8 +664,16 @@ def main():
     # -- index: rank 0 builds (or loads) first so that the cache exists for the others
     if world > 1 and rank != 0:
         dist.barrier()
+    real_queries = None
     if args.workload == "c5":
         ivf, cent = build_index_c5(args, device)
+    elif args.data_file:
+        X, real_queries = load_real(args)
+        args.n, args.d = X.shape
+        if args.n_clusters == ap.get_default("n_clusters"):
+            args.n_clusters = int(args.a * args.n ** 0.5)          # examples/bench.py:73
+        ivf, cent = build_index(args, device, X)
+        del X
     else:
         ivf, cent = build_index(args, device)
     if world > 1 and rank == 0:
@@ -619,18 +681,31 @@ def main():
     dev = ivf.device_index()
     M = ivf.pq.centers.shape[1] // 2
 
-    # -- this rank's batch, normalised on the host exactly like ivf.py:125-127
-    if args.workload == "c5":
-        qs = synth_rows_host(args.nq, args.d, args.seed + 100 + rank, cent, 0.7)
-    else:
-        qs = synth_queries(cent, args.nq, args.seed + 100 + rank, kind=args.data)
-    t_prep = time.perf_counter()
-    qn, qp = ivf._prepare(qs.copy())
-    t_prep = time.perf_counter() - t_prep
+    # -- this rank's batches, normalised on the host exactly like ivf.py:125-127.  The timed loop
+    #    rotates N_BATCHES distinct batches (step i answers batch i % N_BATCHES into its own output
+    #    rows): no step finds the previous step's probe lists, code lines or candidate rows warm
+    #    because they were its own
+    N_BATCHES = max(1, args.batches)
+
+    def make_batch(b):
+        if real_queries is not None:       # the file's queries, rotated by a quarter per batch
+            return np.roll(real_queries, -b * (len(real_queries) // N_BATCHES), axis=0)[:args.nq].copy()
+        if args.workload == "c5":
+            return synth_rows_host(args.nq, args.d, args.seed + 100 + rank + 1000 * b, cent, 0.7)
+        return synth_queries(cent, args.nq, args.seed + 100 + rank + 1000 * b, kind=args.data)
+
+    batches = []
+    for b in range(N_BATCHES):
+        qs_b = make_batch(b)
+        t_prep = time.perf_counter()
+        qn_b, qp_b = ivf._prepare(qs_b.copy())
+        t_prep = time.perf_counter() - t_prep
+        batches.append(dict(qs=qs_b, qn=qn_b, qp=qp_b, q_dev=torch.from_numpy(qn_b).to(device),
+                            qp_dev=torch.from_numpy(np.ascontiguousarray(qp_b)).to(device),
+                            out=torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)))
+    qs, qn, qp = batches[0]["qs"], batches[0]["qn"], batches[0]["qp"]       # batch 0: parity, recall, side legs
+    q_dev, qp_dev, out_dev = batches[0]["q_dev"], batches[0]["qp_dev"], batches[0]["out"]
     qp_is_f64 = qp.dtype != np.float32      # rotated PQ: float64 table-build queries
-    q_dev = torch.from_numpy(qn).to(device)
-    qp_dev = torch.from_numpy(np.ascontiguousarray(qp)).to(device)
-    out_dev = torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)
     own_stream = None
     if args.caller_stream == "own":       # A/B: a non-NULL, non-blocking stream carries the scan chain
         own_stream = torch.cuda.Stream()
@@ -641,27 +716,60 @@ def main():
     dev.set_heap_mode(args.heap_mode)
     dev.set_scan_mode(args.scan_mode)
     _lib.check(_lib.lib().tk_set_scan_form(args.scan_form))
+    n_step = [0]
 
-    def step():
-        dev.query_batch_dev(q_dev.data_ptr(), qp_dev.data_ptr(), qp_is_f64, args.nq, args.k,
-                            args.n_probes, out_dev.data_ptr(), stream=stream)
+    def step(done_event=None):
+        b = batches[n_step[0] % N_BATCHES]
+        n_step[0] += 1
+        dev.query_batch_dev(b["q_dev"].data_ptr(), b["qp_dev"].data_ptr(), qp_is_f64, args.nq, args.k,
+                            args.n_probes, b["out"].data_ptr(), stream=stream, done_event=done_event)
 
-    for _ in range(args.warmup):
-        step()
-    dev.join(stream)
-    torch.cuda.synchronize()
+    # warm-up: --warmup steps, and at least --warmup-seconds of steps whatever the flag says (clocks,
+    # caches, the allocator and every workspace of the pipeline settle; the driver's 5 steps are 4 ms)
+    tw = time.perf_counter()
+    n_warm = 0
+    while n_warm < args.warmup or time.perf_counter() - tw < args.warmup_seconds:
+        for _ in range(8):
+            step()
+        n_warm += 8
+        dev.join(stream)
+        torch.cuda.synchronize()
+    n_step[0] = 0
     if world > 1:
         dist.barrier()
     dev.set_profiling(4)        # HIP events around the stages of every 4th batch, read after the region
+    # Timed region: `windows` x --steps steps in one continuous run, bracketed by barrier +
+    # synchronize on both sides.  A completion event (recorded by the library behind the last kernel
+    # of a batch, on whichever internal stream it ran) closes every window of EXACTLY --steps steps;
+    # ms_per_step = the median window.  Why not one window: with several batches in flight a region
+    # pays the pipeline's fill and drain once (~1.5 ms: 10 % of a 20-step region, 1 % of a 200-step
+    # one) — the windows behind the first measure what a server that keeps submitting sustains,
+    # the whole-region figure (fill and drain included) is reported beside it as `drained`.
+    K = args.steps
+    n_win = args.windows if args.windows > 0 else max(3, min(15, -(-600 // K)))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
+    for e in evs:
+        e.record()              # materialises the HIP event; the library re-records it
     torch.cuda.synchronize()
+    # (a completion event belongs to ONE sub-batch of the index: a batch that the index cuts into
+    #  several — distance rows beyond a workspace — closes its windows by draining instead)
+    by_events = args.nq <= dev.max_sub_batch(args.k, args.n_probes)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    evs[0].record()
+    for w in range(n_win):
+        for i in range(K):
+            step(evs[w + 1].cuda_event if (by_events and i == K - 1) else None)
+        if not by_events:
+            dev.join(stream)
+            evs[w + 1].record()
     dev.join(stream)            # the caller's stream waits for every batch in flight
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    region = time.perf_counter() - t0
+    win_ms = [evs[w].elapsed_time(evs[w + 1]) for w in range(n_win)]      # window 0 includes the fill
+    steady = sorted(win_ms[1:]) if n_win > 1 else win_ms
+    elapsed = steady[len(steady) // 2] * 1e-3        # seconds per --steps steps: the median window
     stages, scan_bytes, n_prof = dev.last_profile()
     raw_leg = None if args.profile_only else raw_stream_leg(args, dev, qs, out_dev, device, world)
     # the same kernels with ONE batch in flight (no co-running batches), for reference
@@ -678,6 +786,7 @@ def main():
     if args.profile_only:
         if rank == 0:
             print(json.dumps({"profile_only": True, "ms_per_step": elapsed / args.steps * 1e3,
+                              "ms_per_step_drained": region / (n_win * K) * 1e3, "windows_ms": win_ms,
                               "stage_ms": stages, "isolated_stage_ms": iso_stages,
                               "scan_bytes": scan_bytes, "iso_scan_bytes": iso_bytes}), flush=True)
         if world > 1:
@@ -878,8 +987,18 @@ def main():
                   f"queries/sec at Recall10@10, {args.data} {args.metric} d={args.d} (synthetic), IVF+4-bit PQ",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "timing": {"windows": n_win, "steps_per_window": K, "window_ms": win_ms,
+                   "ms_per_step_is": "median over the windows behind the first, each EXACTLY --steps steps of one "
+                                     "continuous run (completion events of the batches; fill and drain of the "
+                                     "pipeline are in `drained`)",
+                   "drained": {"steps": n_win * K, "ms_per_step": region / (n_win * K) * 1e3,
+                               "queries_per_s": args.nq * world * n_win * K / region,
+                               "note": "the whole region by the host clock, barrier + synchronize on both "
+                                       "sides, pipeline fill and drain included"},
+                   "warmup_steps_run": n_warm, "distinct_batches": N_BATCHES},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int8 (saturating PQ sums) + f32 (tables, rescoring)", "data": "synthetic",
+        "dtype": "int8 (saturating PQ sums) + f32 (tables, rescoring)",
+        "data": "synthetic" if not args.data_file else f"file {os.path.basename(args.data_file)}",
         "config": {"workload": ("c5 (BASELINE configs[4] on one GPU): 3000 Gaussian clusters sigma 0.7 generated in "
                                 "HBM (seeded counter-based generator), index built on the device, PQ rotated to 64 "
                                 "dims, euclidean, "
@@ -898,7 +1017,8 @@ def main():
                                            f"in {truth_s * 1e3:.0f} ms"),
                    "parallelism": f"replica x{world} (queries sharded)",
                    "batches_in_flight": args.pipeline},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "bound_measured": "valu-issue (measured: profiles/r02_scan_forms.md; see `valu`); hbm by contract",
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "achieved_is": "ALGORITHMIC GB/s (one code byte per (query, code) pair); the fabric "
                                     "carries `traffic` bytes per launch: four queries share each fetched "

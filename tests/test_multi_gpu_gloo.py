@@ -195,10 +195,38 @@ def _coalesce_worker(rank, world, port, tag, nq, k, n_probes, ret):
         first = idx.submit(qn, qp, k, n_probes)             # waits for a second batch
         out = idx.submit(qn.flip(0).contiguous(), qp.flip(0).contiguous(), k, n_probes)
         third = idx.submit(qn, qp, k, n_probes)             # flushed alone by join()
-        idx.join()
+        tail = idx.join()                                   # ... which hands its rows back
+        assert tail is idx.last_flushed
+        qh1 = -(-nq // world)
+        tail_rows = tail[:, :-1].reshape(world * qh1, k)[:nq].numpy().copy()
+        # a batch with other arguments never shares an exchange with the queued one
+        a = idx.submit(qn, qp, k, n_probes)
+        b = idx.submit(qn, qp, k, 2)                        # flushes `a` alone first, then waits
+        assert a is None and b is None
+        alone = idx.last_flushed[:, :-1].reshape(world * qh1, k)[:nq].numpy().copy()
+        other = idx.join()[:, :-1].reshape(world * qh1, k)[:nq].numpy().copy()
+        # a submit()ted batch that overflows its regions is reported by join(), which grows the
+        # capacity; the batch submitted again is then answered
+        idx2 = ListShardedIndex(None, engine=eng, owner=owner, list_sizes=g["list_sizes"])
+        idx2.capacity[(nq, n_probes)] = 3
+        idx2.submit(qn, qp, k, n_probes)
+        raised = False
+        try:
+            idx2.join()
+        except RuntimeError as e:
+            raised = "overflowed" in str(e)
+        assert raised and idx2.capacity[(nq, n_probes)] > 3
+        while True:
+            again = idx2.submit(qn, qp, k, n_probes)
+            try:
+                idx2.join()
+                break
+            except RuntimeError:
+                pass
+        again_rows = again[:, :-1].reshape(world * qh1, k)[:nq].numpy().copy()
         qh = -(-2 * nq // world)
         ret[rank] = (first is None, third is None, out[:, :-1].reshape(world * qh, k)[:2 * nq].numpy().copy(),
-                     bool(out[:, -1].any()))
+                     bool(out[:, -1].any()), tail_rows, alone, other, again_rows)
     finally:
         dist.destroy_process_group()
 
@@ -214,11 +242,16 @@ def test_list_sharded_coalesced_submits_gloo():
     ret = mgr.dict()
     mp.spawn(_coalesce_worker, args=(world, port, tag, nq, k, n_probes, ret), nprocs=world, join=True)
     exp = golden(f"g6_ivf_{tag}.npz")[f"ids_p{n_probes}"][:nq]
+    exp2 = golden(f"g6_ivf_{tag}.npz")["ids_p2"][:nq]
     for r in range(world):
-        first_none, third_none, rows, overflow = ret[r]
+        first_none, third_none, rows, overflow, tail_rows, alone, other, again_rows = ret[r]
+        np.testing.assert_array_equal(again_rows, exp)      # after the overflow join() reported
         assert first_none and third_none and not overflow
         np.testing.assert_array_equal(rows[:nq], exp)
         np.testing.assert_array_equal(rows[nq:], exp[::-1])
+        np.testing.assert_array_equal(tail_rows, exp)       # join() returns the batch it flushed
+        np.testing.assert_array_equal(alone, exp)           # flushed when the arguments changed
+        np.testing.assert_array_equal(other, exp2)
 
 
 def _mismatch_worker(rank, world, port, ret):

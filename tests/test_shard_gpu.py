@@ -284,6 +284,64 @@ def test_sharded_two_processes_one_gpu(exchange):
             np.testing.assert_array_equal(ret[r][p], g[f"ids_p{p}"])
 
 
+def _rccl_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from test_hip_parity import ivf_from_fixture
+        from tinyknn_amd.multi_gpu import ListShardedIndex
+        out = {}
+        for tag in ("g6_ivf_an100", "g6_ivf_an100b2"):      # distinct labels / every point in two lists
+            g = golden(tag + ".npz")
+            ivf = ivf_from_fixture(None, g)
+            qn, qp = ivf._prepare(np.array(g["qs"], dtype=np.float32))
+            qn_t, qp_t = torch.from_numpy(qn).cuda(), torch.from_numpy(np.ascontiguousarray(qp)).cuda()
+            for exchange in ("dense", "filtered"):
+                idx = ListShardedIndex(ivf, depth=4, exchange=exchange, force_collectives=True)
+                assert idx.backend == "nccl" and idx.world == 1 and idx.force
+                for p in (1, 5, 10):
+                    out[(tag, exchange, p)] = idx.query_batch(g["qs"], 10, n_probes=p)
+                # four batches in flight, each on its own stream: the collectives of different
+                # batches are issued from different streams
+                outs = [idx.submit(qn_t, qp_t, 10, 10) for _ in range(8)]
+                idx.join()
+                torch.cuda.synchronize()
+                out[(tag, exchange, "flight")] = [o.cpu().numpy() for o in outs[-4:]]
+                idx.engine.dev.close()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rccl_world1_forced_collectives():
+    """The RCCL branch on the one-GPU box: ONE rank, backend nccl, the exchanges forced through
+    torch.distributed (TINYKNN_FORCE_COLLECTIVES / force_collectives) instead of device copies —
+    uint8 MIN all-reduce of the bounds, equal-split all_to_all_single of the distance regions,
+    variable-split all_to_all_single of the (n, 5) int32 records, all_gather_into_tensor of probe
+    lists and ids, four batches in flight on four streams.  Golden ids, both exchanges, distinct and
+    repeating labels."""
+    import torch.multiprocessing as mp
+    port = 31500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    out = ret[0]
+    for tag in ("g6_ivf_an100", "g6_ivf_an100b2"):
+        g = golden(tag + ".npz")
+        nq = len(g["qs"])
+        for exchange in ("dense", "filtered"):
+            for p in (1, 5, 10):
+                np.testing.assert_array_equal(out[(tag, exchange, p)], g[f"ids_p{p}"])
+            for got in out[(tag, exchange, "flight")]:
+                assert not got[:, -1].any()
+                np.testing.assert_array_equal(got[:, :-1].reshape(-1, 10)[:nq], g["ids_p10"])
+
+
 def test_resident_index_sharded_in_place(oracle):
     """IVF.build_resident on every simulated rank (same seed: same vectors, lists and codes),
     each rank's index sharded where it lies (tk_index_shard_resident): ids of the unsharded

@@ -1748,6 +1748,8 @@ extern "C" int tk_index_shard_usage(tk_index *ix, int slot, int64_t *max_stream_
     return TK_OK;
 }
 
+// (signed tables only, as everything behind IVF.query: ivf.py:128 builds distance_table, never
+// udistance_table; the kernels' 0x7f fill and int8 minima assume it)
 // ---- filtered exchange: bound -> [min all-reduce] -> filter ->
 // [all-to-all of the counts and of the records] -> finish_filtered.  `scan_dev` is the buffer
 // tk_index_shard_scan_dev of the same slot filled (it stays on the rank), with the same nq,
@@ -2058,6 +2060,15 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
             act.insert(act.end(), all_centers + (size_t)j * d, all_centers + (size_t)(j + 1) * d);
         }
     const int64_t L = (int64_t)sizes.size();
+    {   // the reference groups the rows by RAW centre id into n_active lists and asserts
+        // max(index) < n_active (utils.py:128, IVF.build -> group_data_by_indices): it only builds
+        // when no empty centre precedes a used one.  Same contract here (the host build asserts too).
+        int64_t last = -1;
+        for (int64_t j = 0; j < C; j++)
+            if (cnt[(size_t)j] > 0) last = j;
+        ARGCHECK(last < L, "a centre that received no row precedes one that did: the reference's "
+                           "group_data_by_indices asserts max(index) < n_active (utils.py:128)");
+    }
     std::vector<int64_t> coff((size_t)L + 1, 0), ioff((size_t)L + 1, 0);
     int64_t maxc = 0;
     for (int64_t i = 0; i < L; i++) {

@@ -7,6 +7,7 @@ kernel pipeline of libtinyknn_hip.so: distance tables -> coarse scan + heap +
 rescoring -> probed-list scan -> exact heap replay -> exact rescoring.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -39,6 +40,7 @@ class QueryStream:
             raise _lib.TinyKnnHipError("no BLAS bound for the exact host front end: " +
                                        str(_front.info()["why"]))
         self._dev = dev                 # keeps the index alive
+        dev._live_streams.add(self)     # ... and the index closes its sessions before it goes
         self.max_nq, self.k = int(max_nq), int(k)
         R = dev._R
         self._s = _lib.lib().tk_stream_create(
@@ -172,6 +174,7 @@ class DeviceIndex:
         self.angular = ivf.metric == "angular"
         self._R = None
         self._streams = {}
+        self._live_streams = weakref.WeakSet()
         if pq.R is not None:    # fast mode (device front end) needs the rotation on the device
             R = np.ascontiguousarray(pq.R, dtype=np.float64)
             _lib.check(L.tk_index_set_rotation(self._h, R.ctypes.data, R.shape[1]))
@@ -200,6 +203,7 @@ class DeviceIndex:
         self.angular = ivf.metric == "angular"
         self._R = None if pq.R is None else np.ascontiguousarray(pq.R, dtype=np.float64)
         self._streams = {}
+        self._live_streams = weakref.WeakSet()
         self.list_sizes = None
         self.code_bytes = 0
         return self
@@ -236,8 +240,14 @@ class DeviceIndex:
         (tk_index_shard_resident): only the codes of the lists it owns stay in HBM."""
         own = np.ascontiguousarray(owner, dtype=np.int32)
         assert own.shape == (self.n_lists,)
+        prev = getattr(self, "_sharded_as", None)
+        if prev is not None:        # a second ListShardedIndex on the same IVF: same partition only
+            if prev[1:] == (int(rank), int(world)) and np.array_equal(prev[0], own):
+                return
+            raise RuntimeError("this index is already list-sharded in place with another partition")
         _lib.check(_lib.lib().tk_index_shard_resident(self._h, _lib.ptr(own, _lib._i32p), int(rank), int(world)))
         self.rank, self.world = int(rank), int(world)
+        self._sharded_as = (own.copy(), int(rank), int(world))
 
     def export_lists(self, codes=True, ids=True):
         """(list_sizes, packed codes (chunks, M) uint64 or None, ids or None) back on the host
@@ -273,7 +283,9 @@ class DeviceIndex:
         return self._h
 
     def close(self):
-        for st in getattr(self, "_streams", {}).values():
+        # every session on this index, the caller's own included: a session that outlived the
+        # index would drain and join a freed handle
+        for st in list(getattr(self, "_live_streams", ())):
             st.close()
         self._streams = {}
         if getattr(self, "_h", None):
@@ -386,11 +398,18 @@ class DeviceIndex:
         return out
 
     def query_batch_dev(self, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, out_ptr,
-                        pass_1=None, stream=0):
-        """Device pointers in, device pointer out, enqueued on `stream` (no sync)."""
-        _lib.check(_lib.lib().tk_index_query_batch_dev(
-            self._h, qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
-            int(pass_1 or 0), out_ptr, stream))
+                        pass_1=None, stream=0, done_event=None):
+        """Device pointers in, device pointer out, enqueued on `stream` (no sync).
+        done_event: a hipEvent_t (integer handle) recorded behind the batch's last kernel, on
+        whichever internal stream that runs (tk_index_query_batch_dev_ex)."""
+        if done_event is None:
+            _lib.check(_lib.lib().tk_index_query_batch_dev(
+                self._h, qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
+                int(pass_1 or 0), out_ptr, stream))
+        else:
+            _lib.check(_lib.lib().tk_index_query_batch_dev_ex(
+                self._h, qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
+                int(pass_1 or 0), out_ptr, None, C.c_void_p(int(done_event)), stream))
 
     def shard_coarse_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1,
                          probes_home_ptr, stream=0):
@@ -489,9 +508,18 @@ class IVF:
 
     # device handles are not picklable (the reference pickles (pq, ivf), bench.py:88-103)
     def __getstate__(self):
+        self._require_host_copy("pickle")
         st = dict(self.__dict__)
         st["_dev"] = None
         return st
+
+    def _require_host_copy(self, what):
+        """An index built in HBM (build_resident) keeps its lists, codes and vectors on the
+        device only; what needs them on the host says so instead of failing on a None."""
+        if getattr(self, "pq_transformed_points", 0) is None:
+            raise RuntimeError(f"IVF.{what}: this index was built in HBM (build_resident): its lists, codes "
+                               "and vectors live on the device only — device_index().export_lists() / "
+                               "read_rows() fetch them")
 
     # ---- offline ---------------------------------------------------------
     def fit(self, X, verbose=False):
@@ -626,6 +654,7 @@ class IVF:
     def save(self, path):
         """Flat binary (.npz): PQ codebook (+ rotation), coarse centres and their codes, list
         sizes, packed codes and ids of all lists concatenated list-major, rescoring vectors."""
+        self._require_host_copy("save")
         L = len(self.active_centers)
         M = self.pq.centers.shape[1] // self.pq.dims_per_block
         tds = [self.pq_transformed_points[i] for i in range(L)]
@@ -715,6 +744,14 @@ class IVF:
             self._dev = DeviceIndex(self)
         return self._dev
 
+    def _unsharded_device_index(self):
+        dev = self.device_index()
+        if dev.world != 1 or getattr(dev, "_sharded_as", None) is not None:
+            raise RuntimeError("this IVF's device index has been list-sharded in place (ListShardedIndex on an "
+                               f"index built in HBM: rank {dev.rank} of {dev.world}); query it through the "
+                               "ListShardedIndex")
+        return dev
+
     def _prepare(self, qs):
         """Host side of ivf.py:125-128: float32, metric normalisation (numpy, in
         place for a contiguous float32 input as in the reference), padding and the
@@ -738,7 +775,7 @@ class IVF:
         q = np.ascontiguousarray(q, dtype=np.float32)
         assert self.data.shape[1] == q.shape[0]
         qn, qp = self._prepare(q[None, :])
-        out = self.device_index().query_batch(qn, qp, k, n_probes, pass_1)[0]
+        out = self._unsharded_device_index().query_batch(qn, qp, k, n_probes, pass_1)[0]
         return out[out != -1] if out[-1] == -1 else out
 
     def query_batch(self, qs, k, n_probes=1, pass_1=None, fast=False):
@@ -748,6 +785,7 @@ class IVF:
         call.)  fast=True: normalisation, padding and rotation run on the device instead
         of numpy's per-query BLAS calls (35 ms per 10 000 queries on the host) — within
         1 ulp of them, so a rare id can differ from the reference's; the default is exact."""
+        self._unsharded_device_index()
         if fast:
             return self.device_index().query_batch_raw(qs, k, n_probes, pass_1)
         R = self.pq.R

@@ -211,7 +211,8 @@ class ListShardedIndex:
     """
 
     def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None,
-                 coarse="home", coalesce=1, exchange="dense", calibrate=True):
+                 coarse="home", coalesce=1, exchange="dense", calibrate=True, force_collectives=None):
+        import os
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -220,6 +221,15 @@ class ListShardedIndex:
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         self.backend = dist.get_backend(group) if on else None
+        # force_collectives (or TINYKNN_FORCE_COLLECTIVES=1): with ONE rank the exchanges are
+        # device copies; forced, they go through torch.distributed all the same — on a one-GPU box
+        # that is how the RCCL code path (uint8 MIN all-reduce, equal- and variable-split
+        # all_to_all_single, all_gather_into_tensor, issued from several streams) gets executed
+        if force_collectives is None:
+            force_collectives = os.environ.get("TINYKNN_FORCE_COLLECTIVES", "0") not in ("", "0")
+        self.force = bool(force_collectives)
+        if self.force and not on:
+            raise RuntimeError("force_collectives needs an initialised process group (world size 1 is fine)")
         resident = getattr(ivf, "pq_transformed_points", 0) is None     # IVF.build_resident
         if list_sizes is None and resident:
             list_sizes = ivf.list_sizes
@@ -255,12 +265,16 @@ class ListShardedIndex:
                          if self.device == "cuda" and depth > 1 else None)
         self._pending = []
         self._deferred = None
+        self._need = {}             # (nq, n_probes) -> longest streams seen by query_prepared
+        self._ovf = None            # device counter: overflow / bad-record flags of submit()ted batches
+        self._ovf_keys = set()      # capacities to grow if that counter is non-zero at join()
+        self.last_flushed = None    # gathered tensor of the batch join() flushed (coalesce > 1)
 
     def _check_same_index(self, ivf):
         """Every rank must hold the SAME index (same centres, same lists): positions in the
         exchange are computed, not transmitted.  An index fitted per rank from an unseeded RNG
         differs silently — compare a checksum once, at construction."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         import zlib
         crc = zlib.crc32(np.ascontiguousarray(self.list_sizes).tobytes())
@@ -279,7 +293,7 @@ class ListShardedIndex:
 
     # -- collectives (RCCL on device tensors; any other backend is staged through the host)
     def _all_to_all(self, recv, send):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             recv.copy_(send)
         elif self.backend == "nccl" or self.device == "cpu":
             self.dist.all_to_all_single(recv, send, group=self.group)
@@ -289,7 +303,7 @@ class ListShardedIndex:
             recv.copy_(r)
 
     def _all_gather(self, out, inp):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             out.copy_(inp)
         elif self.backend == "nccl" or self.device == "cpu":
             self.dist.all_gather_into_tensor(out, inp, group=self.group)
@@ -299,7 +313,7 @@ class ListShardedIndex:
             out.copy_(o)
 
     def _all_reduce_min(self, t_):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.backend == "nccl" or self.device == "cpu":
             self.dist.all_reduce(t_, op=self.dist.ReduceOp.MIN, group=self.group)
@@ -310,7 +324,7 @@ class ListShardedIndex:
 
     def _all_to_all_rows(self, recv, send, rsplit, ssplit):
         """Variable splits along dim 0."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             recv.copy_(send)
         elif self.backend == "nccl" or self.device == "cpu":
             self.dist.all_to_all_single(recv, send, rsplit, ssplit, group=self.group)
@@ -446,7 +460,7 @@ class ListShardedIndex:
         if not hasattr(self.engine, "usage"):
             return None
         u = int(self.engine.usage(slot))
-        if self.world > 1:
+        if self.world > 1 or self.force:
             t_ = self.torch.tensor([u], dtype=self.torch.int64,
                                    device=self.device if self.backend == "nccl" else "cpu")
             self.dist.all_reduce(t_, op=self.dist.ReduceOp.MAX, group=self.group)
@@ -470,8 +484,14 @@ class ListShardedIndex:
                 raise RuntimeError("filtered exchange: a record outside the home rank's rows")
             need = self._usage(slot)
             if not g[:, -1].any():
-                if need is not None and self.calibrate and int(1.25 * need) + 64 < 0.8 * cap:
-                    self.capacity[(nq, n_probes)] = int(1.25 * need) + 64
+                # trim only on the evidence of SEVERAL batches (their longest stream, +35 %): one
+                # batch's streams say little about the next batch's, and a pipelined submit() only
+                # learns of an overflow at join()
+                if need is not None and self.calibrate:
+                    seen = self._need.setdefault((nq, n_probes), [])
+                    seen.append(need)
+                    if len(seen) >= 2 and int(1.35 * max(seen)) + 64 < 0.8 * cap:
+                        self.capacity[(nq, n_probes)] = int(1.35 * max(seen)) + 64
                 return g[:, :-1].reshape(self.world * qh, k)[:nq]
             worst = qh * min(n_probes, len(self.list_sizes)) * int((self.list_sizes.max() + 15) // 16)
             assert cap < worst, "overflow at the worst-case capacity"
@@ -497,6 +517,8 @@ class ListShardedIndex:
         it went into (rows in query order over the coalesced batches, last column = overflow
         flag), or None while the batch waits for `coalesce - 1` more (join() flushes)."""
         if self.coalesce > 1:
+            if self._queue and self._qargs != (k, n_probes, pass_1):
+                self._flush()           # batches with other arguments never share an exchange
             self._queue.append((qn, qp))
             self._qargs = (k, n_probes, pass_1)
             if len(self._queue) < self.coalesce:
@@ -512,17 +534,23 @@ class ListShardedIndex:
         qn = t.cat([a for a, _ in self._queue]) if len(self._queue) > 1 else self._queue[0][0]
         qp = t.cat([b for _, b in self._queue]) if len(self._queue) > 1 else self._queue[0][1]
         self._queue = []
-        return self._submit_one(qn, qp, k, n_probes, pass_1)
+        self.last_flushed = self._submit_one(qn, qp, k, n_probes, pass_1)
+        return self.last_flushed
 
     def _submit_one(self, qn, qp, k, n_probes=1, pass_1=None):
         t = self.torch
         cap = self._capacity(qn.shape[0], n_probes)
+        self._ovf_keys.add((qn.shape[0], n_probes))
         if self._streams is None:
-            return self._enqueue(qn, qp, k, n_probes, pass_1, cap)
+            out = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
+            self._note_flags(out)
+            return out
         st = self._streams[self._calls % self.depth]
         st.wait_stream(t.cuda.current_stream())
         with t.cuda.stream(st):
             state = self._enqueue_front(qn, qp, k, n_probes, pass_1, cap)
+            if state["f"] is None:
+                self._note_flags(state["out"])
         # filtered exchange: the host must read this batch's record counts before it can enqueue
         # the second half — it does so only after the NEXT batch's first half is in the queue
         # (same order on every rank), so that the device is never idle while the host waits
@@ -537,12 +565,37 @@ class ListShardedIndex:
             st, state = self._deferred
             self._deferred = None
             with self.torch.cuda.stream(st):
-                self._enqueue_back(state)
+                self._note_flags(self._enqueue_back(state))
+
+    def _note_flags(self, out):
+        """The flag column of a submit()ted batch (every rank's overflow / bad-record flag) is
+        added to a device counter, on the batch's stream: join() reads it once."""
+        if self._ovf is None:
+            self._ovf = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+        self._ovf += out[:, -1].sum()
 
     def join(self):
-        self._flush()
+        """Flushes a partly filled coalesced batch (its gathered tensor: the return value and
+        `last_flushed`), re-joins the batches in flight, and RAISES if any batch since the last
+        join overflowed its exchange regions (its rows are then invalid): the capacities have been
+        grown, submit the batches again."""
+        flushed = self._flush()
         self._finish_deferred()
         if self._streams is not None:
             cur = self.torch.cuda.current_stream()
             for st in self._streams:
                 cur.wait_stream(st)
+        if self._ovf is not None and self._ovf_keys:
+            bad = int(self._ovf.item())         # (synchronises with the batches in flight)
+            keys, self._ovf_keys = self._ovf_keys, set()
+            if bad:
+                self._ovf.zero_()
+                for key in keys:
+                    nq, n_probes = key
+                    qh = -(-nq // self.world)
+                    worst = qh * min(n_probes, len(self.list_sizes)) * int((self.list_sizes.max() + 15) // 16)
+                    self.capacity[key] = min(2 * self._capacity(nq, n_probes), worst)
+                    self._need.pop(key, None)
+                raise RuntimeError("ListShardedIndex: a batch in flight overflowed its exchange regions (or "
+                                   "carried a bad record); capacities doubled — submit the batches again")
+        return flushed
