@@ -1,0 +1,297 @@
+// mfma_scan.hip — round-3 microbenchmark (go/no-go for the matrix-core scan of the probed lists
+// behind the first one): plain int32 sums of table entries as a one-hot(code) x
+// table int8 contraction on v_mfma_i32_32x32x32_i8, saturated to int8 on the way out.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o bin/mfma_scan mfma_scan.hip && bin/mfma_scan
+//
+// One wave = one unit (list, tile of 32 (query, list) pairs, range of chunk pairs):
+//   B operand: lane (q = lane & 31, h = lane >> 5) holds the 16-byte table row of block 2p + h of
+//              its pair's query for every block pair p — 26 x 4 VGPRs, loaded once per unit;
+//   A operand: rows = the 32 rows of two consecutive 16-row chunks; lane (r, h) turns nibble h of
+//              byte r of the chunk's 16-byte group p into a 16-byte one-hot through a 256-byte
+//              LDS table (one ds_read_b128: distinct entries sit on distinct banks);
+//   D: 32 rows x 32 queries of int32 sums; lane (q, h) holds rows {0-3, 8-11, 16-19, 24-27} + 4h,
+//      clamps them to int8, and after two v_permlane32_swap holds the whole 16-byte block of
+//      (chunk 2cp + h, query q): one 16-byte store + one minimum byte per lane.
+// Checked against a host restatement on every output byte.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define CHECK(x)                                                                        \
+    do {                                                                                \
+        hipError_t e_ = (x);                                                            \
+        if (e_ != hipSuccess) {                                                         \
+            fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                    \
+        }                                                                               \
+    } while (0)
+
+struct Job {
+    const uint4 *codes;            // tiled layout of kernels.h
+    const uint4 *tables;           // (nq, M) 16-byte rows
+    const int64_t *list_chunk_off; // n_lists + 1
+    const int *unit_prefix;        // n_lists + 1: units before each list
+    const int *pair_off;           // n_lists + 1: records before each list
+    const int *pair_q, *pair_f0;   // records: query, first flat chunk of its row range
+    uint4 *dist;
+    int64_t cap;
+    uint8_t *mins;
+    int64_t min_stride;
+    int n_lists, cpu;              // cpu: chunk pairs per unit
+};
+
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
+{
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x04000c0cu);
+    return lo | hi;
+}
+
+__device__ __forceinline__ int clamp8(int x) { return min(max(x, -128), 127); }
+
+// swap(a in lanes 32..63, b in lanes 0..31)
+__device__ __forceinline__ void swap_halves(uint32_t &a, uint32_t &b)
+{
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+#else
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+#endif
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void scan_mfma_kernel(Job j)
+{
+    __shared__ uint4 lut[16];
+    const int lane = threadIdx.x;
+    if (lane < 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        w[lane >> 2] = 1u << (8 * (lane & 3));
+        lut[lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    const int M = 2 * P;
+    const int u = blockIdx.x;
+    int lo = 0, hi = j.n_lists;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (j.unit_prefix[mid] <= u) lo = mid; else hi = mid;
+    }
+    const int l = lo;
+    const int64_t c0 = j.list_chunk_off[l];
+    const int C = (int)(j.list_chunk_off[l + 1] - c0);
+    const int CP = (C + 1) >> 1;
+    const int SP = (CP + j.cpu - 1) / j.cpu;
+    const int local = u - j.unit_prefix[l];
+    const int t = local / SP, s = local - t * SP;
+    const int r = lane & 31, h = lane >> 5;
+    const int cnt = j.pair_off[l + 1] - j.pair_off[l];
+    const bool valid = 32 * t + r < cnt;
+    const int rec = j.pair_off[l] + 32 * t + (valid ? r : 0);
+    const int qi = j.pair_q[rec];
+    const int f0 = j.pair_f0[rec];
+    v4i B[P];
+    {
+        const v4i *trow = (const v4i *)(j.tables + (int64_t)qi * M + h);
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            B[p] = trow[2 * p];
+            if (!valid) B[p] = (v4i){0, 0, 0, 0};
+        }
+    }
+    const int rr = r & 15;
+    const int off = 8 * (rr & 3) + 4 * h;
+    const int cp1 = (s + 1) * j.cpu < CP ? (s + 1) * j.cpu : CP;
+    uint4 *drow = j.dist + (int64_t)qi * j.cap + f0;
+    uint8_t *mrow = j.mins + (int64_t)qi * j.min_stride + f0;
+    const unsigned char *lutb = (const unsigned char *)lut;
+    for (int cp = s * j.cpu; cp < cp1; cp++) {
+        int c = 2 * cp + (r >> 4);
+        c = c < C ? c : C - 1;
+        const int64_t gc = c0 + c;
+        const uint32_t *src = (const uint32_t *)(j.codes + ((gc >> 3) * (int64_t)P) * 8 + (gc & 7)) + (rr >> 2);
+        uint32_t x[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) x[p] = src[p * 32];
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const uint32_t a_off = ((x[p] >> off) & 15u) << 4;
+            const v4i A = *(const v4i *)(lutb + a_off);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[p], acc, 0, 0, 0);
+        }
+        int o[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) o[i] = clamp8(acc[i]);
+        uint32_t X = pack4(o[0], o[1], o[2], o[3]), Y = pack4(o[4], o[5], o[6], o[7]);
+        uint32_t Z = pack4(o[8], o[9], o[10], o[11]), W = pack4(o[12], o[13], o[14], o[15]);
+        uint32_t mA = (uint32_t)min(min(min(o[0], o[1]), min(o[2], o[3])), min(min(o[4], o[5]), min(o[6], o[7])));
+        uint32_t mB = (uint32_t)min(min(min(o[8], o[9]), min(o[10], o[11])), min(min(o[12], o[13]), min(o[14], o[15])));
+        swap_halves(X, Z);
+        swap_halves(Y, W);
+        swap_halves(mA, mB);
+        const int mn = min((int)mA, (int)mB);
+        const int cc = 2 * cp + h;
+        if (valid && cc < C) {
+            drow[cc] = make_uint4(X, Z, Y, W);
+            mrow[cc] = (uint8_t)mn;
+        }
+    }
+}
+
+static double now_ms(hipEvent_t a, hipEvent_t b)
+{
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+}
+
+int main(int argc, char **argv)
+{
+    const int P = 26, M = 52;
+    int n_lists = argc > 1 ? atoi(argv[1]) : 1087;
+    int C = argc > 2 ? atoi(argv[2]) : 69;           // chunks per list
+    int nq = argc > 3 ? atoi(argv[3]) : 10000;
+    int S = argc > 4 ? atoi(argv[4]) : 9;            // lists probed per query
+    int cpu = argc > 5 ? atoi(argv[5]) : 12;         // chunk pairs per unit
+    srand(1);
+    // codes: random bytes, tiled layout; every list C chunks (+/- a few)
+    std::vector<int64_t> coff(n_lists + 1, 0);
+    for (int l = 0; l < n_lists; l++) coff[l + 1] = coff[l] + std::max(1, C + (rand() % 7) - 3);
+    const int64_t total = coff[n_lists];
+    const int64_t tiled = (total + 7) / 8 * 8 * P;
+    std::vector<uint8_t> codes((size_t)tiled * 16);
+    for (auto &b : codes) b = (uint8_t)(rand() & 0xff);
+    std::vector<int8_t> tables((size_t)nq * M * 16);
+    for (auto &b : tables) b = (int8_t)((rand() % 28) - 4);
+    for (int q = 0; q < nq; q += 97)                 // some queries with large entries: clamps
+        for (int i = 0; i < M * 16; i++) tables[(size_t)q * M * 16 + i] = (int8_t)((rand() % 256) - 128);
+    // probes: S distinct lists per query; rows laid out back to back
+    std::vector<std::vector<int>> by_list(n_lists);
+    std::vector<int> q_f0((size_t)nq * S);
+    int64_t cap = 0;
+    for (int q = 0; q < nq; q++) {
+        int f = 0;
+        for (int s = 0; s < S; s++) {
+            int l;
+            bool dup;
+            do {
+                l = rand() % n_lists;
+                dup = false;
+                for (int s2 = 0; s2 < s; s2++) dup |= (q_f0[(size_t)q * S + s2] >> 20) == l;
+            } while (dup);
+            q_f0[(size_t)q * S + s] = (l << 20);     // remember the list in the high bits for the dup test
+            by_list[l].push_back(q * S + s);
+            (void)f;
+        }
+    }
+    std::vector<int> rowpos((size_t)nq * S);
+    for (int q = 0; q < nq; q++) {
+        int f = 0;
+        for (int s = 0; s < S; s++) {
+            const int l = q_f0[(size_t)q * S + s] >> 20;
+            rowpos[(size_t)q * S + s] = f;
+            f += (int)(coff[l + 1] - coff[l]);
+        }
+        cap = std::max<int64_t>(cap, f);
+    }
+    const int64_t min_stride = (cap + 15) / 16 * 16;
+    std::vector<int> pair_off(n_lists + 1, 0), unit_prefix(n_lists + 1, 0), pair_q, pair_f0;
+    for (int l = 0; l < n_lists; l++) {
+        for (int id : by_list[l]) {
+            pair_q.push_back(id / S);
+            pair_f0.push_back(rowpos[id]);
+        }
+        pair_off[l + 1] = (int)pair_q.size();
+        const int cnt = (int)by_list[l].size();
+        const int CP = (int)((coff[l + 1] - coff[l] + 1) / 2);
+        unit_prefix[l + 1] = unit_prefix[l] + ((cnt + 31) / 32) * ((CP + cpu - 1) / cpu);
+    }
+    const int U = unit_prefix[n_lists];
+    double pairs_chunks = 0;
+    for (int l = 0; l < n_lists; l++) pairs_chunks += (double)by_list[l].size() * (coff[l + 1] - coff[l]);
+    printf("lists %d x ~%d chunks, %d queries x %d probes: %d units, %.2f M (chunk, query) pairs, cap %lld\n",
+           n_lists, C, nq, S, U, pairs_chunks / 1e6, (long long)cap);
+
+    uint4 *d_codes, *d_tables, *d_dist;
+    uint8_t *d_mins;
+    int64_t *d_coff;
+    int *d_up, *d_po, *d_pq, *d_pf;
+    CHECK(hipMalloc(&d_codes, codes.size()));
+    CHECK(hipMalloc(&d_tables, tables.size()));
+    CHECK(hipMalloc(&d_dist, (size_t)nq * cap * 16));
+    CHECK(hipMalloc(&d_mins, (size_t)nq * min_stride));
+    CHECK(hipMalloc(&d_coff, coff.size() * 8));
+    CHECK(hipMalloc(&d_up, unit_prefix.size() * 4));
+    CHECK(hipMalloc(&d_po, pair_off.size() * 4));
+    CHECK(hipMalloc(&d_pq, pair_q.size() * 4 + 4));
+    CHECK(hipMalloc(&d_pf, pair_f0.size() * 4 + 4));
+    CHECK(hipMemcpy(d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_tables, tables.data(), tables.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_coff, coff.data(), coff.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_up, unit_prefix.data(), unit_prefix.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_po, pair_off.data(), pair_off.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_pq, pair_q.data(), pair_q.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_pf, pair_f0.data(), pair_f0.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemset(d_dist, 0xee, (size_t)nq * cap * 16));
+    CHECK(hipMemset(d_mins, 0xee, (size_t)nq * min_stride));
+    Job j{d_codes, d_tables, d_coff, d_up, d_po, d_pq, d_pf, d_dist, cap, d_mins, min_stride, n_lists, cpu};
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(scan_mfma_kernel<26>, dim3(U), dim3(64), 0, 0, j);
+    CHECK(hipDeviceSynchronize());
+    const int reps = 20;
+    CHECK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(scan_mfma_kernel<26>, dim3(U), dim3(64), 0, 0, j);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    const double ms = now_ms(e0, e1) / reps;
+    printf("scan_mfma_kernel: %.4f ms per launch = %.2f G (chunk, query)/s, %.1f GB/s algorithmic (26 B per (query, code)), "
+           "%.1f cycles per (chunk, query) per SIMD at 2.4 GHz\n",
+           ms, pairs_chunks / ms / 1e6, pairs_chunks * 416 / ms / 1e6, ms * 1e-3 * 2.4e9 * 1024 / pairs_chunks);
+
+    // ---- check every byte against the host
+    std::vector<uint8_t> dist((size_t)nq * cap * 16), mins((size_t)nq * min_stride);
+    CHECK(hipMemcpy(dist.data(), d_dist, dist.size(), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(mins.data(), d_mins, mins.size(), hipMemcpyDeviceToHost));
+    long long bad = 0, checked = 0;
+    for (int l = 0; l < n_lists && bad < 10; l++) {
+        const int Cl = (int)(coff[l + 1] - coff[l]);
+        for (size_t k = 0; k < by_list[l].size(); k += (l % 16 == 0 ? 1 : 7)) {
+            const int q = pair_q[pair_off[l] + k], f0 = pair_f0[pair_off[l] + k];
+            for (int c = 0; c < Cl; c++) {
+                const int64_t gc = coff[l] + c;
+                int mn = 127;
+                for (int row = 0; row < 16; row++) {
+                    int sum = 0;
+                    for (int p = 0; p < P; p++) {
+                        const uint8_t byte = codes[((size_t)(((gc >> 3) * P + p) * 8 + (gc & 7))) * 16 + row];
+                        sum += tables[((size_t)q * M + 2 * p) * 16 + (byte & 15)];
+                        sum += tables[((size_t)q * M + 2 * p + 1) * 16 + (byte >> 4)];
+                    }
+                    const int o = sum < -128 ? -128 : (sum > 127 ? 127 : sum);
+                    mn = std::min(mn, o);
+                    const int got = (int8_t)dist[((size_t)q * cap + f0 + c) * 16 + row];
+                    checked++;
+                    if (got != o && bad++ < 10) printf("MISMATCH list %d q %d chunk %d row %d: got %d want %d\n", l, q, c, row, got, o);
+                }
+                if ((int8_t)mins[(size_t)q * min_stride + f0 + c] != mn && bad++ < 10)
+                    printf("MIN MISMATCH list %d q %d chunk %d: got %d want %d\n", l, q, c,
+                           (int8_t)mins[(size_t)q * min_stride + f0 + c], mn);
+            }
+        }
+    }
+    printf("checked %lld bytes: %s\n", checked, bad ? "MISMATCHES" : "all identical to the host's clamp(plain sum)");
+    return bad ? 1 : 0;
+}
