@@ -230,6 +230,23 @@ int tk_index_set_heap_mode(tk_index *ix, int mode);
  * 1 = always query-major, 2 = always list-major.  Identical outputs. */
 int tk_index_set_scan_mode(tk_index *ix, int mode);
 
+/* Probed lists behind the first ones as PLAIN integer sums on the int8 matrix cores
+ * (v_mfma_i32_32x32x32_i8: one-hot(code) x table), clamped to int8.  For a query whose table
+ * bounds the negative mass of each of the reference's saturating chains by 128, clamp(plain sum)
+ * equals the value compute_block_dists_avx (_fast_pq_256.pyx:126-156) returns wherever that value
+ * is below C = 127 - (negative mass) and is >= C elsewhere; the replay inserts only rows below
+ * its bound, which never rises (_fast_pq_256.pyx:73-123), so once the bound is <= C the replay
+ * over the plain sums IS the replay over the reference's values.  The first probed lists of a
+ * query (until they hold 2 * pass_1 rows) stay on the exact kernel; the lane replay checks the
+ * condition per query and the queries that fail it are scanned again exactly and replayed again:
+ * results are identical to mode 1 in every case (tests/test_plain_scan_gpu.py).
+ * 0 = automatic (list-major batches, signed tables, <= 52 blocks, lane replay), 1 = off.
+ * Environment TINYKNN_PLAIN_SCAN=0 switches it off process-wide. */
+int tk_index_set_plain_scan(tk_index *ix, int mode);
+/* Debug/test hook: caps every query's limit C (INT_MAX = off; -128 sends every query with a
+ * plain slot through the re-scan path). */
+int tk_debug_plain_limit(int limit);
+
 /* Form of the list-major scan kernel (process-wide; A/B timing, identical outputs).
  * 1 = the table rows a 64-unit block needs are staged once per block in the wave's
  * LDS region and read with ds_read_b128, one query's rows live at a time (4 waves per SIMD);

@@ -22,8 +22,8 @@
 #include <algorithm>
 #include <vector>
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+// the kernel under test is the library's own (one source of truth)
+#include "../../tinyknn_amd/csrc/plain_scan.hip"
 
 #define CHECK(x)                                                                        \
     do {                                                                                \
@@ -33,121 +33,6 @@ typedef int v16i __attribute__((ext_vector_type(16)));
             exit(1);                                                                    \
         }                                                                               \
     } while (0)
-
-struct Job {
-    const uint4 *codes;            // tiled layout of kernels.h
-    const uint4 *tables;           // (nq, M) 16-byte rows
-    const int64_t *list_chunk_off; // n_lists + 1
-    const int *unit_prefix;        // n_lists + 1: units before each list
-    const int *pair_off;           // n_lists + 1: records before each list
-    const int *pair_q, *pair_f0;   // records: query, first flat chunk of its row range
-    uint4 *dist;
-    int64_t cap;
-    uint8_t *mins;
-    int64_t min_stride;
-    int n_lists, cpu;              // cpu: chunk pairs per unit
-};
-
-__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
-{
-    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
-    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x04000c0cu);
-    return lo | hi;
-}
-
-__device__ __forceinline__ int clamp8(int x) { return min(max(x, -128), 127); }
-
-// swap(a in lanes 32..63, b in lanes 0..31)
-__device__ __forceinline__ void swap_halves(uint32_t &a, uint32_t &b)
-{
-#if __has_builtin(__builtin_amdgcn_permlane32_swap)
-    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0];
-    b = r[1];
-#else
-    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-#endif
-}
-
-template <int P>
-__global__ __launch_bounds__(64) void scan_mfma_kernel(Job j)
-{
-    __shared__ uint4 lut[16];
-    const int lane = threadIdx.x;
-    if (lane < 16) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        w[lane >> 2] = 1u << (8 * (lane & 3));
-        lut[lane] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    __syncthreads();
-    const int M = 2 * P;
-    const int u = blockIdx.x;
-    int lo = 0, hi = j.n_lists;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (j.unit_prefix[mid] <= u) lo = mid; else hi = mid;
-    }
-    const int l = lo;
-    const int64_t c0 = j.list_chunk_off[l];
-    const int C = (int)(j.list_chunk_off[l + 1] - c0);
-    const int CP = (C + 1) >> 1;
-    const int SP = (CP + j.cpu - 1) / j.cpu;
-    const int local = u - j.unit_prefix[l];
-    const int t = local / SP, s = local - t * SP;
-    const int r = lane & 31, h = lane >> 5;
-    const int cnt = j.pair_off[l + 1] - j.pair_off[l];
-    const bool valid = 32 * t + r < cnt;
-    const int rec = j.pair_off[l] + 32 * t + (valid ? r : 0);
-    const int qi = j.pair_q[rec];
-    const int f0 = j.pair_f0[rec];
-    v4i B[P];
-    {
-        const v4i *trow = (const v4i *)(j.tables + (int64_t)qi * M + h);
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            B[p] = trow[2 * p];
-            if (!valid) B[p] = (v4i){0, 0, 0, 0};
-        }
-    }
-    const int rr = r & 15;
-    const int off = 8 * (rr & 3) + 4 * h;
-    const int cp1 = (s + 1) * j.cpu < CP ? (s + 1) * j.cpu : CP;
-    uint4 *drow = j.dist + (int64_t)qi * j.cap + f0;
-    uint8_t *mrow = j.mins + (int64_t)qi * j.min_stride + f0;
-    const unsigned char *lutb = (const unsigned char *)lut;
-    for (int cp = s * j.cpu; cp < cp1; cp++) {
-        int c = 2 * cp + (r >> 4);
-        c = c < C ? c : C - 1;
-        const int64_t gc = c0 + c;
-        const uint32_t *src = (const uint32_t *)(j.codes + ((gc >> 3) * (int64_t)P) * 8 + (gc & 7)) + (rr >> 2);
-        uint32_t x[P];
-#pragma unroll
-        for (int p = 0; p < P; p++) x[p] = src[p * 32];
-        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const uint32_t a_off = ((x[p] >> off) & 15u) << 4;
-            const v4i A = *(const v4i *)(lutb + a_off);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[p], acc, 0, 0, 0);
-        }
-        int o[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) o[i] = clamp8(acc[i]);
-        uint32_t X = pack4(o[0], o[1], o[2], o[3]), Y = pack4(o[4], o[5], o[6], o[7]);
-        uint32_t Z = pack4(o[8], o[9], o[10], o[11]), W = pack4(o[12], o[13], o[14], o[15]);
-        uint32_t mA = (uint32_t)min(min(min(o[0], o[1]), min(o[2], o[3])), min(min(o[4], o[5]), min(o[6], o[7])));
-        uint32_t mB = (uint32_t)min(min(min(o[8], o[9]), min(o[10], o[11])), min(min(o[12], o[13]), min(o[14], o[15])));
-        swap_halves(X, Z);
-        swap_halves(Y, W);
-        swap_halves(mA, mB);
-        const int mn = min((int)mA, (int)mB);
-        const int cc = 2 * cp + h;
-        if (valid && cc < C) {
-            drow[cc] = make_uint4(X, Z, Y, W);
-            mrow[cc] = (uint8_t)mn;
-        }
-    }
-}
 
 static double now_ms(hipEvent_t a, hipEvent_t b)
 {
@@ -163,7 +48,7 @@ int main(int argc, char **argv)
     int C = argc > 2 ? atoi(argv[2]) : 69;           // chunks per list
     int nq = argc > 3 ? atoi(argv[3]) : 10000;
     int S = argc > 4 ? atoi(argv[4]) : 9;            // lists probed per query
-    int cpu = argc > 5 ? atoi(argv[5]) : 12;         // chunk pairs per unit
+    int cpu = argc > 5 ? atoi(argv[5]) : 512;        // persistent workgroups
     srand(1);
     // codes: random bytes, tiled layout; every list C chunks (+/- a few)
     std::vector<int64_t> coff(n_lists + 1, 0);
@@ -188,9 +73,9 @@ int main(int argc, char **argv)
             do {
                 l = rand() % n_lists;
                 dup = false;
-                for (int s2 = 0; s2 < s; s2++) dup |= (q_f0[(size_t)q * S + s2] >> 20) == l;
+                for (int s2 = 0; s2 < s; s2++) dup |= q_f0[(size_t)q * S + s2] == l;
             } while (dup);
-            q_f0[(size_t)q * S + s] = (l << 20);     // remember the list in the high bits for the dup test
+            q_f0[(size_t)q * S + s] = l;
             by_list[l].push_back(q * S + s);
             (void)f;
         }
@@ -199,14 +84,15 @@ int main(int argc, char **argv)
     for (int q = 0; q < nq; q++) {
         int f = 0;
         for (int s = 0; s < S; s++) {
-            const int l = q_f0[(size_t)q * S + s] >> 20;
+            const int l = q_f0[(size_t)q * S + s];
             rowpos[(size_t)q * S + s] = f;
             f += (int)(coff[l + 1] - coff[l]);
         }
         cap = std::max<int64_t>(cap, f);
     }
+    if (argc > 6) cap = std::max<int64_t>(cap, atoll(argv[6]));      // row stride override (chunks)
     const int64_t min_stride = (cap + 15) / 16 * 16;
-    std::vector<int> pair_off(n_lists + 1, 0), unit_prefix(n_lists + 1, 0), pair_q, pair_f0;
+    std::vector<int> pair_off(n_lists + 1, 0), unit_prefix(tk_unit_prefix_ints(n_lists), 0), pair_q, pair_f0;
     for (int l = 0; l < n_lists; l++) {
         for (int id : by_list[l]) {
             pair_q.push_back(id / S);
@@ -215,9 +101,12 @@ int main(int argc, char **argv)
         pair_off[l + 1] = (int)pair_q.size();
         const int cnt = (int)by_list[l].size();
         const int CP = (int)((coff[l + 1] - coff[l] + 1) / 2);
-        unit_prefix[l + 1] = unit_prefix[l] + ((cnt + 31) / 32) * ((CP + cpu - 1) / cpu);
+        unit_prefix[l + 1] = unit_prefix[l] + ((cnt + 31) / 32); (void)CP;
     }
     const int U = unit_prefix[n_lists];
+    std::vector<int> unit_desc;
+    for (int l = 0; l < n_lists; l++)
+        for (int t = 0; t < unit_prefix[l + 1] - unit_prefix[l]; t++) { unit_desc.push_back(l); unit_desc.push_back(t); }
     double pairs_chunks = 0;
     for (int l = 0; l < n_lists; l++) pairs_chunks += (double)by_list[l].size() * (coff[l + 1] - coff[l]);
     printf("lists %d x ~%d chunks, %d queries x %d probes: %d units, %.2f M (chunk, query) pairs, cap %lld\n",
@@ -226,7 +115,7 @@ int main(int argc, char **argv)
     uint4 *d_codes, *d_tables, *d_dist;
     uint8_t *d_mins;
     int64_t *d_coff;
-    int *d_up, *d_po, *d_pq, *d_pf;
+    int *d_up, *d_po, *d_pq, *d_pf, *d_ud;
     CHECK(hipMalloc(&d_codes, codes.size()));
     CHECK(hipMalloc(&d_tables, tables.size()));
     CHECK(hipMalloc(&d_dist, (size_t)nq * cap * 16));
@@ -234,6 +123,8 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&d_coff, coff.size() * 8));
     CHECK(hipMalloc(&d_up, unit_prefix.size() * 4));
     CHECK(hipMalloc(&d_po, pair_off.size() * 4));
+    CHECK(hipMalloc(&d_ud, unit_desc.size() * 4 + 8));
+    CHECK(hipMemcpy(d_ud, unit_desc.data(), unit_desc.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_pq, pair_q.size() * 4 + 4));
     CHECK(hipMalloc(&d_pf, pair_f0.size() * 4 + 4));
     CHECK(hipMemcpy(d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
@@ -245,19 +136,27 @@ int main(int argc, char **argv)
     CHECK(hipMemcpy(d_pf, pair_f0.data(), pair_f0.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemset(d_dist, 0xee, (size_t)nq * cap * 16));
     CHECK(hipMemset(d_mins, 0xee, (size_t)nq * min_stride));
-    Job j{d_codes, d_tables, d_coff, d_up, d_po, d_pq, d_pf, d_dist, cap, d_mins, min_stride, n_lists, cpu};
+    TkScanJob j;
+    j.codes = d_codes; j.tables = d_tables; j.list_chunk_off = d_coff; j.n_lists = n_lists;
+    j.unit_prefix = d_up; j.pair_off = d_po; j.pair_q = d_pq; j.pair_f0 = d_pf;
+    j.unit_desc = d_ud;
+    j.dist = d_dist; j.cap = cap; j.mins = d_mins; j.min_stride = min_stride;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(scan_mfma_kernel<26>, dim3(U), dim3(64), 0, 0, j);
-    CHECK(hipDeviceSynchronize());
     const int reps = 20;
+    auto launch = [&]() {
+        CHECK(hipMemsetAsync(d_up + TK_PLAIN_COUNTER_OFF(n_lists), 0, 4, 0));
+        if (tk_launch_scan_plain(j, M, TK_ORDER_AVX, cpu, 0)) { fprintf(stderr, "launch failed\n"); exit(1); }
+    };
+    launch();
+    CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(scan_mfma_kernel<26>, dim3(U), dim3(64), 0, 0, j);
+    for (int i = 0; i < reps; i++) launch();
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     const double ms = now_ms(e0, e1) / reps;
-    printf("scan_mfma_kernel: %.4f ms per launch = %.2f G (chunk, query)/s, %.1f GB/s algorithmic (26 B per (query, code)), "
+    printf("scan_plain_kernel: %.4f ms per launch = %.2f G (chunk, query)/s, %.1f GB/s algorithmic (26 B per (query, code)), "
            "%.1f cycles per (chunk, query) per SIMD at 2.4 GHz\n",
            ms, pairs_chunks / ms / 1e6, pairs_chunks * 416 / ms / 1e6, ms * 1e-3 * 2.4e9 * 1024 / pairs_chunks);
 

@@ -1,0 +1,91 @@
+"""plain_scan.hip on the GPU: the probed lists behind the first ones scored as plain sums on the
+int8 matrix cores.  Results must be IDENTICAL to the exact kernel's (and so to the reference's):
+ids, probe lists and heap arrays (layout included), with the automatic rule, with every query
+forced through the re-scan path, and with the path switched off."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+G6 = ["an100", "an100b2", "eu128", "an20", "eu20"]
+
+
+@pytest.fixture(scope="module")
+def tk():
+    import tinyknn_amd
+    from tinyknn_amd import _lib
+    assert _lib.device_count() >= 1, "no GPU visible"
+    return tinyknn_amd
+
+
+@pytest.fixture()
+def limit_hook(tk):
+    from tinyknn_amd import _lib
+    yield lambda v: _lib.check(_lib.lib().tk_debug_plain_limit(int(v)))
+    _lib.check(_lib.lib().tk_debug_plain_limit(2 ** 31 - 1))
+
+
+@pytest.mark.parametrize("tag", G6)
+@pytest.mark.parametrize("mode", ["auto", "rescan-all", "off"])
+def test_golden_ids_and_heaps(tk, tag, mode, limit_hook):
+    from test_hip_parity import ivf_from_fixture
+    g = golden(f"g6_ivf_{tag}.npz")
+    ivf = ivf_from_fixture(tk, g)
+    dev = ivf.device_index()
+    dev.set_scan_mode(2)            # list-major: the form the plain kernel rides with
+    dev.set_plain_scan(mode != "off")
+    if mode == "rescan-all":
+        limit_hook(-128)            # no bound is <= -128 ... every query with a plain slot is redone
+    for n_probes in g["probes_list"]:
+        n_probes = int(n_probes)
+        out, dbg = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, debug=True)
+        np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
+        np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])
+        np.testing.assert_array_equal(dbg["heap_val"], g[f"heap_val_p{n_probes}"])
+        np.testing.assert_array_equal(out, g[f"ids_p{n_probes}"])
+        # small heaps make more slots plain (they are full after fewer rows)
+        for pass_1 in (3, 17):
+            a, da = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1, debug=True)
+            dev.set_plain_scan(False)
+            b, db = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1, debug=True)
+            dev.set_plain_scan(mode != "off")
+            np.testing.assert_array_equal(da["heap_idx"], db["heap_idx"])
+            np.testing.assert_array_equal(da["heap_val"], db["heap_val"])
+            np.testing.assert_array_equal(a, b)
+
+
+def test_pipelined_batches_vs_oracle(tk, oracle):
+    """60k x 100 angular, batches in flight (depth 2), plain on: rows of every batch equal the
+    oracle's; a table with entries far below -128 in total (scaled-up query) is left to the exact
+    kernel (TK_PLAIN_NEVER) and still answers identically."""
+    import torch
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(10)
+    n, d, nq = 60000, 100, 2000
+    cent = np.random.randn(300, d)
+    X = (cent[np.random.randint(300, size=n)] + 0.7 * np.random.randn(n, d)).astype(np.float32)
+    qs = (cent[np.random.randint(300, size=nq)] + 0.7 * np.random.randn(nq, d)).astype(np.float32)
+    ivf = IVF("angular", 244, FastPQ(2))
+    ivf.fit(X[:20000]).build(X, n_probes=1)
+    L = len(ivf.active_centers)
+    ox = oracle.OracleIndex(ivf.pq.centers, 2, ivf.pq.R, ivf.pq.sqrt_n_blocks, ivf.active_centers,
+                            ivf.pq_transformed_centers.packed,
+                            [ivf.pq_transformed_points[i].packed for i in range(L)],
+                            [ivf.pq_transformed_points[i].size for i in range(L)],
+                            [ivf.ids[i] for i in range(L)], ivf.data)
+    qn, qp = ivf._prepare(qs.copy())
+    dev = ivf.device_index()
+    dev.set_pipeline(2)
+    q_dev, qp_dev = torch.from_numpy(qn).cuda(), torch.from_numpy(np.ascontiguousarray(qp)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for n_probes in (2, 10, 20):
+        want = ox.query_batch(qn, 10, n_probes)
+        outs = [torch.full((nq, 10), -1, dtype=torch.int64, device="cuda") for _ in range(5)]
+        for o in outs:
+            dev.query_batch_dev(q_dev.data_ptr(), qp_dev.data_ptr(), False, nq, 10, n_probes, o.data_ptr(), stream=st)
+        dev.join(st)
+        torch.cuda.synchronize()
+        for o in outs:
+            np.testing.assert_array_equal(o.cpu().numpy(), want)

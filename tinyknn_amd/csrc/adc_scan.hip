@@ -222,12 +222,11 @@ void tk_launch_scan_flat(const uint4 *codes, int64_t chunks, int M, const uint4 
 // Probed lists of one query, concatenated in probe order into a flat chunk
 // range [0, prefix[S]); lane f of the grid owns flat chunk f.
 template <int ORDER, bool SIGNED>
-__global__ __launch_bounds__(256) void scan_probes_kernel(
+__device__ __forceinline__ void scan_probes_row(
     const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
     const int *__restrict__ slot_prefix, const int64_t *__restrict__ slot_chunk0, int S,
-    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride)
+    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride, int q)
 {
-    const int q = blockIdx.y;
     const int *prefix = slot_prefix + (int64_t)q * (S + 1);
     const int total = prefix[S];
     const int f0 = blockIdx.x * 256 + (threadIdx.x & ~63);
@@ -251,17 +250,72 @@ __global__ __launch_bounds__(256) void scan_probes_kernel(
     }
 }
 
+// only_list (or NULL): [count, q_0, q_1, ...] — score only these queries; the gridDim.y rows of
+// blocks stride over them (the re-scan of the queries the lane replay flagged, plain_scan.hip)
+template <int ORDER, bool SIGNED>
+__global__ __launch_bounds__(256) void scan_probes_kernel(
+    const uint4 *__restrict__ codes, int P, const uint4 *__restrict__ tables, int M,
+    const int *__restrict__ slot_prefix, const int64_t *__restrict__ slot_chunk0, int S,
+    uint4 *__restrict__ dist, int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride,
+    const int *__restrict__ only_list)
+{
+    if (only_list) {
+        const int count = only_list[0];
+        for (int i = blockIdx.y; i < count; i += gridDim.y)
+            scan_probes_row<ORDER, SIGNED>(codes, P, tables, M, slot_prefix, slot_chunk0, S, dist, cap, mins,
+                                           min_stride, only_list[1 + i]);
+        return;
+    }
+    scan_probes_row<ORDER, SIGNED>(codes, P, tables, M, slot_prefix, slot_chunk0, S, dist, cap, mins,
+                                   min_stride, blockIdx.y);
+}
+
+// ids of the flagged queries, in order: list[0] = count, list[1..] = ids (one workgroup)
+__global__ __launch_bounds__(1024) void flagged_list_kernel(const unsigned char *__restrict__ flags, int64_t nq,
+                                                            int *__restrict__ list)
+{
+    __shared__ int s_base, s_wave[16];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t b = 0; b < nq; b += 1024) {
+        const int64_t q = b + threadIdx.x;
+        const bool f = q < nq && flags[q];
+        const uint64_t m = __builtin_amdgcn_ballot_w64(f);
+        if (lane == 0) s_wave[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; w++) before += s_wave[w];
+        if (f) list[1 + before + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)q;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) list[0] = s_base;
+}
+
+void tk_launch_flagged_list(const unsigned char *flags, int64_t nq, int *list, hipStream_t s)
+{
+    if (nq == 0) return;
+    hipLaunchKernelGGL(flagged_list_kernel, dim3(1), dim3(1024), 0, s, flags, nq, list);
+}
+
 void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
                            const int *slot_prefix, const int64_t *slot_chunk0, int S,
                            int max_flat_chunks, uint4 *dist, int64_t cap, uint8_t *mins,
-                           int64_t min_stride, int signd, int order, hipStream_t s)
+                           int64_t min_stride, int signd, int order, hipStream_t s,
+                           const int *only)
 {
     if (nq == 0 || max_flat_chunks == 0 || S == 0) return;
-    dim3 grid((unsigned)((max_flat_chunks + 255) / 256), (unsigned)nq);
+    dim3 grid((unsigned)((max_flat_chunks + 255) / 256), (unsigned)(only ? (nq < 32 ? nq : 32) : nq));
     int P = M / 2;
 #define TK_LAUNCH(O, S_)                                                                      \
     hipLaunchKernelGGL((scan_probes_kernel<O, S_>), grid, dim3(256), 0, s, codes, P, tables,  \
-                       M, slot_prefix, slot_chunk0, S, dist, cap, mins, min_stride)
+                       M, slot_prefix, slot_chunk0, S, dist, cap, mins, min_stride, only)
     if (order == TK_ORDER_AVX) {
         if (signd) TK_LAUNCH(TK_ORDER_AVX, true); else TK_LAUNCH(TK_ORDER_AVX, false);
     } else {
@@ -766,6 +820,125 @@ void tk_launch_unit_pairs(int64_t nq, const int64_t *probes, int S, int64_t n_li
                        (int)n_lists, pair_off, unit_prefix, cursor, pair_q);
     hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
                        probes, S, nq, n_lists, slot_prefix, pair_off, cursor, pair_q, pair_f0);
+}
+
+// ---- two pair sets in one pass (plain_scan.hip): slots below slot_exact[q] -> the exact
+// kernel's units (records padded to groups of 4), the others -> tiles of 32 pairs of the plain
+// kernel (records not padded).  One workgroup scans both sets.
+__global__ __launch_bounds__(1024) void pairs_scan2_kernel(int *__restrict__ count, int *__restrict__ count2,
+                                                           const int64_t *__restrict__ list_chunk_off,
+                                                           int n_lists, int *__restrict__ pair_off,
+                                                           int *__restrict__ unit_prefix,
+                                                           int *__restrict__ cursor, int *__restrict__ pair_q,
+                                                           int *__restrict__ pair_off2,
+                                                           int *__restrict__ unit_prefix2,
+                                                           int *__restrict__ cursor2,
+                                                           int *__restrict__ unit_desc2)
+{
+    __shared__ int s_a[1024], s_b[1024];
+    __shared__ int carry_a, carry_b;
+    for (int set = 0; set < 2; set++) {
+        if (threadIdx.x == 0) carry_a = carry_b = 0;
+        __syncthreads();
+        int *cnt_p = set ? count2 : count;
+        int *off_p = set ? pair_off2 : pair_off;
+        int *unit_p = set ? unit_prefix2 : unit_prefix;
+        int *cur_p = set ? cursor2 : cursor;
+        for (int base = 0; base < n_lists; base += 1024) {
+            const int l = base + threadIdx.x;
+            int rec = 0, unit = 0, cnt = 0;
+            if (l < n_lists) {
+                cnt = cnt_p[l];
+                cnt_p[l] = 0;   // zero again for the next batch
+                if (set == 0) {
+                    const int groups = (cnt + TK_UNIT_Q - 1) / TK_UNIT_Q;
+                    rec = groups * TK_UNIT_Q;
+                    unit = groups * (int)(list_chunk_off[l + 1] - list_chunk_off[l]);
+                } else {
+                    rec = cnt;
+                    unit = list_chunk_off[l + 1] > list_chunk_off[l] ? (cnt + 31) / 32 : 0;
+                }
+            }
+            s_a[threadIdx.x] = rec;
+            s_b[threadIdx.x] = unit;
+            __syncthreads();
+            for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+                int ra = threadIdx.x >= o ? s_a[threadIdx.x - o] : 0;
+                int rb = threadIdx.x >= o ? s_b[threadIdx.x - o] : 0;
+                __syncthreads();
+                s_a[threadIdx.x] += ra;
+                s_b[threadIdx.x] += rb;
+                __syncthreads();
+            }
+            if (l < n_lists) {
+                const int off = carry_a + s_a[threadIdx.x] - rec;
+                off_p[l] = off;
+                unit_p[l] = carry_b + s_b[threadIdx.x] - unit;
+                cur_p[l] = 0;
+                if (set == 0)
+                    for (int t = cnt; t < rec; t++) pair_q[off + t] = -1;   // padding records
+                else        // (list, tile) of every unit: the plain kernel looks its unit up in one load
+                    for (int t = 0; t < unit; t++) {
+                        unit_desc2[2 * (unit_p[l] + t)] = l;
+                        unit_desc2[2 * (unit_p[l] + t) + 1] = t;
+                    }
+            }
+            __syncthreads();
+            if (threadIdx.x == 1023) {
+                carry_a += s_a[1023];
+                carry_b += s_b[1023];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            off_p[n_lists] = carry_a;
+            unit_p[n_lists] = carry_b;
+        }
+        if (set == 0 && threadIdx.x < TK_TICKETS) unit_prefix[TK_TICKET_OFF(n_lists) + threadIdx.x * 32] = 0;
+        if (set == 1 && threadIdx.x == 0) unit_prefix2[TK_PLAIN_COUNTER_OFF(n_lists)] = 0;
+        __syncthreads();
+    }
+}
+
+__global__ void pairs_fill2_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
+                                   int64_t n_lists, const int *__restrict__ slot_prefix,
+                                   const int *__restrict__ slot_exact, const int *__restrict__ pair_off,
+                                   int *__restrict__ cursor, int *__restrict__ pair_q,
+                                   int *__restrict__ pair_f0, const int *__restrict__ pair_off2,
+                                   int *__restrict__ cursor2, int *__restrict__ pair_q2,
+                                   int *__restrict__ pair_f02)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * S) return;
+    const int64_t qi = i / S;
+    const int s = (int)(i - qi * S);
+    int64_t cl = probes[i];
+    if (cl < 0) cl += n_lists;
+    const int f0 = slot_prefix[qi * (S + 1) + s];
+    if (s < slot_exact[qi]) {
+        const int pos = atomicAdd(&cursor[cl], 1);
+        pair_q[pair_off[cl] + pos] = (int)qi;
+        pair_f0[pair_off[cl] + pos] = f0;
+    } else {
+        const int pos = atomicAdd(&cursor2[cl], 1);
+        pair_q2[pair_off2[cl] + pos] = (int)qi;
+        pair_f02[pair_off2[cl] + pos] = f0;
+    }
+}
+
+void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
+                           const int64_t *list_chunk_off, const int *slot_prefix,
+                           const int *slot_exact, const TkPairSet &ex, const TkPairSet &pl,
+                           hipStream_t s)
+{
+    if (nq == 0 || S == 0) return;
+    const int64_t np = nq * S;
+    hipLaunchKernelGGL(pairs_scan2_kernel, dim3(1), dim3(1024), 0, s, ex.count, pl.count, list_chunk_off,
+                       (int)n_lists, ex.pair_off, ex.unit_prefix, ex.cursor, ex.pair_q, pl.pair_off,
+                       pl.unit_prefix, pl.cursor, pl.unit_desc);
+    hipLaunchKernelGGL(pairs_fill2_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, probes, S,
+                       nq, n_lists, slot_prefix, slot_exact, ex.pair_off, ex.cursor, ex.pair_q, ex.pair_f0,
+                       pl.pair_off, pl.cursor, pl.pair_q, pl.pair_f0);
 }
 
 void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_lists, int *pair_off,

@@ -559,7 +559,8 @@ struct Work {
     DevBuf tables, shift, scale, cdist, cheap_idx, cheap_val, probes, slot_prefix, slot_chunk0,
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
-        c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage, pos_lens, pos_off;
+        c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage, pos_lens, pos_off,
+        qlim, slot_exact, p_count, p_cursor, p_pair_off, p_unit_prefix, p_pair_q, p_pair_f0, flag_list, p_unit_desc;   // plain_scan.hip
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -573,7 +574,8 @@ struct Work {
                        &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
-                       &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage, &pos_lens, &pos_off};
+                       &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage, &pos_lens, &pos_off,
+                       &qlim, &slot_exact, &p_count, &p_cursor, &p_pair_off, &p_unit_prefix, &p_pair_q, &p_pair_f0, &flag_list, &p_unit_desc};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -629,6 +631,8 @@ struct tk_index {
     // index-static descriptors of the coarse stage, staging buffers of the host API
     DevBuf cslots_i, cslots_l, c_chunk_off, q, qpq, stage;
     int scan_mode = 0;         // 0 auto, 1 query-major kernel, 2 list-major (units) kernel
+    int plain_mode = 0;        // 0 auto: probed lists behind the first ones as plain sums on the matrix
+                               // cores where the lemma of plain_scan.hip allows; 1: exact kernel only
     bool host_out_kernel = false;   // a batch's pinned host copy of the ids is written by a kernel
     // per-batch workspaces: `depth` batches may be in flight (tk_index_set_pipeline),
     // each on its own internal stream
@@ -878,6 +882,27 @@ static int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &
     return TK_OK;
 }
 
+// Plain sums on the matrix cores for the probed lists behind the first ones (plain_scan.hip):
+// signed tables (all of IVF.query), at most 26 block pairs, a replay that starts from fresh heaps
+// on packed entries (the lane kernels check the lemma's condition per query and flag the queries
+// to re-scan), an unsharded index.  TINYKNN_PLAIN_SCAN=0 / tk_index_set_plain_scan(ix, 1): off.
+static bool plain_env_on()
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("TINYKNN_PLAIN_SCAN");
+        on = !(e && e[0] == '0');
+    }
+    return on != 0;
+}
+static bool plain_possible(const tk_index *ix, const Plan &p)
+{
+    if (ix->plain_mode == 1 || !plain_env_on() || ix->sharded || p.S < 2 || !tk_plain_fits(ix->M)) return false;
+    if (ix->heap_mode != 0 || ix->scan_mode == 1 || p.cap * 16 > 0xffffff) return false;
+    if (ix->ids_unique) return p.R <= TK_LANES_MAX_R;
+    return ix->have_ids32 && tk_lanes_dedupe_fits(p.R, p.S) && ix->total_ids < (1ll << 31);
+}
+
 static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
 {
     const int M = ix->M;
@@ -916,6 +941,20 @@ static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
     TRY(w.c_unit_prefix.ensure(tk_unit_prefix_ints(1) * 4));
     TRY(w.c_pair_q.ensure(((size_t)nq + 4) * 4));
     TRY(w.c_pair_f0.ensure(((size_t)nq + 4) * 4));
+    if (plain_possible(ix, p)) {
+        TRY(w.qlim.ensure((size_t)nq * 4));
+        TRY(w.slot_exact.ensure((size_t)nq * 4));
+        const void *before = w.p_count.p;
+        TRY(w.p_count.ensure(L * 4));
+        if (w.p_count.p != before) HIPCHECK(hipMemset(w.p_count.p, 0, w.p_count.cap));
+        TRY(w.p_cursor.ensure(L * 4));
+        TRY(w.p_pair_off.ensure((L + 1) * 4));
+        TRY(w.p_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
+        TRY(w.p_pair_q.ensure(((size_t)nq * p.S + 4) * 4));
+        TRY(w.p_pair_f0.ensure(((size_t)nq * p.S + 4) * 4));
+        TRY(w.flag_list.ensure(((size_t)nq + 1) * 4));
+        TRY(w.p_unit_desc.ensure(((size_t)nq * p.S / 32 + L + 8) * 8));
+    }
     return TK_OK;
 }
 
@@ -1006,13 +1045,15 @@ static bool coarse_units(const tk_index *ix, int64_t nq)
 }
 
 static int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_t nq,
-                        hipStream_t st, Prof &pf)
+                        hipStream_t st, Prof &pf, bool plain = false)
 {
     TRY(pf.mark(st));
     // 1. distance tables                                   fast_pq.py:186-222
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
                            qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>(), w.shift.p,
                            w.scale.as<double>(), st);
+    if (plain)      // per query: below which value clamp(plain sum) is the saturated value
+        tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st);
     if (coarse_units(ix, nq))
         // every query scans the one list of coded centres: list-major, no idle lanes
         tk_launch_identity_pairs(nq, (int)ix->center_chunks, w.c_pair_off.as<int>(),
@@ -1057,6 +1098,29 @@ static TkScanJob list_job(const tk_index *ix, const Work &w, const Plan &p)
     j.mins = w.mins.as<uint8_t>();
     j.min_stride = p.cap_min;
     return j;
+}
+
+static TkScanJob plain_job(const tk_index *ix, const Work &w, const Plan &p)
+{
+    TkScanJob j = list_job(ix, w, p);
+    j.unit_prefix = w.p_unit_prefix.as<int>();
+    j.pair_off = w.p_pair_off.as<int>();
+    j.pair_q = w.p_pair_q.as<int>();
+    j.pair_f0 = w.p_pair_f0.as<int>();
+    j.unit_desc = w.p_unit_desc.as<int>();
+    return j;
+}
+
+// persistent workgroups of the plain kernel: two per CU (58 KB of LDS, 256 registers per lane)
+static int plain_blocks()
+{
+    static int n = -1;
+    if (n < 0) {
+        const char *e = getenv("TINYKNN_PLAIN_BLOCKS");
+        n = e ? atoi(e) : 512;
+        n = n < 1 ? 512 : n;
+    }
+    return n;
 }
 
 // 2a. coarse scan = the scan of dtable.top(centers)          ivf.py:131, fast_pq.py:284-312
@@ -1118,33 +1182,71 @@ static int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64
 
 // per-slot descriptors of the probed lists of `nq` queries
 static void coarse_slots(tk_index *ix, Work &w, const int64_t *probes, int64_t nq, const Plan &p,
-                         int *pair_count, const int *owner, int me, hipStream_t st)
+                         int *pair_count, const int *owner, int me, hipStream_t st, bool plain = false)
 {
     tk_launch_make_slots(probes, nullptr, p.S, nq, ix->n_lists, ix->list_chunk_off.as<int64_t>(),
                          ix->list_n.as<int64_t>(), ix->ids_off.as<int64_t>(),
                          w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
                          w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(), pair_count,
-                         owner, me, st);
+                         owner, me, st, plain ? w.qlim.as<int>() : nullptr, p.R,
+                         plain ? w.slot_exact.as<int>() : nullptr, plain ? w.p_count.as<int>() : nullptr);
+}
+
+// the pair lists of a batch: one set for the exact list-major kernel, with `plain` a second one
+// (the slots behind slot_exact[q]) for the plain kernel
+static void unit_pairs(tk_index *ix, Work &w, int64_t nq, const Plan &p, bool plain, hipStream_t st)
+{
+    if (!plain) {
+        tk_launch_unit_pairs(nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
+                             ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
+                             w.u_count.as<int>(), w.u_pair_off.as<int>(),
+                             w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
+                             w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
+                             nq * p.S + 4 * ix->n_lists, st);
+        return;
+    }
+    TkPairSet ex{w.u_count.as<int>(), w.u_cursor.as<int>(), w.u_pair_off.as<int>(),
+                 w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>()};
+    TkPairSet pl{w.p_count.as<int>(), w.p_cursor.as<int>(), w.p_pair_off.as<int>(),
+                 w.p_unit_prefix.as<int>(), w.p_pair_q.as<int>(), w.p_pair_f0.as<int>(),
+                 w.p_unit_desc.as<int>()};
+    tk_launch_unit_pairs2(nq, w.probes.as<int64_t>(), p.S, ix->n_lists, ix->list_chunk_off.as<int64_t>(),
+                          w.slot_prefix.as<int>(), w.slot_exact.as<int>(), ex, pl, st);
 }
 
 static int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
-                             int *pair_count, const int *owner, int me, hipStream_t st, Prof &pf)
+                             int *pair_count, const int *owner, int me, hipStream_t st, Prof &pf,
+                             bool plain = false)
 {
     TRY(coarse_replay_probes(ix, w, q_dev, nq, p, w.probes.as<int64_t>(), st, pf));
-    coarse_slots(ix, w, w.probes.as<int64_t>(), nq, p, pair_count, owner, me, st);
+    coarse_slots(ix, w, w.probes.as<int64_t>(), nq, p, pair_count, owner, me, st, plain);
     return TK_OK;
 }
 
 // Stages 3b-4: the heap replay over the distance rows of queries [q0, q0 + nq) of the
 // batch's slot arrays (dist/mins/heaps: `nq` rows starting at row 0), then the exact
 // rescoring.  q_dev: row 0 = query q0.
-static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq, int k,
-                      const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf)
+// the queries the lane replay flagged (bound above the table's limit at the first plain block:
+// plain_scan.hip): every probed list again with the exact kernel, then the replay again
+static void rescan_flagged(tk_index *ix, Work &w, int64_t q0, int64_t nq, const Plan &p, hipStream_t st)
 {
+    int *list = w.flag_list.as<int>();
+    tk_launch_flagged_list(w.repeat_flag.as<unsigned char>() + q0, nq, list, st);
+    tk_launch_scan_probes(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>() + q0 * ix->M, nq,
+                          w.slot_prefix.as<int>() + q0 * (p.S + 1), w.slot_chunk0.as<int64_t>() + q0 * p.S,
+                          p.S, (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(), p.cap_min, 1,
+                          ix->order, st, list);
+}
+
+static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq, int k,
+                      const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf, bool plain = false)
+{
+    const int *slot_exact = plain ? w.slot_exact.as<int>() + q0 : nullptr;
+    const int *qlim = plain ? w.qlim.as<int>() + q0 : nullptr;
     const int *slot_prefix = w.slot_prefix.as<int>() + q0 * (p.S + 1);
     const int *slot_n = w.slot_n.as<int>() + q0 * p.S;
     const int64_t *slot_loff = w.slot_loff.as<int64_t>() + q0 * p.S;
-    const unsigned char *repeat_flag = w.repeat_flag.as<unsigned char>() + q0;
+    unsigned char *repeat_flag = w.repeat_flag.as<unsigned char>() + q0;
     // heaps start fresh here, so packed entries apply.  Distinct labels: one query per
     // lane (or per wave for big heaps), and the few queries whose probe list wrapped a -1
     // (a list may then be scanned twice) re-run with the duplicate test.  Repeating labels
@@ -1169,20 +1271,28 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
                                              slot_loff, p.S, ix->ids.as<int64_t>(),
                                              w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
                                              p.R, 1, 0, repeat_flag, w.mins.as<uint8_t>(),
-                                             p.cap_min, nullptr, st))
+                                             p.cap_min, nullptr, st, slot_exact, qlim))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
+        if (plain) rescan_flagged(ix, w, q0, nq, p, st);
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                      p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                      w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
     } else if (packed_ok && ix->have_ids32 && ix->heap_mode == 0 && tk_lanes_dedupe_fits(p.R, p.S) &&
                ix->total_ids < (1ll << 31)) {
         // repeating labels that fit int32: one query per lane with the duplicate test
+        // (plain: the queries whose probe list wrapped are left to the packed kernel below too)
         if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
                                         slot_loff, p.S, ix->ids.as<int64_t>(),
                                         w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), p.R, 1,
-                                        0, nullptr, w.mins.as<uint8_t>(), p.cap_min,
-                                        ix->ids32.as<int32_t>(), st))
+                                        0, plain ? repeat_flag : nullptr, w.mins.as<uint8_t>(), p.cap_min,
+                                        ix->ids32.as<int32_t>(), st, slot_exact, qlim))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
+        if (plain) {
+            rescan_flagged(ix, w, q0, nq, p, st);
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
+        }
     } else if (packed_ok) {
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                      p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
@@ -1230,6 +1340,7 @@ struct Pending {
     Plan p;
     int64_t *out_dev;
     bool units;
+    bool plain;             // probed lists behind the first ones by the plain kernel (plain_scan.hip)
     bool coarse_launched;   // its coarse scan has been enqueued
     int64_t *host_out;      // pinned host copy of the ids, enqueued behind the rescoring (or NULL)
     bool host_out_kernel;   // ... written by copy_words_kernel instead of the copy engine
@@ -1247,17 +1358,12 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
     hipStream_t st = b.st;
     TRY(prof_begin(ix, w, b.nq, p, st, b.pf));
     b.units = use_units(ix, b.nq, p);
-    TRY(stage_tables(ix, w, qpq_dev, qpq_f64, b.nq, st, b.pf));
+    b.plain = b.units && plain_possible(ix, p);
+    TRY(stage_tables(ix, w, qpq_dev, qpq_f64, b.nq, st, b.pf, b.plain));
     launch_coarse_scan(ix, w, b.nq, p, st);
     TRY(stage_coarse_rest(ix, w, b.q_dev, b.nq, p, b.units ? w.u_count.as<int>() : nullptr, nullptr,
-                          0, st, b.pf));
-    if (b.units)
-        tk_launch_unit_pairs(b.nq, w.probes.as<int64_t>(), p.S, ix->n_lists,
-                             ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
-                             w.u_count.as<int>(), w.u_pair_off.as<int>(),
-                             w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
-                             w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
-                             b.nq * p.S + 4 * ix->n_lists, st);
+                          0, st, b.pf, b.plain));
+    if (b.units) unit_pairs(ix, w, b.nq, p, b.plain, st);
     TRY(b.pf.mark(st));
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
     if (b.units)
@@ -1272,8 +1378,10 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
                               w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), p.S,
                               (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(),
                               p.cap_min, 1, ix->order, st);
+    if (b.plain && tk_launch_scan_plain(plain_job(ix, w, p), M, ix->order, plain_blocks(), st))
+        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
     TRY(b.pf.mark(st));
-    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf));
+    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf, b.plain));
     TRY(batch_epilogue(b, st));
     HIPCHECK(hipGetLastError());
     return TK_OK;
@@ -1346,13 +1454,16 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
                                                     ((double)ix->total_chunks / (double)ix->n_lists) : 0.0),
                               st);
     }
+    if (prev && prev->plain &&
+        tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order, plain_blocks(), st))
+        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
     if (prev) {
         // heap replay + rescoring of the previous batch on its stream
         TRY(prev->pf.mark(st));
         HIPCHECK(hipEventRecord(prev->w->scanned, st));
         HIPCHECK(hipStreamWaitEvent(prev->sl, prev->w->scanned, 0));
         TRY(stage_back(ix, *prev->w, prev->q_dev, 0, prev->nq, prev->k, prev->p, prev->out_dev,
-                       prev->sl, prev->pf));
+                       prev->sl, prev->pf, prev->plain));
         TRY(batch_epilogue(*prev, prev->sl));
         HIPCHECK(hipEventRecord(prev->w->done, prev->sl));
         prev->w->busy = true;
@@ -1369,14 +1480,8 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         }
         TRY(stage_coarse_rest(ix, w, cur->q_dev, cur->nq, cur->p,
                               cur->units ? w.u_count.as<int>() : nullptr, nullptr, 0, cur->sf,
-                              cur->pf));
-        if (cur->units)
-            tk_launch_unit_pairs(cur->nq, w.probes.as<int64_t>(), cur->p.S, ix->n_lists,
-                                 ix->list_chunk_off.as<int64_t>(), w.slot_prefix.as<int>(),
-                                 w.u_count.as<int>(), w.u_pair_off.as<int>(),
-                                 w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
-                                 w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
-                                 cur->nq * cur->p.S + 4 * ix->n_lists, cur->sf);
+                              cur->pf, cur->plain));
+        if (cur->units) unit_pairs(ix, w, cur->nq, cur->p, cur->plain, cur->sf);
         HIPCHECK(hipEventRecord(w.front_done, cur->sf));
     }
     HIPCHECK(hipGetLastError());
@@ -1449,6 +1554,7 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         b.p = p;
         b.out_dev = out_ids_dev + o * k;
         b.units = false;
+        b.plain = false;
         b.coarse_launched = false;
         b.host_out = out_ids_pinned;
         b.host_out_kernel = ix->host_out_kernel;
@@ -1506,7 +1612,8 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         TRY(reserve(ix, w, sub, k, p));
         TRY(prof_begin(ix, w, b.nq, p, b.sl, b.pf));
         b.units = use_units(ix, b.nq, p);
-        TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, stt, b.pf));
+        b.plain = b.units && plain_possible(ix, p);
+        TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, stt, b.pf, b.plain));
         HIPCHECK(hipEventRecord(w.tables_done, stt));
         // this call's launch: list scan of call c-3 + coarse scan of call c-1
         TRY(pipeline_advance(ix, false));
@@ -2536,6 +2643,22 @@ extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
     ARGCHECK(mode >= 0 && mode <= 2, "mode");
     TRY(flush_pending(ix));
     ix->scan_mode = mode;
+    return TK_OK;
+}
+
+extern "C" int tk_index_set_plain_scan(tk_index *ix, int mode)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix, "null index");
+    ARGCHECK(mode >= 0 && mode <= 1, "mode");
+    TRY(flush_pending(ix));
+    ix->plain_mode = mode;
+    return TK_OK;
+}
+
+extern "C" int tk_debug_plain_limit(int limit)
+{
+    tk_plain_force_limit(limit);
     return TK_OK;
 }
 

@@ -382,9 +382,9 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
-    const unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
+    unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
     int64_t cap_min, const int32_t *__restrict__ labels32, unsigned long long *__restrict__ dbg,
-    int prio, int wave_lds)
+    int prio, int wave_lds, const int *__restrict__ slot_exact, const int *__restrict__ qlim)
 {
     // dbg != NULL (tk_debug_replay_timers): cycle counters of the wave's phases, 8 per workgroup:
     // total, block search, insert (all of it), LDS sift levels, rounds, LDS iterations, search
@@ -458,6 +458,12 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     uint32_t bound = SIGNED ? 0x7fu : 0xffu;
 
     const int total = (valid && S > 0) ? prefix[S] : 0;   // flat chunks of this lane's query
+    // plain_scan.hip: the slots from slot_exact[q] on carry clamp(plain sums), which equal the
+    // reference's values below qlim[q] and are >= qlim[q] elsewhere: the replay over them is the
+    // replay over the exact values iff the bound is <= qlim[q] when the first of their blocks is
+    // reached.  b_plain follows the bound across the exact blocks; checked at the end.
+    const int plain0 = (slot_exact && valid) ? prefix[slot_exact[qc]] : 0x7fffffff;
+    uint32_t b_plain = SIGNED ? 0x7fu : 0xffu;
     const uint4 *mrow = (const uint4 *)(mins + qc * cap_min);   // per-block minima, 16 per uint4
     int nseg = (total + 15) >> 4;
     int max_nseg = nseg;
@@ -688,7 +694,10 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                         }
                     }
                 }
-                if (bits == 0) bound = h0 >> 24;          // refresh after the block, :123
+                if (bits == 0) {
+                    bound = h0 >> 24;                     // refresh after the block, :123
+                    b_plain = cur < plain0 ? bound : b_plain;
+                }
             }
             d_ins += TK_TICK() - d_ti;
         }
@@ -712,6 +721,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     if (R > 5) H[5 * LW + lane] = h5;
     if (R > 6) H[6 * LW + lane] = h6;
     if (!valid) return;
+    if (slot_exact && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) skip[q] = 1;   // re-scan + replay again
     // ---- resolve flat positions (or slots) to labels
     const int64_t *loffs = slot_label_off + qs * S;
     for (int j = 0; j < R; j++) {
@@ -966,11 +976,12 @@ extern "C" int tk_debug_replay_timers(int arm, int64_t min_nq, unsigned long lon
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
-                                int signd, int slots_uniform, const unsigned char *skip,
+                                int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
-                                hipStream_t s)
+                                hipStream_t s, const int *slot_exact, const int *qlim)
 {
     if (nq == 0 || R == 0) return 0;
+    if (!slot_exact || !qlim || !skip || !signd) slot_exact = qlim = nullptr;
     const int dedupe = labels32 != nullptr;
     // Queries per wave.  With the duplicate test a 64-query wave needs 140+ KB of LDS at
     // R = 111: one workgroup per CU, and the two replay kernels of the pipelined mode (2 x 157
@@ -1062,7 +1073,8 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
 #define TK_LAUNCH3(S_, D_, P_, L_)                                                              \
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, P_, L_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
-                       slots_uniform, skip, nbuf, mins, cap_min, labels32, dbg, prio, wave_lds)
+                       slots_uniform, skip, nbuf, mins, cap_min, labels32, dbg, prio, wave_lds,   \
+                       slot_exact, qlim)
     if (LWr == 32) {
         if (dedupe) { if (signd) TK_LAUNCH3(true, true, false, 32); else TK_LAUNCH3(false, true, false, 32); }
         else { if (signd) TK_LAUNCH3(true, false, false, 32); else TK_LAUNCH3(false, false, false, 32); }

@@ -41,10 +41,14 @@ void tk_launch_scan_flat(const uint4 *codes, int64_t chunks, int M, const uint4 
 // Probed-list scan: query q scans the lists slot 0..S-1 named by
 // slot_chunk0[q][s] (first global chunk) and slot_prefix[q][s..s+1] (flat chunk
 // range inside the query's distance row).  dist: (nq, cap) uint4.
+// only ([count, q_0, q_1, ...] from tk_launch_flagged_list, or NULL): score only these queries
 void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64_t nq,
                            const int *slot_prefix, const int64_t *slot_chunk0, int S,
                            int max_flat_chunks, uint4 *dist, int64_t cap, uint8_t *mins,
-                           int64_t min_stride, int signd, int order, hipStream_t s);
+                           int64_t min_stride, int signd, int order, hipStream_t s,
+                           const int *only = nullptr);
+// list (nq + 1 ints): list[0] = number of flagged queries, list[1..] = their ids in order
+void tk_launch_flagged_list(const unsigned char *flags, int64_t nq, int *list, hipStream_t s);
 
 // List-major form of the probed-list scan for large batches.  tk_launch_unit_pairs
 // groups the (query, slot) pairs by list (scan + fill kernels; `count` comes from
@@ -71,11 +75,35 @@ struct TkScanJob {
     int64_t cap;
     uint8_t *mins;
     int64_t min_stride;
+    const int *unit_desc = nullptr;   // plain kernel: (list, tile) of every unit, 2 ints each
 };
 // table rows of the list-major kernel: 1 = staged per block in LDS (default), 0 = per-lane
 // global loads (the round-1 form; A/B switch)
 void tk_set_scan_tables(int lds);
 int tk_get_scan_tables(void);
+// ---- plain-sum scan on the int8 matrix cores (plain_scan.hip) ----
+// qlim[q]: the bound below which clamp(plain sum) IS the reference's saturated value for query q
+// (C of the lemma in plain_scan.hip), or TK_PLAIN_NEVER when the query's table rules it out
+#define TK_PLAIN_NEVER (-(1 << 30))
+#define TK_PLAIN_COUNTER_OFF(n_lists) ((((n_lists) + 1 + 31) / 32 + 1) * 32)
+void tk_launch_table_limits(const uint4 *tables, int M, int order, int64_t nq, int *qlim, hipStream_t s);
+void tk_plain_force_limit(int v);      // debug: cap every query's limit (INT_MAX = off)
+int tk_plain_fits(int M);
+// TkScanJob with unit_prefix = tiles of 32 pairs before each list (+ the work counter at
+// TK_PLAIN_COUNTER_OFF); pair records are not padded.  Returns -1 for unsupported M.
+int tk_launch_scan_plain(const TkScanJob &j, int M, int order, int n_blocks, hipStream_t s);
+// the second pair set (plain pairs) beside the first in ONE pass: see tk_launch_unit_pairs2
+struct TkPairSet {
+    int *count, *cursor, *pair_off, *unit_prefix, *pair_q, *pair_f0;
+    int *unit_desc = nullptr;      // plain set: (list, tile) per unit, 2 ints each (nq * S / 32 + n_lists + 1 units)
+};
+// (query, slot) pairs grouped by list, split at slot_exact[q]: slots below it -> set `ex` (units
+// of the list-major exact kernel), the others -> set `pl` (tiles of the plain kernel)
+void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
+                           const int64_t *list_chunk_off, const int *slot_prefix,
+                           const int *slot_exact, const TkPairSet &ex, const TkPairSet &pl,
+                           hipStream_t s);
+
 // two jobs in ONE launch sharing one pool of 64-unit blocks (pipelined mode: the list scan
 // of one batch and the coarse scan of the next); signed tables
 void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
@@ -112,12 +140,15 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 // slot table
 #define TK_LANES_MAX_R_DEDUPE 149
 int tk_lanes_dedupe_fits(int R, int S);     // ... and the slot table of S probed lists fits too
+// slot_exact / qlim (both nq ints, or NULL): slots from slot_exact[q] on carry clamp(plain sums)
+// (plain_scan.hip); a query whose bound at its first such block is above qlim[q] gets skip[q] = 1
+// written (skip must then be writable) and is to be re-scanned exactly and replayed again.
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
-                                int signd, int slots_uniform, const unsigned char *skip,
+                                int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
-                                hipStream_t s);
+                                hipStream_t s, const int *slot_exact = nullptr, const int *qlim = nullptr);
 
 // Wave-per-query replay on packed 32-bit entries from FRESH heaps (R*4 B of LDS, or
 // R*12 with `dedupe`: int64 labels per slot + the reference's duplicate-label test,
@@ -154,11 +185,17 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
 // probes (nq, kc) list ids -> per-slot scan descriptors; pair_count (n_lists, zeroed, or
 // NULL) receives the number of (query, slot) pairs per list — with `owner` (n_lists ranks,
 // list-sharded index) only for the lists owned by `me`
+// qlim / R / slot_exact / pair_count2 (all or none): slot_exact[q] = number of leading probed lists
+// that stay on the exact kernel — until they hold 2R rows, all of them for a query whose table
+// rules the plain sums out (qlim = TK_PLAIN_NEVER) or whose probe list wrapped; the pairs behind
+// them are counted in pair_count2
 void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
                           int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
-                          int *pair_count, const int *owner, int me, hipStream_t s);
+                          int *pair_count, const int *owner, int me, hipStream_t s,
+                          const int *qlim = nullptr, int R = 0, int *slot_exact = nullptr,
+                          int *pair_count2 = nullptr);
 
 // the exclusive scans of tk_launch_unit_pairs alone (the caller fills the records)
 void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_lists, int *pair_off,

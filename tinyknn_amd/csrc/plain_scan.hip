@@ -1,0 +1,375 @@
+// plain_scan.hip — the probed lists BEHIND the first ones on the int8 matrix cores (gfx950).
+//
+// What it replaces: the same compute_block_dists_avx / compute_block_dists chain of
+// _fast_pq_256.pyx:126-156 / _fast_pq.pyx:209-236 that adc_scan.hip restates with v_perm_b32 and
+// saturating v_pk_add_i16 — for the (query, list) pairs where a PLAIN integer sum provably gives
+// the same replay.
+//
+// Lemma (proved in DESIGN §3.1b, checked row by row by scripts/r03_plain_sum_stats.py and
+// tests/test_plain_scan_lemma.py).  Let T be a query's signed table, chain c the blocks one
+// saturating accumulator of the reference adds up (AVX order: blocks with (m >> 1) & 1 == c;
+// SSE order: all blocks), N_c = sum over the chain's blocks of max(0, -min_code T[m][code]) and
+// C = 127 - N_0 - N_1.  If N_0 <= 128 and N_1 <= 128 then for every stored code with plain sum S
+//      S <  C  =>  the reference's saturated value v == max(S, -128)
+//      S >= C  =>  v >= C
+// (a clamp at -128 inside a chain is impossible, and a clamp at +127 leaves v >= 127 - N and needs
+// a prefix sum > 127, i.e. S >= 128 - N).  So o = clamp(S, -128, 127) equals v wherever v < C and
+// is >= C elsewhere.  The reference inserts a row only if its value is below the bound captured
+// at its block's start, and that bound never rises (_fast_pq_256.pyx:73-123): once the bound is
+// <= C, a replay over o is the replay over v — same inserts, same values, same heap arrays.
+// The heap replay checks exactly that (bound at the first plain block <= C, per query) and flags
+// the queries for which it does not hold; those are re-scanned by the exact kernel and replayed
+// again (api.hip: stage_back).  Nothing is approximated.
+//
+// S is a one-hot(code) x table contraction, 16 x M deep: v_mfma_i32_32x32x32_i8, one
+// instruction per block pair for 32 rows x 32 queries.
+//   B operand: lane (q = lane & 31, h = lane >> 5) holds the 16-byte table row of block 2p + h
+//              of its pair's query for every block pair p (registers; staged per unit through
+//              LDS with coalesced loads, the next unit's tile fetched while this one computes);
+//   A operand: rows = the 32 rows of two consecutive 16-row chunks; lane (r, h) turns nibble h
+//              of byte r of the chunks' 16-byte group p into a 16-byte one-hot through a
+//              256-byte LDS table (ds_read_b128: distinct entries sit on distinct banks);
+//   D: lane (q, h) holds rows {0-3, 8-11, 16-19, 24-27} + 4h of query q; clamped to int8, and
+//      after two v_permlane32_swap the lane holds the whole 16-byte block of (chunk 2cp + h,
+//      query q): one 16-byte store + the block's minimum byte.
+// Work: persistent 256-thread workgroups draw units = (list, tile of 32 pairs of that list)
+// from a counter; the four waves take the list's chunk pairs round-robin; the code groups of a
+// chunk pair arrive by ONE 16-byte load per lane, two chunk pairs ahead, and are re-sliced
+// through a per-wave LDS region.
+#include <limits.h>
+#include <stdlib.h>
+
+#include "kernels.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// C of the lemma per query, or TK_PLAIN_NEVER when a chain's negative mass exceeds 128
+__global__ __launch_bounds__(256) void table_limits_kernel(const uint4 *__restrict__ tables, int M_used,
+                                                           int M, int avx, int64_t nq, int force,
+                                                           int *__restrict__ qlim)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    int n0 = 0, n1 = 0;
+    for (int m = lane; m < M_used; m += 64) {
+        const uint4 t = tables[q * M + m];
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+        int mn = 127;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int v = (int)(int8_t)(w[i] >> (8 * b));
+                mn = v < mn ? v : mn;
+            }
+        const int neg = mn < 0 ? -mn : 0;
+        if (avx && ((m >> 1) & 1)) n1 += neg; else n0 += neg;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        n0 += __shfl_xor(n0, o, 64);
+        n1 += __shfl_xor(n1, o, 64);
+    }
+    if (lane == 0) {
+        int c = (n0 <= 128 && n1 <= 128) ? 127 - n0 - n1 : TK_PLAIN_NEVER;
+        if (force != INT_MAX && c > force) c = force;     // debug: provoke the re-scan path
+        qlim[q] = c;
+    }
+}
+
+static int g_plain_force = INT_MAX;
+void tk_plain_force_limit(int v) { g_plain_force = v; }
+
+void tk_launch_table_limits(const uint4 *tables, int M, int order, int64_t nq, int *qlim, hipStream_t s)
+{
+    if (nq == 0) return;
+    const int avx = order == TK_ORDER_AVX;
+    const int M_used = avx ? (M & ~3) : M;       // the AVX kernels read block pairs two at a time
+    static bool env = false;
+    if (!env) {
+        const char *e = getenv("TINYKNN_PLAIN_FORCE_LIMIT");
+        if (e) g_plain_force = atoi(e);
+        env = true;
+    }
+    hipLaunchKernelGGL(table_limits_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, tables,
+                       M_used, M, avx, nq, g_plain_force, qlim);
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
+{
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x04000c0cu);
+    return lo | hi;
+}
+
+__device__ __forceinline__ int clamp8(int x) { return min(max(x, -128), 127); }
+
+// a: lanes 32..63 <-> b: lanes 0..31
+__device__ __forceinline__ void swap_halves(uint32_t &a, uint32_t &b)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+// PT: block pairs the registers are sized for (P <= PT at run time)
+template <int PT>
+struct PlainShape {
+    static constexpr int PS = (PT + 3) & ~3;      // dwords per (chunk, dword) row of the code staging
+    static constexpr int TROW = 2 * PT + 1;       // uint4 per query row of a staged table tile
+    static constexpr int TL = (32 * 2 * PT + 255) / 256;
+    static constexpr size_t lds = 256 + (size_t)4 * 8 * PS * 4 + (size_t)2 * 32 * TROW * 16 + 16 + 2 * 64 * 4;
+};
+
+// EXACT: P == PT (the common shapes, M = 52 and M = 32): no guards around the block pairs, and
+// the one-hot operands are requested DEPTH block pairs ahead of the MFMA that takes them (an LDS
+// round trip is 100+ cycles with eight waves on the CU's LDS, an MFMA 32).
+//
+// The chunk-pair loop holds NO conditional vector-memory operation: loads and stores count
+// together, in issue order, in one counter (vmcnt), and behind a branch the compiler can only wait
+// for all of them — the prefetched code groups would then wait for the previous iteration's
+// scattered stores (measured: 56 % of the wave cycles in s_waitcnt).  So lanes without work of
+// their own CLONE a lane that has some — a pair past the tile's last one the last pair, the second
+// chunk of an odd chunk pair the first — and load / store the same bytes at the same addresses.
+template <int PT, bool EXACT>
+__global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, int M)
+{
+    if (EXACT) P = PT;
+    using SH = PlainShape<PT>;
+    constexpr int PS = SH::PS, TROW = SH::TROW, TL = SH::TL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_plain[];
+    uint4 *lut = (uint4 *)smem_plain;                                   // 16 one-hot entries
+    uint32_t *stage = (uint32_t *)(smem_plain + 256);                   // [4 waves][8][PS]
+    uint4 *tile = (uint4 *)(smem_plain + 256 + 4 * 8 * PS * 4);         // [2][32][TROW]
+    int *s_unit = (int *)(smem_plain + 256 + 4 * 8 * PS * 4 + 2 * 32 * TROW * 16);   // [2]
+    int *s_q = s_unit + 4;                                              // [2][32] query of a tile's pairs
+    int *s_f0 = s_q + 64;                                               // [2][32] ... and their row offset
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        w[threadIdx.x >> 2] = 1u << (8 * (threadIdx.x & 3));
+        lut[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    const int n_units = j.unit_prefix[j.n_lists];
+    int *counter = const_cast<int *>(j.unit_prefix) + TK_PLAIN_COUNTER_OFF(j.n_lists);
+    const int r = lane & 31, h = lane >> 5;
+    const int rr = r & 15;
+    const uint32_t rot = (uint32_t)(8 * (rr & 3) + 4 * h + 28) & 31u;    // rotate right: nibble -> bits 4..7
+    const unsigned char *lutb = (const unsigned char *)lut;
+    const bool loader = lane < 2 * P;
+    const int ll = loader ? lane : 2 * P - 1;     // (lanes past the 2P groups clone the last loader)
+    const int lch = ll / P, lp = ll - lch * P;
+    uint32_t *st = stage + wave * 8 * PS;
+    const uint32_t *rd = st + ((r >> 4) * 4 + (rr >> 2)) * PS;
+    const int rows_m = 2 * P;                     // table rows (blocks) used per query
+
+    // (a binary search through unit_prefix here was ten dependent trips to L2 per look-up, three
+    // look-ups per unit: longer than the unit's arithmetic)
+    auto locate = [&](int u, int &l, int &t) {
+        const int2 d = ((const int2 *)j.unit_desc)[u];
+        l = __builtin_amdgcn_readfirstlane(d.x);
+        t = __builtin_amdgcn_readfirstlane(d.y);
+    };
+    // query and row offset of a unit's 32 pairs -> LDS (pairs past the last one: the last one)
+    auto stage_pairs = [&](int b, int l, int t) {
+        if (threadIdx.x < 32) {
+            const int cnt = j.pair_off[l + 1] - j.pair_off[l] - 32 * t;      // >= 1
+            const int rec = j.pair_off[l] + 32 * t + (threadIdx.x < cnt ? threadIdx.x : cnt - 1);
+            s_q[b * 32 + threadIdx.x] = j.pair_q[rec];
+            s_f0[b * 32 + threadIdx.x] = j.pair_f0[rec];
+        }
+    };
+    // slice k (of TL) of the table rows of a unit's 32 pairs: one 16-byte load per thread,
+    // coalesced per query row; kept in registers for the length of ONE chunk pair only.
+    // Element i = threadIdx.x + 256 k of the tile is (pair i / rows_m, row i % rows_m): the pair
+    // and row of slice 0 are computed once, the next slice's by stepping 256 elements on.
+    const int sl_pr0 = threadIdx.x / rows_m, sl_m0 = threadIdx.x - sl_pr0 * rows_m;
+    const int step_pr = 256 / rows_m, step_m = 256 - step_pr * rows_m;
+    int sl_pr = sl_pr0, sl_m = sl_m0;
+    auto slice_next = [&]() {
+        sl_pr += step_pr;
+        sl_m += step_m;
+        if (sl_m >= rows_m) { sl_m -= rows_m; sl_pr++; }
+    };
+    auto fetch_slice = [&](int b) -> uint4 {       // unconditional (rows past the tile: row 31's)
+        const int qs = s_q[b * 32 + (sl_pr < 32 ? sl_pr : 31)];
+        return j.tables[(int64_t)qs * M + sl_m];
+    };
+    auto store_slice = [&](int b, const uint4 v) {
+        if (sl_pr < 32) tile[(b * 32 + sl_pr) * TROW + sl_m] = v;
+    };
+    if (threadIdx.x == 0) s_unit[0] = atomicAdd(counter, 1);
+    __syncthreads();
+    int u = s_unit[0];
+    int buf = 0;
+    if (u < n_units) {
+        int l0, t0;
+        locate(u, l0, t0);
+        stage_pairs(0, l0, t0);
+        __syncthreads();
+        for (int k = 0; k < TL; k++) {
+            store_slice(0, fetch_slice(0));
+            slice_next();
+        }
+    }
+    while (u < n_units) {     // (workgroup-uniform: every wave reaches the barriers)
+        if (threadIdx.x == 0) s_unit[buf ^ 1] = atomicAdd(counter, 1);
+        __syncthreads();                   // tile[buf] is complete; the next unit is known
+        int un = s_unit[buf ^ 1];
+        int l, t;
+        locate(u, l, t);
+        // the next unit's tile travels to the other LDS buffer one slice per chunk pair (after
+        // the last unit: this unit's once more, so that the loop below has one shape)
+        {
+            int nl = l, nt = t;
+            if (un < n_units) locate(un, nl, nt);
+            stage_pairs(buf ^ 1, nl, nt);
+        }
+        sl_pr = sl_pr0;
+        sl_m = sl_m0;
+        int ks = 0;
+        const int64_t c0 = j.list_chunk_off[l];
+        const int C = (int)(j.list_chunk_off[l + 1] - c0);
+        const int CP = (C + 1) >> 1;
+        const int qi = s_q[buf * 32 + r];          // (written a unit ago, or before the first barrier pair)
+        const int f0 = s_f0[buf * 32 + r];
+        int nvalid = j.pair_off[l + 1] - j.pair_off[l] - 32 * t;
+        nvalid = nvalid < 32 ? nvalid : 32;
+        const int rc = r < nvalid ? r : nvalid - 1;
+        v4i B[PT];
+#pragma unroll
+        for (int p = 0; p < PT; p++)
+            if (EXACT || p < P) B[p] = *(const v4i *)&tile[(buf * 32 + rc) * TROW + 2 * p + h];
+        uint4 *drow = j.dist + (int64_t)qi * j.cap + f0;
+        uint8_t *mrow = j.mins + (int64_t)qi * j.min_stride + f0;
+        auto fetch = [&](int cp) -> uint4 {        // unconditional (chunks past the list: its last)
+            int c = 2 * cp + lch;
+            c = c < C ? c : C - 1;
+            const int64_t gc = c0 + c;
+            return j.codes[((gc >> 3) * (int64_t)(M >> 1) + lp) * 8 + (gc & 7)];
+        };
+        __syncthreads();                   // the next unit's pairs are staged
+        int cp = wave;
+        uint4 g0 = fetch(cp), g1 = fetch(cp + 4);
+        for (; cp < CP; cp += 4) {
+            const uint4 g2 = fetch(cp + 8);
+            const uint4 tslice = fetch_slice(buf ^ 1);
+            if (loader) {
+                st[(lch * 4 + 0) * PS + lp] = g0.x;
+                st[(lch * 4 + 1) * PS + lp] = g0.y;
+                st[(lch * 4 + 2) * PS + lp] = g0.z;
+                st[(lch * 4 + 3) * PS + lp] = g0.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (the staging region is rewritten one iteration later, after this iteration's reads:
+            // LDS operations of one wave complete in issue order)
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (EXACT) {
+                uint32_t x[PS];
+#pragma unroll
+                for (int k = 0; k < PS / 4; k++) {
+                    const uint4 v = *(const uint4 *)(rd + 4 * k);
+                    x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+                }
+                v4i A[PT];
+#pragma unroll
+                for (int p = 0; p < PT; p++)
+                    A[p] = *(const v4i *)(lutb + (__builtin_amdgcn_alignbit(x[p], x[p], rot) & 0xf0u));
+#pragma unroll
+                for (int p = 0; p < PT; p++)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[p], B[p], acc, 0, 0, 0);
+                // schedule: the x reads, DEPTH one-hot reads, then one MFMA per further one-hot read
+                constexpr int DEPTH = 6 < PT ? 6 : PT;
+                __builtin_amdgcn_sched_group_barrier(0x100, PS / 4 + DEPTH, 0);
+#pragma unroll
+                for (int p = 0; p < PT - DEPTH; p++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, DEPTH, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PS / 4; k++) {
+                    const uint4 v = *(const uint4 *)(rd + 4 * k);
+                    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int p = 4 * k + i;
+                        if (p < PT && p < P) {
+                            const uint32_t a_off = __builtin_amdgcn_alignbit(x[i], x[i], rot) & 0xf0u;
+                            const v4i A = *(const v4i *)(lutb + a_off);
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[p], acc, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int o[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) o[i] = clamp8(acc[i]);
+            uint32_t X = pack4(o[0], o[1], o[2], o[3]), Y = pack4(o[4], o[5], o[6], o[7]);
+            uint32_t Z = pack4(o[8], o[9], o[10], o[11]), W = pack4(o[12], o[13], o[14], o[15]);
+            uint32_t mA = (uint32_t)min(min(min(o[0], o[1]), min(o[2], o[3])), min(min(o[4], o[5]), min(o[6], o[7])));
+            uint32_t mB = (uint32_t)min(min(min(o[8], o[9]), min(o[10], o[11])), min(min(o[12], o[13]), min(o[14], o[15])));
+            swap_halves(X, Z);
+            swap_halves(Y, W);
+            swap_halves(mA, mB);
+            const int mn = min((int)mA, (int)mB);
+            int cc = 2 * cp + h;
+            cc = cc < C ? cc : C - 1;      // odd list: the second half holds the first chunk again
+            drow[cc] = make_uint4(X, Z, Y, W);
+            mrow[cc] = (uint8_t)mn;
+            if (ks < TL) {
+                store_slice(buf ^ 1, tslice);
+                slice_next();
+                ks++;
+            }
+            g0 = g1;
+            g1 = g2;
+        }
+        for (; ks < TL; ks++) {
+            store_slice(buf ^ 1, fetch_slice(buf ^ 1));
+            slice_next();
+        }
+        u = un;
+        buf ^= 1;
+    }
+}
+
+int tk_plain_fits(int M) { return M >= 2 && M % 2 == 0 && M / 2 <= 26; }
+
+// j.unit_prefix: tiles of 32 pairs before each list (n_lists + 1), then the work counter (zeroed
+// by the kernel that wrote the table); P block pairs are summed (AVX order: an odd trailing pair
+// is not read by the reference's kernel either, _fast_pq_256.pyx:135-149)
+int tk_launch_scan_plain(const TkScanJob &j, int M, int order, int n_blocks, hipStream_t s)
+{
+    if (!j.unit_prefix) return 0;
+    int P = M / 2;
+    if (order == TK_ORDER_AVX) P &= ~1;
+    if (P < 1 || P > 26) return -1;
+#define TK_LAUNCH(PT_, EX_)                                                                         \
+    do {                                                                                            \
+        static bool attr_ = false;                                                                  \
+        if (!attr_) {                                                                               \
+            if (hipFuncSetAttribute((const void *)scan_plain_kernel<PT_, EX_>,                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,                     \
+                                    (int)PlainShape<PT_>::lds) != hipSuccess)                       \
+                return -1;                                                                          \
+            attr_ = true;                                                                           \
+        }                                                                                           \
+        hipLaunchKernelGGL((scan_plain_kernel<PT_, EX_>), dim3(n_blocks), dim3(256),                \
+                           PlainShape<PT_>::lds, s, j, P, M);                                       \
+    } while (0)
+    if (P == 26) TK_LAUNCH(26, true);
+    else if (P == 16) TK_LAUNCH(16, true);
+    else if (P <= 8) TK_LAUNCH(8, false);
+    else if (P <= 16) TK_LAUNCH(16, false);
+    else TK_LAUNCH(26, false);
+#undef TK_LAUNCH
+    return 0;
+}

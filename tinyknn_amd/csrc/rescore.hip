@@ -310,13 +310,18 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
                                   int64_t *__restrict__ slot_label_off,
                                   unsigned char *__restrict__ repeat_flag,
                                   int *__restrict__ pair_count, const int *__restrict__ owner,
-                                  int me)
+                                  int me, const int *__restrict__ qlim, int R,
+                                  int *__restrict__ slot_exact, int *__restrict__ pair_count2)
 {
     int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     int acc = 0;
     bool wrapped = false;  // a wrapped id may name a list that is probed twice
     slot_prefix[qi * (S + 1)] = 0;
+    // leading slots that stay exact: until the lists scanned so far hold 2R rows (the heap is then
+    // full of real values and its bound far below the table's limit; the replay checks)
+    int e = S;
+    int64_t rows = 0;
     for (int s = 0; s < S; s++) {
         int64_t cl = probes[qi * S + s];
         if (cl < 0) { cl += n_lists; wrapped = true; }
@@ -326,9 +331,18 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
         slot_chunk0[qi * S + s] = c0;
         slot_n[qi * S + s] = (int)list_n[cl];
         slot_label_off[qi * S + s] = ids_off[cl];
-        // pairs per list, for the list-major scan (sharded index: of the lists I own)
-        if (pair_count && (!owner || owner[cl] == me)) atomicAdd(&pair_count[cl], 1);
+        rows += list_n[cl];
+        if (e == S && rows >= 2 * (int64_t)R) e = s + 1;
     }
+    if (!slot_exact || wrapped || qlim[qi] == TK_PLAIN_NEVER) e = S;
+    if (slot_exact) slot_exact[qi] = e;
+    if (pair_count)
+        for (int s = 0; s < S; s++) {
+            int64_t cl = probes[qi * S + s];
+            if (cl < 0) cl += n_lists;
+            // pairs per list, for the list-major scan (sharded index: of the lists I own)
+            if (!owner || owner[cl] == me) atomicAdd(s < e ? &pair_count[cl] : &pair_count2[cl], 1);
+        }
     if (repeat_flag) repeat_flag[qi] = wrapped;
 }
 
@@ -336,11 +350,14 @@ void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
                           int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
-                          int *pair_count, const int *owner, int me, hipStream_t s)
+                          int *pair_count, const int *owner, int me, hipStream_t s,
+                          const int *qlim, int R, int *slot_exact, int *pair_count2)
 {
     (void)probe_count;
     if (nq == 0) return;
+    if (!qlim || !pair_count2) slot_exact = nullptr;
     hipLaunchKernelGGL(make_slots_kernel, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, s,
                        probes, kc, nq, n_lists, list_chunk_off, list_n, ids_off, slot_prefix,
-                       slot_chunk0, slot_n, slot_label_off, repeat_flag, pair_count, owner, me);
+                       slot_chunk0, slot_n, slot_label_off, repeat_flag, pair_count, owner, me,
+                       qlim, R, slot_exact, pair_count2);
 }

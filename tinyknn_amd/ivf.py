@@ -480,6 +480,12 @@ class DeviceIndex:
         """0: automatic, 1: query-major scan, 2: list-major scan (see tinyknn_hip.h)."""
         _lib.check(_lib.lib().tk_index_set_scan_mode(self._h, int(mode)))
 
+    def set_plain_scan(self, on):
+        """Probed lists behind the first ones as plain sums on the int8 matrix cores where that
+        is provably the same replay (tinyknn_hip.h: tk_index_set_plain_scan); True = automatic
+        (default), False = the exact kernel for every list.  Identical results either way."""
+        _lib.check(_lib.lib().tk_index_set_plain_scan(self._h, 0 if on else 1))
+
     def set_profiling(self, on):
         _lib.check(_lib.lib().tk_index_set_profiling(self._h, int(on)))
 
