@@ -20,6 +20,8 @@
 // mode uses v_pk_add_u16 clamp.  One VGPR carries two rows; the AVX order keeps
 // two such accumulator sets (block pairs p even / p odd) and merges them with
 // one final saturating add, the SSE order keeps one.
+#include <string.h>
+
 #include "kernels.h"
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -407,7 +409,7 @@ __device__ __forceinline__ void scan_units_block(
     const int64_t *__restrict__ list_chunk_off, int n_lists, const int *__restrict__ unit_prefix,
     const int *__restrict__ pair_off, const int *__restrict__ pair_q,
     const int *__restrict__ pair_f0, uint4 *__restrict__ dist, int64_t cap,
-    uint8_t *__restrict__ mins, int64_t min_stride, int U, int blk)
+    uint8_t *__restrict__ mins, int64_t min_stride, int U, int blk, int max_chunks = 0)
 {
     const uint32_t cA = 0x020c000cu, cB = 0x030c010cu;
     const int u0 = blk << 6;
@@ -421,7 +423,8 @@ __device__ __forceinline__ void scan_units_block(
     }
     const int l = lo;
     const int64_t c0 = list_chunk_off[l];
-    const int C = (int)(list_chunk_off[l + 1] - c0);
+    int C = (int)(list_chunk_off[l + 1] - c0);
+    C = (max_chunks > 0 && max_chunks < C) ? max_chunks : C;     // head pairs: the list's first chunks only
     const int local = uu - unit_prefix[l];
     const int qg = local / C, c = local - qg * C;
     const int rec = pair_off[l] + TK_UNIT_Q * qg;
@@ -709,30 +712,32 @@ __global__ __launch_bounds__(256, (FORM == 1 ? 4 : 3)) void scan_units_kernel(
 // of batch b+1 (pipelined mode, api.hip).  Either job may be absent (unit_prefix == NULL).
 // The work counters are those of the first job present.
 template <int ORDER, bool SIGNED, int FORM>
-__global__ __launch_bounds__(256, (FORM == 1 ? 4 : 3)) void scan_units2_kernel(TkScanJob a, TkScanJob b, int P,
-                                                                int M, int gmax)
+__global__ __launch_bounds__(256, (FORM == 1 ? 4 : 3)) void scan_units2_kernel(TkScanJob a, TkScanJob b, TkScanJob c,
+                                                                int P, int M, int gmax)
 {
     extern __shared__ uint4 tk_lds_tables[];
     uint4 *lw = tk_lds_tables + (threadIdx.x >> 6) * (gmax * TK_UNIT_Q * M);
     const int UA = a.unit_prefix ? a.unit_prefix[a.n_lists] : 0;
     const int UB = b.unit_prefix ? b.unit_prefix[b.n_lists] : 0;
-    const int NBA = (UA + 63) >> 6, NBB = (UB + 63) >> 6;
+    const int UC = c.unit_prefix ? c.unit_prefix[c.n_lists] : 0;
+    const int NBA = (UA + 63) >> 6, NBB = (UB + 63) >> 6, NBC = (UC + 63) >> 6;
     int *ticket = a.unit_prefix ? const_cast<int *>(a.unit_prefix) + TK_TICKET_OFF(a.n_lists)
-                                : const_cast<int *>(b.unit_prefix) + TK_TICKET_OFF(b.n_lists);
-    ticketed_blocks(NBA + NBB, ticket, [&](int blk) {
+                : b.unit_prefix ? const_cast<int *>(b.unit_prefix) + TK_TICKET_OFF(b.n_lists)
+                                : const_cast<int *>(c.unit_prefix) + TK_TICKET_OFF(c.n_lists);
+    ticketed_blocks(NBA + NBB + NBC, ticket, [&](int blk) {
         // one copy of the block body: the job's fields are picked with wave-uniform selects
-        const bool first = blk < NBA;
-        const TkScanJob &j = first ? a : b;
+        const int which = blk < NBA ? 0 : (blk < NBA + NBB ? 1 : 2);
+        const TkScanJob &j = which == 0 ? a : (which == 1 ? b : c);
+        const int U = which == 0 ? UA : (which == 1 ? UB : UC);
+        const int jb = which == 0 ? blk : (which == 1 ? blk - NBA : blk - NBA - NBB);
         if (FORM != 0)
             scan_units_block_lds<ORDER, SIGNED, FORM == 1>(j.codes, P, j.tables, M, j.list_chunk_off, j.n_lists,
                                                 j.unit_prefix, j.pair_off, j.pair_q, j.pair_f0, j.dist,
-                                                j.cap, j.mins, j.min_stride, first ? UA : UB,
-                                                first ? blk : blk - NBA, lw, gmax);
+                                                j.cap, j.mins, j.min_stride, U, jb, lw, gmax);
         else
             scan_units_block<ORDER, SIGNED>(j.codes, P, j.tables, M, j.list_chunk_off, j.n_lists,
                                             j.unit_prefix, j.pair_off, j.pair_q, j.pair_f0, j.dist,
-                                            j.cap, j.mins, j.min_stride, first ? UA : UB,
-                                            first ? blk : blk - NBA);
+                                            j.cap, j.mins, j.min_stride, U, jb, j.max_chunks);
     });
 }
 
@@ -822,41 +827,39 @@ void tk_launch_unit_pairs(int64_t nq, const int64_t *probes, int S, int64_t n_li
                        probes, S, nq, n_lists, slot_prefix, pair_off, cursor, pair_q, pair_f0);
 }
 
-// ---- two pair sets in one pass (plain_scan.hip): slots below slot_exact[q] -> the exact
-// kernel's units (records padded to groups of 4), the others -> tiles of 32 pairs of the plain
-// kernel (records not padded).  One workgroup scans both sets.
-__global__ __launch_bounds__(1024) void pairs_scan2_kernel(int *__restrict__ count, int *__restrict__ count2,
-                                                           const int64_t *__restrict__ list_chunk_off,
-                                                           int n_lists, int *__restrict__ pair_off,
-                                                           int *__restrict__ unit_prefix,
-                                                           int *__restrict__ cursor, int *__restrict__ pair_q,
-                                                           int *__restrict__ pair_off2,
-                                                           int *__restrict__ unit_prefix2,
-                                                           int *__restrict__ cursor2,
-                                                           int *__restrict__ unit_desc2)
+// ---- three pair sets in one pass (plain_scan.hip): set 0 = slots below slot_exact[q] -> the
+// exact kernel's units (records padded to groups of 4); set 1 = the plain kernel's tiles of 32
+// pairs (records not padded); set 2 = head pairs (slot 0 of a query in head mode, also in set 1)
+// -> units of the exact kernel over the first head_chunks chunks of the list.
+struct PairSets {
+    int *count[3], *cursor[3], *pair_off[3], *unit_prefix[3], *pair_q[3], *pair_f0[3];
+    int *unit_desc;
+};
+
+__global__ __launch_bounds__(1024) void pairs_scan3_kernel(PairSets ps, const int64_t *__restrict__ list_chunk_off,
+                                                           int n_lists, int head_chunks)
 {
     __shared__ int s_a[1024], s_b[1024];
     __shared__ int carry_a, carry_b;
-    for (int set = 0; set < 2; set++) {
+    for (int set = 0; set < 3; set++) {
         if (threadIdx.x == 0) carry_a = carry_b = 0;
         __syncthreads();
-        int *cnt_p = set ? count2 : count;
-        int *off_p = set ? pair_off2 : pair_off;
-        int *unit_p = set ? unit_prefix2 : unit_prefix;
-        int *cur_p = set ? cursor2 : cursor;
+        int *cnt_p = ps.count[set], *off_p = ps.pair_off[set], *unit_p = ps.unit_prefix[set];
+        int *cur_p = ps.cursor[set], *pq = ps.pair_q[set];
         for (int base = 0; base < n_lists; base += 1024) {
             const int l = base + threadIdx.x;
             int rec = 0, unit = 0, cnt = 0;
             if (l < n_lists) {
                 cnt = cnt_p[l];
                 cnt_p[l] = 0;   // zero again for the next batch
-                if (set == 0) {
+                const int C = (int)(list_chunk_off[l + 1] - list_chunk_off[l]);
+                if (set != 1) {
                     const int groups = (cnt + TK_UNIT_Q - 1) / TK_UNIT_Q;
                     rec = groups * TK_UNIT_Q;
-                    unit = groups * (int)(list_chunk_off[l + 1] - list_chunk_off[l]);
+                    unit = groups * (set == 2 && head_chunks < C ? head_chunks : C);
                 } else {
                     rec = cnt;
-                    unit = list_chunk_off[l + 1] > list_chunk_off[l] ? (cnt + 31) / 32 : 0;
+                    unit = C > 0 ? (cnt + 31) / 32 : 0;
                 }
             }
             s_a[threadIdx.x] = rec;
@@ -872,15 +875,16 @@ __global__ __launch_bounds__(1024) void pairs_scan2_kernel(int *__restrict__ cou
             }
             if (l < n_lists) {
                 const int off = carry_a + s_a[threadIdx.x] - rec;
+                const int ubase = carry_b + s_b[threadIdx.x] - unit;
                 off_p[l] = off;
-                unit_p[l] = carry_b + s_b[threadIdx.x] - unit;
+                unit_p[l] = ubase;
                 cur_p[l] = 0;
-                if (set == 0)
-                    for (int t = cnt; t < rec; t++) pair_q[off + t] = -1;   // padding records
+                if (set != 1)
+                    for (int t = cnt; t < rec; t++) pq[off + t] = -1;   // padding records
                 else        // (list, tile) of every unit: the plain kernel looks its unit up in one load
                     for (int t = 0; t < unit; t++) {
-                        unit_desc2[2 * (unit_p[l] + t)] = l;
-                        unit_desc2[2 * (unit_p[l] + t) + 1] = t;
+                        ps.unit_desc[2 * (ubase + t)] = l;
+                        ps.unit_desc[2 * (ubase + t) + 1] = t;
                     }
             }
             __syncthreads();
@@ -894,19 +898,15 @@ __global__ __launch_bounds__(1024) void pairs_scan2_kernel(int *__restrict__ cou
             off_p[n_lists] = carry_a;
             unit_p[n_lists] = carry_b;
         }
-        if (set == 0 && threadIdx.x < TK_TICKETS) unit_prefix[TK_TICKET_OFF(n_lists) + threadIdx.x * 32] = 0;
-        if (set == 1 && threadIdx.x == 0) unit_prefix2[TK_PLAIN_COUNTER_OFF(n_lists)] = 0;
+        if (set != 1 && threadIdx.x < TK_TICKETS) unit_p[TK_TICKET_OFF(n_lists) + threadIdx.x * 32] = 0;
+        if (set == 1 && threadIdx.x == 0) unit_p[TK_PLAIN_COUNTER_OFF(n_lists)] = 0;
         __syncthreads();
     }
 }
 
-__global__ void pairs_fill2_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
+__global__ void pairs_fill3_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
                                    int64_t n_lists, const int *__restrict__ slot_prefix,
-                                   const int *__restrict__ slot_exact, const int *__restrict__ pair_off,
-                                   int *__restrict__ cursor, int *__restrict__ pair_q,
-                                   int *__restrict__ pair_f0, const int *__restrict__ pair_off2,
-                                   int *__restrict__ cursor2, int *__restrict__ pair_q2,
-                                   int *__restrict__ pair_f02)
+                                   const int *__restrict__ slot_exact, PairSets ps)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * S) return;
@@ -915,30 +915,38 @@ __global__ void pairs_fill2_kernel(const int64_t *__restrict__ probes, int S, in
     int64_t cl = probes[i];
     if (cl < 0) cl += n_lists;
     const int f0 = slot_prefix[qi * (S + 1) + s];
-    if (s < slot_exact[qi]) {
-        const int pos = atomicAdd(&cursor[cl], 1);
-        pair_q[pair_off[cl] + pos] = (int)qi;
-        pair_f0[pair_off[cl] + pos] = f0;
+    const int e = slot_exact[qi];
+    auto put = [&](int set) {
+        const int pos = atomicAdd(&ps.cursor[set][cl], 1);
+        ps.pair_q[set][ps.pair_off[set][cl] + pos] = (int)qi;
+        ps.pair_f0[set][ps.pair_off[set][cl] + pos] = f0;
+    };
+    if (e == 0 && s == 0) {        // head mode: first chunks exact, the whole list plain (overwritten)
+        put(2);
+        put(1);
     } else {
-        const int pos = atomicAdd(&cursor2[cl], 1);
-        pair_q2[pair_off2[cl] + pos] = (int)qi;
-        pair_f02[pair_off2[cl] + pos] = f0;
+        put(s < e ? 0 : 1);
     }
 }
 
 void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
                            const int64_t *list_chunk_off, const int *slot_prefix,
                            const int *slot_exact, const TkPairSet &ex, const TkPairSet &pl,
-                           hipStream_t s)
+                           const TkPairSet &hd, int head_chunks, hipStream_t s)
 {
     if (nq == 0 || S == 0) return;
     const int64_t np = nq * S;
-    hipLaunchKernelGGL(pairs_scan2_kernel, dim3(1), dim3(1024), 0, s, ex.count, pl.count, list_chunk_off,
-                       (int)n_lists, ex.pair_off, ex.unit_prefix, ex.cursor, ex.pair_q, pl.pair_off,
-                       pl.unit_prefix, pl.cursor, pl.unit_desc);
-    hipLaunchKernelGGL(pairs_fill2_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, probes, S,
-                       nq, n_lists, slot_prefix, slot_exact, ex.pair_off, ex.cursor, ex.pair_q, ex.pair_f0,
-                       pl.pair_off, pl.cursor, pl.pair_q, pl.pair_f0);
+    PairSets ps;
+    const TkPairSet *sets[3] = {&ex, &pl, &hd};
+    for (int i = 0; i < 3; i++) {
+        ps.count[i] = sets[i]->count; ps.cursor[i] = sets[i]->cursor; ps.pair_off[i] = sets[i]->pair_off;
+        ps.unit_prefix[i] = sets[i]->unit_prefix; ps.pair_q[i] = sets[i]->pair_q; ps.pair_f0[i] = sets[i]->pair_f0;
+    }
+    ps.unit_desc = pl.unit_desc;
+    hipLaunchKernelGGL(pairs_scan3_kernel, dim3(1), dim3(1024), 0, s, ps, list_chunk_off, (int)n_lists,
+                       head_chunks);
+    hipLaunchKernelGGL(pairs_fill3_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, probes, S,
+                       nq, n_lists, slot_prefix, slot_exact, ps);
 }
 
 void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_lists, int *pair_off,
@@ -1043,11 +1051,15 @@ void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_
 }
 
 void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
-                           hipStream_t s)
+                           hipStream_t s, const TkScanJob *cj)
 {
-    if (!a.unit_prefix && !b.unit_prefix) return;
+    TkScanJob c;
+    memset(&c, 0, sizeof c);
+    if (cj) c = *cj;
+    if (!a.unit_prefix && !b.unit_prefix && !c.unit_prefix) return;
     const int P = M / 2;
     int form = g_scan_form;
+    if (a.max_chunks || b.max_chunks || c.max_chunks) form = 0;      // (only the global-load form knows heads)
     const int gmax = scan_form_gmax(M, form);
     const size_t lds = (size_t)4 * gmax * TK_UNIT_Q * M * 16;
 #define TK_LAUNCH(O, F_)                                                                          \
@@ -1055,7 +1067,7 @@ void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int or
         static bool attr_ = false;                                                                \
         if (F_ != 0 && !attr_) { lds_attr(scan_units2_kernel<O, true, F_>); attr_ = true; }       \
         hipLaunchKernelGGL((scan_units2_kernel<O, true, F_>), dim3(n_blocks), dim3(256), lds, s, a, \
-                           b, P, M, gmax);                                                        \
+                           b, c, P, M, gmax);                                                     \
     } while (0)
 #define TK_LAUNCH1(O)                                  \
     do {                                               \

@@ -560,7 +560,8 @@ struct Work {
         slot_n, slot_loff, dist, heap_idx, heap_val, repeat_flag, cmins, mins, u_count, u_cursor,
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
         c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage, pos_lens, pos_off,
-        qlim, slot_exact, p_count, p_cursor, p_pair_off, p_unit_prefix, p_pair_q, p_pair_f0, flag_list, p_unit_desc;   // plain_scan.hip
+        qlim, slot_exact, p_count, p_cursor, p_pair_off, p_unit_prefix, p_pair_q, p_pair_f0, flag_list, p_unit_desc,
+        plain0, h_count, h_cursor, h_pair_off, h_unit_prefix, h_pair_q, h_pair_f0;   // plain_scan.hip
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -575,7 +576,8 @@ struct Work {
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
                        &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage, &pos_lens, &pos_off,
-                       &qlim, &slot_exact, &p_count, &p_cursor, &p_pair_off, &p_unit_prefix, &p_pair_q, &p_pair_f0, &flag_list, &p_unit_desc};
+                       &qlim, &slot_exact, &p_count, &p_cursor, &p_pair_off, &p_unit_prefix, &p_pair_q, &p_pair_f0, &flag_list, &p_unit_desc,
+                       &plain0, &h_count, &h_cursor, &h_pair_off, &h_unit_prefix, &h_pair_q, &h_pair_f0};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -954,6 +956,15 @@ static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
         TRY(w.p_pair_f0.ensure(((size_t)nq * p.S + 4) * 4));
         TRY(w.flag_list.ensure(((size_t)nq + 1) * 4));
         TRY(w.p_unit_desc.ensure(((size_t)nq * p.S / 32 + L + 8) * 8));
+        TRY(w.plain0.ensure((size_t)nq * 4));
+        const void *hb = w.h_count.p;
+        TRY(w.h_count.ensure(L * 4));
+        if (w.h_count.p != hb) HIPCHECK(hipMemset(w.h_count.p, 0, w.h_count.cap));
+        TRY(w.h_cursor.ensure(L * 4));
+        TRY(w.h_pair_off.ensure((L + 1) * 4));
+        TRY(w.h_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
+        TRY(w.h_pair_q.ensure(((size_t)nq + 4 * L) * 4));
+        TRY(w.h_pair_f0.ensure(((size_t)nq + 4 * L) * 4));
     }
     return TK_OK;
 }
@@ -1111,6 +1122,20 @@ static TkScanJob plain_job(const tk_index *ix, const Work &w, const Plan &p)
     return j;
 }
 
+// head pairs: the first ceil(2R / 16) chunks of the first probed list of a query in head mode
+static int head_chunks(const Plan &p) { return (2 * p.R + 15) >> 4; }
+
+static TkScanJob head_job(const tk_index *ix, const Work &w, const Plan &p)
+{
+    TkScanJob j = list_job(ix, w, p);
+    j.unit_prefix = w.h_unit_prefix.as<int>();
+    j.pair_off = w.h_pair_off.as<int>();
+    j.pair_q = w.h_pair_q.as<int>();
+    j.pair_f0 = w.h_pair_f0.as<int>();
+    j.max_chunks = head_chunks(p);
+    return j;
+}
+
 // persistent workgroups of the plain kernel: two per CU (58 KB of LDS, 256 registers per lane)
 static int plain_blocks()
 {
@@ -1189,7 +1214,8 @@ static void coarse_slots(tk_index *ix, Work &w, const int64_t *probes, int64_t n
                          w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
                          w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(), pair_count,
                          owner, me, st, plain ? w.qlim.as<int>() : nullptr, p.R,
-                         plain ? w.slot_exact.as<int>() : nullptr, plain ? w.p_count.as<int>() : nullptr);
+                         plain ? w.slot_exact.as<int>() : nullptr, plain ? w.p_count.as<int>() : nullptr,
+                         plain ? w.plain0.as<int>() : nullptr, plain ? w.h_count.as<int>() : nullptr);
 }
 
 // the pair lists of a batch: one set for the exact list-major kernel, with `plain` a second one
@@ -1210,8 +1236,10 @@ static void unit_pairs(tk_index *ix, Work &w, int64_t nq, const Plan &p, bool pl
     TkPairSet pl{w.p_count.as<int>(), w.p_cursor.as<int>(), w.p_pair_off.as<int>(),
                  w.p_unit_prefix.as<int>(), w.p_pair_q.as<int>(), w.p_pair_f0.as<int>(),
                  w.p_unit_desc.as<int>()};
+    TkPairSet hd{w.h_count.as<int>(), w.h_cursor.as<int>(), w.h_pair_off.as<int>(),
+                 w.h_unit_prefix.as<int>(), w.h_pair_q.as<int>(), w.h_pair_f0.as<int>()};
     tk_launch_unit_pairs2(nq, w.probes.as<int64_t>(), p.S, ix->n_lists, ix->list_chunk_off.as<int64_t>(),
-                          w.slot_prefix.as<int>(), w.slot_exact.as<int>(), ex, pl, st);
+                          w.slot_prefix.as<int>(), w.slot_exact.as<int>(), ex, pl, hd, head_chunks(p), st);
 }
 
 static int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
@@ -1241,7 +1269,7 @@ static void rescan_flagged(tk_index *ix, Work &w, int64_t q0, int64_t nq, const 
 static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq, int k,
                       const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf, bool plain = false)
 {
-    const int *slot_exact = plain ? w.slot_exact.as<int>() + q0 : nullptr;
+    const int *slot_exact = plain ? w.plain0.as<int>() + q0 : nullptr;     // (first plain chunk per query)
     const int *qlim = plain ? w.qlim.as<int>() + q0 : nullptr;
     const int *slot_prefix = w.slot_prefix.as<int>() + q0 * (p.S + 1);
     const int *slot_n = w.slot_n.as<int>() + q0 * p.S;
@@ -1366,7 +1394,16 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
     if (b.units) unit_pairs(ix, w, b.nq, p, b.plain, st);
     TRY(b.pf.mark(st));
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
-    if (b.units)
+    // (plain first: the exact kernel then overwrites the head chunks of the lists in head mode)
+    if (b.plain && tk_launch_scan_plain(plain_job(ix, w, p), M, ix->order, plain_blocks(), st))
+        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
+    if (b.plain) {
+        TkScanJob none;
+        memset(&none, 0, sizeof none);
+        const TkScanJob hj = head_job(ix, w, p);
+        tk_launch_scan_units2(list_job(ix, w, p), none, M, ix->order,
+                              getenv("TINYKNN_SCAN_BLOCKS_ISO") ? atoi(getenv("TINYKNN_SCAN_BLOCKS_ISO")) : 768, st, &hj);
+    } else if (b.units)
         tk_launch_scan_units(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), b.nq, p.S, ix->n_lists,
                              ix->list_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                              w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(),
@@ -1378,8 +1415,6 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
                               w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), p.S,
                               (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(),
                               p.cap_min, 1, ix->order, st);
-    if (b.plain && tk_launch_scan_plain(plain_job(ix, w, p), M, ix->order, plain_blocks(), st))
-        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
     TRY(b.pf.mark(st));
     TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf, b.plain));
     TRY(batch_epilogue(b, st));
@@ -1445,18 +1480,21 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
                               prev->p.S, (int)prev->p.cap, prev->w->dist.as<uint4>(), prev->p.cap,
                               prev->w->mins.as<uint8_t>(), prev->p.cap_min, 1, ix->order, st);
     if (cur && !fuse_cur) launch_coarse_scan(ix, *cur->w, cur->nq, cur->p, st);
+    // (plain first: the exact kernel then overwrites the head chunks of the lists in head mode)
+    if (prev && prev->plain &&
+        tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order, plain_blocks(), st))
+        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
     if (fuse_prev || fuse_cur) {
         TkScanJob none;
         memset(&none, 0, sizeof none);
+        TkScanJob hj = none;
+        if (prev && prev->plain) hj = head_job(ix, *prev->w, prev->p);
         tk_launch_scan_units2(fuse_prev ? list_job(ix, *prev->w, prev->p) : none,
                               fuse_cur ? coarse_job(ix, *cur->w, cur->p) : none, M, ix->order,
                               scan_blocks_pipelined(fuse_prev ? (double)prev->nq * prev->p.S / 4.0 *
                                                     ((double)ix->total_chunks / (double)ix->n_lists) : 0.0),
-                              st);
+                              st, &hj);
     }
-    if (prev && prev->plain &&
-        tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order, plain_blocks(), st))
-        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
     if (prev) {
         // heap replay + rescoring of the previous batch on its stream
         TRY(prev->pf.mark(st));

@@ -331,6 +331,39 @@ __device__ __forceinline__ uint32_t mask_lt16(const uint4 v, uint32_t bound8)
     return m;
 }
 
+// The same 16-bit mask by byte-parallel arithmetic (22 VALU instead of ~75: the lane replay is a
+// dependent-issue chain on a wave that has its SIMD to itself, so its time IS its instruction
+// count).  Per dword: bytes as unsigned (signed: top bits flipped), x < b per byte from
+// t = (x | H) - (b & ~H) — no borrow crosses a byte — as  (~x7 & b7) | (~(x7 ^ b7) & ~t7)  in bit 7
+// of every byte; v_dot4_u32_u8 with weights 1,2,4,8 / 16,..,128 gathers the four 0x80 flags of a
+// dword into a nibble.  `bb`: the bound's byte (biased for SIGNED) in all four bytes.
+template <bool SIGNED>
+__device__ __forceinline__ uint32_t bound_bytes(uint32_t bound8)
+{
+    const uint32_t b = SIGNED ? (bound8 ^ 0x80u) : bound8;
+    return __builtin_amdgcn_perm(b, b, 0u);       // byte 0 in every byte
+}
+
+template <bool SIGNED>
+__device__ __forceinline__ uint32_t lt4(uint32_t x, uint32_t bb, uint32_t bl)
+{
+    const uint32_t H = 0x80808080u;
+    const uint32_t xu = SIGNED ? (x ^ H) : x;
+    const uint32_t t = (xu | H) - bl;
+    return ((~xu & bb) | (~(xu ^ bb) & ~t)) & H;
+}
+
+template <bool SIGNED>
+__device__ __forceinline__ uint32_t mask_lt16_swar(const uint4 v, uint32_t bb)
+{
+    const uint32_t bl = bb & 0x7f7f7f7fu;
+    uint32_t lo = __builtin_amdgcn_udot4(lt4<SIGNED>(v.x, bb, bl), 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(lt4<SIGNED>(v.y, bb, bl), 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(lt4<SIGNED>(v.z, bb, bl), 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(lt4<SIGNED>(v.w, bb, bl), 0x80402010u, hi, false);
+    return (lo >> 7) | (hi << 1);
+}
+
 // `pos < n` (_fast_pq_256.pyx:111) once, ahead of the replay: the rows that pad the last chunk
 // of a probed list (code of the zero vector, fast_pq.py:165) get the largest distance value —
 // nothing is ever below a bound with it, which is exactly what the reference's row test
@@ -384,7 +417,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
     unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
     int64_t cap_min, const int32_t *__restrict__ labels32, unsigned long long *__restrict__ dbg,
-    int prio, int wave_lds, const int *__restrict__ slot_exact, const int *__restrict__ qlim)
+    int prio, int wave_lds, const int *__restrict__ plain0_arr, const int *__restrict__ qlim)
 {
     // dbg != NULL (tk_debug_replay_timers): cycle counters of the wave's phases, 8 per workgroup:
     // total, block search, insert (all of it), LDS sift levels, rounds, LDS iterations, search
@@ -456,13 +489,14 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
              h4 = TK_FRESH(4), h5 = TK_FRESH(5), h6 = TK_FRESH(6);
 #undef TK_FRESH
     uint32_t bound = SIGNED ? 0x7fu : 0xffu;
+    uint32_t bb = bound_bytes<SIGNED>(bound);     // the bound's byte, biased, in all four bytes (mask_lt16_swar)
 
     const int total = (valid && S > 0) ? prefix[S] : 0;   // flat chunks of this lane's query
-    // plain_scan.hip: the slots from slot_exact[q] on carry clamp(plain sums), which equal the
+    // plain_scan.hip: the blocks from flat chunk plain0 on carry clamp(plain sums), which equal the
     // reference's values below qlim[q] and are >= qlim[q] elsewhere: the replay over them is the
     // replay over the exact values iff the bound is <= qlim[q] when the first of their blocks is
     // reached.  b_plain follows the bound across the exact blocks; checked at the end.
-    const int plain0 = (slot_exact && valid) ? prefix[slot_exact[qc]] : 0x7fffffff;
+    const int plain0 = (plain0_arr && valid) ? plain0_arr[qc] : 0x7fffffff;
     uint32_t b_plain = SIGNED ? 0x7fu : 0xffu;
     const uint4 *mrow = (const uint4 *)(mins + qc * cap_min);   // per-block minima, 16 per uint4
     int nseg = (total + 15) >> 4;
@@ -518,7 +552,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     if (max_nseg > 0) {
         mins_nx = TK_MINS_ROW(0);
         if (PRED && max_nseg > 1) mins_n2 = TK_MINS_ROW(1);
-        if (PRED) pf = mask_lt16<SIGNED>(mins_nx, bound) & seg_mask(0);
+        if (PRED) pf = mask_lt16_swar<SIGNED>(mins_nx, bb) & seg_mask(0);
         TK_FETCH_BLOCKS(0, pf)
     }
     for (int g = 0; g < max_nseg; g++) {
@@ -533,7 +567,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
             mins_nx = mins_n2;
             if (g + 2 < max_nseg) mins_n2 = TK_MINS_ROW(g + 2);
             if (g + 1 < max_nseg) {
-                pf = mask_lt16<SIGNED>(mins_nx, bound) & seg_mask(g + 1);
+                pf = mask_lt16_swar<SIGNED>(mins_nx, bb) & seg_mask(g + 1);
                 TK_FETCH_BLOCKS(g + 1, pf)
             }
         } else if (g + 1 < max_nseg) {
@@ -545,7 +579,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
         kmax = kmax < 0 ? 0 : (kmax > 16 ? 16 : kmax);
         // blocks whose minimum is below the bound at segment start: a superset of the
         // blocks the reference enters (the bound only decreases)
-        uint32_t hit = mask_lt16<SIGNED>(mins_cur, bound);
+        uint32_t hit = mask_lt16_swar<SIGNED>(mins_cur, bb);
         hit &= kmax >= 16 ? 0xffffu : ((1u << kmax) - 1u);
         uint32_t bits = 0;
         uint4 dd = make_uint4(0, 0, 0, 0);
@@ -564,7 +598,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                 // `pos < n` (:111): the rows that pad a list's last chunk were set to the largest
                 // value by pad_fix_kernel and can never be below a bound — no row count, and
                 // with distinct labels no slot cursor at all, is needed here
-                bits = mask_lt16<SIGNED>(dd, bound);          // cmp_mask, _fast_pq_256.pyx:81-90
+                bits = mask_lt16_swar<SIGNED>(dd, bb);        // cmp_mask, _fast_pq_256.pyx:81-90
                 if (DEDUPE && bits) {
                     while (cur >= SE[s * LW + lane]) s++;   // next probed list (empty ones stepped over)
                     lab_base = SB[s * LW + lane] + 16 * cur;
@@ -696,6 +730,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                 }
                 if (bits == 0) {
                     bound = h0 >> 24;                     // refresh after the block, :123
+                    bb = bound_bytes<SIGNED>(bound);
                     b_plain = cur < plain0 ? bound : b_plain;
                 }
             }
@@ -721,7 +756,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     if (R > 5) H[5 * LW + lane] = h5;
     if (R > 6) H[6 * LW + lane] = h6;
     if (!valid) return;
-    if (slot_exact && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) skip[q] = 1;   // re-scan + replay again
+    if (plain0_arr && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) skip[q] = 1;   // re-scan + replay again
     // ---- resolve flat positions (or slots) to labels
     const int64_t *loffs = slot_label_off + qs * S;
     for (int j = 0; j < R; j++) {
@@ -978,10 +1013,10 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
-                                hipStream_t s, const int *slot_exact, const int *qlim)
+                                hipStream_t s, const int *plain0, const int *qlim)
 {
     if (nq == 0 || R == 0) return 0;
-    if (!slot_exact || !qlim || !skip || !signd) slot_exact = qlim = nullptr;
+    if (!plain0 || !qlim || !skip || !signd) plain0 = qlim = nullptr;
     const int dedupe = labels32 != nullptr;
     // Queries per wave.  With the duplicate test a 64-query wave needs 140+ KB of LDS at
     // R = 111: one workgroup per CU, and the two replay kernels of the pipelined mode (2 x 157
@@ -1074,7 +1109,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, P_, L_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, nbuf, mins, cap_min, labels32, dbg, prio, wave_lds,   \
-                       slot_exact, qlim)
+                       plain0, qlim)
     if (LWr == 32) {
         if (dedupe) { if (signd) TK_LAUNCH3(true, true, false, 32); else TK_LAUNCH3(false, true, false, 32); }
         else { if (signd) TK_LAUNCH3(true, false, false, 32); else TK_LAUNCH3(false, false, false, 32); }

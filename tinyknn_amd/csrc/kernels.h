@@ -76,6 +76,7 @@ struct TkScanJob {
     uint8_t *mins;
     int64_t min_stride;
     const int *unit_desc = nullptr;   // plain kernel: (list, tile) of every unit, 2 ints each
+    int max_chunks = 0;               // list-major kernel: only the first max_chunks chunks of a list (0: all)
 };
 // table rows of the list-major kernel: 1 = staged per block in LDS (default), 0 = per-lane
 // global loads (the round-1 form; A/B switch)
@@ -99,15 +100,17 @@ struct TkPairSet {
 };
 // (query, slot) pairs grouped by list, split at slot_exact[q]: slots below it -> set `ex` (units
 // of the list-major exact kernel), the others -> set `pl` (tiles of the plain kernel)
+// hd (head pairs: the first probed list of a query in head mode, slot_exact[q] == 0): units of the
+// exact kernel over the first head_chunks chunks of a list only; such a pair is ALSO in set pl
 void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
                            const int64_t *list_chunk_off, const int *slot_prefix,
                            const int *slot_exact, const TkPairSet &ex, const TkPairSet &pl,
-                           hipStream_t s);
+                           const TkPairSet &hd, int head_chunks, hipStream_t s);
 
 // two jobs in ONE launch sharing one pool of 64-unit blocks (pipelined mode: the list scan
 // of one batch and the coarse scan of the next); signed tables
 void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
-                           hipStream_t s);
+                           hipStream_t s, const TkScanJob *c = nullptr);
 void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq, int S,
                           int64_t n_lists, const int64_t *list_chunk_off, const int *pair_off,
                           const int *unit_prefix, const int *pair_q, const int *pair_f0,
@@ -140,15 +143,15 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 // slot table
 #define TK_LANES_MAX_R_DEDUPE 149
 int tk_lanes_dedupe_fits(int R, int S);     // ... and the slot table of S probed lists fits too
-// slot_exact / qlim (both nq ints, or NULL): slots from slot_exact[q] on carry clamp(plain sums)
-// (plain_scan.hip); a query whose bound at its first such block is above qlim[q] gets skip[q] = 1
-// written (skip must then be writable) and is to be re-scanned exactly and replayed again.
+// plain0 / qlim (both nq ints, or NULL): the blocks from flat chunk plain0[q] on carry clamp(plain
+// sums) (plain_scan.hip); a query whose bound at its first such block is above qlim[q] gets
+// skip[q] = 1 written (skip must then be writable) and is to be re-scanned exactly and replayed again.
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
-                                hipStream_t s, const int *slot_exact = nullptr, const int *qlim = nullptr);
+                                hipStream_t s, const int *plain0 = nullptr, const int *qlim = nullptr);
 
 // Wave-per-query replay on packed 32-bit entries from FRESH heaps (R*4 B of LDS, or
 // R*12 with `dedupe`: int64 labels per slot + the reference's duplicate-label test,
@@ -185,17 +188,20 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
 // probes (nq, kc) list ids -> per-slot scan descriptors; pair_count (n_lists, zeroed, or
 // NULL) receives the number of (query, slot) pairs per list — with `owner` (n_lists ranks,
 // list-sharded index) only for the lists owned by `me`
-// qlim / R / slot_exact / pair_count2 (all or none): slot_exact[q] = number of leading probed lists
-// that stay on the exact kernel — until they hold 2R rows, all of them for a query whose table
-// rules the plain sums out (qlim = TK_PLAIN_NEVER) or whose probe list wrapped; the pairs behind
-// them are counted in pair_count2
+// qlim / R / slot_exact / plain0 / pair_count2 / pair_count3 (all or none): the exact kernel keeps
+// what a query scans until the heap is full of real values and its bound far below the table's
+// limit — 2R rows.  First list at least that long ("head mode", slot_exact[q] = 0): its first
+// ceil(2R / 16) chunks (pair counted in pair_count3 AND, for the plain kernel, in pair_count2);
+// otherwise the leading slot_exact[q] >= 1 lists that hold 2R rows together.  All of them for a query
+// whose table rules the plain sums out (qlim = TK_PLAIN_NEVER) or whose probe list wrapped.
+// plain0[q] = first flat chunk of the query's row that carries plain sums.
 void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
                           int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
                           int *pair_count, const int *owner, int me, hipStream_t s,
                           const int *qlim = nullptr, int R = 0, int *slot_exact = nullptr,
-                          int *pair_count2 = nullptr);
+                          int *pair_count2 = nullptr, int *plain0 = nullptr, int *pair_count3 = nullptr);
 
 // the exclusive scans of tk_launch_unit_pairs alone (the caller fills the records)
 void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_lists, int *pair_off,

@@ -365,8 +365,10 @@ int tk_launch_scan_plain(const TkScanJob &j, int M, int order, int n_blocks, hip
         hipLaunchKernelGGL((scan_plain_kernel<PT_, EX_>), dim3(n_blocks), dim3(256),                \
                            PlainShape<PT_>::lds, s, j, P, M);                                       \
     } while (0)
-    if (P == 26) TK_LAUNCH(26, true);
-    else if (P == 16) TK_LAUNCH(16, true);
+    static int lean = -1;      // A/B: TINYKNN_PLAIN_LEAN=1: the guarded form (fewer registers, shallow prefetch)
+    if (lean < 0) lean = getenv("TINYKNN_PLAIN_LEAN") ? atoi(getenv("TINYKNN_PLAIN_LEAN")) : 0;
+    if (P == 26 && !lean) TK_LAUNCH(26, true);
+    else if (P == 16 && !lean) TK_LAUNCH(16, true);
     else if (P <= 8) TK_LAUNCH(8, false);
     else if (P <= 16) TK_LAUNCH(16, false);
     else TK_LAUNCH(26, false);

@@ -311,7 +311,8 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
                                   unsigned char *__restrict__ repeat_flag,
                                   int *__restrict__ pair_count, const int *__restrict__ owner,
                                   int me, const int *__restrict__ qlim, int R,
-                                  int *__restrict__ slot_exact, int *__restrict__ pair_count2)
+                                  int *__restrict__ slot_exact, int *__restrict__ pair_count2,
+                                  int *__restrict__ plain0, int *__restrict__ pair_count3)
 {
     int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
@@ -334,14 +335,29 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
         rows += list_n[cl];
         if (e == S && rows >= 2 * (int64_t)R) e = s + 1;
     }
-    if (!slot_exact || wrapped || qlim[qi] == TK_PLAIN_NEVER) e = S;
-    if (slot_exact) slot_exact[qi] = e;
+    const bool plain_ok = slot_exact && !wrapped && qlim[qi] != TK_PLAIN_NEVER;
+    const int e_walk = e;
+    if (!plain_ok) e = S;
+    bool head = false;
+    if (slot_exact) {
+        // head mode: the first list alone holds 2R rows and is longer than the head
+        const int E = (2 * R + 15) >> 4;
+        head = plain_ok && e_walk == 1 && slot_prefix[qi * (S + 1) + 1] > E;
+        slot_exact[qi] = head ? 0 : e;
+        plain0[qi] = head ? E : slot_prefix[qi * (S + 1) + e];
+    }
     if (pair_count)
         for (int s = 0; s < S; s++) {
             int64_t cl = probes[qi * S + s];
             if (cl < 0) cl += n_lists;
             // pairs per list, for the list-major scan (sharded index: of the lists I own)
-            if (!owner || owner[cl] == me) atomicAdd(s < e ? &pair_count[cl] : &pair_count2[cl], 1);
+            if (owner && owner[cl] != me) continue;
+            if (head && s == 0) {
+                atomicAdd(&pair_count3[cl], 1);
+                atomicAdd(&pair_count2[cl], 1);
+            } else {
+                atomicAdd(s < e ? &pair_count[cl] : &pair_count2[cl], 1);
+            }
         }
     if (repeat_flag) repeat_flag[qi] = wrapped;
 }
@@ -351,13 +367,14 @@ void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
                           int *slot_n, int64_t *slot_label_off, unsigned char *repeat_flag,
                           int *pair_count, const int *owner, int me, hipStream_t s,
-                          const int *qlim, int R, int *slot_exact, int *pair_count2)
+                          const int *qlim, int R, int *slot_exact, int *pair_count2, int *plain0,
+                          int *pair_count3)
 {
     (void)probe_count;
     if (nq == 0) return;
-    if (!qlim || !pair_count2) slot_exact = nullptr;
+    if (!qlim || !pair_count2 || !plain0 || !pair_count3) slot_exact = nullptr;
     hipLaunchKernelGGL(make_slots_kernel, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, s,
                        probes, kc, nq, n_lists, list_chunk_off, list_n, ids_off, slot_prefix,
                        slot_chunk0, slot_n, slot_label_off, repeat_flag, pair_count, owner, me,
-                       qlim, R, slot_exact, pair_count2);
+                       qlim, R, slot_exact, pair_count2, plain0, pair_count3);
 }
