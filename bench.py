@@ -509,15 +509,24 @@ def measure_traffic(args):
             acc = {}
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == c and "scan_units_kernel" in r["Kernel_Name"]:
-                        coarse = r["Kernel_Name"].split("(")[0].rstrip(">").rstrip().endswith("true")
-                        acc.setdefault(coarse, []).append(float(r["Counter_Value"]))
-            if False not in acc:
+                    name = r["Kernel_Name"]
+                    # the scan launches of one batch in flight: the plain kernel (matrix cores), the
+                    # exact list-major launch (heads + whole lists), the coarse scan
+                    key = ("plain" if "scan_plain_kernel" in name else
+                           "units2" if "scan_units2_kernel" in name else
+                           "units" if "scan_units_kernel" in name else None)
+                    if r["Counter_Name"] == c and key:
+                        acc.setdefault(key + ("_coarse" if key == "units" and
+                                              name.split("(")[0].rstrip(">").rstrip().endswith("true") else ""),
+                                       []).append(float(r["Counter_Value"]))
+            if not acc:
                 if c == "SQ_INSTS_VALU":     # an extra: the traffic figure stands without it
                     tot[c] = None
                     continue
-                return None, f"no scan_units_kernel rows in the {c} pass"
-            tot[c] = sum(sum(v) / len(v) for v in acc.values())     # list scan + coarse scan, KiB
+                return None, f"no scan kernel rows in the {c} pass"
+            tot[c] = sum(sum(v) / len(v) for v in acc.values())     # every scan launch of a batch, KiB
+            measure_traffic.parts = getattr(measure_traffic, "parts", {})
+            measure_traffic.parts[c] = {k_: sum(v) / len(v) for k_, v in acc.items()}
         except Exception as e:     # noqa: BLE001 - profiling is an extra
             if c == "SQ_INSTS_VALU":
                 tot[c] = None
@@ -527,12 +536,32 @@ def measure_traffic(args):
             shutil.rmtree(tmp, ignore_errors=True)
     measure_traffic.valu_insts = tot["SQ_INSTS_VALU"]      # wave-instructions, list + coarse scan
     return (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024, \
-        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this script in this run (pipeline 1: list " \
-        "scan + coarse scan launches summed; FETCH x2 per the gfx950 correction)"
+        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this script in this run (pipeline 1: plain " \
+        "kernel + exact list-major launch + coarse scan summed; FETCH x2 per the gfx950 correction)"
 
 
 VALU_RATE_PER_SIMD = 0.52e9      # wave-instructions/s/SIMD of the scan's VOP3/VOP3P mix, measured:
                                  # profiles/r02_valu_issue_rate_microbench.txt (4.0-4.6 cycles each)
+
+
+I8_MFMA_PEAK_TOPS = 5000.0      # dense int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores)
+
+
+def plain_roofline(st, M, nq):
+    """The plain-sum scan (plain_scan.hip): its matrix-core work per batch.  A unit = 32 pairs x a
+    list's chunk pairs; per chunk pair M/2 v_mfma_i32_32x32x32_i8 = M/2 x 32768 multiply-adds
+    (one-hot(code) x table: 15 of 16 products are by zero — this is matrix-core OCCUPANCY, the
+    useful work is the 26 B per (query, code) of `achieved`)."""
+    if not st or not st["plain_units"]:
+        return None
+    mfma = st["plain_unit_chunk_pairs"] * (M // 2)
+    return dict(st, mfma_instructions_per_batch=mfma, int8_ops_per_batch=mfma * 2 * 32768,
+                mfma_floor_ms=mfma * 32 / (1024 * 2.4e9) * 1e3, peak_unit="TOP/s int8 dense",
+                peak=I8_MFMA_PEAK_TOPS, tile_fill=st["plain_pairs"] / (32.0 * st["plain_units"]),
+                flagged_fraction=st["flagged_queries"] / float(nq),
+                note="mfma_floor_ms: the batch's MFMA instructions at 32 cycles each on 1024 SIMDs at 2.4 GHz; "
+                     "tile_fill: pairs per 32-pair tile; flagged: queries whose bound at the first plain block "
+                     "was above the table's limit (scanned again exactly, replayed again)")
 
 
 def valu_roofline(scan_ms, iso_stages):
@@ -783,6 +812,7 @@ def main():
     torch.cuda.synchronize()
     iso_stages, iso_bytes, _ = dev.last_profile()
     dev.set_profiling(False)
+    plain_stats = dev.plain_stats()      # of the last batch: tiles, pairs by kernel, queries re-scanned
     if args.profile_only:
         if rank == 0:
             print(json.dumps({"profile_only": True, "ms_per_step": elapsed / args.steps * 1e3,
@@ -792,8 +822,10 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    # the same batch captured ONCE into a hipGraph (stream capture of the seven-stage pipeline,
-    # one batch in flight) and replayed: BASELINE configs[3] asks for a graph-captured batch
+    # BASELINE configs[3]: a hipGraph-captured batch.  (a) one batch, one batch in flight, captured
+    # once and replayed; (b) the PIPELINED mode as one graph: `gsteps` consecutive steps (the rotating
+    # batches) + the join, captured on a side stream — the index's internal streams fork from it
+    # through the events the calls record and are joined again by tk_index_join — and replayed.
     graph = None
     try:
         if world > 1:      # RCCL's watchdog thread touches the device during a global-mode capture
@@ -811,12 +843,61 @@ def main():
             g.replay()
         torch.cuda.synchronize()
         tg = (time.perf_counter() - tg) / 20
-        graph = {"ms_per_replay": tg * 1e3, "queries_per_s": args.nq / tg,
-                 "note": "hipGraph replay of one captured batch (one batch in flight; the pipelined "
-                         "mode hands work to streams outside a capture)",
-                 "identical_to_stream_launch": bool((gout.cpu().numpy() == out_dev.cpu().numpy()).all())}
+        graph = {"one_batch_in_flight": {"ms_per_replay": tg * 1e3, "queries_per_s": args.nq / tg,
+                                         "identical_to_stream_launch": bool((gout.cpu().numpy() == out_dev.cpu().numpy()).all())}}
+        del g
+        # (b)
+        gsteps = 32
+        dev.set_profiling(False)
+        dev.set_pipeline(args.pipeline)
+        dev.reserve(args.nq, args.k, args.n_probes)
+        gouts = [torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device) for _ in range(N_BATCHES)]
+
+        def gstep(i, st):
+            bb = batches[i % N_BATCHES]
+            dev.query_batch_dev(bb["q_dev"].data_ptr(), bb["qp_dev"].data_ptr(), qp_is_f64, args.nq, args.k,
+                                args.n_probes, gouts[i % N_BATCHES].data_ptr(), stream=st)
+
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for i in range(gsteps):      # uncaptured once: workspaces, events and streams exist afterwards
+                gstep(i, side.cuda_stream)
+            dev.join(side.cuda_stream)
+        torch.cuda.synchronize()
+        dev.quiesce()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            cs = torch.cuda.current_stream().cuda_stream
+            for i in range(gsteps):
+                gstep(i, cs)
+            dev.join(cs)
+        dev.quiesce()
+        for o in gouts:
+            o.fill_(-1)
+        g2.replay()
+        torch.cuda.synchronize()
+        same = all(bool((gouts[b_].cpu().numpy() == batches[b_]["out"].cpu().numpy()).all()) for b_ in range(N_BATCHES))
+        tg = time.perf_counter()
+        for _ in range(10):
+            g2.replay()
+        torch.cuda.synchronize()
+        tg = (time.perf_counter() - tg) / 10
+        graph.update({"ms_per_replay": tg * 1e3, "steps_per_replay": gsteps, "ms_per_step": tg / gsteps * 1e3,
+                      "queries_per_s": args.nq * gsteps / tg, "batches_in_flight": args.pipeline,
+                      "identical_to_stream_launch": same,
+                      "note": "the pipelined mode captured as ONE hipGraph (%d steps + join; internal streams "
+                              "forked and joined by events inside the capture), replayed; each replay pays the "
+                              "pipeline's fill and drain once" % gsteps})
+        del g2
+        dev.quiesce()
+        dev.set_pipeline(1)
     except Exception as e:       # capture support is an extra, never the measured path
-        graph = {"error": repr(e)}
+        graph = dict(graph or {}, error=repr(e))
+        try:
+            dev.quiesce()
+            dev.set_pipeline(1)
+        except Exception:
+            pass
     # the same batch through the HOST-pointer entry point (tk_index_query_batch: H2D of the
     # queries, the pipeline, D2H of the ids, synchronous) — the PCIe-inclusive rate
     dev.query_batch(qn, qp, args.k, args.n_probes)
@@ -1029,7 +1110,8 @@ def main():
                                 "scan_units2_kernel<AVX,signed> (one launch: list scan of a batch + coarse scan "
                                 "of a later one)"),
                      "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
-                     "launches_timed": n_prof, "valu": valu_roofline(scan_ms, iso_stages)},
+                     "launches_timed": n_prof, "valu": valu_roofline(scan_ms, iso_stages),
+                     "plain_scan": plain_roofline(plain_stats, M, args.nq)},
         "raw_in_ids_out": raw_leg,
         "roofline_hbm_scale": hbm_leg,
         "stage_ms": stages,

@@ -212,6 +212,14 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
  * needs depth = 1: the pipelined mode hands work to streams outside the capture. */
 int tk_index_set_pipeline(tk_index *ix, int depth);
 int tk_index_join(tk_index *ix, void *stream);
+/* hipGraph of the pipelined mode: tk_index_quiesce (device-synchronising; forgets the completion
+ * events of earlier calls), then capture on a non-NULL stream any number of
+ * tk_index_query_batch_dev calls followed by tk_index_join on that stream.  The internal streams
+ * fork from the capturing stream through the events the calls record on it and are all joined
+ * again by tk_index_join, so the capture is one self-contained graph: replaying it runs the
+ * captured batches at the pipelined rate (workspaces, events and streams must exist beforehand:
+ * run the same calls once uncaptured, tk_index_set_profiling off). */
+int tk_index_quiesce(tk_index *ix);
 
 /* Heap replay strategy.  0 = automatic: when the replay can skip `insert`'s
  * duplicate-label scan without changing the result (fresh heaps and pairwise
@@ -243,6 +251,10 @@ int tk_index_set_scan_mode(tk_index *ix, int mode);
  * 0 = automatic (list-major batches, signed tables, <= 52 blocks, lane replay), 1 = off.
  * Environment TINYKNN_PLAIN_SCAN=0 switches it off process-wide. */
 int tk_index_set_plain_scan(tk_index *ix, int mode);
+/* Accounting of the plain path for the last batch enqueued (synchronises): out8 = plain units
+ * (tiles of 32 pairs), plain pairs, exact pair records, head pair records, queries flagged for the
+ * re-scan, sum over the plain units of the list's chunk pairs, 0, 0. */
+int tk_index_plain_stats(tk_index *ix, int64_t *out8);
 /* Debug/test hook: caps every query's limit C (INT_MAX = off; -128 sends every query with a
  * plain slot through the re-scan path). */
 int tk_debug_plain_limit(int limit);

@@ -326,7 +326,9 @@ def fastpq_transform(centers, dpb, R, data):
 
 
 def assign(X, Y, k, metric):
-    """knn_brute(X, Y, k, metric) (utils.py:66-86) for k <= 2; a trailing 1-row chunk
+    """knn_brute(X, Y, k, metric) (utils.py:66-86) for k <= 16 (k <= 2: numpy's dumb_select;
+    k >= 3: ascending by (value, position) — numpy's own order there is its SIMD quickselect's,
+    ascending on the fixture host, not pinned by the reference); a trailing 1-row chunk
     (len(X) % 100 == 1) is a GEMV in numpy and stays numpy."""
     X = np.ascontiguousarray(X, dtype=np.float32)
     y64 = Y.dtype != np.float32

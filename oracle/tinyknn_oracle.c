@@ -846,14 +846,32 @@ static void dumb_select_first(const double *v, i64 n, int k, i64 *out)
     out[1] = best;
 }
 
-/* knn_brute(X, Y, k, metric) utils.py:66-86, k <= 2.  X: (n, d) float32 (IVF.data after
+/* np.argpartition(part, k, axis=1)[:, :k] for 3 <= k <= 16.  numpy takes its introselect there
+ * (or, where the CPU has AVX-512 / AVX2, x86-simd-sort's argselect): the SET of the first k is the k
+ * smallest; their ORDER is an implementation detail the reference does not pin.  On the fixture
+ * host (numpy 2.2.6, AVX-512) it is ascending for every k <= 9 and every row length tried
+ * (31 .. 10 000); ascending by (value, position) is the canonical order here. */
+static void select_ascending(const double *v, i64 n, int k, i64 *out)
+{
+    for (int t = 0; t < k; t++) {
+        i64 best = -1;
+        for (i64 j = 0; j < n; j++) {
+            int taken = 0;
+            for (int u = 0; u < t; u++) taken |= out[u] == j;
+            if (!taken && (best < 0 || v[j] < v[best])) best = j;
+        }
+        out[t] = best;
+    }
+}
+
+/* knn_brute(X, Y, k, metric) utils.py:66-86, k <= 16.  X: (n, d) float32 (IVF.data after
  * ivf.py:77-79); Y: (L, d) all_centers, float32 or float64; angular: both are divided by
  * their row norms first (utils.py:73-75).  out: (n, k).  Chunks of one row (n % 100 == 1)
  * are a GEMV in numpy and not restated: the caller keeps numpy for that row. */
 int tko_assign(const float *X, i64 n, int d, const void *Y, int y_is_f64, i64 L, int k,
                int angular, i64 *out)
 {
-    if (k < 1 || k > 2 || k > L || d > 4096) return -1;
+    if (k < 1 || k > 16 || k > L || d > 4096) return -1;
     float *Yf = NULL, *ynf = NULL, *xf = (float *)malloc(sizeof(float) * (size_t)d * 3);
     double *Yd = NULL, *ynd = NULL, *xd = (double *)malloc(sizeof(double) * (size_t)d * 2);
     double *part = (double *)malloc(sizeof(double) * (size_t)L);
@@ -900,7 +918,8 @@ int tko_assign(const float *X, i64 n, int d, const void *Y, int y_is_f64, i64 L,
                 part[j] = (double)((xn + ynf[j]) - p);
             }
         }
-        dumb_select_first(part, L, k, out + i * k);
+        if (k <= 2) dumb_select_first(part, L, k, out + i * k);
+        else select_ascending(part, L, k, out + i * k);
     }
     free(xf); free(xd); free(part); free(Yf); free(ynf); free(Yd); free(ynd);
     return 0;

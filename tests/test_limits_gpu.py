@@ -70,15 +70,41 @@ def test_fast_mode_refuses_angular_beyond_128_dims():
         ivf.query_batch(qs, 5, n_probes=3, fast=True)
 
 
-def test_assign_lists_refuses_k_above_two():
+def test_assign_lists_k_range():
+    """k = 1 .. 9 on the device (examples/bench.py:108-111 sweeps build_probes 1 .. 9); beyond: refused."""
     from tinyknn_amd import _lib
     X = np.zeros((100, 16), dtype=np.float32)
-    Y = np.eye(16, dtype=np.float32)[:8]
+    Y = np.eye(16, dtype=np.float32)[:12]
     yn = np.einsum("ij,ij->i", Y, Y)
-    out = np.zeros((100, 3), dtype=np.int64)
+    out = np.zeros((100, 10), dtype=np.int64)
     rc = _lib.lib().tk_assign_lists(_lib.ptr(X, _lib._f32p), 100, 16, 0, Y.ctypes.data, 0, yn.ctypes.data,
-                                    8, 3, _lib.ptr(out, _lib._i64p))
-    assert rc < 0 and b"k must be 1 or 2" in _lib.lib().tk_last_error()
+                                    12, 10, _lib.ptr(out, _lib._i64p))
+    assert rc < 0 and b"k must be 1 .. 9" in _lib.lib().tk_last_error()
+
+
+@pytest.mark.parametrize("k", [3, 5, 9])
+@pytest.mark.parametrize("y64", [False, True])
+def test_assign_lists_up_to_nine_lists_per_row(k, y64):
+    """knn_brute(X, Y, k) for k = 3 .. 9 on the device = numpy's argpartition(part, k)[:, :k] of numpy's
+    own distances on this host (ascending there) = the oracle's restatement."""
+    from oracle import oracle as O
+    from tinyknn_amd import _lib
+    from tinyknn_amd.utils import knn_brute
+    rng = np.random.RandomState(k)
+    n, d, L = 1200, 100, 157
+    X = rng.randn(n, d).astype(np.float32)
+    Y = rng.randn(L, d).astype(np.float64 if y64 else np.float32)
+    for metric in ("euclidean", "angular"):
+        Yn = Y / np.linalg.norm(Y, axis=1, keepdims=True) if metric == "angular" else Y
+        Yn = np.ascontiguousarray(Yn)
+        yn = np.ascontiguousarray(np.einsum("ij,ij->i", Yn, Yn))
+        out = np.zeros((n, k), dtype=np.int64)
+        _lib.check(_lib.lib().tk_assign_lists(_lib.ptr(X, _lib._f32p), n, d, int(metric == "angular"),
+                                              Yn.ctypes.data, int(y64), yn.ctypes.data, L, k,
+                                              _lib.ptr(out, _lib._i64p)))
+        want = knn_brute(X, Y, k=k, metric=metric)
+        np.testing.assert_array_equal(out, want)
+        np.testing.assert_array_equal(out, O.assign(X, Y, k, metric))
 
 
 def test_one_handle_from_several_threads_is_serialised(small):

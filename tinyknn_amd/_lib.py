@@ -133,6 +133,8 @@ SIGNATURES = {
     "tk_index_set_heap_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_set_scan_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_set_plain_scan": (C.c_int, [C.c_void_p, C.c_int]),
+    "tk_index_quiesce": (C.c_int, [C.c_void_p]),
+    "tk_index_plain_stats": (C.c_int, [C.c_void_p, _i64p]),
     "tk_debug_plain_limit": (C.c_int, [C.c_int]),
     "tk_set_scan_form": (C.c_int, [C.c_int]),
     "tk_index_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -513,7 +513,7 @@ extern "C" int tk_assign_lists(const float *X, int64_t n, int d, int normalise, 
     TRY(require_gpu());
     ARGCHECK(X && Y && ynorm2 && nearest, "null buffer");
     ARGCHECK(n >= 0 && d >= 1 && L >= 1 && L < (1ll << 31), "sizes");
-    ARGCHECK(k >= 1 && k <= 2 && k <= L, "k must be 1 or 2 (numpy's dumb_select range)");
+    ARGCHECK(k >= 1 && k <= 9 && k <= L, "k must be 1 .. 9 (the range examples/bench.py:108-111 sweeps)");
     ARGCHECK(d <= 384, "d > 384: OpenBLAS splits K there and the FMA chain no longer holds");
     ARGCHECK(!normalise || d <= 128, "row normalisation on the device needs d <= 128");
     const size_t ysz = y_is_f64 ? 8 : 4;
@@ -1122,8 +1122,21 @@ static TkScanJob plain_job(const tk_index *ix, const Work &w, const Plan &p)
     return j;
 }
 
-// head pairs: the first ceil(2R / 16) chunks of the first probed list of a query in head mode
-static int head_chunks(const Plan &p) { return (2 * p.R + 15) >> 4; }
+// Rows a query scans with the exact kernel before the plain sums take over: 4 x the heap size (the
+// heap is then full of real values and its bound the median of what it has seen).  A/B:
+// TINYKNN_PLAIN_HEAD (multiple of the heap size, default 4: with 2 about one query in 10 000 of the build_probes=2 index still had its bound above the limit there, and ONE flagged query costs the batch a 0.9 ms wave-per-query replay).
+static int head_rows(const Plan &p)
+{
+    static double mult = -1;
+    if (mult < 0) {
+        const char *e = getenv("TINYKNN_PLAIN_HEAD");
+        mult = e ? atof(e) : 4.0;
+        mult = mult < 1.0 ? 1.0 : mult;
+    }
+    return (int)(mult * p.R);
+}
+// head pairs: the first ceil(head_rows / 16) chunks of the first probed list of a query in head mode
+static int head_chunks(const Plan &p) { return (head_rows(p) + 15) >> 4; }
 
 static TkScanJob head_job(const tk_index *ix, const Work &w, const Plan &p)
 {
@@ -1213,7 +1226,7 @@ static void coarse_slots(tk_index *ix, Work &w, const int64_t *probes, int64_t n
                          ix->list_n.as<int64_t>(), ix->ids_off.as<int64_t>(),
                          w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
                          w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(), pair_count,
-                         owner, me, st, plain ? w.qlim.as<int>() : nullptr, p.R,
+                         owner, me, st, plain ? w.qlim.as<int>() : nullptr, head_rows(p),
                          plain ? w.slot_exact.as<int>() : nullptr, plain ? w.p_count.as<int>() : nullptr,
                          plain ? w.plain0.as<int>() : nullptr, plain ? w.h_count.as<int>() : nullptr);
 }
@@ -2149,7 +2162,7 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
 {
     IXLOCK(ix);
     if (!search_centers) search_centers = all_centers;
-    ARGCHECK(n_probes >= 1 && n_probes <= 2 && n_probes <= C, "n_probes must be 1 or 2 (numpy's dumb_select range)");
+    ARGCHECK(n_probes >= 1 && n_probes <= 9 && n_probes <= C, "n_probes must be 1 .. 9");
     const int kp = n_probes;
     ARGCHECK(ix && ix->have_pq && ix->data.p && ix->N > 0, "set_pq and tk_index_alloc_data first");
     ARGCHECK(all_centers && ynorm2 && C >= 1 && C < (1ll << 31), "centres");
@@ -2619,6 +2632,19 @@ extern "C" int tk_index_join(tk_index *ix, void *stream)
     return TK_OK;
 }
 
+// Everything enqueued so far has completed and no workspace remembers an event of it: what a
+// stream capture of the pipelined mode needs first (a captured call must not wait on an event
+// recorded outside the capture).  Synchronises the device.
+extern "C" int tk_index_quiesce(tk_index *ix)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix, "null index");
+    TRY(flush_pending(ix));
+    HIPCHECK(hipDeviceSynchronize());
+    for (Work &w : ix->works) w.busy = false;
+    return TK_OK;
+}
+
 extern "C" int tk_index_query_batch(tk_index *ix, const float *q, const void *q_pq,
                                     int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                                     int64_t *out_ids, int64_t *out_probes, int64_t *out_heap_idx,
@@ -2691,6 +2717,43 @@ extern "C" int tk_index_set_plain_scan(tk_index *ix, int mode)
     ARGCHECK(mode >= 0 && mode <= 1, "mode");
     TRY(flush_pending(ix));
     ix->plain_mode = mode;
+    return TK_OK;
+}
+
+// What the plain path did for the LAST batch enqueued (synchronises): out8 = plain units (tiles of
+// 32 pairs), plain pairs, exact pair records (whole lists, padded to groups of 4), head pair
+// records, queries flagged for the re-scan, sum over the plain units of the list's chunk pairs
+// (x 26 MFMAs of 32 x 32 x 32 = the matrix-core work), 0, 0.  All zero when the path is off.
+extern "C" int tk_index_plain_stats(tk_index *ix, int64_t *out8)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix && out8, "null index / buffer");
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    TRY(flush_pending(ix));
+    HIPCHECK(hipDeviceSynchronize());
+    const Work &w = ix->works[(ix->calls + ix->works.size() - 1) % ix->works.size()];
+    if (!w.p_unit_prefix.p || !w.flag_list.p || ix->n_lists < 1) return TK_OK;
+    const int64_t L = ix->n_lists;
+    int v[4] = {0, 0, 0, 0};
+    HIPCHECK(hipMemcpy(&v[0], w.p_unit_prefix.as<int>() + L, 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&v[1], w.p_pair_off.as<int>() + L, 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&v[2], w.u_pair_off.as<int>() + L, 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&v[3], w.h_pair_off.as<int>() + L, 4, hipMemcpyDeviceToHost));
+    int flagged = 0;
+    HIPCHECK(hipMemcpy(&flagged, w.flag_list.p, 4, hipMemcpyDeviceToHost));
+    out8[0] = v[0]; out8[1] = v[1]; out8[2] = v[2]; out8[3] = v[3]; out8[4] = flagged;
+    if (v[0] > 0) {
+        std::vector<int> desc((size_t)v[0] * 2);
+        std::vector<int64_t> coff((size_t)L + 1);
+        HIPCHECK(hipMemcpy(desc.data(), w.p_unit_desc.p, desc.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(coff.data(), ix->list_chunk_off.p, coff.size() * 8, hipMemcpyDeviceToHost));
+        int64_t cps = 0;
+        for (int u = 0; u < v[0]; u++) {
+            const int l = desc[(size_t)2 * u];
+            if (l >= 0 && l < L) cps += (coff[(size_t)l + 1] - coff[(size_t)l] + 1) / 2;
+        }
+        out8[5] = cps;
+    }
     return TK_OK;
 }
 

@@ -196,6 +196,22 @@ __device__ __forceinline__ void cand_push(Cand<T> (&top)[3], T v, int j)
     }
 }
 
+// NTOP > 3 (k = 3 .. 9: the k nearest in ascending (value, index) order — numpy's own order there
+// is its SIMD quickselect's, ascending on the fixture host, unpinned by the reference): insertion
+// into a sorted list held in registers, branch-free below the first test
+template <typename T, int NTOP>
+__device__ __forceinline__ void cand_insert(Cand<T> (&tp)[NTOP], T v, int j)
+{
+    if (!cand_lt(v, j, tp[NTOP - 1])) return;
+#pragma unroll
+    for (int t = NTOP - 1; t >= 0; t--) {
+        const bool here = cand_lt(v, j, tp[t]);
+        const bool above = t > 0 && cand_lt(v, j, tp[t > 0 ? t - 1 : 0]);
+        if (above) tp[t] = tp[t > 0 ? t - 1 : 0];
+        else if (here) tp[t] = {v, j};
+    }
+}
+
 // ROWS rows per workgroup, C centres per thread and pass (each staged row value feeds C FMAs,
 // each centre value ROWS FMAs), NTOP candidates kept per row: 1 when k == 1, 3 when k == 2
 // (dumb_select's second pass needs the three best overall and part[0]).
@@ -228,7 +244,9 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ X
 #pragma unroll
         for (int t = 0; t < NTOP; t++) top[r][t] = {(T)0, -1};
     auto push = [&](Cand<T> (&tp)[NTOP], T v, int j) {
-        if (NTOP == 1) {
+        if (NTOP > 3) {
+            cand_insert<T, NTOP>(tp, v, j);
+        } else if (NTOP == 1) {
             if (cand_lt(v, j, tp[0])) tp[0] = {v, j};
         } else {
             if (cand_lt(v, j, tp[0])) {
@@ -306,7 +324,11 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ X
             }
         const int m0 = best[0].j;          // first occurrence of the minimum
         nearest[(r0 + r) * k] = m0;
-        if (NTOP > 1 && k == 2) {
+        if (NTOP > 3) {                    // k >= 3: ascending (value, index)
+#pragma unroll
+            for (int t = 1; t < NTOP; t++)
+                if (t < k) nearest[(r0 + r) * k + t] = best[t].j;
+        } else if (NTOP > 1 && k == 2) {
             // dumb_select, second pass: positions 0 and m0 were swapped, so the scan order
             // is 1 .. m0-1, (element 0 at position m0), m0+1 .. L-1, strict "<"
             int second;
@@ -513,8 +535,12 @@ void tk_launch_assign(const float *X, int64_t n, int d, const void *Yt, const vo
                            (const float *)ynorm2, L, k, nearest);
     } else if (k == 1) {
         if (y_is_f64) TK_ASSIGN(double, 16, 2, 1); else TK_ASSIGN(float, 16, 2, 1);
-    } else {
+    } else if (k == 2) {
         if (y_is_f64) TK_ASSIGN(double, 8, 4, 3); else TK_ASSIGN(float, 8, 4, 3);
+    } else {
+        // k = 3 .. 9: nine sorted candidates per row and thread (examples/bench.py:108-111 sweeps
+        // build_probes 1 .. 9)
+        if (y_is_f64) TK_ASSIGN(double, 4, 2, 9); else TK_ASSIGN(float, 4, 4, 9);
     }
 #undef TK_ASSIGN
 }

@@ -188,11 +188,12 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
 // probes (nq, kc) list ids -> per-slot scan descriptors; pair_count (n_lists, zeroed, or
 // NULL) receives the number of (query, slot) pairs per list — with `owner` (n_lists ranks,
 // list-sharded index) only for the lists owned by `me`
-// qlim / R / slot_exact / plain0 / pair_count2 / pair_count3 (all or none): the exact kernel keeps
+// qlim / R (= the rows the exact kernel keeps: 2 x the heap size) / slot_exact / plain0 / pair_count2 /
+// pair_count3 (all or none): the exact kernel keeps
 // what a query scans until the heap is full of real values and its bound far below the table's
-// limit — 2R rows.  First list at least that long ("head mode", slot_exact[q] = 0): its first
-// ceil(2R / 16) chunks (pair counted in pair_count3 AND, for the plain kernel, in pair_count2);
-// otherwise the leading slot_exact[q] >= 1 lists that hold 2R rows together.  All of them for a query
+// limit — R rows.  First list at least that long ("head mode", slot_exact[q] = 0): its first
+// ceil(R / 16) chunks (pair counted in pair_count3 AND, for the plain kernel, in pair_count2);
+// otherwise the leading slot_exact[q] >= 1 lists that hold R rows together.  All of them for a query
 // whose table rules the plain sums out (qlim = TK_PLAIN_NEVER) or whose probe list wrapped.
 // plain0[q] = first flat chunk of the query's row that carries plain sums.
 void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,

@@ -333,7 +333,7 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
         slot_n[qi * S + s] = (int)list_n[cl];
         slot_label_off[qi * S + s] = ids_off[cl];
         rows += list_n[cl];
-        if (e == S && rows >= 2 * (int64_t)R) e = s + 1;
+        if (e == S && rows >= (int64_t)R) e = s + 1;        // (R here: the rows the exact kernel keeps)
     }
     const bool plain_ok = slot_exact && !wrapped && qlim[qi] != TK_PLAIN_NEVER;
     const int e_walk = e;
@@ -341,7 +341,7 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
     bool head = false;
     if (slot_exact) {
         // head mode: the first list alone holds 2R rows and is longer than the head
-        const int E = (2 * R + 15) >> 4;
+        const int E = (R + 15) >> 4;
         head = plain_ok && e_walk == 1 && slot_prefix[qi * (S + 1) + 1] > E;
         slot_exact[qi] = head ? 0 : e;
         plain0[qi] = head ? E : slot_prefix[qi * (S + 1) + e];

@@ -472,6 +472,18 @@ class DeviceIndex:
     def join(self, stream=0):
         _lib.check(_lib.lib().tk_index_join(self._h, stream))
 
+    def plain_stats(self):
+        """What the plain (matrix-core) scan did for the last batch (tk_index_plain_stats)."""
+        o = np.zeros(8, dtype=np.int64)
+        _lib.check(_lib.lib().tk_index_plain_stats(self._h, _lib.ptr(o, _lib._i64p)))
+        return dict(plain_units=int(o[0]), plain_pairs=int(o[1]), exact_pair_records=int(o[2]),
+                    head_pair_records=int(o[3]), flagged_queries=int(o[4]), plain_unit_chunk_pairs=int(o[5]))
+
+    def quiesce(self):
+        """Wait for everything enqueued and forget its completion events (before a stream
+        capture of the pipelined mode: tinyknn_hip.h, tk_index_quiesce)."""
+        _lib.check(_lib.lib().tk_index_quiesce(self._h))
+
     def set_heap_mode(self, mode):
         """0: automatic (lane-per-query), 1: general wave kernel, 2: packed wave kernel."""
         _lib.check(_lib.lib().tk_index_set_heap_mode(self._h, int(mode)))
@@ -583,7 +595,7 @@ class IVF:
         """knn_brute(data, all_centers, n_probes, metric) (utils.py:66-86): whole 100-row
         chunks on the GPU, the last partial chunk — a differently shaped GEMM — in numpy."""
         Y = np.asarray(self.all_centers)
-        exact_ok = (data.dtype == np.float32 and n_probes <= 2 and n_probes < len(Y)
+        exact_ok = (data.dtype == np.float32 and n_probes <= 9 and n_probes < len(Y)
                     and data.shape[1] <= 384
                     and (self.metric != "angular" or data.shape[1] <= 128))
         if not exact_ok:
