@@ -501,11 +501,15 @@ def measure_traffic(args):
     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         tmp = tempfile.mkdtemp(prefix="tk_pmc_")
         cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", tmp, "--", sys.executable, me,
-               "--steps", "3", "--warmup", "1", "--pipeline", "1", "--profile-only", "--shard", "none",
-               "--cache-dir", args.cache_dir]
+               "--steps", "3", "--warmup", "1", "--warmup-seconds", "0", "--windows", "1", "--pipeline", "1",
+               "--profile-only", "--shard", "none", "--cache-dir", args.cache_dir,
+               "--workload", args.workload, "--n", str(args.n), "--d", str(args.d),
+               "--n-clusters", str(args.n_clusters), "--nq", str(args.nq), "--k", str(args.k),
+               "--n-probes", str(args.n_probes), "--metric", args.metric, "--data", args.data,
+               "--build-probes", str(args.build_probes), "--seed", str(args.seed)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=420, check=True)
+                           stderr=subprocess.DEVNULL, timeout=600, check=True)
             acc = {}
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
@@ -949,7 +953,7 @@ def main():
     default_wl = (args.workload, args.n, args.d, args.n_clusters, args.nq, args.n_probes, args.metric,
                   args.data, args.build_probes) == ("glove", 1183514, 100, 1087, 10000, 10, "angular",
                                                     "glove-like", 1)
-    if args.traffic == "auto" and default_wl and world == 1:
+    if args.traffic == "auto" and (default_wl or args.workload == "c5") and world == 1 and not args.data_file:
         traffic, traffic_src = measure_traffic(args)
     hbm_leg = None
     if not args.no_hbm_leg and world == 1:

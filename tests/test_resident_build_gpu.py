@@ -197,3 +197,67 @@ def test_resident_build_two_lists_per_row(oracle, metric):
             _, want = ox.query(qn[i], 10, n_probes, debug=True)
             np.testing.assert_array_equal(dbg["heap_idx"][i], want["heap_idx"])
             np.testing.assert_array_equal(dbg["heap_val"][i], want["heap_val"])
+
+
+def test_reduced_c5_lists_far_longer_than_the_heap(oracle, tmp_path):
+    """BASELINE configs[4] scaled to one test: 6 M x 128 generated and built in HBM, 1 500 lists of
+    ~4 000 rows (36 heaps' worth each), PQ rotated to 64 dims (M = 32, float64 table math),
+    n_probes 10: probe lists, heap arrays (layout included) and final ids against the CPU oracle
+    fed with the exported lists; the oracle's vector file is sparse (only the candidates' rows
+    travel).  One batch in flight AND batches in flight (the plain-sum kernel, head mode, the
+    pipelined streams) must both reproduce it."""
+    import torch
+    from tinyknn_amd import IVF, FastPQ
+    n, d, nq, seed, n_lists = 6_000_000, 128, 2000, 17, 1500
+    cent = np.random.RandomState(2).randn(400, d).astype(np.float32)
+    ivf = IVF("euclidean", n_lists, FastPQ(2))
+    sample = synth_rows(200_000, d, seed, cent, 0.7)
+    # coarse centres = rows of the data set itself (the sample is its first rows): every centre is
+    # then the nearest centre of at least one row — tk_index_build_dev, like the reference's
+    # group_data_by_indices (utils.py:128), refuses an empty list in front of a used one
+    rng = np.random.RandomState(3)
+    ivf.all_centers = sample[rng.choice(len(sample), n_lists, replace=False)].copy()
+    np.random.seed(5)
+    ivf.pq.fit(sample[:20000])
+    ivf.build_resident(n, d, seed, cent, 0.7)
+    dev = ivf.device_index()
+    sizes, codes, ids = dev.export_lists()
+    assert sizes.min() > 0 and np.median(sizes) > 10 * 111
+    chunks = (sizes + 15) // 16
+    coff = np.concatenate([[0], np.cumsum(chunks)])
+    ioff = np.concatenate([[0], np.cumsum(sizes)])
+    L = len(sizes)
+    data = np.memmap(str(tmp_path / "rows.f32"), dtype=np.float32, mode="w+", shape=(n, d))
+    ox = oracle.OracleIndex(ivf.pq.centers, 2, ivf.pq.R, ivf.pq.sqrt_n_blocks, ivf.active_centers,
+                            ivf.pq_transformed_centers.packed, [codes[coff[i]:coff[i + 1]] for i in range(L)],
+                            list(sizes), [ids[ioff[i]:ioff[i + 1]] for i in range(L)], data)
+    assert ox.data is data or np.may_share_memory(ox.data, data)
+    qs = synth_rows(nq, d, seed + 1, cent, 0.7)
+    qn, qp = ivf._prepare(qs.copy())
+    for n_probes in (10, 3):
+        out, dbg = dev.query_batch(qn, qp, 10, n_probes, debug=True)        # one batch in flight
+        rows = np.unique(dbg["heap_idx"][dbg["heap_idx"] >= 0])
+        data[rows] = dev.read_rows(rows)
+        want = ox.query_batch(qn, 10, n_probes)
+        np.testing.assert_array_equal(out, want)
+        for i in range(0, nq, 37):
+            _, w = ox.query(qn[i], 10, n_probes, debug=True)
+            np.testing.assert_array_equal(w["probes"], dbg["probes"][i])
+            np.testing.assert_array_equal(w["heap_idx"], dbg["heap_idx"][i])
+            np.testing.assert_array_equal(w["heap_val"], dbg["heap_val"][i])
+        st = dev.plain_stats()
+        assert st["plain_units"] > 0 and st["head_pair_records"] >= nq // 2     # the matrix-core path ran
+        # batches in flight
+        dev.set_pipeline(2)
+        q_dev, qp_dev = torch.from_numpy(qn).cuda(), torch.from_numpy(np.ascontiguousarray(qp)).cuda()
+        s_ = torch.cuda.current_stream().cuda_stream
+        outs = [torch.full((nq, 10), -1, dtype=torch.int64, device="cuda") for _ in range(4)]
+        for o in outs:
+            dev.query_batch_dev(q_dev.data_ptr(), qp_dev.data_ptr(), qp.dtype != np.float32, nq, 10, n_probes,
+                                o.data_ptr(), stream=s_)
+        dev.join(s_)
+        torch.cuda.synchronize()
+        for o in outs:
+            np.testing.assert_array_equal(o.cpu().numpy(), want)
+        dev.set_pipeline(1)
+    dev.close()

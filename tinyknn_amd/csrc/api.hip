@@ -1122,21 +1122,25 @@ static TkScanJob plain_job(const tk_index *ix, const Work &w, const Plan &p)
     return j;
 }
 
-// Rows a query scans with the exact kernel before the plain sums take over: 4 x the heap size (the
-// heap is then full of real values and its bound the median of what it has seen).  A/B:
-// TINYKNN_PLAIN_HEAD (multiple of the heap size, default 4: with 2 about one query in 10 000 of the build_probes=2 index still had its bound above the limit there, and ONE flagged query costs the batch a 0.9 ms wave-per-query replay).
-static int head_rows(const Plan &p)
+// Rows a query scans with the exact kernel before the plain sums take over, in heap sizes: the heap
+// is then full of real values and its bound a low quantile of what it has seen.  2 where labels are
+// distinct (a flagged query is then re-played by the packed kernel without the duplicate test:
+// ~0.15 ms of one wave), 4 where they repeat (build_probes >= 2: with 2 about one query in 10 000
+// was still flagged, and ONE flagged query costs its batch a 0.9 ms wave-per-query replay with
+// the duplicate test; with 4 none in the bench batches).  A/B: TINYKNN_PLAIN_HEAD.
+static int head_rows(const tk_index *ix, const Plan &p)
 {
-    static double mult = -1;
-    if (mult < 0) {
+    static double forced = -1;
+    if (forced < 0) {
         const char *e = getenv("TINYKNN_PLAIN_HEAD");
-        mult = e ? atof(e) : 4.0;
-        mult = mult < 1.0 ? 1.0 : mult;
+        forced = e ? atof(e) : 0.0;
+        forced = forced < 0.0 ? 0.0 : forced;
     }
+    const double mult = forced >= 1.0 ? forced : (ix->ids_unique ? 2.0 : 4.0);
     return (int)(mult * p.R);
 }
 // head pairs: the first ceil(head_rows / 16) chunks of the first probed list of a query in head mode
-static int head_chunks(const Plan &p) { return (head_rows(p) + 15) >> 4; }
+static int head_chunks(const tk_index *ix, const Plan &p) { return (head_rows(ix, p) + 15) >> 4; }
 
 static TkScanJob head_job(const tk_index *ix, const Work &w, const Plan &p)
 {
@@ -1145,7 +1149,7 @@ static TkScanJob head_job(const tk_index *ix, const Work &w, const Plan &p)
     j.pair_off = w.h_pair_off.as<int>();
     j.pair_q = w.h_pair_q.as<int>();
     j.pair_f0 = w.h_pair_f0.as<int>();
-    j.max_chunks = head_chunks(p);
+    j.max_chunks = head_chunks(ix, p);
     return j;
 }
 
@@ -1226,7 +1230,7 @@ static void coarse_slots(tk_index *ix, Work &w, const int64_t *probes, int64_t n
                          ix->list_n.as<int64_t>(), ix->ids_off.as<int64_t>(),
                          w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
                          w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(), pair_count,
-                         owner, me, st, plain ? w.qlim.as<int>() : nullptr, head_rows(p),
+                         owner, me, st, plain ? w.qlim.as<int>() : nullptr, head_rows(ix, p),
                          plain ? w.slot_exact.as<int>() : nullptr, plain ? w.p_count.as<int>() : nullptr,
                          plain ? w.plain0.as<int>() : nullptr, plain ? w.h_count.as<int>() : nullptr);
 }
@@ -1252,7 +1256,7 @@ static void unit_pairs(tk_index *ix, Work &w, int64_t nq, const Plan &p, bool pl
     TkPairSet hd{w.h_count.as<int>(), w.h_cursor.as<int>(), w.h_pair_off.as<int>(),
                  w.h_unit_prefix.as<int>(), w.h_pair_q.as<int>(), w.h_pair_f0.as<int>()};
     tk_launch_unit_pairs2(nq, w.probes.as<int64_t>(), p.S, ix->n_lists, ix->list_chunk_off.as<int64_t>(),
-                          w.slot_prefix.as<int>(), w.slot_exact.as<int>(), ex, pl, hd, head_chunks(p), st);
+                          w.slot_prefix.as<int>(), w.slot_exact.as<int>(), ex, pl, hd, head_chunks(ix, p), st);
 }
 
 static int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
@@ -1314,7 +1318,14 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
                                              p.R, 1, 0, repeat_flag, w.mins.as<uint8_t>(),
                                              p.cap_min, nullptr, st, slot_exact, qlim))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
-        if (plain) rescan_flagged(ix, w, q0, nq, p, st);
+        if (plain) {
+            // flag 2 = the lane replay's "bound above the limit at the first plain block": exact
+            // re-scan, then the packed kernel from a fresh heap (labels are distinct: no duplicate test)
+            rescan_flagged(ix, w, q0, nq, p, st);
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 2, 0, st);
+        }
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                      p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                      w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
