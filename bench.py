@@ -285,6 +285,18 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
         else:
             res["filtered_exchange"] = {k_: r[k_] for k_ in ("queries_per_s", "ms_per_step",
                                                              "identical_rows_vs_replica", "exchange")}
+    # the same with ONE step per exchange (fixed Q = --nq queries per exchange: SURVEY 8e's definition
+    # of strong scaling), beside the coalesced figure above
+    if co > 1:
+        idx.exchange = kinds[0]
+        idx.coalesce = 1
+        r1 = _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, 1, kinds[0])
+        res["fixed_q_per_exchange"] = {k_: r1[k_] for k_ in ("queries_per_s", "ms_per_step",
+                                                              "identical_rows_vs_replica", "steps_coalesced_per_exchange")}
+        idx.coalesce = co
+    res["streams"] = ("by role: front (coarse stages, probe all-gather) / scan (every scan, in order) / two replay "
+                      "streams (exchange, replay, rescoring, id gather)" if idx._roles is not None and kinds[0] == "dense"
+                      else "one stream per batch in flight")
     return res
 
 

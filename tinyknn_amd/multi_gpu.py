@@ -263,6 +263,20 @@ class ListShardedIndex:
         self._calls = 0
         self._streams = ([torch.cuda.Stream() for _ in range(depth)]
                          if self.device == "cuda" and depth > 1 else None)
+        # dense exchange, batches in flight: streams by ROLE, as the unsharded pipeline has them
+        #  — every scan on ONE stream, in order (two scans at once only stretch each
+        # other), the coarse stages + probe all-gathers on a front stream, exchange + replay +
+        # rescoring + id gather alternating between two more; handed over by events.  One stream per
+        # BATCH (the older form, still what the filtered exchange uses) lets scans of different
+        # batches run against each other.  Measured at W = 1 (profiles/r03/shard_streams_ab.txt): no
+        # gain — 11.97 M queries/s coalesced / 10.3 M at one step per exchange by role, 11.84 M / 11.2 M
+        # by batch: what a sharded batch costs beyond the unsharded one is its own kernels (positions,
+        # unpack, the exact scan of every list), not the stream structure.  Off by default;
+        # TINYKNN_SHARD_ROLES=1 selects it.
+        self._roles = None
+        if self._streams is not None and os.environ.get("TINYKNN_SHARD_ROLES", "0") == "1":
+            self._roles = dict(front=torch.cuda.Stream(), scan=torch.cuda.Stream(),
+                               replay=[torch.cuda.Stream(), torch.cuda.Stream()], done={})
         self._pending = []
         self._deferred = None
         self._need = {}             # (nq, n_probes) -> longest streams seen by query_prepared
@@ -545,6 +559,8 @@ class ListShardedIndex:
             out = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
             self._note_flags(out)
             return out
+        if self._roles is not None and self._exchange_kind(k, n_probes, pass_1) == "dense":
+            return self._submit_roles(qn, qp, k, n_probes, pass_1, cap)
         st = self._streams[self._calls % self.depth]
         st.wait_stream(t.cuda.current_stream())
         with t.cuda.stream(st):
@@ -559,6 +575,48 @@ class ListShardedIndex:
         if state["f"] is None:
             self._deferred = None
         return state["out"]
+
+    def _submit_roles(self, qn, qp, k, n_probes, pass_1, cap):
+        """One dense-exchange batch over the role streams (see __init__)."""
+        t = self.torch
+        R = self._roles
+        nq = qn.shape[0]
+        slot = self._calls % self.depth
+        n = self._calls
+        self._calls += 1
+        b = self._buffers(slot, nq, k, cap)
+        qh = -(-nq // self.world)
+        cur = t.cuda.current_stream()
+        first = R["front"] if self.coarse == "home" else R["scan"]
+        first.wait_stream(cur)                       # the caller's queries
+        if slot in R["done"]:                        # the slot's buffers: free once its last batch is out
+            first.wait_event(R["done"][slot])
+        p_all = None
+        if self.coarse == "home":
+            with t.cuda.stream(R["front"]):
+                b["flag"].zero_()
+                p_home, p_all = self._probe_buffers(slot, nq, n_probes)
+                self.engine.coarse(slot, qn, qp, k, n_probes, pass_1, p_home)
+                self._all_gather(p_all, p_home)
+            R["scan"].wait_stream(R["front"])
+        with t.cuda.stream(R["scan"]):
+            if self.coarse != "home":
+                b["flag"].zero_()
+            self.engine.scan(slot, qn, qp, k, n_probes, pass_1, cap, b["send"], b["flag"], probes_all=p_all)
+            scanned = t.cuda.Event()
+            scanned.record(R["scan"])
+        rs = R["replay"][n % 2]
+        rs.wait_event(scanned)
+        with t.cuda.stream(rs):
+            self._all_to_all(b["recv"], b["send"])
+            self.engine.finish(slot, qn, k, n_probes, pass_1, cap, b["recv"], b["home"][:qh * k])
+            self._gather_ids(b, qh, k)
+            out = b["all"].view(self.world, qh * k + 1)
+            self._note_flags(out)
+            done = t.cuda.Event()
+            done.record(rs)
+        R["done"][slot] = done
+        return out
 
     def _finish_deferred(self):
         if self._deferred is not None:
@@ -585,6 +643,9 @@ class ListShardedIndex:
             cur = self.torch.cuda.current_stream()
             for st in self._streams:
                 cur.wait_stream(st)
+            if self._roles is not None:
+                for st in [self._roles["front"], self._roles["scan"]] + self._roles["replay"]:
+                    cur.wait_stream(st)
         if self._ovf is not None and self._ovf_keys:
             bad = int(self._ovf.item())         # (synchronises with the batches in flight)
             keys, self._ovf_keys = self._ovf_keys, set()
