@@ -248,12 +248,18 @@ int tk_index_set_scan_mode(tk_index *ix, int mode);
  * query (until they hold 2 * pass_1 rows) stay on the exact kernel; the lane replay checks the
  * condition per query and the queries that fail it are scanned again exactly and replayed again:
  * results are identical to mode 1 in every case (tests/test_plain_scan_gpu.py).
- * 0 = automatic (list-major batches, signed tables, <= 52 blocks, lane replay), 1 = off.
+ * 0 = automatic (list-major batches, signed tables, <= 52 blocks, lane replay): a flagged query
+ * costs two scans and two replays, so the path first proves itself on ONE probe batch (the batches
+ * behind it stay exact until its flagged count has come back — read from a page-locked word, never
+ * waited for), is used while at most 1 % of a batch's queries are flagged, and otherwise pauses
+ * for 256..4096 batches before the next probe (data without structure: 42 % flagged on iid
+ * vectors); 1 = off; 2 = always (no pausing: tests, A/B).  Every mode returns identical results.
  * Environment TINYKNN_PLAIN_SCAN=0 switches it off process-wide. */
 int tk_index_set_plain_scan(tk_index *ix, int mode);
 /* Accounting of the plain path for the last batch enqueued (synchronises): out8 = plain units
  * (tiles of 32 pairs), plain pairs, exact pair records, head pair records, queries flagged for the
- * re-scan, sum over the plain units of the list's chunk pairs, 0, 0. */
+ * re-scan, sum over the plain units of the list's chunk pairs, state of mode 0 (0 probe next,
+ * 1 waiting for the probe's count, 2 on, 3 paused), batches left of the pause. */
 int tk_index_plain_stats(tk_index *ix, int64_t *out8);
 /* Debug/test hook: caps every query's limit C (INT_MAX = off; -128 sends every query with a
  * plain slot through the re-scan path). */

@@ -35,7 +35,7 @@ def test_golden_ids_and_heaps(tk, tag, mode, limit_hook):
     ivf = ivf_from_fixture(tk, g)
     dev = ivf.device_index()
     dev.set_scan_mode(2)            # list-major: the form the plain kernel rides with
-    dev.set_plain_scan(mode != "off")
+    dev.set_plain_scan("always" if mode != "off" else False)
     if mode == "rescan-all":
         limit_hook(-128)            # no bound is <= -128 ... every query with a plain slot is redone
     for n_probes in g["probes_list"]:
@@ -50,7 +50,7 @@ def test_golden_ids_and_heaps(tk, tag, mode, limit_hook):
             a, da = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1, debug=True)
             dev.set_plain_scan(False)
             b, db = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1, debug=True)
-            dev.set_plain_scan(mode != "off")
+            dev.set_plain_scan("always" if mode != "off" else False)
             np.testing.assert_array_equal(da["heap_idx"], db["heap_idx"])
             np.testing.assert_array_equal(da["heap_val"], db["heap_val"])
             np.testing.assert_array_equal(a, b)
@@ -78,6 +78,7 @@ def test_pipelined_batches_vs_oracle(tk, oracle):
     qn, qp = ivf._prepare(qs.copy())
     dev = ivf.device_index()
     dev.set_pipeline(2)
+    dev.set_plain_scan("always")
     q_dev, qp_dev = torch.from_numpy(qn).cuda(), torch.from_numpy(np.ascontiguousarray(qp)).cuda()
     st = torch.cuda.current_stream().cuda_stream
     for n_probes in (2, 10, 20):
@@ -89,3 +90,43 @@ def test_pipelined_batches_vs_oracle(tk, oracle):
         torch.cuda.synchronize()
         for o in outs:
             np.testing.assert_array_equal(o.cpu().numpy(), want)
+
+
+def test_automatic_mode_pauses_on_data_without_structure(tk):
+    """Mode 0 (default): one probe batch goes the plain way; on iid vectors far more than 1 % of its
+    queries fail the lemma's condition, the path is paused (the batches behind the probe run on the
+    exact kernel alone) and every batch — probe, waiting, paused — returns the rows of mode "off".
+    On clustered rows the probe passes and the path stays on."""
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(3)
+    n, d, nq = 40000, 64, 1500
+    for structured in (False, True):
+        if structured:
+            cent = np.random.randn(200, d)
+            X = (cent[np.random.randint(200, size=n)] + 0.4 * np.random.randn(n, d)).astype(np.float32)
+            qs = (cent[np.random.randint(200, size=nq)] + 0.4 * np.random.randn(nq, d)).astype(np.float32)
+        else:
+            X = np.random.randn(n, d).astype(np.float32)
+            qs = np.random.randn(nq, d).astype(np.float32)
+        ivf = IVF("euclidean", 150, FastPQ(2))
+        ivf.fit(X[:15000]).build(X, n_probes=1)
+        qn, qp = ivf._prepare(qs.copy())
+        dev = ivf.device_index()
+        dev.set_scan_mode(2)
+        dev.set_plain_scan(False)
+        want = dev.query_batch(qn, qp, 10, 10)
+        dev.set_plain_scan(True)                      # automatic: next batch is the probe
+        assert dev.plain_stats()["state"] == "probe"
+        got = dev.query_batch(qn, qp, 10, 10)         # (the host API waits for its batch)
+        st = dev.plain_stats()
+        np.testing.assert_array_equal(got, want)
+        assert st["plain_units"] > 0
+        if structured:
+            assert st["flagged_queries"] * 100 <= nq and st["state"] == "on"
+        else:
+            assert st["flagged_queries"] * 100 > nq and st["state"] == "paused" and st["pause_left"] >= 256
+        for _ in range(3):
+            np.testing.assert_array_equal(dev.query_batch(qn, qp, 10, 10), want)
+        st2 = dev.plain_stats()
+        assert (st2["plain_units"] > 0) == structured
+        assert st2["state"] == ("on" if structured else "paused")

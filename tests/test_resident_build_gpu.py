@@ -221,6 +221,7 @@ def test_reduced_c5_lists_far_longer_than_the_heap(oracle, tmp_path):
     ivf.pq.fit(sample[:20000])
     ivf.build_resident(n, d, seed, cent, 0.7)
     dev = ivf.device_index()
+    dev.set_plain_scan("always")            # (mode 0 would decide per batch: tests/test_plain_scan_gpu.py)
     sizes, codes, ids = dev.export_lists()
     assert sizes.min() > 0 and np.median(sizes) > 10 * 111
     chunks = (sizes + 15) // 16

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void scan_probes_kernel(
 
 // ids of the flagged queries, in order: list[0] = count, list[1..] = ids (one workgroup)
 __global__ __launch_bounds__(1024) void flagged_list_kernel(const unsigned char *__restrict__ flags, int64_t nq,
-                                                            int *__restrict__ list)
+                                                            int *__restrict__ list, volatile int *host_count)
 {
     __shared__ int s_base, s_wave[16];
     if (threadIdx.x == 0) s_base = 0;
@@ -297,13 +297,16 @@ __global__ __launch_bounds__(1024) void flagged_list_kernel(const unsigned char 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) list[0] = s_base;
+    if (threadIdx.x == 0) {
+        list[0] = s_base;
+        if (host_count) *host_count = s_base;      // page-locked host word: read without a synchronisation
+    }
 }
 
-void tk_launch_flagged_list(const unsigned char *flags, int64_t nq, int *list, hipStream_t s)
+void tk_launch_flagged_list(const unsigned char *flags, int64_t nq, int *list, hipStream_t s, int *host_count)
 {
     if (nq == 0) return;
-    hipLaunchKernelGGL(flagged_list_kernel, dim3(1), dim3(1024), 0, s, flags, nq, list);
+    hipLaunchKernelGGL(flagged_list_kernel, dim3(1), dim3(1024), 0, s, flags, nq, list, host_count);
 }
 
 void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64_t nq,

@@ -48,7 +48,9 @@ void tk_launch_scan_probes(const uint4 *codes, int M, const uint4 *tables, int64
                            int64_t min_stride, int signd, int order, hipStream_t s,
                            const int *only = nullptr);
 // list (nq + 1 ints): list[0] = number of flagged queries, list[1..] = their ids in order
-void tk_launch_flagged_list(const unsigned char *flags, int64_t nq, int *list, hipStream_t s);
+// host_count (page-locked host word or NULL) receives the count too
+void tk_launch_flagged_list(const unsigned char *flags, int64_t nq, int *list, hipStream_t s,
+                            int *host_count = nullptr);
 
 // List-major form of the probed-list scan for large batches.  tk_launch_unit_pairs
 // groups the (query, slot) pairs by list (scan + fill kernels; `count` comes from
@@ -89,6 +91,7 @@ int tk_get_scan_tables(void);
 #define TK_PLAIN_COUNTER_OFF(n_lists) ((((n_lists) + 1 + 31) / 32 + 1) * 32)
 void tk_launch_table_limits(const uint4 *tables, int M, int order, int64_t nq, int *qlim, hipStream_t s);
 void tk_plain_force_limit(int v);      // debug: cap every query's limit (INT_MAX = off)
+int tk_plain_forced(void);             // ... is such a cap set?
 int tk_plain_fits(int M);
 // TkScanJob with unit_prefix = tiles of 32 pairs before each list (+ the work counter at
 // TK_PLAIN_COUNTER_OFF); pair records are not padded.  Returns -1 for unsupported M.

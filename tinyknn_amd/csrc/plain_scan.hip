@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void table_limits_kernel(const uint4 *__restri
 
 static int g_plain_force = INT_MAX;
 void tk_plain_force_limit(int v) { g_plain_force = v; }
+int tk_plain_forced(void) { return g_plain_force != INT_MAX; }
 
 void tk_launch_table_limits(const uint4 *tables, int M, int order, int64_t nq, int *qlim, hipStream_t s)
 {

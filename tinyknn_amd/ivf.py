@@ -477,7 +477,8 @@ class DeviceIndex:
         o = np.zeros(8, dtype=np.int64)
         _lib.check(_lib.lib().tk_index_plain_stats(self._h, _lib.ptr(o, _lib._i64p)))
         return dict(plain_units=int(o[0]), plain_pairs=int(o[1]), exact_pair_records=int(o[2]),
-                    head_pair_records=int(o[3]), flagged_queries=int(o[4]), plain_unit_chunk_pairs=int(o[5]))
+                    head_pair_records=int(o[3]), flagged_queries=int(o[4]), plain_unit_chunk_pairs=int(o[5]),
+                    state=("probe", "wait", "on", "paused")[int(o[6]) & 3], pause_left=int(o[7]))
 
     def quiesce(self):
         """Wait for everything enqueued and forget its completion events (before a stream
@@ -495,8 +496,11 @@ class DeviceIndex:
     def set_plain_scan(self, on):
         """Probed lists behind the first ones as plain sums on the int8 matrix cores where that
         is provably the same replay (tinyknn_hip.h: tk_index_set_plain_scan); True = automatic
-        (default), False = the exact kernel for every list.  Identical results either way."""
-        _lib.check(_lib.lib().tk_index_set_plain_scan(self._h, 0 if on else 1))
+        (default: the path has to prove itself on a probe batch, and is paused while more than
+        1 % of the queries need the exact re-scan), False = the exact kernel for every list,
+        "always" = no pausing (tests, A/B).  Identical results in every mode."""
+        mode = 2 if on == "always" else (0 if on else 1)
+        _lib.check(_lib.lib().tk_index_set_plain_scan(self._h, mode))
 
     def set_profiling(self, on):
         _lib.check(_lib.lib().tk_index_set_profiling(self._h, int(on)))
