@@ -270,7 +270,7 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     co = args.shard_coalesce if args.shard_coalesce > 0 else max(3, world)    # auto: a rank's home share = one batch
     co = max(1, min(co, 131072 // args.nq))
     idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co,
-                           force_collectives=args.force_collectives)
+                           force_collectives=args.force_collectives, counts=args.shard_counts)
     if args.shard_exchange == "auto":
         idx.exchange = "auto"          # ListShardedIndex._exchange_kind: filtered where lists are long
         kinds = [idx._exchange_kind(args.k, args.n_probes, None)]
@@ -355,11 +355,18 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
     if kind == "filtered":
         # measured in the timed steps, this rank: records (20 B per block that travels) + bounds +
         # counts, against the blocks of whole segments (16 B each, what the dense form needs at least)
+        dense_b = idx.bytes_dense
         filt = {"kind": "filtered (bound after the first probed list; blocks below it as 20-byte records)",
                 "record_bytes_per_rank_per_step": int(idx.bytes_sent // (args.steps * n_win)),
-                "whole_segment_bytes_per_rank_per_step": int(idx.bytes_dense // (args.steps * n_win)),
-                "bytes_ratio": round(idx.bytes_sent / max(1, idx.bytes_dense), 4),
-                "host_syncs_per_exchange": 1}
+                "whole_segment_bytes_per_rank_per_step": int(dense_b // (args.steps * n_win)),
+                "bytes_ratio": round(idx.bytes_sent / max(1, dense_b), 4),
+                "host_syncs_per_exchange": 0 if idx.counts == "device" else 1,
+                "counts": idx.counts + (" (fixed record regions, equal-split all-to-all, counts read on the device)"
+                                        if idx.counts == "device" else " (variable splits read on the host)")}
+        if idx.counts == "device":
+            key = (args.nq * co, args.n_probes)
+            filt["record_region"] = int(idx._region(key[0], key[1], idx._capacity(*key)))
+            filt["records_held_bytes_per_rank_per_step"] = int(20 * idx.records_sent // (args.steps * n_win))
     return {"queries_per_s": args.nq * args.steps / el, "ms_per_step": el / args.steps * 1e3,
             "scaling": "strong (one shared batch of %d queries per step)" % args.nq,
             "identical_rows_vs_replica": same, "rows": args.nq,
@@ -653,6 +660,9 @@ def main():
                     help="queries of the per-query Python-loop CPU baseline (examples/bench.py:118-137)")
     ap.add_argument("--profile-only", action="store_true",
                     help="stop after the timed region + the isolated stages (profiler runs)")
+    ap.add_argument("--shard-counts", default="device", choices=["device", "host"],
+                    help="filtered exchange: record counts read on the device (fixed regions, no host "
+                         "synchronisation) or on the host (variable splits)")
     ap.add_argument("--shard-limit", type=float, default=240.0,
                     help="seconds after which a stuck list-sharded leg is abandoned")
     ap.add_argument("--force-collectives", action="store_true",

@@ -515,6 +515,27 @@ int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_de
                                        int k, int n_probes, int pass_1, const int32_t *records_dev,
                                        int64_t n_records, int64_t *out_ids_home_dev, int *flag_dev,
                                        void *stream);
+/* The filtered exchange WITHOUT its host synchronisation: the records of home rank h go to
+ * records_dev[h * region_records, ...) (room for world * region_records records of 5 int32), so the
+ * all-to-all of the records has equal splits and can be enqueued before any count is known; the
+ * counts (counts_dev[0, world)) travel in their own equal-split all-to-all and are read by the home
+ * rank ON THE DEVICE: tk_index_shard_finish_regions_dev takes the received regions (region s from
+ * source rank s) and counts_recv_dev[world].  A home rank's records beyond region_records are
+ * dropped and *flag_dev |= 1 — the batch's overflow flag, handled like a `capacity` overflow
+ * (region_records = capacity can never overflow: a region holds no more blocks than it has room
+ * for; callers trim it to what the batches need, multi_gpu.py).  Wire bytes: world *
+ * region_records * 20 per rank instead of the exact 20 * records.  acc_dev (or NULL): int64[3]
+ * kept by the caller across batches, updated atomically — [0] largest per-home count seen (what
+ * the regions must hold), [1] += records, [2] += blocks scored. */
+int tk_index_shard_filter_regions_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
+                                      int pass_1, int64_t capacity, const void *scan_dev,
+                                      const uint8_t *bound_dev, int32_t *counts_dev,
+                                      int32_t *records_dev, int64_t region_records, int *flag_dev,
+                                      int64_t *acc_dev, void *stream);
+int tk_index_shard_finish_regions_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq, int k,
+                                      int n_probes, int pass_1, const int32_t *records_dev,
+                                      const int32_t *counts_recv_dev, int64_t region_records,
+                                      int64_t *out_ids_home_dev, int *flag_dev, void *stream);
 
 #ifdef __cplusplus
 }

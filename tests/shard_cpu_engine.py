@@ -188,3 +188,39 @@ class OracleShardEngine:
                 f0 += int(self.chunks[probes[i, s]])
             out[i - self.rank * qh] = self.ox.query_batch(qn[i:i + 1], k, n_probes, pass_1)[0]
         assert want == n_records, "blocks that should not have travelled"
+
+    # ---- the same without the host synchronisation: fixed regions, counts read "on the device"
+    def filter_regions(self, slot, qn, k, n_probes, pass_1, capacity, scan_buf, bound, counts, records,
+                       region, flag, acc=None):
+        import torch
+        W = self.world
+        compact = torch.zeros((W * capacity, 5), dtype=torch.int32)
+        self.filter(slot, qn, k, n_probes, pass_1, capacity, scan_buf, bound, counts, compact)
+        cnt = counts.numpy()[:W]
+        if acc is not None:                             # the caller's books (atomics on the device)
+            a = acc.numpy()
+            a[0] = max(int(a[0]), int(cnt.max()))
+            a[1] += int(cnt.sum())
+            a[2] += int(counts.numpy()[2 * W:].sum())
+        rec = records.numpy().reshape(W, region, 5)
+        rec[:] = -9                                     # (stale bytes must never be read as records)
+        o = 0
+        for h in range(W):
+            n = int(cnt[h])
+            rec[h, :min(n, region)] = compact.numpy()[o:o + min(n, region)]
+            if n > region:
+                flag.numpy()[0] |= 1
+            o += n
+
+    def finish_regions(self, slot, qn, k, n_probes, pass_1, records, counts_recv, region, out_home, flag):
+        import torch
+        W = self.world
+        cnt = counts_recv.numpy()[:W]
+        if (cnt > region).any():                        # a sender overflowed (its flag says so): the
+            out_home.numpy()[:] = -1                    # batch is repeated, nothing to check here
+            return
+        rec = records.numpy().reshape(W, region, 5)
+        got = np.concatenate([rec[s_, :int(cnt[s_])] for s_ in range(W)]) if cnt.sum() else np.zeros((0, 5), np.int32)
+        self.finish_filtered(slot, qn, k, n_probes, pass_1, torch.from_numpy(np.ascontiguousarray(got)),
+                             len(got), out_home, flag)
+

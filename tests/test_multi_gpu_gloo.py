@@ -53,7 +53,7 @@ def test_replica_group_two_ranks(nq):
         np.testing.assert_array_equal(ret[r], exp)
 
 
-def _shard_worker(rank, world, port, tag, nq, k, n_probes, tiny, coarse, ret, exchange="dense"):
+def _shard_worker(rank, world, port, tag, nq, k, n_probes, tiny, coarse, ret, exchange="dense", counts="device"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -75,10 +75,17 @@ def _shard_worker(rank, world, port, tag, nq, k, n_probes, tiny, coarse, ret, ex
         owner = shard_lists(g["list_sizes"], world)
         eng = OracleShardEngine(O, ox, owner, rank, world)
         idx = ListShardedIndex(HostSide(), engine=eng, owner=owner, list_sizes=g["list_sizes"],
-                               coarse=coarse, exchange=exchange)
+                               coarse=coarse, exchange=exchange, counts=counts)
+        assert idx.counts == counts
         if tiny:
             idx.capacity[(nq, n_probes)] = 3      # overflows: the batch must be repeated
+        if tiny == "region":
+            idx.capacity.pop((nq, n_probes))
+            idx.record_region[(nq, n_probes)] = 2    # the record regions overflow, the streams fit
         out = idx.query_batch(g["qn"][:nq], k, n_probes)
+        if exchange == "filtered" and counts == "device":
+            out2 = idx.query_batch(g["qn"][:nq], k, n_probes)      # second look: regions trimmed
+            assert (out2 == out).all() and (nq, n_probes) in idx.record_region
         ret[rank] = (out, idx.capacity[(nq, n_probes)], getattr(eng, "coarse_calls", 0),
                      idx.bytes_sent, idx.bytes_dense)
     finally:
@@ -110,26 +117,33 @@ def test_list_sharded_index_gloo(world, nq, tiny, coarse):
         assert (ret[r][2] > 0) == (coarse == "home")
 
 
+@pytest.mark.parametrize("counts", ["device", "host"])
 @pytest.mark.parametrize("world,nq,tiny,coarse,n_probes", [(2, 24, False, "home", 5), (3, 23, False, "home", 10),
-                                                           (2, 7, True, "replicated", 5), (2, 1, False, "home", 5)])
-def test_list_sharded_filtered_exchange_gloo(world, nq, tiny, coarse, n_probes):
+                                                           (2, 7, True, "replicated", 5), (2, 1, False, "home", 5),
+                                                           (2, 24, "region", "home", 5)])
+def test_list_sharded_filtered_exchange_gloo(world, nq, tiny, coarse, n_probes, counts):
     """exchange="filtered": the bound after the first probed list is min-reduced over the ranks
-    (the CPU engine replays that list with the oracle's query_pq), the records travel with
-    variable splits, and the home rank's engine checks that exactly the blocks the rule names
-    arrived, byte for byte; ids equal the reference's; fewer bytes than the whole segments."""
+    (the CPU engine replays that list with the oracle's query_pq), the records travel — with
+    variable splits read on the host (counts="host"), or in fixed regions with equal splits and the
+    counts beside them (counts="device": nothing is read on the host inside a batch; "region":
+    regions of 2 records overflow, the batch is repeated with larger ones) — and the home rank's
+    engine checks that exactly the blocks the rule names arrived, byte for byte; ids equal the
+    reference's."""
+    if tiny == "region" and counts == "host":
+        pytest.skip("regions belong to counts='device'")
     import torch.multiprocessing as mp
     from conftest import golden
     tag, k = "an100", 10
     port = 35500 + (os.getpid() * 5 + nq + world + n_probes) % 2000
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_shard_worker, args=(world, port, tag, nq, k, n_probes, tiny, coarse, ret, "filtered"),
+    mp.spawn(_shard_worker, args=(world, port, tag, nq, k, n_probes, tiny, coarse, ret, "filtered", counts),
              nprocs=world, join=True)
     g = golden(f"g6_ivf_{tag}.npz")
     exp = g[f"ids_p{n_probes}"][:nq]
     for r in range(world):
         np.testing.assert_array_equal(ret[r][0], exp)
-        assert not tiny or ret[r][1] > 3
+        assert tiny is not True or ret[r][1] > 3
     sent = sum(ret[r][3] for r in range(world))
     dense = sum(ret[r][4] for r in range(world))
     assert dense > 0 and sent > 0      # (the fixture's lists are shorter than the heap: little to drop)

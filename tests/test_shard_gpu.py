@@ -49,7 +49,7 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
     for r, e in enumerate(engines):
         e.scan(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], probes_all=p_all)
     homes = []
-    if exchange == "filtered":
+    if exchange in ("filtered", "filtered-regions"):
         bounds = [torch.zeros(nq, dtype=torch.uint8, device="cuda") for _ in range(world)]
         for r, e in enumerate(engines):
             e.bound(0, qn_t, k, n_probes, pass_1, capacity, sends[r].view(-1), bounds[r])
@@ -58,16 +58,31 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
         if stats is not None:
             stats["bound"] = b_all.cpu().numpy()
         counts, recs = [], []
+        region = None
+        if exchange == "filtered-regions":
+            region = capacity if stats is None or "region" not in stats else int(stats["region"])
         for r, e in enumerate(engines):
             c = torch.full((3 * world,), -5, dtype=torch.int32, device="cuda")
-            rec = torch.full((world * capacity, 5), -9, dtype=torch.int32, device="cuda")
-            e.filter(0, qn_t, k, n_probes, pass_1, capacity, sends[r].view(-1), b_all, c, rec)
+            rec = torch.full((world * (region or capacity), 5), -9, dtype=torch.int32, device="cuda")
+            if region:
+                e.filter_regions(0, qn_t, k, n_probes, pass_1, capacity, sends[r].view(-1), b_all, c, rec,
+                                 region, flags[r])
+            else:
+                e.filter(0, qn_t, k, n_probes, pass_1, capacity, sends[r].view(-1), b_all, c, rec)
             counts.append(c.cpu().numpy())
             recs.append(rec)
         if stats is not None:
+            stats["max_region_count"] = int(max(c[:world].max() for c in counts))
             stats["records"] = int(sum(c[:world].sum() for c in counts))
             stats["dense_blocks"] = int(sum(c[2 * world:].sum() for c in counts))
-        for h, e in enumerate(engines):
+        for h, e in enumerate(engines if region else []):
+            # equal-split all-to-all of the regions and of the counts; the counts stay on the device
+            rrec = torch.cat([recs[s_].view(world, region, 5)[h] for s_ in range(world)]).contiguous()
+            rcnt = torch.tensor([int(counts[s_][h]) for s_ in range(world)], dtype=torch.int32, device="cuda")
+            out = torch.zeros(qh * k, dtype=torch.int64, device="cuda")
+            e.finish_regions(0, qn_t, k, n_probes, pass_1, rrec, rcnt, region, out, flags[h])
+            homes.append(out.view(qh, k))
+        for h, e in enumerate([] if region else engines):
             parts = []
             for s_ in range(world):                                             # all-to-all (splits)
                 o = int(counts[s_][:h].sum())
@@ -118,6 +133,21 @@ def test_sharded_filtered_golden(tag, world, coarse):
                                        exchange="filtered")
         assert not flags.any()
         np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+        # fixed record regions + counts read on the device (tk_index_shard_*_regions_dev): same ids;
+        # regions exactly as large as the largest count pass, one record less raises the flag
+        st = {}
+        ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, coarse=coarse,
+                                       exchange="filtered-regions", stats=st)
+        assert not flags.any()
+        np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+        need = st["max_region_count"]
+        if need > 1:
+            for region, ok in ((need, True), (need - 1, False)):
+                ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, coarse=coarse,
+                                               exchange="filtered-regions", stats={"region": region})
+                assert flags.any() != ok
+                if ok:
+                    np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
 
 
 def test_sharded_overflow_is_flagged_and_harmless():
@@ -301,9 +331,11 @@ def _rccl_worker(rank, world, port, ret):
             ivf = ivf_from_fixture(None, g)
             qn, qp = ivf._prepare(np.array(g["qs"], dtype=np.float32))
             qn_t, qp_t = torch.from_numpy(qn).cuda(), torch.from_numpy(np.ascontiguousarray(qp)).cuda()
-            for exchange in ("dense", "filtered"):
-                idx = ListShardedIndex(ivf, depth=4, exchange=exchange, force_collectives=True)
+            for exchange in ("dense", "filtered", "filtered-host-counts"):
+                idx = ListShardedIndex(ivf, depth=4, exchange=exchange.split("-")[0], force_collectives=True,
+                                       counts="host" if exchange.endswith("host-counts") else "device")
                 assert idx.backend == "nccl" and idx.world == 1 and idx.force
+                assert idx.counts == ("host" if exchange.endswith("host-counts") else "device")
                 for p in (1, 5, 10):
                     out[(tag, exchange, p)] = idx.query_batch(g["qs"], 10, n_probes=p)
                 # four batches in flight, each on its own stream: the collectives of different
@@ -322,9 +354,11 @@ def test_sharded_rccl_world1_forced_collectives():
     """The RCCL branch on the one-GPU box: ONE rank, backend nccl, the exchanges forced through
     torch.distributed (TINYKNN_FORCE_COLLECTIVES / force_collectives) instead of device copies —
     uint8 MIN all-reduce of the bounds, equal-split all_to_all_single of the distance regions,
-    variable-split all_to_all_single of the (n, 5) int32 records, all_gather_into_tensor of probe
-    lists and ids, four batches in flight on four streams.  Golden ids, both exchanges, distinct and
-    repeating labels."""
+    variable-split all_to_all_single of the (n, 5) int32 records (counts="host") and the equal-split
+    one of the fixed record regions with the counts beside them (counts="device", the default: no
+    host synchronisation in a batch), all_gather_into_tensor of probe lists and ids, MAX all-reduce
+    of the region sizes at join(), four batches in flight on four streams.  Golden ids, every
+    exchange, distinct and repeating labels."""
     import torch.multiprocessing as mp
     port = 31500 + os.getpid() % 2000
     mgr = mp.Manager()
@@ -334,7 +368,7 @@ def test_sharded_rccl_world1_forced_collectives():
     for tag in ("g6_ivf_an100", "g6_ivf_an100b2"):
         g = golden(tag + ".npz")
         nq = len(g["qs"])
-        for exchange in ("dense", "filtered"):
+        for exchange in ("dense", "filtered", "filtered-host-counts"):
             for p in (1, 5, 10):
                 np.testing.assert_array_equal(out[(tag, exchange, p)], g[f"ids_p{p}"])
             for got in out[(tag, exchange, "flight")]:

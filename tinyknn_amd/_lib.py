@@ -82,6 +82,12 @@ SIGNATURES = {
     "tk_index_shard_finish_filtered_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
                                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_shard_filter_regions_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_shard_finish_regions_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
+                                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_measure_read_bandwidth": (C.c_int, [C.c_int64, C.c_int, _f64p]),
     "tk_index_alloc_data": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int]),
     "tk_index_synth_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int,

@@ -2047,12 +2047,12 @@ extern "C" int tk_index_shard_bound_dev(tk_index *ix, int slot, int64_t nq, int 
     return TK_OK;
 }
 
-extern "C" int tk_index_shard_filter_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
-                                         int pass_1, int64_t capacity, const void *scan_dev,
-                                         const uint8_t *bound_dev, int32_t *counts_dev,
-                                         int32_t *records_dev, void *stream)
+static int shard_filter_impl(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
+                             int pass_1, int64_t capacity, const void *scan_dev,
+                             const uint8_t *bound_dev, int32_t *counts_dev,
+                             int32_t *records_dev, int64_t region, int *flag_dev, int64_t *acc_dev,
+                             void *stream)
 {
-    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     int64_t qh = 0;
@@ -2077,19 +2077,51 @@ extern "C" int tk_index_shard_filter_dev(tk_index *ix, int slot, int64_t nq, int
                                ix->owner.as<int>(), ix->rank, ix->world, qh, p.cap,
                                w.spos.as<int>(), (const uint4 *)scan_dev, w.smins.as<uint8_t>(),
                                bound_dev, w.pair_cnt.as<int>(), w.pair_off.as<int>(), w.scan_tmp.p,
-                               tmp_bytes, w.tally.as<int>(), counts_dev, records_dev, st))
+                               tmp_bytes, w.tally.as<int>(), counts_dev, records_dev, st, (int)region,
+                               flag_dev, (long long *)acc_dev))
         return fail(TK_ERR_HIP, "hipcub scan failed");
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
 
-extern "C" int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_dev,
-                                                  int64_t nq, int k, int n_probes, int pass_1,
-                                                  const int32_t *records_dev, int64_t n_records,
-                                                  int64_t *out_ids_home_dev, int *flag_dev,
-                                                  void *stream)
+extern "C" int tk_index_shard_filter_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
+                                         int pass_1, int64_t capacity, const void *scan_dev,
+                                         const uint8_t *bound_dev, int32_t *counts_dev,
+                                         int32_t *records_dev, void *stream)
 {
     IXLOCK(ix);
+    return shard_filter_impl(ix, slot, nq, k, n_probes, pass_1, capacity, scan_dev, bound_dev, counts_dev,
+                             records_dev, 0, nullptr, nullptr, stream);
+}
+
+// The same with the records of home rank h at records_dev[h * region_records ...] (room for world *
+// region_records records): the all-to-all that follows has EQUAL splits, so no rank has to read
+// a count on the host before it can enqueue it — counts_dev[0, world) travel beside the records and
+// the home rank reads them on the device (tk_index_shard_finish_regions_dev).  More than
+// region_records records for one home rank: the rest is dropped and *flag_dev |= 1, the overflow
+// flag of the batch (the caller repeats it with larger regions, as with `capacity`).
+// acc_dev (or NULL): three int64 the caller keeps across batches — [0] = largest counts_dev[h] seen
+// (atomic max: what the regions have to hold), [1] += records, [2] += blocks scored.
+extern "C" int tk_index_shard_filter_regions_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
+                                                 int pass_1, int64_t capacity, const void *scan_dev,
+                                                 const uint8_t *bound_dev, int32_t *counts_dev,
+                                                 int32_t *records_dev, int64_t region_records,
+                                                 int *flag_dev, int64_t *acc_dev, void *stream)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix && ix->sharded, "not a list-sharded index");
+    ARGCHECK(region_records >= 1 && region_records * ix->world < (1ll << 31) && flag_dev,
+             "region_records (x world must stay below 2^31) / flag buffer");
+    return shard_filter_impl(ix, slot, nq, k, n_probes, pass_1, capacity, scan_dev, bound_dev, counts_dev,
+                             records_dev, region_records, flag_dev, acc_dev, stream);
+}
+
+static int shard_finish_filtered_impl(tk_index *ix, int slot, const float *q_dev,
+                                      int64_t nq, int k, int n_probes, int pass_1,
+                                      const int32_t *records_dev, int64_t n_records,
+                                      const int32_t *counts_recv_dev, int64_t region,
+                                      int64_t *out_ids_home_dev, int *flag_dev, void *stream)
+{
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     int64_t qh = 0;
@@ -2106,12 +2138,42 @@ extern "C" int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const 
     if (nqh > 0) {
         tk_launch_shard_expand(records_dev, n_records, w.slot_prefix.as<int>() + q0 * (p.S + 1), p.S,
                                nqh, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(), p.cap_min,
-                               flag_dev, st);
+                               flag_dev, st, counts_recv_dev, (int)region);
         Prof pf;
         TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf));
     }
     HIPCHECK(hipGetLastError());
     return TK_OK;
+}
+
+extern "C" int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_dev,
+                                                  int64_t nq, int k, int n_probes, int pass_1,
+                                                  const int32_t *records_dev, int64_t n_records,
+                                                  int64_t *out_ids_home_dev, int *flag_dev,
+                                                  void *stream)
+{
+    IXLOCK(ix);
+    return shard_finish_filtered_impl(ix, slot, q_dev, nq, k, n_probes, pass_1, records_dev, n_records,
+                                      nullptr, 0, out_ids_home_dev, flag_dev, stream);
+}
+
+// records_dev: world regions of region_records records as the equal-split all-to-all delivered
+// them (region s from source rank s); counts_recv_dev[s] of them are real (the all-to-all of the
+// senders' counts_dev[0, world), on the device: no host synchronisation anywhere in the batch)
+extern "C" int tk_index_shard_finish_regions_dev(tk_index *ix, int slot, const float *q_dev,
+                                                 int64_t nq, int k, int n_probes, int pass_1,
+                                                 const int32_t *records_dev,
+                                                 const int32_t *counts_recv_dev,
+                                                 int64_t region_records, int64_t *out_ids_home_dev,
+                                                 int *flag_dev, void *stream)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix && ix->sharded, "not a list-sharded index");
+    ARGCHECK(counts_recv_dev && region_records >= 1 && region_records * ix->world < (1ll << 31),
+             "counts / region_records");
+    return shard_finish_filtered_impl(ix, slot, q_dev, nq, k, n_probes, pass_1, records_dev,
+                                      region_records * ix->world, counts_recv_dev, region_records,
+                                      out_ids_home_dev, flag_dev, stream);
 }
 
 extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq,

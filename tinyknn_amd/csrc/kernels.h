@@ -244,10 +244,12 @@ int tk_launch_shard_filter(const int64_t *probes, const int *slot_prefix, int S,
                            int64_t n_lists, const int *owner, int me, int W, int64_t qh,
                            int64_t cap, const int *spos, const uint4 *scan, const uint8_t *smins,
                            const uint8_t *bound, int *pair_cnt, int *pair_off, void *tmp,
-                           size_t tmp_bytes, int *tally, int *counts, int *rec, hipStream_t s);
+                           size_t tmp_bytes, int *tally, int *counts, int *rec, hipStream_t s,
+                           int region = 0, int *flag = nullptr, long long *acc = nullptr);
 void tk_launch_shard_expand(const int *rec, int64_t n_rec, const int *slot_prefix, int S,
                             int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,
-                            int64_t min_stride, int *bad, hipStream_t s);
+                            int64_t min_stride, int *bad, hipStream_t s,
+                            const int *counts_recv = nullptr, int region = 0);
 
 // ---- offline build path (build.hip) ----
 // labels (n, M) uint8 = FastPQ.transform's per-block nearest centroid; data: (n, dq) padded

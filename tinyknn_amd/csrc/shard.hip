@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void shard_filter_kernel(
     const int *__restrict__ spos, const uint4 *__restrict__ scan,
     const uint8_t *__restrict__ smins, const uint8_t *__restrict__ bound,
     int *__restrict__ pair_cnt, const int *__restrict__ pair_off, int *__restrict__ dense,
-    int *__restrict__ rec)
+    int *__restrict__ rec, int region)
 {
     __shared__ int s_dense[4];
     const int lane = threadIdx.x & 63;
@@ -365,6 +365,17 @@ __global__ __launch_bounds__(256) void shard_filter_kernel(
                 mine = nch;
             } else if (pair_cnt[i] > 0) {
                 int base = pair_off[i];
+                int room = 0x7fffffff;
+                if (region > 0) {
+                    // fixed regions (tk_index_shard_filter_regions_dev): home rank h's records start
+                    // at h * region whatever the other homes hold; what does not fit is dropped
+                    // (shard_counts_kernel raises the overflow flag)
+                    int64_t a = (int64_t)h * qh;
+                    a = a > nq ? nq : a;
+                    const int local = base - pair_off[a * S];
+                    room = region - local;
+                    base = h * region + local;
+                }
                 const int hdr0 = (int)((q - (int64_t)h * qh) * cap + f0);
                 const uint8_t *mp = smins + (int64_t)p;
                 const uint4 *sp = scan + (int64_t)p;
@@ -382,13 +393,15 @@ __global__ __launch_bounds__(256) void shard_filter_kernel(
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const uint64_t m = __ballot(pass[u]);
-                        if (pass[u]) {
-                            const int at = base + __popcll(m & ((1ull << lane) - 1));
+                        const int ahead = __popcll(m & ((1ull << lane) - 1));
+                        if (pass[u] && ahead < room) {
+                            const int at = base + ahead;
                             int *r = rec + (int64_t)at * 5;
                             r[0] = hdr0 + c0 + 64 * u + lane;
                             r[1] = (int)v[u].x; r[2] = (int)v[u].y; r[3] = (int)v[u].z; r[4] = (int)v[u].w;
                         }
                         base += __popcll(m);
+                        room -= __popcll(m);
                     }
                 }
             }
@@ -415,7 +428,8 @@ __global__ __launch_bounds__(256) void shard_filter_kernel(
 // counts[h] = records for home rank h, from the prefix sums (pair_off has nq * S + 1 entries)
 __global__ void shard_counts_kernel(const int *__restrict__ pair_off, int S, int64_t nq, int W,
                                     int64_t qh, const int *__restrict__ tally,
-                                    int *__restrict__ counts)
+                                    int *__restrict__ counts, int region, int *__restrict__ flag,
+                                    long long *__restrict__ acc)
 {
     const int h = threadIdx.x + blockIdx.x * blockDim.x;
     if (h >= W) return;
@@ -423,9 +437,15 @@ __global__ void shard_counts_kernel(const int *__restrict__ pair_off, int S, int
     a = a > nq ? nq : a;
     b = b > nq ? nq : b;
     counts[h] = pair_off[b * S] - pair_off[a * S];
+    if (region > 0 && counts[h] > region && flag) atomicOr(flag, 1);    // (the home rank reads min(count, region))
     int t = 0;
     for (int r = 0; r < 256; r++) t += tally[r * W + h];
     counts[2 * W + h] = t;
+    if (acc) {      // the caller's books, kept on the device: largest region, records, blocks scored
+        atomicMax(&acc[0], (long long)counts[h]);
+        atomicAdd((unsigned long long *)&acc[1], (unsigned long long)counts[h]);
+        atomicAdd((unsigned long long *)&acc[2], (unsigned long long)t);
+    }
 }
 
 int tk_scan_exclusive(void *tmp, size_t *tmp_bytes, const int *in, int *out, int64_t n, hipStream_t s);
@@ -434,20 +454,21 @@ int tk_launch_shard_filter(const int64_t *probes, const int *slot_prefix, int S,
                            int64_t n_lists, const int *owner, int me, int W, int64_t qh,
                            int64_t cap, const int *spos, const uint4 *scan, const uint8_t *smins,
                            const uint8_t *bound, int *pair_cnt, int *pair_off, void *tmp,
-                           size_t tmp_bytes, int *tally, int *counts, int *rec, hipStream_t s)
+                           size_t tmp_bytes, int *tally, int *counts, int *rec, hipStream_t s,
+                           int region, int *flag, long long *acc)
 {
     if (nq == 0 || S == 0) return 0;
     const unsigned grid = (unsigned)((nq * S + 3) / 4);
     hipLaunchKernelGGL(shard_filter_kernel<false>, dim3(grid), dim3(256), 0, s, probes, slot_prefix,
                        S, nq, n_lists, owner, me, W, qh, cap, spos, scan, smins, bound, pair_cnt,
-                       (const int *)nullptr, tally, rec);
+                       (const int *)nullptr, tally, rec, 0);
     // pair_cnt has one more entry (zero, set by the caller) so that pair_off[nq * S] = total
     if (tk_scan_exclusive(tmp, &tmp_bytes, pair_cnt, pair_off, nq * S + 1, s)) return -1;
     hipLaunchKernelGGL(shard_counts_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, s, pair_off,
-                       S, nq, W, qh, tally, counts);
+                       S, nq, W, qh, tally, counts, region, flag, acc);
     hipLaunchKernelGGL(shard_filter_kernel<true>, dim3(grid), dim3(256), 0, s, probes, slot_prefix,
                        S, nq, n_lists, owner, me, W, qh, cap, spos, scan, smins, bound, pair_cnt,
-                       (const int *)pair_off, tally, rec);
+                       (const int *)pair_off, tally, rec, region);
     return 0;
 }
 
@@ -468,10 +489,15 @@ __global__ __launch_bounds__(256) void shard_fill_rows_kernel(
 
 __global__ __launch_bounds__(256) void shard_scatter_kernel(
     const int *__restrict__ rec, int64_t n_rec, int64_t rows, uint4 *__restrict__ dist,
-    int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride, int *__restrict__ bad)
+    int64_t cap, uint8_t *__restrict__ mins, int64_t min_stride, int *__restrict__ bad,
+    const int *__restrict__ counts_recv, int region)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_rec) return;
+    if (region > 0) {       // fixed regions: source rank s sent counts_recv[s] records at s * region
+        const int64_t src = i / region;
+        if (i - src * region >= (int64_t)counts_recv[src]) return;
+    }
     const int *r = rec + i * 5;
     const int64_t hdr = r[0];
     if (hdr < 0 || hdr >= rows * cap) {            // a record that is not ours: never write it
@@ -495,12 +521,14 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(
 
 void tk_launch_shard_expand(const int *rec, int64_t n_rec, const int *slot_prefix, int S,
                             int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,
-                            int64_t min_stride, int *bad, hipStream_t s)
+                            int64_t min_stride, int *bad, hipStream_t s, const int *counts_recv,
+                            int region)
 {
     if (nq_home == 0 || S == 0) return;
     hipLaunchKernelGGL(shard_fill_rows_kernel, dim3((unsigned)nq_home), dim3(256), 0, s,
                        slot_prefix, S, dist, cap, mins, min_stride);
     if (n_rec > 0)
         hipLaunchKernelGGL(shard_scatter_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0,
-                           s, rec, n_rec, nq_home, dist, cap, mins, min_stride, bad);
+                           s, rec, n_rec, nq_home, dist, cap, mins, min_stride, bad, counts_recv,
+                           counts_recv ? region : 0);
 }

@@ -462,6 +462,21 @@ class DeviceIndex:
             self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0), records_ptr,
             int(n_records), out_ptr, flag_ptr, stream))
 
+    def shard_filter_regions_dev(self, slot, nq, k, n_probes, pass_1, capacity, scan_ptr, bound_ptr,
+                                 counts_ptr, records_ptr, region, flag_ptr, acc_ptr=None, stream=0):
+        """... into fixed regions of `region` records per home rank (tk_index_shard_filter_regions_dev)."""
+        _lib.check(_lib.lib().tk_index_shard_filter_regions_dev(
+            self._h, int(slot), nq, int(k), int(n_probes), int(pass_1 or 0), int(capacity),
+            scan_ptr, bound_ptr, counts_ptr, records_ptr, int(region), flag_ptr, acc_ptr, stream))
+
+    def shard_finish_regions_dev(self, slot, qn_ptr, nq, k, n_probes, pass_1, records_ptr,
+                                 counts_recv_ptr, region, out_ptr, flag_ptr, stream=0):
+        """Received regions + their counts on the device -> rows, replay, rescoring
+        (tk_index_shard_finish_regions_dev)."""
+        _lib.check(_lib.lib().tk_index_shard_finish_regions_dev(
+            self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0), records_ptr,
+            counts_recv_ptr, int(region), out_ptr, flag_ptr, stream))
+
     def reserve(self, nq, k, n_probes, pass_1=None):
         _lib.check(_lib.lib().tk_index_reserve(self._h, nq, int(k), int(n_probes), int(pass_1 or 0)))
 

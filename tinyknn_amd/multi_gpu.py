@@ -186,6 +186,24 @@ class _HipShardEngine:
                                            flag.data_ptr(), stream=st)
 
 
+    # ... without the host synchronisation: fixed regions, counts read on the device
+    def filter_regions(self, slot, qn, k, n_probes, pass_1, capacity, scan_buf, bound, counts, records,
+                       region, flag, acc=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_filter_regions_dev(slot, qn.shape[0], k, n_probes, pass_1, capacity,
+                                          scan_buf.data_ptr(), bound.data_ptr(), counts.data_ptr(),
+                                          records.data_ptr(), region, flag.data_ptr(),
+                                          acc_ptr=None if acc is None else acc.data_ptr(), stream=st)
+
+    def finish_regions(self, slot, qn, k, n_probes, pass_1, records, counts_recv, region, out_home, flag):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_finish_regions_dev(slot, qn.data_ptr(), qn.shape[0], k, n_probes, pass_1,
+                                          records.data_ptr(), counts_recv.data_ptr(), region,
+                                          out_home.data_ptr(), flag.data_ptr(), stream=st)
+
+
 class ListShardedIndex:
     """One rank of an IVF index whose inverted lists are sharded by cluster id.
 
@@ -204,14 +222,22 @@ class ListShardedIndex:
     over the ranks, 1 byte per query — only the blocks of the later lists with a distance below
     that bound can matter; they travel as (destination, 16 bytes) records with the splits the
     ranks exchange first, and the home rank replays rows in which every other block holds the
-    largest value.  Same ids; a fraction of the bytes (bytes_sent / bytes_dense count them);
-    one host synchronisation per batch for the split sizes.
+    largest value.  Same ids; a fraction of the bytes (bytes_sent / bytes_dense count them).
+    `counts="device"` (default where the engine has filter_regions / finish_regions): the records
+    of a home rank go to a fixed region of `record_region` records, so the all-to-all has equal
+    splits and is enqueued without reading a count — the counts travel beside it and the home rank
+    reads them on the device; NO host synchronisation in a batch.  Regions start at the region
+    capacity of the dense exchange (which can never overflow) and are trimmed to 1.35 x the largest
+    count seen wherever the host looks at a batch anyway (query_prepared, join); an overflow is the
+    batch's overflow flag, handled as for `capacity`.  `counts="host"`: exact variable splits, one
+    host synchronisation per batch (the round-2 form).
 
     `engine`: object with coarse/scan/finish (default: the HIP engine); tests inject a CPU one.
     """
 
     def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None,
-                 coarse="home", coalesce=1, exchange="dense", calibrate=True, force_collectives=None):
+                 coarse="home", coalesce=1, exchange="dense", calibrate=True, force_collectives=None,
+                 counts="device"):
         import os
         import torch
         import torch.distributed as dist
@@ -247,7 +273,8 @@ class ListShardedIndex:
         sz = self.list_sizes.astype(np.float64)
         self._mean_list = float((sz * sz).sum() / max(sz.sum(), 1.0))    # size-weighted mean rows
         self.calibrate = calibrate
-        self.bytes_sent = self.bytes_dense = 0      # filtered exchange: records vs whole segments
+        self.bytes_sent = 0         # filtered exchange: bytes this rank put on the wire ...
+        self._bytes_dense = 0       # ... against 16 B x the blocks of whole segments (bytes_dense)
         # submit() answers `coalesce` consecutive batches as ONE sharded batch: the latency-bound
         # stages (two heap replays of the home queries, three collectives) cost the same for
         # 1250 as for 3750 home queries, so what bounds a rank is batches per second, not queries
@@ -256,6 +283,15 @@ class ListShardedIndex:
         self.engine = engine if engine is not None else _HipShardEngine(
             ivf, self.owner, self.rank, self.world, depth, resident=resident)
         self.device = self.engine.device
+        assert counts in ("device", "host")
+        if counts == "device" and not (hasattr(self.engine, "filter_regions") and
+                                       hasattr(self.engine, "finish_regions")):
+            counts = "host"
+        self.counts = counts
+        self.record_region = {}     # (nq, n_probes) -> records per home-rank region (counts="device")
+        self._rec_seen = {}         # ... largest per-home count of the batches looked at so far
+        self._acc = None            # device: [largest per-home record count, records, dense blocks] since reset
+        self._acc_keys = set()
         self.capacity = {}          # (nq, n_probes) -> uint4 per region, grows on overflow
         self._bufs = {}
         self._pbufs = {}
@@ -283,6 +319,26 @@ class ListShardedIndex:
         self._ovf = None            # device counter: overflow / bad-record flags of submit()ted batches
         self._ovf_keys = set()      # capacities to grow if that counter is non-zero at join()
         self.last_flushed = None    # gathered tensor of the batch join() flushed (coalesce > 1)
+
+    @property
+    def bytes_dense(self):
+        """16 B x the blocks this rank scored in filtered batches (what the dense form carries at
+        least); with counts="device" the tally lives on the device: reading synchronises."""
+        n = self._bytes_dense
+        if self._acc is not None:
+            n += 16 * int(self._acc[2].item())
+        return n
+
+    @bytes_dense.setter
+    def bytes_dense(self, v):
+        self._bytes_dense = int(v)
+        if self._acc is not None:
+            self._acc[1:].zero_()
+
+    @property
+    def records_sent(self):
+        """records (20 B each) the filtered batches of this rank really held, counts="device"."""
+        return 0 if self._acc is None else int(self._acc[1].item())
 
     def _check_same_index(self, ivf):
         """Every rank must hold the SAME index (same centres, same lists): positions in the
@@ -347,15 +403,75 @@ class ListShardedIndex:
             self.dist.all_to_all_single(r, send.cpu(), rsplit, ssplit, group=self.group)
             recv.copy_(r)
 
-    def _filtered_buffers(self, slot, nq, capacity):
-        key = (nq, capacity)
+    def _filtered_buffers(self, slot, nq, capacity, region=0):
+        key = (nq, capacity, region)
         if self._fbufs.get(slot, (None,))[0] != key:
             t, W = self.torch, self.world
             mk = lambda n, dt: t.empty(n, dtype=dt, device=self.device)
             self._fbufs[slot] = (key, dict(
                 bound=mk(nq, t.uint8), counts=mk(3 * W, t.int32), rcounts=mk(W, t.int32),
-                rec=mk((W * capacity, 5), t.int32), rrec=mk((1024, 5), t.int32)))
+                rec=mk((W * (region or capacity), 5), t.int32),
+                rrec=mk((W * region if region else 1024, 5), t.int32)))
         return self._fbufs[slot][1]
+
+    def _region(self, nq, n_probes, capacity):
+        """records per home-rank region: the dense capacity (never overflows) until batches have
+        been looked at, then what they needed (_note_region)."""
+        r = self.record_region.get((nq, n_probes))
+        return int(capacity if r is None else min(r, capacity))
+
+    def _filtered_regions(self, slot, qn, k, n_probes, pass_1, capacity, b, out_home):
+        """The whole filtered exchange, enqueued: bound -> min all-reduce -> filter into fixed
+        regions -> all-to-all of the counts and (equal splits) of the regions -> finish."""
+        W, t = self.world, self.torch
+        nq = qn.shape[0]
+        region = self._region(nq, n_probes, capacity)
+        f = self._filtered_buffers(slot, nq, capacity, region)
+        self.engine.bound(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"])
+        self._all_reduce_min(f["bound"])
+        if self._acc is None:       # [largest per-home count, records, blocks scored]: atomics in the filter
+            self._acc = t.zeros(3, dtype=t.int64, device=self.device)
+        self.engine.filter_regions(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"],
+                                   f["counts"], f["rec"], region, b["flag"], self._acc)
+        if W == 1 and not self.force:       # one rank: nothing travels, the regions are read where they lie
+            rrec, rcounts = f["rec"], f["counts"]
+        else:
+            self._all_to_all(f["rcounts"], f["counts"][:W])
+            self._all_to_all(f["rrec"], f["rec"])
+            rrec, rcounts = f["rrec"], f["rcounts"]
+        self.engine.finish_regions(slot, qn, k, n_probes, pass_1, rrec, rcounts, region,
+                                   out_home, b["flag"])
+        self._acc_keys.add((nq, n_probes))
+        self.bytes_sent += 20 * W * region + nq + 4 * W
+        return f
+
+    def _note_region(self, keys, need):
+        """`need`: the largest per-home record count of the batches since the last look, already
+        max-reduced over the ranks (every rank must arrive at the same region)."""
+        for key in keys:
+            seen = self._rec_seen.setdefault(key, [])
+            seen.append(int(need))
+            if self.calibrate and len(seen) >= 2:
+                self.record_region[key] = int(1.35 * max(seen)) + 64
+
+    def _max_over_ranks(self, v):
+        if self.world > 1 or self.force:
+            t_ = self.torch.tensor([int(v)], dtype=self.torch.int64,
+                                   device=self.device if self.backend == "nccl" else "cpu")
+            self.dist.all_reduce(t_, op=self.dist.ReduceOp.MAX, group=self.group)
+            v = int(t_.item())
+        return int(v)
+
+    def _take_rec_need(self):
+        """Largest per-home record count of the filtered batches (counts="device") since the last
+        look, max-reduced over the ranks, and the (nq, n_probes) they had — or (None, ()).
+        Synchronises; every rank calls it at the same point."""
+        if self._acc is None or not self._acc_keys:
+            return None, ()
+        v = int(self._acc[0].item())
+        self._acc[0] = 0
+        keys, self._acc_keys = self._acc_keys, set()
+        return self._max_over_ranks(v), keys
 
     def _filtered_front(self, slot, qn, k, n_probes, pass_1, capacity, b):
         """bound -> min all-reduce -> filter -> all-to-all of the counts (all enqueued)."""
@@ -373,14 +489,16 @@ class ListShardedIndex:
         W = self.world
         cnt = f["counts"].cpu().tolist()
         ssplit = cnt[:W]
-        self.bytes_dense += 16 * sum(cnt[2 * W:])
+        self._bytes_dense += 16 * sum(cnt[2 * W:])
         rsplit = f["rcounts"].cpu().tolist()
         n_s, n_r = sum(ssplit), sum(rsplit)
+        self.bytes_sent += 20 * n_s + qn.shape[0] + 4 * W
+        if W == 1 and not self.force:       # one rank: the records are read where they lie
+            return f["rec"], n_s
         if f["rrec"].shape[0] < n_r:
             f["rrec"] = self.torch.empty((int(1.25 * n_r) + 1024, 5), dtype=self.torch.int32,
                                          device=self.device)
         self._all_to_all_rows(f["rrec"][:n_r], f["rec"][:n_s], rsplit, ssplit)
-        self.bytes_sent += 20 * n_s + qn.shape[0] + 4 * W
         return f["rrec"], n_r
 
     def _buffers(self, slot, nq, k, capacity):
@@ -428,11 +546,17 @@ class ListShardedIndex:
             self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"])
         st = dict(slot=slot, qn=qn, k=k, n_probes=n_probes, pass_1=pass_1, capacity=capacity, b=b,
                   out=b["all"].view(self.world, qh * k + 1), f=None)
-        if self._exchange_kind(k, n_probes, pass_1) == "filtered":
+        if self._exchange_kind(k, n_probes, pass_1) == "filtered" and self.counts == "device":
+            self._filtered_regions(slot, qn, k, n_probes, pass_1, capacity, b, b["home"][:qh * k])
+            self._gather_ids(b, qh, k)
+        elif self._exchange_kind(k, n_probes, pass_1) == "filtered":
             st["f"] = self._filtered_front(slot, qn, k, n_probes, pass_1, capacity, b)
         else:
-            self._all_to_all(b["recv"], b["send"])
-            self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, b["recv"], b["home"][:qh * k])
+            recv = b["send"]            # one rank: nothing travels, the segments are read where they lie
+            if self.world > 1 or self.force:
+                self._all_to_all(b["recv"], b["send"])
+                recv = b["recv"]
+            self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, recv, b["home"][:qh * k])
             self._gather_ids(b, qh, k)
         return st
 
@@ -497,16 +621,26 @@ class ListShardedIndex:
             if (g[:, -1] & 2).any():
                 raise RuntimeError("filtered exchange: a record outside the home rank's rows")
             need = self._usage(slot)
+            rec_need, _ = self._take_rec_need()
+            key = (nq, n_probes)
             if not g[:, -1].any():
                 # trim only on the evidence of SEVERAL batches (their longest stream, +35 %): one
                 # batch's streams say little about the next batch's, and a pipelined submit() only
                 # learns of an overflow at join()
                 if need is not None and self.calibrate:
-                    seen = self._need.setdefault((nq, n_probes), [])
+                    seen = self._need.setdefault(key, [])
                     seen.append(need)
                     if len(seen) >= 2 and int(1.35 * max(seen)) + 64 < 0.8 * cap:
-                        self.capacity[(nq, n_probes)] = int(1.35 * max(seen)) + 64
+                        self.capacity[key] = int(1.35 * max(seen)) + 64
+                if rec_need is not None:
+                    self._note_region([key], rec_need)
                 return g[:, :-1].reshape(self.world * qh, k)[:nq]
+            if rec_need is not None and rec_need > self._region(nq, n_probes, cap):
+                # the record regions were too small (counts="device"); the streams may have fitted
+                self.record_region[key] = int(1.25 * rec_need) + 64
+                self._rec_seen.pop(key, None)
+                if need is not None and need <= cap:
+                    continue
             worst = qh * min(n_probes, len(self.list_sizes)) * int((self.list_sizes.max() + 15) // 16)
             assert cap < worst, "overflow at the worst-case capacity"
             grow = 2 * cap if need is None else max(int(1.25 * need) + 64, cap + 1)
@@ -608,8 +742,11 @@ class ListShardedIndex:
         rs = R["replay"][n % 2]
         rs.wait_event(scanned)
         with t.cuda.stream(rs):
-            self._all_to_all(b["recv"], b["send"])
-            self.engine.finish(slot, qn, k, n_probes, pass_1, cap, b["recv"], b["home"][:qh * k])
+            recv = b["send"]
+            if self.world > 1 or self.force:
+                self._all_to_all(b["recv"], b["send"])
+                recv = b["recv"]
+            self.engine.finish(slot, qn, k, n_probes, pass_1, cap, recv, b["home"][:qh * k])
             self._gather_ids(b, qh, k)
             out = b["all"].view(self.world, qh * k + 1)
             self._note_flags(out)
@@ -630,7 +767,9 @@ class ListShardedIndex:
         added to a device counter, on the batch's stream: join() reads it once."""
         if self._ovf is None:
             self._ovf = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
-        self._ovf += out[:, -1].sum()
+            self._ovf_ix = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+        # (an atomic add: batches on different streams may get here at the same time)
+        self._ovf.index_add_(0, self._ovf_ix, out[:, -1].sum().view(1))
 
     def join(self):
         """Flushes a partly filled coalesced batch (its gathered tensor: the return value and
@@ -649,14 +788,21 @@ class ListShardedIndex:
         if self._ovf is not None and self._ovf_keys:
             bad = int(self._ovf.item())         # (synchronises with the batches in flight)
             keys, self._ovf_keys = self._ovf_keys, set()
+            rec_need, rec_keys = self._take_rec_need()
             if bad:
                 self._ovf.zero_()
                 for key in keys:
                     nq, n_probes = key
                     qh = -(-nq // self.world)
                     worst = qh * min(n_probes, len(self.list_sizes)) * int((self.list_sizes.max() + 15) // 16)
+                    if rec_need is not None and key in rec_keys and \
+                            rec_need > self._region(nq, n_probes, self._capacity(nq, n_probes)):
+                        self.record_region[key] = int(1.25 * rec_need) + 64
+                        self._rec_seen.pop(key, None)
                     self.capacity[key] = min(2 * self._capacity(nq, n_probes), worst)
                     self._need.pop(key, None)
                 raise RuntimeError("ListShardedIndex: a batch in flight overflowed its exchange regions (or "
                                    "carried a bad record); capacities doubled — submit the batches again")
+            if rec_need is not None:
+                self._note_region(rec_keys, rec_need)
         return flushed
