@@ -270,7 +270,8 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     co = args.shard_coalesce if args.shard_coalesce > 0 else max(3, world)    # auto: a rank's home share = one batch
     co = max(1, min(co, 131072 // args.nq))
     idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co,
-                           force_collectives=args.force_collectives, counts=args.shard_counts)
+                           force_collectives=args.force_collectives, counts=args.shard_counts,
+                           plain=bool(args.shard_plain))
     if args.shard_exchange == "auto":
         idx.exchange = "auto"          # ListShardedIndex._exchange_kind: filtered where lists are long
         kinds = [idx._exchange_kind(args.k, args.n_probes, None)]
@@ -380,6 +381,11 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
             "coarse_stage": args.shard_coarse + (" (tables for all queries, coarse scan/replay/rescoring of the "
                                                  "rank's nq/W home queries, probe lists all-gathered)"
                                                  if args.shard_coarse == "home" else " on every rank"),
+            "scan": ({"form": "two-phase: first probed lists exactly, bound min-reduced over the ranks, the lists behind "
+                              "them on the int8 matrix cores where the bound allows (tk_index_shard_scan_first_dev / _rest_dev)",
+                      "last_batch_this_rank": idx.engine.dev.shard_plain_stats((idx._calls - 1) % idx.depth)}
+                     if idx._use_plain(args.k, args.n_probes, None) else
+                     {"form": "one phase, exact kernel (tk_index_shard_scan_dev)"}),
             "code_chunks_per_rank": [int(x) for x in load], "batches_in_flight": args.shard_depth,
             "steps_coalesced_per_exchange": co}
 
@@ -663,6 +669,8 @@ def main():
     ap.add_argument("--shard-counts", default="device", choices=["device", "host"],
                     help="filtered exchange: record counts read on the device (fixed regions, no host "
                          "synchronisation) or on the host (variable splits)")
+    ap.add_argument("--shard-plain", type=int, default=1,
+                    help="list-sharded leg: 1 = two-phase scan with the matrix-core kernel (default), 0 = exact kernel only")
     ap.add_argument("--shard-limit", type=float, default=240.0,
                     help="seconds after which a stuck list-sharded leg is abandoned")
     ap.add_argument("--force-collectives", action="store_true",

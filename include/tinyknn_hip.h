@@ -515,6 +515,35 @@ int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_de
                                        int k, int n_probes, int pass_1, const int32_t *records_dev,
                                        int64_t n_records, int64_t *out_ids_home_dev, int *flag_dev,
                                        void *stream);
+/* The sharded scan in two phases, the second on the int8 matrix cores (tk_index_set_plain_scan's
+ * kernel).  The plain sums are the reference's values for a query from the point where its heap's
+ * bound is at most the limit C of its table, and B1 — the bound after the query's FIRST probed list
+ * (ivf.py:137-152 over that list alone) — is known to every rank before the rest is scanned:
+ *   tk_index_shard_scan_first_dev  as tk_index_shard_scan_dev up to the segment positions; the
+ *                                  FIRST slots this rank owns scored exactly into send_dev;
+ *                                  bound_dev[nq] = B1 (order key, as tk_index_shard_bound_dev) of
+ *                                  the queries whose first list this rank owns, 255 elsewhere;
+ *   all-reduce(MIN, uint8)         by the caller;
+ *   tk_index_shard_scan_rest_dev   the slots behind the first: queries with B1 <= C on the plain
+ *                                  kernel, the others on the exact one.  No query is scanned twice,
+ *                                  nothing is repaired afterwards; tk_index_shard_finish_dev / the
+ *                                  filtered exchange (with this bound: no tk_index_shard_bound_dev)
+ *                                  follow as after tk_index_shard_scan_dev and return the same ids.
+ * tk_index_shard_plain: 1 if the two-phase form applies to (k, n_probes, pass_1) — M <= 52,
+ * n_probes >= 2, distinct labels (or tk_index_set_plain_scan(ix, 2)), not switched off; replicated
+ * state only, so every rank answers alike — else 0 (use tk_index_shard_scan_dev), < 0 on error. */
+int tk_index_shard_plain(tk_index *ix, int k, int n_probes, int pass_1);
+int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
+                                  int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                                  const int64_t *probes_all_dev, int64_t capacity, void *send_dev,
+                                  int *flag_dev, uint8_t *bound_dev, void *stream);
+int tk_index_shard_scan_rest_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
+                                 int64_t capacity, void *send_dev, const uint8_t *bound_dev,
+                                 void *stream);
+/* Books of the slot's last tk_index_shard_scan_rest_dev (synchronises): out4 = pairs this rank
+ * scored on the plain kernel, tiles of 32 of them, exact pair records of the slots behind the
+ * first, queries (of all nq) whose bound let them go the plain way. */
+int tk_index_shard_plain_stats(tk_index *ix, int slot, int64_t *out4);
 /* The filtered exchange WITHOUT its host synchronisation: the records of home rank h go to
  * records_dev[h * region_records, ...) (room for world * region_records records of 5 int32), so the
  * all-to-all of the records has equal splits and can be enqueued before any count is known; the

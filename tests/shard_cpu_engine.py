@@ -74,6 +74,27 @@ class OracleShardEngine:
                 seg = self._segment(probes[i, s], tables[i])
                 buf[i // qh, pos[i, s] * 16: pos[i, s] * 16 + len(seg)] = seg
 
+    # ---- the scan in two phases (tk_index_shard_scan_first_dev / _rest_dev).  This engine has no
+    # second kernel: phase 1 scores everything and computes the bound, phase 2 checks that the
+    # bound it is handed is the min-reduced one every rank must hold.
+    def plain_ok(self, k, n_probes, pass_1):
+        return n_probes >= 2
+
+    def scan_first(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, bound, probes_all=None):
+        self.scan(slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=probes_all)
+        self.bound(slot, qn, k, n_probes, pass_1, capacity, send, bound)
+        self.first_bound = bound.numpy().copy()
+
+    def scan_rest(self, slot, qn, k, n_probes, pass_1, capacity, send, bound):
+        b = bound.numpy()
+        mine = self.first_bound != 255
+        np.testing.assert_array_equal(b[mine], self.first_bound[mine])      # my queries: my value survived the MIN
+        qn_ = qn.numpy()
+        probes, _ = self._front(qn_, k, n_probes, pass_1)
+        owned_elsewhere = (self.owner[probes[:, 0]] != self.rank)
+        assert (self.first_bound[owned_elsewhere] == 255).all()
+        self.rest_calls = getattr(self, "rest_calls", 0) + 1
+
     def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home):
         qn = qn.numpy()
         probes, tables = self._front(qn, k, n_probes, pass_1)

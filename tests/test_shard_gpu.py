@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, owner=None,
-                   coarse="home", engines=None, sizes=None, exchange="dense", stats=None):
+                   coarse="home", engines=None, sizes=None, exchange="dense", stats=None, plain=True):
     """-> (ids (nq, k), overflow flags (world,), capacity).  coarse="home": every simulated rank
     runs the coarse stage of its home queries only and the probe lists are gathered by hand;
     "replicated": every rank derives all probe lists itself."""
@@ -46,14 +46,32 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
         for r, e in enumerate(engines):
             e.coarse(0, qn_t, qp_t, k, n_probes, pass_1, homes_p[r])
         p_all = torch.cat(homes_p).contiguous()                                 # all-gather
-    for r, e in enumerate(engines):
-        e.scan(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], probes_all=p_all)
+    # the scan: in two phases (first lists exactly -> bound, min-reduced -> the rest on the matrix
+    # cores where the bound allows) wherever the engine says it applies, else in one
+    two_phase = plain and engines[0].plain_ok(k, n_probes, pass_1)
+    b_red = None
+    if two_phase:
+        firsts = [torch.zeros(nq, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        for r, e in enumerate(engines):
+            e.scan_first(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], firsts[r],
+                         probes_all=p_all)
+        b_red = torch.stack(firsts).min(dim=0).values.contiguous()             # all-reduce(MIN)
+        for r, e in enumerate(engines):
+            e.scan_rest(0, qn_t, k, n_probes, pass_1, capacity, sends[r], b_red)
+        if stats is not None:
+            stats["two_phase"] = True
+            stats["plain"] = [e.dev.shard_plain_stats(0) for e in engines]
+    else:
+        for r, e in enumerate(engines):
+            e.scan(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], probes_all=p_all)
     homes = []
     if exchange in ("filtered", "filtered-regions"):
         bounds = [torch.zeros(nq, dtype=torch.uint8, device="cuda") for _ in range(world)]
         for r, e in enumerate(engines):
             e.bound(0, qn_t, k, n_probes, pass_1, capacity, sends[r].view(-1), bounds[r])
         b_all = torch.stack(bounds).min(dim=0).values.contiguous()             # all-reduce(MIN)
+        if b_red is not None:       # the first lists were scored exactly: the same bound either way
+            assert torch.equal(b_all, b_red)
         assert (torch.stack(bounds) != 255).sum(dim=0).le(1).all()             # one owner per query
         if stats is not None:
             stats["bound"] = b_all.cpu().numpy()
@@ -148,6 +166,50 @@ def test_sharded_filtered_golden(tag, world, coarse):
                 assert flags.any() != ok
                 if ok:
                     np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_two_phase_scan_on_the_matrix_cores(world):
+    """tk_index_shard_scan_first_dev / _rest_dev: first lists exactly, their bound min-reduced, the
+    lists behind them on the plain kernel for the queries whose bound allows — golden ids for both
+    exchanges; with repeating labels only on request (tk_index_set_plain_scan(ix, 2)), same ids."""
+    from test_hip_parity import ivf_from_fixture
+    from tinyknn_amd.multi_gpu import _HipShardEngine, shard_lists
+    for tag in ("an100", "eu128", "an100b2"):
+        g = golden(f"g6_ivf_{tag}.npz")
+        ivf = ivf_from_fixture(None, g)
+        sizes = np.array([0 if isinstance(t, np.ndarray) else t.size
+                          for t in ivf.pq_transformed_points[:ivf.active_centers.shape[0]]], dtype=np.int64)
+        owner = shard_lists(sizes, world)
+        for n_probes in (5, 10):
+            for exchange in ("dense", "filtered-regions"):
+                engines = [_HipShardEngine(ivf, owner, r, world, 1) for r in range(world)]
+                if tag.endswith("b2"):
+                    assert not engines[0].plain_ok(10, n_probes, None)      # repeating labels: on request only
+                    for e in engines:
+                        e.dev.set_plain_scan("always")
+                assert engines[0].plain_ok(10, n_probes, None)
+                assert not engines[0].plain_ok(10, 1, None)                 # one list: nothing behind it
+                st = {}
+                ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, owner=owner,
+                                               engines=engines, exchange=exchange, stats=st)
+                assert st.get("two_phase") and not flags.any()
+                np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+                nq_ = len(g["qn"])
+                assert all(p_["plain_queries"] == st["plain"][0]["plain_queries"] for p_ in st["plain"])
+                # (the fixtures' lists are shorter than the default heap: few bounds are low enough here —
+                #  the small heaps below send most queries the plain way)
+                assert sum(p_["plain_pairs"] for p_ in st["plain"]) == st["plain"][0]["plain_queries"] * (n_probes - 1)
+                for pass_1 in (3, 40):      # small heaps: low bounds, most queries plain; both ways
+                    st = {}
+                    a, _, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1,
+                                             owner=owner, exchange=exchange, stats=st)
+                    if not tag.endswith("b2"):
+                        assert pass_1 != 3 or st["plain"][0]["plain_queries"] >= nq_ // 2, st["plain"]
+                    b, _, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1,
+                                             owner=owner, exchange=exchange, plain=False)
+                    if not tag.endswith("b2"):
+                        np.testing.assert_array_equal(a, b)
 
 
 def test_sharded_overflow_is_flagged_and_harmless():

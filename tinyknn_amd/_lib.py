@@ -82,6 +82,13 @@ SIGNATURES = {
     "tk_index_shard_finish_filtered_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
                                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_shard_plain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tk_index_shard_scan_first_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_shard_scan_rest_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                               C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_shard_plain_stats": (C.c_int, [C.c_void_p, C.c_int, _i64p]),
     "tk_index_shard_filter_regions_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -932,13 +932,8 @@ __global__ void pairs_fill3_kernel(const int64_t *__restrict__ probes, int S, in
     }
 }
 
-void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
-                           const int64_t *list_chunk_off, const int *slot_prefix,
-                           const int *slot_exact, const TkPairSet &ex, const TkPairSet &pl,
-                           const TkPairSet &hd, int head_chunks, hipStream_t s)
+static PairSets pair_sets(const TkPairSet &ex, const TkPairSet &pl, const TkPairSet &hd)
 {
-    if (nq == 0 || S == 0) return;
-    const int64_t np = nq * S;
     PairSets ps;
     const TkPairSet *sets[3] = {&ex, &pl, &hd};
     for (int i = 0; i < 3; i++) {
@@ -946,6 +941,25 @@ void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_l
         ps.unit_prefix[i] = sets[i]->unit_prefix; ps.pair_q[i] = sets[i]->pair_q; ps.pair_f0[i] = sets[i]->pair_f0;
     }
     ps.unit_desc = pl.unit_desc;
+    return ps;
+}
+
+void tk_launch_pairs_scan3(const TkPairSet &ex, const TkPairSet &pl, const TkPairSet &hd,
+                           const int64_t *list_chunk_off, int64_t n_lists, int head_chunks,
+                           hipStream_t s)
+{
+    hipLaunchKernelGGL(pairs_scan3_kernel, dim3(1), dim3(1024), 0, s, pair_sets(ex, pl, hd),
+                       list_chunk_off, (int)n_lists, head_chunks);
+}
+
+void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
+                           const int64_t *list_chunk_off, const int *slot_prefix,
+                           const int *slot_exact, const TkPairSet &ex, const TkPairSet &pl,
+                           const TkPairSet &hd, int head_chunks, hipStream_t s)
+{
+    if (nq == 0 || S == 0) return;
+    const int64_t np = nq * S;
+    PairSets ps = pair_sets(ex, pl, hd);
     hipLaunchKernelGGL(pairs_scan3_kernel, dim3(1), dim3(1024), 0, s, ps, list_chunk_off, (int)n_lists,
                        head_chunks);
     hipLaunchKernelGGL(pairs_fill3_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, probes, S,

@@ -561,10 +561,12 @@ struct Work {
         u_pair_off, u_unit_prefix, u_pair_q, u_pair_f0, c_pair_off, c_unit_prefix, c_pair_q,
         c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage, pos_lens, pos_off,
         qlim, slot_exact, p_count, p_cursor, p_pair_off, p_unit_prefix, p_pair_q, p_pair_f0, flag_list, p_unit_desc,
-        plain0, h_count, h_cursor, h_pair_off, h_unit_prefix, h_pair_q, h_pair_f0;   // plain_scan.hip
+        plain0, h_count, h_cursor, h_pair_off, h_unit_prefix, h_pair_q, h_pair_f0,   // plain_scan.hip
+        plain_q;                                                                       // two-phase sharded scan
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
+    bool shard_first = false;       // tk_index_shard_scan_first_dev ran: _rest_dev is owed
     // pipelined mode (depth > 1): hand-offs between the caller's stream and a latency stream
     hipEvent_t tables_done = nullptr, coarse_scanned = nullptr, front_done = nullptr,
                scanned = nullptr, done = nullptr;
@@ -1992,6 +1994,224 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     w.shard_nq = nq;
     w.shard_capacity = capacity;
     HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+// ---- the same scan in two phases, the second on the matrix cores (plain_scan.hip) ----
+// tk_index_shard_scan_dev scores every owned (query, list) segment with the exact kernel.  The
+// plain kernel is 3 x faster, and exact for a query from the point where its heap's bound is at
+// most the limit C of its table — and B1, the bound after the query's FIRST probed list, is a
+// number every rank can know before it scans the rest: the owner of that list replays it by value
+// (shard_first_bound_kernel, the filtered exchange's), a 1-byte MIN all-reduce spreads it.  So:
+//   tk_index_shard_scan_first_dev   as _scan_dev up to the positions; exact scan of the FIRST
+//                                   slots this rank owns into send_dev; bound_dev[nq] = B1 of the
+//                                   queries whose first list it owns, 255 elsewhere
+//   all-reduce(MIN, uint8)          by the caller
+//   tk_index_shard_scan_rest_dev    the slots behind the first: of the queries with B1 <= C on the
+//                                   plain kernel, of the others on the exact one — no query is
+//                                   ever scanned twice and nothing has to be repaired afterwards:
+//                                   the replay at home (tk_index_shard_finish_dev, or the filtered
+//                                   exchange with this very bound) is the reference's by the lemma
+// tk_index_shard_plain: does this apply to (k, n_probes, pass_1)?  Replicated state only (every
+// rank answers alike): M <= 52, n_probes >= 2, distinct labels (or tk_index_set_plain_scan(ix, 2)),
+// not switched off.  Otherwise callers use tk_index_shard_scan_dev.
+static bool shard_plain_possible(const tk_index *ix, const Plan &p)
+{
+    if (ix->plain_mode == 1 || !plain_env_on() || !ix->sharded || p.S < 2 || !tk_plain_fits(ix->M)) return false;
+    return ix->ids_unique || ix->plain_mode == 2;
+}
+
+extern "C" int tk_index_shard_plain(tk_index *ix, int k, int n_probes, int pass_1)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    return shard_plain_possible(ix, p) ? 1 : 0;
+}
+
+static int reserve_shard_plain(tk_index *ix, Work &w, int64_t nq, const Plan &p)
+{
+    const size_t L = (size_t)ix->n_lists;
+    TRY(w.qlim.ensure((size_t)nq * 4));
+    TRY(w.plain_q.ensure((size_t)nq + 16));
+    DevBuf *zeroed[] = {&w.p_count, &w.h_count};
+    for (DevBuf *b : zeroed) {
+        const void *before = b->p;
+        TRY(b->ensure(L * 4));
+        if (b->p != before) HIPCHECK(hipMemset(b->p, 0, b->cap));
+    }
+    TRY(w.p_cursor.ensure(L * 4));
+    TRY(w.p_pair_off.ensure((L + 1) * 4));
+    TRY(w.p_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
+    TRY(w.p_pair_q.ensure(((size_t)nq * p.S + 4) * 4));
+    TRY(w.p_pair_f0.ensure(((size_t)nq * p.S + 4) * 4));
+    TRY(w.p_unit_desc.ensure(((size_t)nq * p.S / 32 + L + 8) * 8));
+    TRY(w.h_cursor.ensure(L * 4));
+    TRY(w.h_pair_off.ensure((L + 1) * 4));
+    TRY(w.h_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
+    TRY(w.h_pair_q.ensure((4 * L + 4) * 4));
+    TRY(w.h_pair_f0.ensure((4 * L + 4) * 4));
+    return TK_OK;
+}
+
+extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float *q_dev,
+                                             const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
+                                             int n_probes, int pass_1, const int64_t *probes_all_dev,
+                                             int64_t capacity, void *send_dev, int *flag_dev,
+                                             uint8_t *bound_dev, void *stream)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, capacity, p, qh));
+    ARGCHECK(send_dev && flag_dev && bound_dev, "send/flag/bound buffers");
+    ARGCHECK(shard_plain_possible(ix, p), "tk_index_shard_plain says no: use tk_index_shard_scan_dev");
+    Work &w = ix->works[(size_t)slot];
+    hipStream_t st = (hipStream_t)stream;
+    TRY(reserve_shard(ix, w, nq, qh, p));
+    TRY(reserve_shard_plain(ix, w, nq, p));
+    TRY(w.smins.ensure((size_t)ix->world * capacity + 16));
+    TRY(w.usage.ensure((size_t)ix->world * 2 * 8));
+    Prof pf;
+    const int *owner = ix->owner.as<int>();
+    const int64_t *probes = probes_all_dev;
+    if (probes) {
+        coarse_slots(ix, w, probes, nq, p, nullptr, owner, ix->rank, st);
+    } else {
+        TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
+        launch_coarse_scan(ix, w, nq, p, st);
+        TRY(stage_coarse_rest(ix, w, q_dev, nq, p, nullptr, owner, ix->rank, st, pf));
+        probes = w.probes.as<int64_t>();
+    }
+    // the limits C of all nq tables (built by _shard_coarse_dev or just above)
+    tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st);
+    {
+        const int64_t n1 = nq * p.S + (int64_t)ix->world * qh * p.S + 1;
+        ARGCHECK(n1 < (1ll << 31), "too many (query, list) entries for one sharded batch");
+        TRY(w.pos_lens.ensure((size_t)n1 * 8));
+        TRY(w.pos_off.ensure((size_t)n1 * 8));
+        size_t tmp_bytes = 0;
+        ARGCHECK(tk_scan_exclusive64(nullptr, &tmp_bytes, w.pos_lens.as<long long>(),
+                                     w.pos_off.as<long long>(), n1, st) == 0,
+                 "hipcub scan (size query) failed");
+        TRY(w.scan_tmp.ensure(tmp_bytes + 16));
+        if (tk_launch_shard_positions(probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists, owner,
+                                      ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
+                                      w.rpos.as<int>(), flag_dev, w.usage.as<long long>(),
+                                      w.pos_lens.as<long long>(), w.pos_off.as<long long>(),
+                                      w.scan_tmp.p, tmp_bytes, st))
+            return fail(TK_ERR_HIP, "hipcub scan failed");
+    }
+    // first slots: exact, straight into the send buffer
+    tk_launch_shard_count_first(probes, p.S, nq, ix->n_lists, owner, ix->rank, w.u_count.as<int>(), st);
+    tk_launch_pairs_scan(w.u_count.as<int>(), ix->local_chunk_off.as<int64_t>(), ix->n_lists,
+                         w.u_pair_off.as<int>(), w.u_unit_prefix.as<int>(), w.u_cursor.as<int>(),
+                         w.u_pair_q.as<int>(), st);
+    tk_launch_shard_pairs_fill(probes, p.S, nq, ix->n_lists, owner, ix->rank, w.spos.as<int>(),
+                               w.u_pair_off.as<int>(), w.u_cursor.as<int>(), w.u_pair_q.as<int>(),
+                               w.u_pair_f0.as<int>(), st, 0, 1);
+    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
+                         ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
+                         w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
+                         (uint4 *)send_dev, 0, w.smins.as<uint8_t>(), 0, 1, ix->order, 768, st);
+    w.shard_probes = probes;
+    w.shard_nq = nq;
+    w.shard_capacity = capacity;
+    w.shard_first = true;
+    // B1 of the queries whose first list lies here (ivf.py:137-152 over that list alone, by value)
+    tk_launch_shard_first_bound(probes, w.slot_prefix.as<int>(), w.slot_n.as<int>(), p.S, nq,
+                                ix->n_lists, owner, ix->rank, w.spos.as<int>(), (const uint4 *)send_dev,
+                                w.smins.as<uint8_t>(), p.R, bound_dev, st);
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+extern "C" int tk_index_shard_scan_rest_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
+                                            int pass_1, int64_t capacity, void *send_dev,
+                                            const uint8_t *bound_dev, void *stream)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, capacity, p, qh));
+    ARGCHECK(send_dev && bound_dev, "send/bound buffers");
+    Work &w = ix->works[(size_t)slot];
+    ARGCHECK(w.shard_first && w.shard_probes && w.shard_nq == nq && w.shard_capacity == capacity,
+             "tk_index_shard_scan_first_dev of this slot (same nq and capacity) comes first");
+    w.shard_first = false;
+    hipStream_t st = (hipStream_t)stream;
+    const int *owner = ix->owner.as<int>();
+    const int64_t *probes = w.shard_probes;
+    // a segment that overflowed its region is scored by the plain kernel to the tail of the
+    // buffer (the batch is repeated anyway): the longest list must fit there
+    const int64_t tail = (int64_t)ix->world * capacity - ix->max_list_chunks;
+    const int allow = tail >= 0 ? 1 : 0;
+    tk_launch_shard_count_rest(probes, p.S, nq, ix->n_lists, owner, ix->rank, bound_dev,
+                               w.qlim.as<int>(), allow, w.plain_q.as<uint8_t>(), w.u_count.as<int>(),
+                               w.p_count.as<int>(), st);
+    TkPairSet ex{w.u_count.as<int>(), w.u_cursor.as<int>(), w.u_pair_off.as<int>(),
+                 w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>()};
+    TkPairSet pl{w.p_count.as<int>(), w.p_cursor.as<int>(), w.p_pair_off.as<int>(),
+                 w.p_unit_prefix.as<int>(), w.p_pair_q.as<int>(), w.p_pair_f0.as<int>(),
+                 w.p_unit_desc.as<int>()};
+    TkPairSet hd{w.h_count.as<int>(), w.h_cursor.as<int>(), w.h_pair_off.as<int>(),
+                 w.h_unit_prefix.as<int>(), w.h_pair_q.as<int>(), w.h_pair_f0.as<int>()};   // (stays empty)
+    tk_launch_pairs_scan3(ex, pl, hd, ix->local_chunk_off.as<int64_t>(), ix->n_lists, 0, st);
+    tk_launch_shard_pairs_fill(probes, p.S, nq, ix->n_lists, owner, ix->rank, w.spos.as<int>(),
+                               w.u_pair_off.as<int>(), w.u_cursor.as<int>(), w.u_pair_q.as<int>(),
+                               w.u_pair_f0.as<int>(), st, 1, p.S, w.plain_q.as<uint8_t>(), 0);
+    tk_launch_shard_pairs_fill(probes, p.S, nq, ix->n_lists, owner, ix->rank, w.spos.as<int>(),
+                               w.p_pair_off.as<int>(), w.p_cursor.as<int>(), w.p_pair_q.as<int>(),
+                               w.p_pair_f0.as<int>(), st, 1, p.S, w.plain_q.as<uint8_t>(), 1,
+                               (int)(tail > 0 ? tail : 0));
+    TkScanJob pj;
+    pj.codes = ix->codes.as<uint4>();
+    pj.tables = w.tables.as<uint4>();
+    pj.list_chunk_off = ix->local_chunk_off.as<int64_t>();
+    pj.n_lists = (int)ix->n_lists;
+    pj.unit_prefix = w.p_unit_prefix.as<int>();
+    pj.pair_off = w.p_pair_off.as<int>();
+    pj.pair_q = w.p_pair_q.as<int>();
+    pj.pair_f0 = w.p_pair_f0.as<int>();
+    pj.unit_desc = w.p_unit_desc.as<int>();
+    pj.dist = (uint4 *)send_dev;
+    pj.cap = 0;
+    pj.mins = w.smins.as<uint8_t>();
+    pj.min_stride = 0;
+    if (tk_launch_scan_plain(pj, ix->M, ix->order, plain_blocks(), st))
+        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
+    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
+                         ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
+                         w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
+                         (uint4 *)send_dev, 0, w.smins.as<uint8_t>(), 0, 1, ix->order, 768, st);
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+// Books of the slot's last tk_index_shard_scan_rest_dev (synchronises): out4 = (query, list) pairs
+// this rank scored on the plain kernel, tiles of 32 of them, pair records of the exact kernel for
+// the slots behind the first (padded to groups of 4), queries (of all nq) that went the plain way.
+extern "C" int tk_index_shard_plain_stats(tk_index *ix, int slot, int64_t *out4)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix && ix->sharded && out4, "sharded index and an output buffer");
+    ARGCHECK(slot >= 0 && slot < ix->depth, "slot must be < the pipeline depth");
+    Work &w = ix->works[(size_t)slot];
+    for (int i = 0; i < 4; i++) out4[i] = 0;
+    if (!w.p_pair_off.p || !w.plain_q.p || !w.shard_probes || w.shard_first) return TK_OK;
+    HIPCHECK(hipDeviceSynchronize());
+    const int64_t L = ix->n_lists;
+    int v[3] = {0, 0, 0};
+    HIPCHECK(hipMemcpy(&v[0], w.p_pair_off.as<int>() + L, 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&v[1], w.p_unit_prefix.as<int>() + L, 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&v[2], w.u_pair_off.as<int>() + L, 4, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> pq((size_t)w.shard_nq);
+    HIPCHECK(hipMemcpy(pq.data(), w.plain_q.p, pq.size(), hipMemcpyDeviceToHost));
+    int64_t n = 0;
+    for (uint8_t b : pq) n += b != 0;
+    out4[0] = v[0]; out4[1] = v[1]; out4[2] = v[2]; out4[3] = n;
     return TK_OK;
 }
 

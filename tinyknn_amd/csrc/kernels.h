@@ -225,7 +225,20 @@ int tk_launch_shard_positions(const int64_t *probes, const int *slot_prefix, int
                               hipStream_t s);
 void tk_launch_shard_pairs_fill(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
                                 const int *owner, int me, const int *spos, const int *pair_off,
-                                int *cursor, int *pair_q, int *pair_f0, hipStream_t s);
+                                int *cursor, int *pair_q, int *pair_f0, hipStream_t s, int s_lo = 0,
+                                int s_hi = 0x7fffffff, const uint8_t *sel = nullptr, int want = 0,
+                                int ovf_pos = -1);
+// two-phase scan: pairs per list of the first slots; of the slots behind them by kernel (plain_q)
+void tk_launch_shard_count_first(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
+                                 const int *owner, int me, int *count, hipStream_t s);
+void tk_launch_shard_count_rest(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
+                                const int *owner, int me, const uint8_t *bound, const int *qlim,
+                                int allow, uint8_t *plain_q, int *count_exact, int *count_plain,
+                                hipStream_t s);
+// the exclusive scans of tk_launch_unit_pairs2 alone (the caller fills the records)
+void tk_launch_pairs_scan3(const TkPairSet &ex, const TkPairSet &pl, const TkPairSet &hd,
+                           const int64_t *list_chunk_off, int64_t n_lists, int head_chunks,
+                           hipStream_t s);
 // slot_prefix: rows of the home queries; dist/mins: (nq_home, cap) / (nq_home, min_stride)
 void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_prefix, int S,
                             int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,

@@ -138,27 +138,99 @@ __global__ void shard_pairs_fill_kernel(const int64_t *__restrict__ probes, int 
                                         int64_t n_lists, const int *__restrict__ owner, int me,
                                         const int *__restrict__ spos,
                                         const int *__restrict__ pair_off, int *__restrict__ cursor,
-                                        int *__restrict__ pair_q, int *__restrict__ pair_f0)
+                                        int *__restrict__ pair_q, int *__restrict__ pair_f0,
+                                        int s_lo, int s_hi, const uint8_t *__restrict__ sel, int want,
+                                        int ovf_pos)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * S) return;
+    const int64_t q = i / S;
+    const int sl = (int)(i - q * S);
+    if (sl < s_lo || sl >= s_hi) return;             // (two-phase scan: first lists, then the rest)
+    if (sel && (int)sel[q] != want) return;          // ... the rest by kernel: exact / plain
     int64_t cl = probes[i];
     if (cl < 0) cl += n_lists;
     if (owner[cl] != me) return;
     const int pos = atomicAdd(&cursor[cl], 1);
     const int p = spos[i];
-    pair_q[pair_off[cl] + pos] = p >= 0 ? (int)(i / S) : -1;
-    pair_f0[pair_off[cl] + pos] = p >= 0 ? p : 0;
+    // a segment that did not fit its region (the batch is flagged and repeated): a padding record
+    // for the exact kernel; the plain kernel has none — it scores the pair to ovf_pos, the tail of
+    // the buffer, where the longest list fits
+    if (ovf_pos >= 0) {
+        pair_q[pair_off[cl] + pos] = (int)q;
+        pair_f0[pair_off[cl] + pos] = p >= 0 ? p : ovf_pos;
+    } else {
+        pair_q[pair_off[cl] + pos] = p >= 0 ? (int)q : -1;
+        pair_f0[pair_off[cl] + pos] = p >= 0 ? p : 0;
+    }
 }
 
 void tk_launch_shard_pairs_fill(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
                                 const int *owner, int me, const int *spos, const int *pair_off,
-                                int *cursor, int *pair_q, int *pair_f0, hipStream_t s)
+                                int *cursor, int *pair_q, int *pair_f0, hipStream_t s, int s_lo,
+                                int s_hi, const uint8_t *sel, int want, int ovf_pos)
 {
     const int64_t np = nq * S;
     if (np == 0) return;
     hipLaunchKernelGGL(shard_pairs_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
-                       probes, S, nq, n_lists, owner, me, spos, pair_off, cursor, pair_q, pair_f0);
+                       probes, S, nq, n_lists, owner, me, spos, pair_off, cursor, pair_q, pair_f0,
+                       s_lo, s_hi, sel, want, ovf_pos);
+}
+
+// ---- two-phase scan (tk_index_shard_scan_first_dev / _rest_dev): pairs per list of the first slots ...
+__global__ void shard_count_first_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
+                                         int64_t n_lists, const int *__restrict__ owner, int me,
+                                         int *__restrict__ count)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int64_t cl = probes[q * S];
+    if (cl < 0) cl += n_lists;
+    if (owner[cl] == me) atomicAdd(&count[cl], 1);
+}
+
+// ... and of the slots behind them, by kernel.  plain_q[q] = 1: the bound after the query's first
+// list — min-reduced over the ranks, the same byte everywhere — is at most the table's limit
+// (plain_scan.hip's lemma: from there on the replay over clamp(plain sums) IS the replay over the
+// reference's values), so every rank scores its lists of that query on the matrix cores; else exactly.
+__global__ void shard_count_rest_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
+                                        int64_t n_lists, const int *__restrict__ owner, int me,
+                                        const uint8_t *__restrict__ bound, const int *__restrict__ qlim,
+                                        int allow, uint8_t *__restrict__ plain_q,
+                                        int *__restrict__ count_exact, int *__restrict__ count_plain)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    bool wrapped = false;
+    for (int sl = 0; sl < S; sl++) wrapped |= probes[q * S + sl] < 0;
+    const int b = (int)(int8_t)(bound[q] ^ 0x80u);             // (order key -> the distance byte)
+    const int lim = qlim[q];
+    const bool pl = allow && !wrapped && lim != TK_PLAIN_NEVER && b <= lim;
+    plain_q[q] = pl ? 1 : 0;
+    for (int sl = 1; sl < S; sl++) {
+        int64_t cl = probes[q * S + sl];
+        if (cl < 0) cl += n_lists;
+        if (owner[cl] == me) atomicAdd(pl ? &count_plain[cl] : &count_exact[cl], 1);
+    }
+}
+
+void tk_launch_shard_count_first(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
+                                 const int *owner, int me, int *count, hipStream_t s)
+{
+    if (nq == 0 || S == 0) return;
+    hipLaunchKernelGGL(shard_count_first_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+                       probes, S, nq, n_lists, owner, me, count);
+}
+
+void tk_launch_shard_count_rest(const int64_t *probes, int S, int64_t nq, int64_t n_lists,
+                                const int *owner, int me, const uint8_t *bound, const int *qlim,
+                                int allow, uint8_t *plain_q, int *count_exact, int *count_plain,
+                                hipStream_t s)
+{
+    if (nq == 0 || S == 0) return;
+    hipLaunchKernelGGL(shard_count_rest_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+                       probes, S, nq, n_lists, owner, me, bound, qlim, allow, plain_q, count_exact,
+                       count_plain);
 }
 
 // Received segments -> the home queries' distance rows (the layout the replay kernels

@@ -462,6 +462,35 @@ class DeviceIndex:
             self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0), records_ptr,
             int(n_records), out_ptr, flag_ptr, stream))
 
+    def shard_plain(self, k, n_probes, pass_1=None):
+        """Does the two-phase scan with the matrix-core kernel apply (tk_index_shard_plain)?"""
+        r = _lib.lib().tk_index_shard_plain(self._h, int(k), int(n_probes), int(pass_1 or 0))
+        if r < 0:
+            _lib.check(r)
+        return bool(r)
+
+    def shard_scan_first_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1, capacity,
+                             send_ptr, flag_ptr, bound_ptr, stream=0, probes_all_ptr=None):
+        """Phase 1 of the two-phase sharded scan: first slots exactly + their bound
+        (tk_index_shard_scan_first_dev); the caller min-reduces the bound over the ranks."""
+        _lib.check(_lib.lib().tk_index_shard_scan_first_dev(
+            self._h, int(slot), qn_ptr, qpq_ptr, int(bool(qpq_is_f64)), nq, int(k), int(n_probes),
+            int(pass_1 or 0), probes_all_ptr, int(capacity), send_ptr, flag_ptr, bound_ptr, stream))
+
+    def shard_scan_rest_dev(self, slot, nq, k, n_probes, pass_1, capacity, send_ptr, bound_ptr, stream=0):
+        """Phase 2: the slots behind the first, on the plain kernel where the reduced bound allows
+        (tk_index_shard_scan_rest_dev)."""
+        _lib.check(_lib.lib().tk_index_shard_scan_rest_dev(
+            self._h, int(slot), nq, int(k), int(n_probes), int(pass_1 or 0), int(capacity), send_ptr,
+            bound_ptr, stream))
+
+    def shard_plain_stats(self, slot=0):
+        """What the slot's last two-phase scan did on this rank (tk_index_shard_plain_stats)."""
+        o = np.zeros(4, dtype=np.int64)
+        _lib.check(_lib.lib().tk_index_shard_plain_stats(self._h, int(slot), _lib.ptr(o, _lib._i64p)))
+        return dict(plain_pairs=int(o[0]), plain_tiles=int(o[1]), exact_pair_records_behind_first=int(o[2]),
+                    plain_queries=int(o[3]))
+
     def shard_filter_regions_dev(self, slot, nq, k, n_probes, pass_1, capacity, scan_ptr, bound_ptr,
                                  counts_ptr, records_ptr, region, flag_ptr, acc_ptr=None, stream=0):
         """... into fixed regions of `region` records per home rank (tk_index_shard_filter_regions_dev)."""

@@ -155,6 +155,24 @@ class _HipShardEngine:
                                 flag.data_ptr(), stream=st,
                                 probes_all_ptr=None if probes_all is None else probes_all.data_ptr())
 
+    # the scan in two phases, the second on the matrix cores (tk_index_shard_scan_first_dev / _rest_dev)
+    def plain_ok(self, k, n_probes, pass_1):
+        return self.dev.shard_plain(k, n_probes, pass_1)
+
+    def scan_first(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, bound, probes_all=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_scan_first_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
+                                      qn.shape[0], k, n_probes, pass_1, capacity, send.data_ptr(),
+                                      flag.data_ptr(), bound.data_ptr(), stream=st,
+                                      probes_all_ptr=None if probes_all is None else probes_all.data_ptr())
+
+    def scan_rest(self, slot, qn, k, n_probes, pass_1, capacity, send, bound):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_scan_rest_dev(slot, qn.shape[0], k, n_probes, pass_1, capacity, send.data_ptr(),
+                                     bound.data_ptr(), stream=st)
+
     def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home):
         import torch
         st = torch.cuda.current_stream().cuda_stream
@@ -232,12 +250,18 @@ class ListShardedIndex:
     batch's overflow flag, handled as for `capacity`.  `counts="host"`: exact variable splits, one
     host synchronisation per batch (the round-2 form).
 
+    `plain=True` (default; where the engine has scan_first / scan_rest and says plain_ok): the scan
+    in two phases — the first probed lists exactly, their bound B1 min-reduced over the ranks (one
+    byte per query; the same reduction the filtered exchange needs, which then does not repeat it),
+    the lists behind them on the int8 matrix cores for every query whose B1 is at most the limit of
+    its table (plain_scan.hip's lemma), exactly for the others.  Same ids.
+
     `engine`: object with coarse/scan/finish (default: the HIP engine); tests inject a CPU one.
     """
 
     def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None,
                  coarse="home", coalesce=1, exchange="dense", calibrate=True, force_collectives=None,
-                 counts="device"):
+                 counts="device", plain=True):
         import os
         import torch
         import torch.distributed as dist
@@ -288,10 +312,12 @@ class ListShardedIndex:
                                        hasattr(self.engine, "finish_regions")):
             counts = "host"
         self.counts = counts
+        self.plain = bool(plain) and all(hasattr(self.engine, a) for a in ("plain_ok", "scan_first", "scan_rest"))
         self.record_region = {}     # (nq, n_probes) -> records per home-rank region (counts="device")
         self._rec_seen = {}         # ... largest per-home count of the batches looked at so far
         self._acc = None            # device: [largest per-home record count, records, dense blocks] since reset
         self._acc_keys = set()
+        self._plain_ok = {}
         self.capacity = {}          # (nq, n_probes) -> uint4 per region, grows on overflow
         self._bufs = {}
         self._pbufs = {}
@@ -420,18 +446,20 @@ class ListShardedIndex:
         r = self.record_region.get((nq, n_probes))
         return int(capacity if r is None else min(r, capacity))
 
-    def _filtered_regions(self, slot, qn, k, n_probes, pass_1, capacity, b, out_home):
+    def _filtered_regions(self, slot, qn, k, n_probes, pass_1, capacity, b, out_home, bound=None):
         """The whole filtered exchange, enqueued: bound -> min all-reduce -> filter into fixed
         regions -> all-to-all of the counts and (equal splits) of the regions -> finish."""
         W, t = self.world, self.torch
         nq = qn.shape[0]
         region = self._region(nq, n_probes, capacity)
         f = self._filtered_buffers(slot, nq, capacity, region)
-        self.engine.bound(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"])
-        self._all_reduce_min(f["bound"])
+        if bound is None:       # (the two-phase scan has reduced it already)
+            self.engine.bound(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"])
+            self._all_reduce_min(f["bound"])
+            bound = f["bound"]
         if self._acc is None:       # [largest per-home count, records, blocks scored]: atomics in the filter
             self._acc = t.zeros(3, dtype=t.int64, device=self.device)
-        self.engine.filter_regions(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"],
+        self.engine.filter_regions(slot, qn, k, n_probes, pass_1, capacity, b["send"], bound,
                                    f["counts"], f["rec"], region, b["flag"], self._acc)
         if W == 1 and not self.force:       # one rank: nothing travels, the regions are read where they lie
             rrec, rcounts = f["rec"], f["counts"]
@@ -473,13 +501,15 @@ class ListShardedIndex:
         keys, self._acc_keys = self._acc_keys, set()
         return self._max_over_ranks(v), keys
 
-    def _filtered_front(self, slot, qn, k, n_probes, pass_1, capacity, b):
+    def _filtered_front(self, slot, qn, k, n_probes, pass_1, capacity, b, bound=None):
         """bound -> min all-reduce -> filter -> all-to-all of the counts (all enqueued)."""
         W = self.world
         f = self._filtered_buffers(slot, qn.shape[0], capacity)
-        self.engine.bound(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"])
-        self._all_reduce_min(f["bound"])
-        self.engine.filter(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"],
+        if bound is None:       # (the two-phase scan has reduced it already)
+            self.engine.bound(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"])
+            self._all_reduce_min(f["bound"])
+            bound = f["bound"]
+        self.engine.filter(slot, qn, k, n_probes, pass_1, capacity, b["send"], bound,
                            f["counts"], f["rec"])
         self._all_to_all(f["rcounts"], f["counts"][:W])
         return f
@@ -512,6 +542,31 @@ class ListShardedIndex:
                 flag=mk(1, t.int32), home=mk(qh * k + 1, t.int64), all=mk(W * (qh * k + 1), t.int64)))
         return self._bufs[slot][1]
 
+    def _use_plain(self, k, n_probes, pass_1):
+        """Two-phase scan for these arguments?  (replicated state only: the same on every rank)"""
+        if not self.plain:
+            return False
+        key = (k, n_probes, pass_1)
+        if key not in self._plain_ok:
+            self._plain_ok[key] = bool(self.engine.plain_ok(k, n_probes, pass_1))
+        return self._plain_ok[key]
+
+    def _scan(self, slot, qn, qp, k, n_probes, pass_1, capacity, b, probes_all=None):
+        """The scan of the owned segments into b["send"]; returns the min-reduced bound after the
+        first probed lists (two-phase form) or None."""
+        if not self._use_plain(k, n_probes, pass_1):
+            self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"],
+                             probes_all=probes_all)
+            return None
+        nq = qn.shape[0]
+        if b.get("bound") is None or b["bound"].shape[0] != nq:
+            b["bound"] = self.torch.empty(nq, dtype=self.torch.uint8, device=self.device)
+        self.engine.scan_first(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"],
+                               b["bound"], probes_all=probes_all)
+        self._all_reduce_min(b["bound"])
+        self.engine.scan_rest(slot, qn, k, n_probes, pass_1, capacity, b["send"], b["bound"])
+        return b["bound"]
+
     def _probe_buffers(self, slot, nq, n_probes):
         kc = min(n_probes, len(self.list_sizes))
         key = (nq, kc)
@@ -540,17 +595,16 @@ class ListShardedIndex:
             p_home, p_all = self._probe_buffers(slot, nq, n_probes)
             self.engine.coarse(slot, qn, qp, k, n_probes, pass_1, p_home)
             self._all_gather(p_all, p_home)
-            self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"],
-                             probes_all=p_all)
+            bound = self._scan(slot, qn, qp, k, n_probes, pass_1, capacity, b, probes_all=p_all)
         else:
-            self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"])
+            bound = self._scan(slot, qn, qp, k, n_probes, pass_1, capacity, b)
         st = dict(slot=slot, qn=qn, k=k, n_probes=n_probes, pass_1=pass_1, capacity=capacity, b=b,
                   out=b["all"].view(self.world, qh * k + 1), f=None)
         if self._exchange_kind(k, n_probes, pass_1) == "filtered" and self.counts == "device":
-            self._filtered_regions(slot, qn, k, n_probes, pass_1, capacity, b, b["home"][:qh * k])
+            self._filtered_regions(slot, qn, k, n_probes, pass_1, capacity, b, b["home"][:qh * k], bound)
             self._gather_ids(b, qh, k)
         elif self._exchange_kind(k, n_probes, pass_1) == "filtered":
-            st["f"] = self._filtered_front(slot, qn, k, n_probes, pass_1, capacity, b)
+            st["f"] = self._filtered_front(slot, qn, k, n_probes, pass_1, capacity, b, bound)
         else:
             recv = b["send"]            # one rank: nothing travels, the segments are read where they lie
             if self.world > 1 or self.force:
@@ -736,7 +790,7 @@ class ListShardedIndex:
         with t.cuda.stream(R["scan"]):
             if self.coarse != "home":
                 b["flag"].zero_()
-            self.engine.scan(slot, qn, qp, k, n_probes, pass_1, cap, b["send"], b["flag"], probes_all=p_all)
+            self._scan(slot, qn, qp, k, n_probes, pass_1, cap, b, probes_all=p_all)
             scanned = t.cuda.Event()
             scanned.record(R["scan"])
         rs = R["replay"][n % 2]
