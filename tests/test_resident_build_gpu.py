@@ -247,7 +247,8 @@ def test_reduced_c5_lists_far_longer_than_the_heap(oracle, tmp_path):
             np.testing.assert_array_equal(w["heap_idx"], dbg["heap_idx"][i])
             np.testing.assert_array_equal(w["heap_val"], dbg["heap_val"][i])
         st = dev.plain_stats()
-        assert st["plain_units"] > 0 and st["head_pair_records"] >= nq // 2     # the matrix-core path ran
+        # (n_probes = 3: 4 pairs per list — such a batch goes to the query-major kernel, not the plain one)
+        assert n_probes != 10 or (st["plain_units"] > 0 and st["head_pair_records"] >= nq // 2), st
         # batches in flight
         dev.set_pipeline(2)
         q_dev, qp_dev = torch.from_numpy(qn).cuda(), torch.from_numpy(np.ascontiguousarray(qp)).cuda()

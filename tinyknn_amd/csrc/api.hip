@@ -3135,7 +3135,7 @@ extern "C" int tk_index_plain_stats(tk_index *ix, int64_t *out8)
     for (int i = 0; i < 8; i++) out8[i] = 0;
     TRY(flush_pending(ix));
     HIPCHECK(hipDeviceSynchronize());
-    plain_poll(ix);
+    if (plain_adaptive(ix)) plain_poll(ix);
     out8[6] = ix->plain_state;
     out8[7] = ix->plain_state == PLAIN_OFF ? ix->plain_skip : 0;
     const Work &w = ix->works[(ix->calls + ix->works.size() - 1) % ix->works.size()];
