@@ -508,7 +508,7 @@ def hbm_scale_leg(device):
     return res
 
 
-def measure_traffic(args):
+def measure_traffic(args, plain_on=True):
     """HBM bytes per scan launch from PMC counters, measured NOW: two child runs of this script
     under rocprofv3 (--pmc FETCH_SIZE, then --pmc WRITE_SIZE: they do not fit one pass), one
     batch in flight so that the list scan and the coarse scan are separate launches.  gfx950
@@ -533,7 +533,10 @@ def measure_traffic(args):
                "--n-probes", str(args.n_probes), "--metric", args.metric, "--data", args.data,
                "--build-probes", str(args.build_probes), "--seed", str(args.seed)]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+            # the child answers 4 batches: too few for the plain path to prove itself (probe, wait, on).
+            # It runs in the state the parent's timed region settled in — always plain, or never.
+            mode = {"TINYKNN_PLAIN_ADAPT": "0"} if plain_on else {"TINYKNN_PLAIN_SCAN": "0"}
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", **mode), stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=600, check=True)
             acc = {}
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
@@ -593,13 +596,23 @@ def plain_roofline(st, M, nq):
                      "was above the table's limit (scanned again exactly, replayed again)")
 
 
-def valu_roofline(scan_ms, iso_stages):
-    """The bound the scan kernel actually runs against (profiles/r02_scan_forms.md): VALU issue.
+def valu_roofline(scan_ms, iso_stages, plain_on=False):
+    """The bound the EXACT scan kernel runs against (profiles/r02_scan_forms.md): VALU issue.
     floor = SQ_INSTS_VALU of the list + coarse scan (PMC child run of this script, in this run) /
     (1024 SIMDs x the measured issue rate of the kernel's instruction mix)."""
     n = getattr(measure_traffic, "valu_insts", None)
     if not n:
         return None
+    if plain_on:
+        # the issue rate above was measured on the exact kernel's VOP3/VOP3P mix (v_perm, packed adds:
+        # 4.0-4.6 cycles each); most of a batch's scan now runs in the plain kernel, whose VALU work
+        # (one v_alignbit per one-hot operand, clamps, packs) issues at the plain VOP2 rate and is
+        # not what bounds it (MFMA + LDS round trips: `plain_scan`).  The count stays, the floor goes.
+        return {"wave_instructions_per_launch": n, "floor_ms": None, "frac_isolated": None,
+                "frac_timed_region": None,
+                "note": "SQ_INSTS_VALU of plain kernel + exact launch + coarse scan (PMC child run); the "
+                        "issue-rate floor of round 2 applies to the exact kernel's instruction mix only and is "
+                        "not computed while the plain path carries the batch: see roofline.plain_scan"}
     floor_ms = n / (1024 * VALU_RATE_PER_SIMD) * 1e3
     iso = iso_stages["scan"] + iso_stages["coarse_scan"]
     return {"wave_instructions_per_launch": n, "issue_rate_per_simd": VALU_RATE_PER_SIMD,
@@ -986,7 +999,7 @@ def main():
                   args.data, args.build_probes) == ("glove", 1183514, 100, 1087, 10000, 10, "angular",
                                                     "glove-like", 1)
     if args.traffic == "auto" and (default_wl or args.workload == "c5") and world == 1 and not args.data_file:
-        traffic, traffic_src = measure_traffic(args)
+        traffic, traffic_src = measure_traffic(args, bool(plain_stats and plain_stats.get("plain_units")))
     hbm_leg = None
     if not args.no_hbm_leg and world == 1:
         try:
@@ -1135,19 +1148,29 @@ def main():
                                            f"in {truth_s * 1e3:.0f} ms"),
                    "parallelism": f"replica x{world} (queries sharded)",
                    "batches_in_flight": args.pipeline},
-        "roofline": {"bound": "hbm", "bound_measured": "valu-issue (measured: profiles/r02_scan_forms.md; see `valu`); hbm by contract",
+        "roofline": {"bound": "hbm",
+                     "bound_measured": ("plain kernel: matrix-core issue + LDS round trips of the one-hot operands "
+                                        "(`plain_scan`: its MFMA floor, DESIGN 3.1b), exact launches: VALU issue "
+                                        "(profiles/r02_scan_forms.md); hbm by contract"
+                                        if plain_stats and plain_stats.get("plain_units") else
+                                        "valu-issue (measured: profiles/r02_scan_forms.md; see `valu`); hbm by contract"),
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "achieved_is": "ALGORITHMIC GB/s (one code byte per (query, code) pair); the fabric "
                                     "carries `traffic` bytes per launch: four queries share each fetched "
                                     "code byte and the code set sits in L2/Infinity Cache",
                      "device_copy_GBps_measured": copy_gbps, "device_read_GBps_measured": read_gbps,
-                     "kernel": ("scan_probes_kernel<AVX,signed>" if args.scan_mode == 1 else
+                     "kernel": ("scan_plain_kernel<26> + scan_units2_kernel<AVX,signed>: the two scan launches of a batch, "
+                                "back to back on the scan stream, timed as one (plain sums on the matrix cores for the "
+                                "lists behind the first; exact kernel for the heads of the first lists + the coarse "
+                                "scan of a later batch)"
+                                if plain_stats and plain_stats.get("plain_units") and args.pipeline > 1 else
+                                "scan_probes_kernel<AVX,signed>" if args.scan_mode == 1 else
                                 "scan_units_kernel<AVX,signed>" if args.pipeline == 1 else
                                 "scan_units2_kernel<AVX,signed> (one launch: list scan of a batch + coarse scan "
                                 "of a later one)"),
                      "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
-                     "launches_timed": n_prof, "valu": valu_roofline(scan_ms, iso_stages),
+                     "launches_timed": n_prof, "valu": valu_roofline(scan_ms, iso_stages, bool(plain_stats and plain_stats.get("plain_units"))),
                      "plain_scan": plain_roofline(plain_stats, M, args.nq)},
         "raw_in_ids_out": raw_leg,
         "roofline_hbm_scale": hbm_leg,

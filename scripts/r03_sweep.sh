@@ -4,7 +4,7 @@ for np_ in 1 5 10 20 50; do
   python bench.py --n-probes $np_ --steps 50 --shard none --cpu-sample 1000 --no-hbm-leg --traffic none > $O/glove_np$np_.json 2>> $O/sweep.err
 done
 python bench.py --data sift-like --metric euclidean --d 128 --n 1000000 --n-clusters 1000 --steps 50 --shard none --cpu-sample 2000 --no-hbm-leg --traffic none > $O/sift_np10.json 2>> $O/sweep.err
-python bench.py --build-probes 2 --steps 50 --shard none --cpu-sample 2000 --no-hbm-leg --traffic none > $O/glove_build_probes2.json 2>> $O/sweep.err
+for bp in 2 3 5; do python bench.py --build-probes $bp --steps 50 --shard none --cpu-sample 2000 --no-hbm-leg --traffic none > $O/glove_build_probes$bp.json 2>> $O/sweep.err; done
 TINYKNN_PLAIN_SCAN=0 python bench.py --steps 50 --shard none --no-cpu --no-hbm-leg --traffic none > $O/glove_np10_plain_scan_off.json 2>> $O/sweep.err
 python3 - <<'PY'
 import json, glob
