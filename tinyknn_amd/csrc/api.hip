@@ -681,6 +681,9 @@ extern "C" tk_index *tk_index_create(void)
     if (require_gpu() != TK_OK) return nullptr;
     tk_index *ix = new tk_index();
     ix->works.resize(1);
+    // A/B: TINYKNN_PLAIN_SCAN=2 starts every index in mode 2 (plain always, repeating labels too)
+    const char *e = getenv("TINYKNN_PLAIN_SCAN");
+    if (e && e[0] == '2') ix->plain_mode = 2;
     return ix;
 }
 

@@ -1027,12 +1027,12 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     static int lanes_dedupe = -1;
     if (lanes_dedupe < 0) {
         const char *e = getenv("TINYKNN_REPLAY_LANES");
-        lanes_dedupe = (e && atoi(e) == 64) ? 64 : 32;
+        lanes_dedupe = (e && atoi(e) == 64) ? 64 : (e && atoi(e) == 16) ? 16 : 32;
     }
     static int lanes_plain = -1;      // distinct labels: 64 (A/B: TINYKNN_REPLAY_LANES_PLAIN=32)
     if (lanes_plain < 0) {
         const char *e = getenv("TINYKNN_REPLAY_LANES_PLAIN");
-        lanes_plain = (e && atoi(e) == 32) ? 32 : 64;
+        lanes_plain = (e && atoi(e) == 32) ? 32 : (e && atoi(e) == 16) ? 16 : 64;
     }
     const int LWr = dedupe ? lanes_dedupe : lanes_plain;
     // heap columns (+ label slots) + 16 staged blocks per lane, scaled to the columns in use
@@ -1053,7 +1053,11 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                              (const void *)heap_replay_lanes_kernel<true, true, false, 32>,
                              (const void *)heap_replay_lanes_kernel<false, true, false, 32>,
                              (const void *)heap_replay_lanes_kernel<true, false, false, 32>,
-                             (const void *)heap_replay_lanes_kernel<false, false, false, 32>};
+                             (const void *)heap_replay_lanes_kernel<false, false, false, 32>,
+                             (const void *)heap_replay_lanes_kernel<true, true, false, 16>,
+                             (const void *)heap_replay_lanes_kernel<false, true, false, 16>,
+                             (const void *)heap_replay_lanes_kernel<true, false, false, 16>,
+                             (const void *)heap_replay_lanes_kernel<false, false, false, 16>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
@@ -1114,6 +1118,11 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     if (LWr == 32) {
         if (dedupe) { if (signd) TK_LAUNCH3(true, true, false, 32); else TK_LAUNCH3(false, true, false, 32); }
         else { if (signd) TK_LAUNCH3(true, false, false, 32); else TK_LAUNCH3(false, false, false, 32); }
+        return 0;
+    }
+    if (LWr == 16) {     // (A/B: a quarter-filled wave per 16 queries — four times the waves, a quarter of the LDS each)
+        if (dedupe) { if (signd) TK_LAUNCH3(true, true, false, 16); else TK_LAUNCH3(false, true, false, 16); }
+        else { if (signd) TK_LAUNCH3(true, false, false, 16); else TK_LAUNCH3(false, false, false, 16); }
         return 0;
     }
 #define TK_LAUNCH2(S_, D_, P_) TK_LAUNCH3(S_, D_, P_, 64)
