@@ -272,6 +272,12 @@ int tk_debug_plain_limit(int limit);
  * form; DEFAULT: measured faster, profiles/r02_scan_forms.md).  Tables with more than 156 blocks
  * fall back to 0. */
 int tk_set_scan_form(int form);
+/* Form of the exact rescoring kernel for float32 vectors with d % 4 == 0, d <= 256 (process-wide;
+ * identical outputs — the summation order of every row is numpy's in each form): 2 = candidate rows
+ * read by the wave as one stream of 16-byte pieces and staged through LDS in tiles of 32 rows
+ * (DEFAULT), 1 = tiles of 64 rows, 0 = every lane walks its own row (the only form for float64
+ * operands and other d).  Environment TINYKNN_RESCORE_STAGED sets the initial value. */
+int tk_set_rescore_form(int form);
 
 /* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
  * around the stages (no synchronisation in the query call; 1 = every batch).

@@ -323,6 +323,16 @@ def test_ivf_query_golden(tk, tag):
         dev.set_scan_mode(2)
         out2 = dev.query_batch(g["qn"], g["qpq"], k, n_probes)
         np.testing.assert_array_equal(out2, g[f"ids_p{n_probes}"])
+        # every form of the rescoring kernel (lane per row / rows staged through LDS in tiles of 64 /
+        # of 32: the default) sums a row in numpy's order: the same ids
+        from tinyknn_amd import _lib
+        try:
+            for form in (0, 1, 2):
+                _lib.check(_lib.lib().tk_set_rescore_form(form))
+                np.testing.assert_array_equal(dev.query_batch(g["qn"], g["qpq"], k, n_probes),
+                                              g[f"ids_p{n_probes}"])
+        finally:
+            _lib.check(_lib.lib().tk_set_rescore_form(2))
         dev.set_scan_mode(0)
         out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
         np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])

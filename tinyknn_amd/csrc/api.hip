@@ -3095,6 +3095,13 @@ extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
     return TK_OK;
 }
 
+extern "C" int tk_set_rescore_form(int form)
+{
+    ARGCHECK(form >= 0 && form <= 2, "form must be 0, 1 or 2");
+    tk_set_rescore_staged(form);
+    return TK_OK;
+}
+
 extern "C" int tk_set_scan_form(int form)
 {
     ARGCHECK(form >= 0 && form <= 2, "form must be 0, 1 or 2");

@@ -83,6 +83,9 @@ struct TkScanJob {
 // table rows of the list-major kernel: 1 = staged per block in LDS (default), 0 = per-lane
 // global loads (the round-1 form; A/B switch)
 void tk_set_scan_tables(int lds);
+// rescoring: 0 = a lane walks its own row, 1 / 2 = rows staged through LDS in tiles of 64 / 32 (default 2)
+void tk_set_rescore_staged(int mode);
+int tk_get_rescore_staged(void);
 int tk_get_scan_tables(void);
 // ---- plain-sum scan on the int8 matrix cores (plain_scan.hip) ----
 // qlim[q]: the bound below which clamp(plain sum) IS the reference's saturated value for query q
