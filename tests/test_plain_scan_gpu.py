@@ -130,3 +130,32 @@ def test_automatic_mode_pauses_on_data_without_structure(tk):
         st2 = dev.plain_stats()
         assert (st2["plain_units"] > 0) == structured
         assert st2["state"] == ("on" if structured else "paused")
+
+
+@pytest.mark.parametrize("d,metric", [(12, "euclidean"), (40, "angular"), (72, "euclidean"), (104, "angular")])
+def test_every_register_shape_of_the_plain_kernel(tk, d, metric):
+    """M = d / 2 blocks: 6, 20, 36, 52 -> the guarded forms for P <= 8 / 16 / 26 block pairs and the
+    unguarded one at P = 26 (M = 32 -> P = 16 unguarded is the eu128 fixture).  Plain pinned on,
+    list-major: heap arrays (layout included) and ids equal to the exact kernel's, with small and
+    default heaps."""
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(d)
+    n, nq, n_lists = 30000, 600, 60
+    cent = np.random.randn(80, d)
+    X = (cent[np.random.randint(80, size=n)] + 0.5 * np.random.randn(n, d)).astype(np.float32)
+    qs = (cent[np.random.randint(80, size=nq)] + 0.5 * np.random.randn(nq, d)).astype(np.float32)
+    ivf = IVF(metric, n_lists, FastPQ(2))
+    ivf.fit(X[:10000]).build(X, n_probes=1)
+    qn, qp = ivf._prepare(qs.copy())
+    dev = ivf.device_index()
+    dev.set_scan_mode(2)
+    for n_probes, pass_1 in ((4, None), (8, 7), (8, None)):
+        dev.set_plain_scan(False)
+        want, dw = dev.query_batch(qn, qp, 10, n_probes, pass_1=pass_1, debug=True)
+        dev.set_plain_scan("always")
+        got, dg = dev.query_batch(qn, qp, 10, n_probes, pass_1=pass_1, debug=True)
+        st = dev.plain_stats()
+        assert st["plain_units"] > 0 and st["plain_pairs"] > 0, st
+        np.testing.assert_array_equal(dg["heap_idx"], dw["heap_idx"])
+        np.testing.assert_array_equal(dg["heap_val"], dw["heap_val"])
+        np.testing.assert_array_equal(got, want)

@@ -666,6 +666,7 @@ struct tk_index {
     hipEvent_t ev_front_in = nullptr;        // front stream (input copies) -> the table build's stream
     std::vector<struct Pending *> pending;   // calls whose list scan is still to be enqueued (<= 2)
     hipStream_t front_stream = nullptr;      // coarse replays + descriptors of all batches, in order
+    hipStream_t front_stream2 = nullptr;     // A/B (TINYKNN_FRONT_STREAMS=2): ... of the odd calls
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
     uint64_t prof_seen = 0;
@@ -701,6 +702,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
     for (Work &w : ix->works) w.release();
     for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
     if (ix->front_stream) (void)hipStreamDestroy(ix->front_stream);
+    if (ix->front_stream2) (void)hipStreamDestroy(ix->front_stream2);
     if (ix->ev_in) (void)hipEventDestroy(ix->ev_in);
     if (ix->ev_front_in) (void)hipEventDestroy(ix->ev_front_in);
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
@@ -1573,6 +1575,12 @@ static int tables_stream_mode()
 }
 static bool tables_on_replay_stream() { return tables_stream_mode() != 0; }
 
+static int front_streams()
+{
+    static const int n = getenv("TINYKNN_FRONT_STREAMS") ? atoi(getenv("TINYKNN_FRONT_STREAMS")) : 1;
+    return n == 2 ? 2 : 1;
+}
+
 static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
 {
     const int M = ix->M;
@@ -1747,6 +1755,13 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         if (!ix->front_stream)
             HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking));
         b.sf = ix->front_stream;
+        // A/B: two front streams, batches alternate (a batch's tables and the rest of its coarse stage
+        // stay on ONE stream; the events the scan launch merges belong to calls c-1 and c-3: same parity)
+        if (front_streams() == 2) {
+            if (!ix->front_stream2)
+                HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream2, hipStreamNonBlocking));
+            if (ix->calls & 1) b.sf = ix->front_stream2;
+        }
         b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
         ix->calls++;
         hipEvent_t *evs[] = {&w.tables_done, &w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
@@ -1826,6 +1841,12 @@ extern "C" void *tk_index_input_stream(tk_index *ix)
     if (!ix->front_stream &&
         hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking) != hipSuccess)
         return nullptr;
+    if (front_streams() == 2 && (ix->calls & 1)) {      // (the stream the NEXT call's tables go to)
+        if (!ix->front_stream2 &&
+            hipStreamCreateWithFlags(&ix->front_stream2, hipStreamNonBlocking) != hipSuccess)
+            return nullptr;
+        return ix->front_stream2;
+    }
     return ix->front_stream;
 }
 
