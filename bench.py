@@ -579,7 +579,7 @@ VALU_RATE_PER_SIMD = 0.52e9      # wave-instructions/s/SIMD of the scan's VOP3/V
 I8_MFMA_PEAK_TOPS = 5000.0      # dense int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores)
 
 
-def plain_roofline(st, M, nq):
+def plain_roofline(st, M, nq, scan_ms=None, iso_scan_ms=None):
     """The plain-sum scan (plain_scan.hip): its matrix-core work per batch.  A unit = 32 pairs x a
     list's chunk pairs; per chunk pair M/2 v_mfma_i32_32x32x32_i8 = M/2 x 32768 multiply-adds
     (one-hot(code) x table: 15 of 16 products are by zero — this is matrix-core OCCUPANCY, the
@@ -587,8 +587,15 @@ def plain_roofline(st, M, nq):
     if not st or not st["plain_units"]:
         return None
     mfma = st["plain_unit_chunk_pairs"] * (M // 2)
+    floor = mfma * 32 / (1024 * 2.4e9) * 1e3
     return dict(st, mfma_instructions_per_batch=mfma, int8_ops_per_batch=mfma * 2 * 32768,
-                mfma_floor_ms=mfma * 32 / (1024 * 2.4e9) * 1e3, peak_unit="TOP/s int8 dense",
+                mfma_floor_ms=floor,
+                # the scan STAGE = plain kernel + the exact launch behind it (heads of the first lists,
+                # and in the timed region the coarse scan of a later batch): lower bounds of the
+                # plain kernel's own fraction of the matrix-core ceiling
+                mfma_floor_over_scan_stage_isolated=(floor / iso_scan_ms if iso_scan_ms else None),
+                mfma_floor_over_scan_stage_timed_region=(floor / scan_ms if scan_ms else None),
+                peak_unit="TOP/s int8 dense",
                 peak=I8_MFMA_PEAK_TOPS, tile_fill=st["plain_pairs"] / (32.0 * st["plain_units"]),
                 flagged_fraction=st["flagged_queries"] / float(nq),
                 note="mfma_floor_ms: the batch's MFMA instructions at 32 cycles each on 1024 SIMDs at 2.4 GHz; "
@@ -1171,7 +1178,7 @@ def main():
                                 "of a later one)"),
                      "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
                      "launches_timed": n_prof, "valu": valu_roofline(scan_ms, iso_stages, bool(plain_stats and plain_stats.get("plain_units"))),
-                     "plain_scan": plain_roofline(plain_stats, M, args.nq)},
+                     "plain_scan": plain_roofline(plain_stats, M, args.nq, scan_ms, iso_stages.get("scan"))},
         "raw_in_ids_out": raw_leg,
         "roofline_hbm_scale": hbm_leg,
         "stage_ms": stages,
