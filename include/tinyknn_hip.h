@@ -278,6 +278,12 @@ int tk_set_scan_form(int form);
  * (DEFAULT), 1 = tiles of 64 rows, 0 = every lane walks its own row (the only form for float64
  * operands and other d).  Environment TINYKNN_RESCORE_STAGED sets the initial value. */
 int tk_set_rescore_form(int form);
+/* Form of the plain-sum kernel for M = 52 and M = 32 (process-wide; identical outputs): 0 = the table
+ * operand of a unit's 32 queries held in registers (212 per lane, two waves per SIMD; DEFAULT),
+ * 1 = read from LDS for every MFMA (128 registers, 31 KB per workgroup, four waves per SIMD: the same
+ * speed alone and per batch, half the stretch beside the replays — profiles/r03/ab_pipeline_knobs.txt),
+ * 2 = the same at three waves per SIMD.  Environment TINYKNN_PLAIN_FORM sets the initial value. */
+int tk_set_plain_form(int form);
 
 /* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
  * around the stages (no synchronisation in the query call; 1 = every batch).

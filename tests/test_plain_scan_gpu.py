@@ -132,10 +132,10 @@ def test_automatic_mode_pauses_on_data_without_structure(tk):
         assert st2["state"] == ("on" if structured else "paused")
 
 
-@pytest.mark.parametrize("d,metric", [(12, "euclidean"), (40, "angular"), (72, "euclidean"), (104, "angular")])
+@pytest.mark.parametrize("d,metric", [(12, "euclidean"), (40, "angular"), (64, "angular"), (72, "euclidean"), (104, "angular")])
 def test_every_register_shape_of_the_plain_kernel(tk, d, metric):
-    """M = d / 2 blocks: 6, 20, 36, 52 -> the guarded forms for P <= 8 / 16 / 26 block pairs and the
-    unguarded one at P = 26 (M = 32 -> P = 16 unguarded is the eu128 fixture).  Plain pinned on,
+    """M = d / 2 blocks: 6, 20, 32, 36, 52 -> the guarded forms for P <= 8 / 16 / 26 block pairs and the
+    unguarded ones at P = 16 and P = 26, the latter two also with the table operand read from LDS.  Plain pinned on,
     list-major: heap arrays (layout included) and ids equal to the exact kernel's, with small and
     default heaps."""
     from tinyknn_amd import IVF, FastPQ
@@ -149,13 +149,19 @@ def test_every_register_shape_of_the_plain_kernel(tk, d, metric):
     qn, qp = ivf._prepare(qs.copy())
     dev = ivf.device_index()
     dev.set_scan_mode(2)
+    from tinyknn_amd import _lib
     for n_probes, pass_1 in ((4, None), (8, 7), (8, None)):
         dev.set_plain_scan(False)
         want, dw = dev.query_batch(qn, qp, 10, n_probes, pass_1=pass_1, debug=True)
         dev.set_plain_scan("always")
-        got, dg = dev.query_batch(qn, qp, 10, n_probes, pass_1=pass_1, debug=True)
-        st = dev.plain_stats()
-        assert st["plain_units"] > 0 and st["plain_pairs"] > 0, st
-        np.testing.assert_array_equal(dg["heap_idx"], dw["heap_idx"])
-        np.testing.assert_array_equal(dg["heap_val"], dw["heap_val"])
-        np.testing.assert_array_equal(got, want)
+        try:
+            for form in (0, 1, 2):      # table operand in registers / from LDS per MFMA (M = 52 and 32 only)
+                _lib.check(_lib.lib().tk_set_plain_form(form))
+                got, dg = dev.query_batch(qn, qp, 10, n_probes, pass_1=pass_1, debug=True)
+                st = dev.plain_stats()
+                assert st["plain_units"] > 0 and st["plain_pairs"] > 0, st
+                np.testing.assert_array_equal(dg["heap_idx"], dw["heap_idx"])
+                np.testing.assert_array_equal(dg["heap_val"], dw["heap_val"])
+                np.testing.assert_array_equal(got, want)
+        finally:
+            _lib.check(_lib.lib().tk_set_plain_form(0))

@@ -151,6 +151,7 @@ SIGNATURES = {
     "tk_debug_plain_limit": (C.c_int, [C.c_int]),
     "tk_set_scan_form": (C.c_int, [C.c_int]),
     "tk_set_rescore_form": (C.c_int, [C.c_int]),
+    "tk_set_plain_form": (C.c_int, [C.c_int]),
     "tk_index_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_last_profile": (C.c_int, [C.c_void_p, _f32p, _f64p, _i32p]),
 }

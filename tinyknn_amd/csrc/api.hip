@@ -664,6 +664,7 @@ struct tk_index {
     std::vector<hipStream_t> lat_streams;    // `depth` of them (pipelined mode)
     hipEvent_t ev_in = nullptr;              // caller's stream -> a batch's stream
     hipEvent_t ev_front_in = nullptr;        // front stream (input copies) -> the table build's stream
+    bool input_on_front = false;             // tk_index_input_stream has handed the front stream out
     std::vector<struct Pending *> pending;   // calls whose list scan is still to be enqueued (<= 2)
     hipStream_t front_stream = nullptr;      // coarse replays + descriptors of all batches, in order
     hipStream_t front_stream2 = nullptr;     // A/B (TINYKNN_FRONT_STREAMS=2): ... of the odd calls
@@ -1779,9 +1780,12 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         hipStream_t stt = b.sf;
         if (tables_stream_mode() == 1) stt = b.sl;
         else if (tables_stream_mode() == 2) stt = ix->lat_streams[ix->calls % (uint64_t)ix->depth];   // (calls is already c + 1)
-        HIPCHECK(hipEventRecord(ix->ev_in, caller));
-        HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
-        if (stt != b.sf) {      // input copies arrive on the front stream (tk_index_input_stream)
+        else if (tables_stream_mode() == 3) stt = caller;      // the scan chain itself (it has the slack since the LDS-operand plain kernel)
+        if (stt != caller) {
+            HIPCHECK(hipEventRecord(ix->ev_in, caller));
+            HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
+        }
+        if (stt != b.sf && ix->input_on_front) {      // input copies arrive on the front stream (tk_index_input_stream)
             if (!ix->ev_front_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_front_in, hipEventDisableTiming));
             HIPCHECK(hipEventRecord(ix->ev_front_in, b.sf));
             HIPCHECK(hipStreamWaitEvent(stt, ix->ev_front_in, 0));
@@ -1841,6 +1845,7 @@ extern "C" void *tk_index_input_stream(tk_index *ix)
     if (!ix->front_stream &&
         hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking) != hipSuccess)
         return nullptr;
+    ix->input_on_front = true;
     if (front_streams() == 2 && (ix->calls & 1)) {      // (the stream the NEXT call's tables go to)
         if (!ix->front_stream2 &&
             hipStreamCreateWithFlags(&ix->front_stream2, hipStreamNonBlocking) != hipSuccess)
@@ -3113,6 +3118,13 @@ extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
     ARGCHECK(mode >= 0 && mode <= 2, "mode");
     TRY(flush_pending(ix));
     ix->heap_mode = mode;
+    return TK_OK;
+}
+
+extern "C" int tk_set_plain_form(int form)
+{
+    ARGCHECK(form >= 0 && form <= 2, "form must be 0, 1 or 2");
+    tk_plain_set_form(form);
     return TK_OK;
 }
 

@@ -1034,7 +1034,12 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
         const char *e = getenv("TINYKNN_REPLAY_LANES_PLAIN");
         lanes_plain = (e && atoi(e) == 32) ? 32 : (e && atoi(e) == 16) ? 16 : 64;
     }
-    const int LWr = dedupe ? lanes_dedupe : lanes_plain;
+    static int lanes_coarse = -1;     // the coarse replay (one list, small heap) alone (A/B: TINYKNN_REPLAY_LANES_COARSE=32 / 16)
+    if (lanes_coarse < 0) {
+        const char *e = getenv("TINYKNN_REPLAY_LANES_COARSE");
+        lanes_coarse = (e && (atoi(e) == 32 || atoi(e) == 16)) ? atoi(e) : 0;
+    }
+    const int LWr = dedupe ? lanes_dedupe : (slots_uniform && lanes_coarse) ? lanes_coarse : lanes_plain;
     // heap columns (+ label slots) + 16 staged blocks per lane, scaled to the columns in use
     const size_t fixed = tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64;
     // one staged segment (16 blocks x LW lanes x 16 B); the next one waits in registers

@@ -95,6 +95,7 @@ int tk_get_scan_tables(void);
 void tk_launch_table_limits(const uint4 *tables, int M, int order, int64_t nq, int *qlim, hipStream_t s);
 void tk_plain_force_limit(int v);      // debug: cap every query's limit (INT_MAX = off)
 int tk_plain_forced(void);             // ... is such a cap set?
+void tk_plain_set_form(int form);      // 0 = table operand in registers (default), 1 / 2 = read from LDS per MFMA (A/B)
 int tk_plain_fits(int M);
 // TkScanJob with unit_prefix = tiles of 32 pairs before each list (+ the work counter at
 // TK_PLAIN_COUNTER_OFF); pair records are not padded.  Returns -1 for unsupported M.

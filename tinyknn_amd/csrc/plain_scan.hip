@@ -277,9 +277,19 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
                     x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
                 }
                 v4i A[PT];
+#if defined(TK_PLAIN_EXPERIMENT) && TK_PLAIN_EXPERIMENT == 1
+                // (scripts/micro only: WRONG results — the one-hot operands without their LDS reads,
+                //  to see what those reads cost)
+#pragma unroll
+                for (int p = 0; p < PT; p++) {
+                    const int t = (int)(__builtin_amdgcn_alignbit(x[p], x[p], rot) & 0xf0u);
+                    A[p] = v4i{t, t ^ 1, t ^ 2, t ^ 3};
+                }
+#else
 #pragma unroll
                 for (int p = 0; p < PT; p++)
                     A[p] = *(const v4i *)(lutb + (__builtin_amdgcn_alignbit(x[p], x[p], rot) & 0xf0u));
+#endif
 #pragma unroll
                 for (int p = 0; p < PT; p++)
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[p], B[p], acc, 0, 0, 0);
@@ -323,8 +333,15 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
             const int mn = min((int)mA, (int)mB);
             int cc = 2 * cp + h;
             cc = cc < C ? cc : C - 1;      // odd list: the second half holds the first chunk again
+#if defined(TK_PLAIN_EXPERIMENT) && TK_PLAIN_EXPERIMENT == 2
+            if (mn == 12345) {      // (scripts/micro only: WRONG results — no stores)
+                drow[cc] = make_uint4(X, Z, Y, W);
+                mrow[cc] = (uint8_t)mn;
+            }
+#else
             drow[cc] = make_uint4(X, Z, Y, W);
             mrow[cc] = (uint8_t)mn;
+#endif
             if (ks < TL) {
                 store_slice(buf ^ 1, tslice);
                 slice_next();
@@ -342,7 +359,171 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same kernel with the table operand read from LDS for every MFMA instead of held in
+// registers for the length of a unit: 104 fewer registers per lane (M = 52), so four waves per
+// SIMD instead of two — the counters of the register form (scripts/r03_pmc_micro.sh) say 42 % of
+// its wave cycles wait, and taking ALL of its one-hot LDS reads away (scripts/micro, wrong results)
+// did not make it faster: it is bound by latency it has too few waves to cover, not by the LDS
+// pipe.  One table tile per workgroup (31 KB with staging: four workgroups per CU), loaded between
+// two barriers at the start of a unit — the other workgroups of the CU cover that.  Exact shapes
+// only (P == PT).  A/B: TINYKNN_PLAIN_FORM (0 = registers, 1 = this).
+template <int PT>
+struct PlainShapeL {
+    static constexpr int PS = (PT + 3) & ~3;
+    static constexpr int TROW = 2 * PT + 1;
+    static constexpr int TL = (32 * 2 * PT + 255) / 256;
+    static constexpr size_t lds = 256 + (size_t)4 * 8 * PS * 4 + (size_t)32 * TROW * 16 + 16 + 2 * 32 * 4;
+};
+
+template <int PT, int WPS>
+__global__ __launch_bounds__(256, WPS) void scan_plain_lds_kernel(TkScanJob j, int M)
+{
+    constexpr int P = PT;
+    using SH = PlainShapeL<PT>;
+    constexpr int PS = SH::PS, TROW = SH::TROW, TL = SH::TL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_plain[];
+    uint4 *lut = (uint4 *)smem_plain;                                   // 16 one-hot entries
+    uint32_t *stage = (uint32_t *)(smem_plain + 256);                   // [4 waves][8][PS]
+    uint4 *tile = (uint4 *)(smem_plain + 256 + 4 * 8 * PS * 4);         // [32][TROW]
+    int *s_unit = (int *)(smem_plain + 256 + 4 * 8 * PS * 4 + 32 * TROW * 16);       // [1] (+ pad)
+    int *s_q = s_unit + 4;                                              // [32]
+    int *s_f0 = s_q + 32;                                               // [32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        w[threadIdx.x >> 2] = 1u << (8 * (threadIdx.x & 3));
+        lut[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    const int n_units = j.unit_prefix[j.n_lists];
+    int *counter = const_cast<int *>(j.unit_prefix) + TK_PLAIN_COUNTER_OFF(j.n_lists);
+    const int r = lane & 31, h = lane >> 5;
+    const int rr = r & 15;
+    const uint32_t rot = (uint32_t)(8 * (rr & 3) + 4 * h + 28) & 31u;
+    const unsigned char *lutb = (const unsigned char *)lut;
+    const bool loader = lane < 2 * P;
+    const int ll = loader ? lane : 2 * P - 1;
+    const int lch = ll / P, lp = ll - lch * P;
+    uint32_t *st = stage + wave * 8 * PS;
+    const uint32_t *rd = st + ((r >> 4) * 4 + (rr >> 2)) * PS;
+    const int rows_m = 2 * P;
+    const int sl_pr0 = threadIdx.x / rows_m, sl_m0 = threadIdx.x - sl_pr0 * rows_m;
+    const int step_pr = 256 / rows_m, step_m = 256 - step_pr * rows_m;
+    for (;;) {
+        if (threadIdx.x == 0) s_unit[0] = atomicAdd(counter, 1);
+        __syncthreads();                   // every wave is done with the previous unit's tile
+        const int u = s_unit[0];
+        if (u >= n_units) break;           // (workgroup-uniform)
+        const int2 d = ((const int2 *)j.unit_desc)[u];
+        const int l = __builtin_amdgcn_readfirstlane(d.x), t = __builtin_amdgcn_readfirstlane(d.y);
+        int nvalid = j.pair_off[l + 1] - j.pair_off[l] - 32 * t;      // >= 1
+        nvalid = nvalid < 32 ? nvalid : 32;
+        if (threadIdx.x < 32) {            // pairs past the tile's last one: the last one
+            const int rec = j.pair_off[l] + 32 * t + (threadIdx.x < nvalid ? (int)threadIdx.x : nvalid - 1);
+            s_q[threadIdx.x] = j.pair_q[rec];
+            s_f0[threadIdx.x] = j.pair_f0[rec];
+        }
+        __syncthreads();
+        {   // the table rows of the tile's 32 pairs: element i = threadIdx.x + 256 k is (pair i / rows_m, row i % rows_m)
+            int pr = sl_pr0, m = sl_m0;
+            uint4 v[TL];
+#pragma unroll
+            for (int k = 0; k < TL; k++) {
+                v[k] = j.tables[(int64_t)s_q[pr < 32 ? pr : 31] * M + m];
+                pr += step_pr;
+                m += step_m;
+                if (m >= rows_m) { m -= rows_m; pr++; }
+            }
+            pr = sl_pr0;
+            m = sl_m0;
+#pragma unroll
+            for (int k = 0; k < TL; k++) {
+                if (pr < 32) tile[pr * TROW + m] = v[k];
+                pr += step_pr;
+                m += step_m;
+                if (m >= rows_m) { m -= rows_m; pr++; }
+            }
+        }
+        const int64_t c0 = j.list_chunk_off[l];
+        const int C = (int)(j.list_chunk_off[l + 1] - c0);
+        const int CP = (C + 1) >> 1;
+        const int qi = s_q[r];
+        const int f0 = s_f0[r];
+        const int rc = r < nvalid ? r : nvalid - 1;
+        const v4i *brow = (const v4i *)&tile[rc * TROW + h];           // block 2p + h: brow[2 * p]
+        uint4 *drow = j.dist + (int64_t)qi * j.cap + f0;
+        uint8_t *mrow = j.mins + (int64_t)qi * j.min_stride + f0;
+        auto fetch = [&](int cp) -> uint4 {        // unconditional (chunks past the list: its last)
+            int c = 2 * cp + lch;
+            c = c < C ? c : C - 1;
+            const int64_t gc = c0 + c;
+            return j.codes[((gc >> 3) * (int64_t)(M >> 1) + lp) * 8 + (gc & 7)];
+        };
+        __syncthreads();                   // the tile is complete
+        int cp = wave;
+        uint4 g0 = fetch(cp), g1 = fetch(cp + 4);
+        for (; cp < CP; cp += 4) {
+            const uint4 g2 = fetch(cp + 8);
+            if (loader) {
+                st[(lch * 4 + 0) * PS + lp] = g0.x;
+                st[(lch * 4 + 1) * PS + lp] = g0.y;
+                st[(lch * 4 + 2) * PS + lp] = g0.z;
+                st[(lch * 4 + 3) * PS + lp] = g0.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t x[PS];
+#pragma unroll
+            for (int k = 0; k < PS / 4; k++) {
+                const uint4 v = *(const uint4 *)(rd + 4 * k);
+                x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+            }
+            v4i A[PT], B[PT];
+#pragma unroll
+            for (int p = 0; p < PT; p++) {
+                A[p] = *(const v4i *)(lutb + (__builtin_amdgcn_alignbit(x[p], x[p], rot) & 0xf0u));
+                B[p] = brow[2 * p];
+            }
+#pragma unroll
+            for (int p = 0; p < PT; p++)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[p], B[p], acc, 0, 0, 0);
+            // schedule: the x reads, DEPTH operand pairs, then one MFMA per further pair
+            constexpr int DEPTH = 3 < PT ? 3 : PT;
+            __builtin_amdgcn_sched_group_barrier(0x100, PS / 4 + 2 * DEPTH, 0);
+#pragma unroll
+            for (int p = 0; p < PT - DEPTH; p++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, DEPTH, 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int o[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) o[i] = clamp8(acc[i]);
+            uint32_t X = pack4(o[0], o[1], o[2], o[3]), Y = pack4(o[4], o[5], o[6], o[7]);
+            uint32_t Z = pack4(o[8], o[9], o[10], o[11]), W = pack4(o[12], o[13], o[14], o[15]);
+            uint32_t mA = (uint32_t)min(min(min(o[0], o[1]), min(o[2], o[3])), min(min(o[4], o[5]), min(o[6], o[7])));
+            uint32_t mB = (uint32_t)min(min(min(o[8], o[9]), min(o[10], o[11])), min(min(o[12], o[13]), min(o[14], o[15])));
+            swap_halves(X, Z);
+            swap_halves(Y, W);
+            swap_halves(mA, mB);
+            const int mn = min((int)mA, (int)mB);
+            int cc = 2 * cp + h;
+            cc = cc < C ? cc : C - 1;
+            drow[cc] = make_uint4(X, Z, Y, W);
+            mrow[cc] = (uint8_t)mn;
+            g0 = g1;
+            g1 = g2;
+        }
+    }
+}
+
 int tk_plain_fits(int M) { return M >= 2 && M % 2 == 0 && M / 2 <= 26; }
+
+static int g_plain_form = -1;       // -1: not read yet (environment, default 0)
+void tk_plain_set_form(int form) { g_plain_form = form; }
 
 // j.unit_prefix: tiles of 32 pairs before each list (n_lists + 1), then the work counter (zeroed
 // by the kernel that wrote the table); P block pairs are summed (AVX order: an odd trailing pair
@@ -368,6 +549,26 @@ int tk_launch_scan_plain(const TkScanJob &j, int M, int order, int n_blocks, hip
     } while (0)
     static int lean = -1;      // A/B: TINYKNN_PLAIN_LEAN=1: the guarded form (fewer registers, shallow prefetch)
     if (lean < 0) lean = getenv("TINYKNN_PLAIN_LEAN") ? atoi(getenv("TINYKNN_PLAIN_LEAN")) : 0;
+    // A/B: TINYKNN_PLAIN_FORM / tk_plain_set_form: 1 = table operand from LDS per MFMA, four waves per
+    // SIMD; 2 = the same at three
+    if (g_plain_form < 0) g_plain_form = getenv("TINYKNN_PLAIN_FORM") ? atoi(getenv("TINYKNN_PLAIN_FORM")) : 0;
+    const int form = g_plain_form;
+#define TK_LAUNCH_L(PT_, WPS_)                                                                      \
+    do {                                                                                            \
+        static bool attr_ = false;                                                                  \
+        if (!attr_) {                                                                               \
+            if (hipFuncSetAttribute((const void *)scan_plain_lds_kernel<PT_, WPS_>,                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,                     \
+                                    (int)PlainShapeL<PT_>::lds) != hipSuccess)                      \
+                return -1;                                                                          \
+            attr_ = true;                                                                           \
+        }                                                                                           \
+        hipLaunchKernelGGL((scan_plain_lds_kernel<PT_, WPS_>), dim3(n_blocks * (form == 2 ? 3 : 4) / 2), dim3(256), \
+                           PlainShapeL<PT_>::lds, s, j, M);                                         \
+    } while (0)
+    if (form == 1 && P == 26) { TK_LAUNCH_L(26, 4); return 0; }
+    if (form == 2 && P == 26) { TK_LAUNCH_L(26, 3); return 0; }
+    if (form == 1 && P == 16) { TK_LAUNCH_L(16, 4); return 0; }
     if (P == 26 && !lean) TK_LAUNCH(26, true);
     else if (P == 16 && !lean) TK_LAUNCH(16, true);
     else if (P <= 8) TK_LAUNCH(8, false);
