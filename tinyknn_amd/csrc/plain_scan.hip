@@ -108,6 +108,17 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
 
 __device__ __forceinline__ int clamp8(int x) { return min(max(x, -128), 127); }
 
+// One-hot operand: entry (nibble) of the 256-byte LDS table, addressed as (rotated code dword & 0xf0) |
+// table address — ONE v_and_or_b32 because the table is 256-byte aligned (an add of the dynamic LDS
+// base, a relocated literal the compiler cannot fold, cost a third instruction per MFMA: 26 of the
+// loop's 129 vector instructions, and the loop is issue-bound: profiles/r03/ab_pipeline_knobs.txt)
+typedef __attribute__((address_space(3))) const v4i lds_cv4i;
+__device__ __forceinline__ v4i one_hot(uint32_t lut0, uint32_t x, uint32_t rot)
+{
+    const uint32_t a = (__builtin_amdgcn_alignbit(x, x, rot) & 0xf0u) | lut0;
+    return *(lds_cv4i *)(uintptr_t)a;
+}
+
 // a: lanes 32..63 <-> b: lanes 0..31
 __device__ __forceinline__ void swap_halves(uint32_t &a, uint32_t &b)
 {
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
     if (EXACT) P = PT;
     using SH = PlainShape<PT>;
     constexpr int PS = SH::PS, TROW = SH::TROW, TL = SH::TL;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_plain[];
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem_plain[];
     uint4 *lut = (uint4 *)smem_plain;                                   // 16 one-hot entries
     uint32_t *stage = (uint32_t *)(smem_plain + 256);                   // [4 waves][8][PS]
     uint4 *tile = (uint4 *)(smem_plain + 256 + 4 * 8 * PS * 4);         // [2][32][TROW]
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
     const int r = lane & 31, h = lane >> 5;
     const int rr = r & 15;
     const uint32_t rot = (uint32_t)(8 * (rr & 3) + 4 * h + 28) & 31u;    // rotate right: nibble -> bits 4..7
-    const unsigned char *lutb = (const unsigned char *)lut;
+    const uint32_t lut0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_plain;   // 256-byte aligned
     const bool loader = lane < 2 * P;
     const int ll = loader ? lane : 2 * P - 1;     // (lanes past the 2P groups clone the last loader)
     const int lch = ll / P, lp = ll - lch * P;
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
 #else
 #pragma unroll
                 for (int p = 0; p < PT; p++)
-                    A[p] = *(const v4i *)(lutb + (__builtin_amdgcn_alignbit(x[p], x[p], rot) & 0xf0u));
+                    A[p] = one_hot(lut0, x[p], rot);
 #endif
 #pragma unroll
                 for (int p = 0; p < PT; p++)
@@ -311,8 +322,7 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
                     for (int i = 0; i < 4; i++) {
                         const int p = 4 * k + i;
                         if (p < PT && p < P) {
-                            const uint32_t a_off = __builtin_amdgcn_alignbit(x[i], x[i], rot) & 0xf0u;
-                            const v4i A = *(const v4i *)(lutb + a_off);
+                            const v4i A = one_hot(lut0, x[i], rot);
                             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[p], acc, 0, 0, 0);
                         }
                     }
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(256, WPS) void scan_plain_lds_kernel(TkScanJob j, i
     constexpr int P = PT;
     using SH = PlainShapeL<PT>;
     constexpr int PS = SH::PS, TROW = SH::TROW, TL = SH::TL;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_plain[];
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem_plain[];
     uint4 *lut = (uint4 *)smem_plain;                                   // 16 one-hot entries
     uint32_t *stage = (uint32_t *)(smem_plain + 256);                   // [4 waves][8][PS]
     uint4 *tile = (uint4 *)(smem_plain + 256 + 4 * 8 * PS * 4);         // [32][TROW]
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(256, WPS) void scan_plain_lds_kernel(TkScanJob j, i
     const int r = lane & 31, h = lane >> 5;
     const int rr = r & 15;
     const uint32_t rot = (uint32_t)(8 * (rr & 3) + 4 * h + 28) & 31u;
-    const unsigned char *lutb = (const unsigned char *)lut;
+    const uint32_t lut0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_plain;   // 256-byte aligned
     const bool loader = lane < 2 * P;
     const int ll = loader ? lane : 2 * P - 1;
     const int lch = ll / P, lp = ll - lch * P;
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(256, WPS) void scan_plain_lds_kernel(TkScanJob j, i
             v4i A[PT], B[PT];
 #pragma unroll
             for (int p = 0; p < PT; p++) {
-                A[p] = *(const v4i *)(lutb + (__builtin_amdgcn_alignbit(x[p], x[p], rot) & 0xf0u));
+                A[p] = one_hot(lut0, x[p], rot);
                 B[p] = brow[2 * p];
             }
 #pragma unroll
