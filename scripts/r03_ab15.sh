@@ -1,0 +1,17 @@
+# round 3 A/B on one box: front stream at the highest queue priority
+R=$PWD; O=$R/gpurun_out/r03_ab15; mkdir -p $O
+run() { name=$1; shift
+  env "$@" > $O/$name.json 2> $O/$name.err
+  python3 - $O/$name.json $name <<'PY'
+import json, sys
+j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+r = lambda d: {k: round(v, 3) for k, v in d.items()}
+print(sys.argv[2].ljust(22), "ms", round(j["ms_per_step"], 3), "host", round(j["host_enqueue_ms_per_step"], 3), r(j["stage_ms"]), flush=True)
+PY
+}
+B="--shard none --traffic none --profile-only --steps 50"
+run base X=1 python bench.py $B &&
+run frontprio TINYKNN_FRONT_PRIO=1 python bench.py $B &&
+run frontprio_form1 TINYKNN_FRONT_PRIO=1 TINYKNN_PLAIN_FORM=1 python bench.py $B &&
+run base2 X=1 python bench.py $B &&
+run frontprio2 TINYKNN_FRONT_PRIO=1 python bench.py $B

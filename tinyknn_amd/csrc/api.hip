@@ -1609,7 +1609,12 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
                               prev->w->mins.as<uint8_t>(), prev->p.cap_min, 1, ix->order, st);
     if (cur && !fuse_cur) launch_coarse_scan(ix, *cur->w, cur->nq, cur->p, st);
     // (plain first: the exact kernel then overwrites the head chunks of the lists in head mode)
-    if (prev && prev->plain &&
+#ifdef TK_TIMING_EXPERIMENTS      // (wrong results on purpose: what does the batch cost without this kernel?)
+    static const int dbg_skip_scan = getenv("TINYKNN_DEBUG_SKIP") ? atoi(getenv("TINYKNN_DEBUG_SKIP")) : 0;
+#else
+    constexpr int dbg_skip_scan = 0;
+#endif
+    if (prev && prev->plain && !(dbg_skip_scan & 16) &&
         tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order, plain_blocks(), st))
         return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
     if (fuse_prev || fuse_cur) {
@@ -1753,8 +1758,17 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
             }
             ix->lat_streams.push_back(st);
         }
-        if (!ix->front_stream)
-            HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking));
+        if (!ix->front_stream) {
+            // A/B: TINYKNN_FRONT_PRIO=1 creates the front stream at the highest queue priority (its
+            // small kernels — coarse replay, descriptors — sit on the cycle's critical loop and are
+            // placed late beside the persistent scan grids)
+            static const int fp = getenv("TINYKNN_FRONT_PRIO") ? atoi(getenv("TINYKNN_FRONT_PRIO")) : 0;
+            int lo = 0, hi = 0;
+            if (fp && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+                HIPCHECK(hipStreamCreateWithPriority(&ix->front_stream, hipStreamNonBlocking, hi));
+            else
+                HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking));
+        }
         b.sf = ix->front_stream;
         // A/B: two front streams, batches alternate (a batch's tables and the rest of its coarse stage
         // stay on ONE stream; the events the scan launch merges belong to calls c-1 and c-3: same parity)
