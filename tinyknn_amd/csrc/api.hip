@@ -1491,6 +1491,7 @@ struct Pending {
     bool units;
     bool plain;             // probed lists behind the first ones by the plain kernel (plain_scan.hip)
     bool coarse_launched;   // its coarse scan has been enqueued
+    bool desc_done = false; // (TINYKNN_DESC_STREAM=1) its slot descriptors and pair lists have been enqueued
     int64_t *host_out;      // pinned host copy of the ids, enqueued behind the rescoring (or NULL)
     bool host_out_kernel;   // ... written by copy_words_kernel instead of the copy engine
     hipEvent_t user_ev;     // recorded behind that copy (or NULL)
@@ -1582,10 +1583,35 @@ static int front_streams()
     return n == 2 ? 2 : 1;
 }
 
+// A/B (TINYKNN_DESC_STREAM=1): the slot descriptors and pair lists of a batch are built on the SCAN
+// stream, one call after its coarse stage ran on the front stream — behind the launch of that call,
+// in front of the launch that scans the batch, in order on one stream: no event in between.  The
+// front stream then carries the table build + coarse replay + coarse rescoring only (the cycle is
+// bound by what that stream executes serially: DESIGN 3.5).
+static int desc_on_scan_stream()
+{
+    static const int m = getenv("TINYKNN_DESC_STREAM") ? atoi(getenv("TINYKNN_DESC_STREAM")) : 0;
+    return m == 1;
+}
+
+static int make_descriptors(tk_index *ix, Pending &b, hipStream_t st)
+{
+    Work &w = *b.w;
+    HIPCHECK(hipStreamWaitEvent(st, w.front_done, 0));       // (here: the batch's probe lists exist)
+    coarse_slots(ix, w, w.probes.as<int64_t>(), b.nq, b.p, b.units ? w.u_count.as<int>() : nullptr, nullptr, 0,
+                 st, b.plain);
+    if (b.units) unit_pairs(ix, w, b.nq, b.p, b.plain, st);
+    b.desc_done = true;
+    return TK_OK;
+}
+
 static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
 {
     const int M = ix->M;
     hipStream_t st = prev ? prev->st : cur->st;
+    const bool desc_s = desc_on_scan_stream();
+    // (start-up and drain: the batch about to be scanned has no descriptors yet)
+    if (desc_s && prev && !prev->desc_done) TRY(make_descriptors(ix, *prev, st));
     // what the launch waits for lives on the front stream, in order: ..., front_done(c-3),
     // tables_done(c-1), ... — the later event covers the earlier one, and every hand-over
     // between streams is a barrier packet the command processor spends microseconds on
@@ -1596,7 +1622,7 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         cur->coarse_launched = true;
     }
     if (prev) {
-        if (!(merge && cur && prev->sf == cur->sf))
+        if (!desc_s && !(merge && cur && prev->sf == cur->sf))
             HIPCHECK(hipStreamWaitEvent(st, prev->w->front_done, 0));
         TRY(prev->pf.mark(st));
     }
@@ -1649,12 +1675,23 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
             HIPCHECK(hipEventRecord(w.coarse_scanned, st));
             HIPCHECK(hipStreamWaitEvent(cur->sf, w.coarse_scanned, 0));
         }
-        TRY(stage_coarse_rest(ix, w, cur->q_dev, cur->nq, cur->p,
-                              cur->units ? w.u_count.as<int>() : nullptr, nullptr, 0, cur->sf,
-                              cur->pf, cur->plain));
-        if (cur->units) unit_pairs(ix, w, cur->nq, cur->p, cur->plain, cur->sf);
+        if (desc_s) {
+            TRY(coarse_replay_probes(ix, w, cur->q_dev, cur->nq, cur->p, w.probes.as<int64_t>(), cur->sf, cur->pf));
+        } else {
+            TRY(stage_coarse_rest(ix, w, cur->q_dev, cur->nq, cur->p,
+                                  cur->units ? w.u_count.as<int>() : nullptr, nullptr, 0, cur->sf,
+                                  cur->pf, cur->plain));
+            if (cur->units) unit_pairs(ix, w, cur->nq, cur->p, cur->plain, cur->sf);
+            cur->desc_done = true;
+        }
         HIPCHECK(hipEventRecord(w.front_done, cur->sf));
     }
+    if (desc_s)     // the batch whose coarse stage ran one call ago: its descriptors, behind this call's launch
+        for (Pending *m : ix->pending)
+            if (m != prev && m != cur && m->coarse_launched && !m->desc_done) {
+                TRY(make_descriptors(ix, *m, st));
+                break;
+            }
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
