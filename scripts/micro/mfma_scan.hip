@@ -107,6 +107,22 @@ int main(int argc, char **argv)
     std::vector<int> unit_desc;
     for (int l = 0; l < n_lists; l++)
         for (int t = 0; t < unit_prefix[l + 1] - unit_prefix[l]; t++) { unit_desc.push_back(l); unit_desc.push_back(t); }
+    // one wave per unit (round 4): (list, tile, chunk pairs [a, b)), K chunk pairs per unit
+    const int K = argc > 7 ? atoi(argv[7]) : 12;
+    const int variant = argc > 8 ? atoi(argv[8]) : 1;      // 0: workgroup per tile (round 3), 1: wave per unit
+    std::vector<int> unit_prefix4(tk_unit_prefix_ints(n_lists), 0), unit_desc4;
+    for (int l = 0; l < n_lists; l++) {
+        const int CP = (int)((coff[l + 1] - coff[l] + 1) / 2);
+        const int tiles = unit_prefix[l + 1] - unit_prefix[l];
+        const int nsub = (CP + K - 1) / K;
+        for (int t = 0; t < tiles; t++)
+            for (int sb = 0; sb < nsub; sb++) {
+                unit_desc4.push_back(l); unit_desc4.push_back(t);
+                unit_desc4.push_back(sb * K); unit_desc4.push_back(std::min(CP, (sb + 1) * K));
+            }
+        unit_prefix4[l + 1] = (int)(unit_desc4.size() / 4);
+    }
+    printf("wave form: %d units of <= %d chunk pairs\n", unit_prefix4[n_lists], K);
     double pairs_chunks = 0;
     for (int l = 0; l < n_lists; l++) pairs_chunks += (double)by_list[l].size() * (coff[l + 1] - coff[l]);
     printf("lists %d x ~%d chunks, %d queries x %d probes: %d units, %.2f M (chunk, query) pairs, cap %lld\n",
@@ -125,6 +141,11 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&d_po, pair_off.size() * 4));
     CHECK(hipMalloc(&d_ud, unit_desc.size() * 4 + 8));
     CHECK(hipMemcpy(d_ud, unit_desc.data(), unit_desc.size() * 4, hipMemcpyHostToDevice));
+    int *d_ud4, *d_up4;
+    CHECK(hipMalloc(&d_ud4, unit_desc4.size() * 4 + 16));
+    CHECK(hipMemcpy(d_ud4, unit_desc4.data(), unit_desc4.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_up4, unit_prefix4.size() * 4));
+    CHECK(hipMemcpy(d_up4, unit_prefix4.data(), unit_prefix4.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_pq, pair_q.size() * 4 + 4));
     CHECK(hipMalloc(&d_pf, pair_f0.size() * 4 + 4));
     CHECK(hipMemcpy(d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
@@ -141,12 +162,14 @@ int main(int argc, char **argv)
     j.unit_prefix = d_up; j.pair_off = d_po; j.pair_q = d_pq; j.pair_f0 = d_pf;
     j.unit_desc = d_ud;
     j.dist = d_dist; j.cap = cap; j.mins = d_mins; j.min_stride = min_stride;
+    if (variant >= 1) { j.unit_desc4 = d_ud4; j.unit_prefix = d_up4; }
+    tk_plain_set_flush(variant == 2);      // 1: a store per chunk pair, 2: through the LDS tile, a line per query
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const int reps = 20;
     auto launch = [&]() {
-        CHECK(hipMemsetAsync(d_up + TK_PLAIN_COUNTER_OFF(n_lists), 0, 4, 0));
+        CHECK(hipMemsetAsync(const_cast<int *>(j.unit_prefix) + TK_PLAIN_COUNTER_OFF(n_lists), 0, 8 * 32 * 4, 0));
         if (tk_launch_scan_plain(j, M, TK_ORDER_AVX, cpu, 0)) { fprintf(stderr, "launch failed\n"); exit(1); }
     };
     launch();
@@ -160,6 +183,30 @@ int main(int argc, char **argv)
            "%.1f cycles per (chunk, query) per SIMD at 2.4 GHz\n",
            ms, pairs_chunks / ms / 1e6, pairs_chunks * 416 / ms / 1e6, ms * 1e-3 * 2.4e9 * 1024 / pairs_chunks);
 
+#ifdef TK_PLAIN_CLOCK
+    {
+        unsigned long long z[4] = {0, 0, 0, 0}, ck[4];
+        CHECK(hipMemcpyToSymbol(HIP_SYMBOL(tk_plain_clock), z, sizeof z));
+        for (int i = 0; i < 5; i++) launch();
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpyFromSymbol(ck, HIP_SYMBOL(tk_plain_clock), sizeof ck));
+        printf("in-kernel clock: %.3f GHz (s_memtime / s_memrealtime x 100 MHz), %.0f cycles = %.1f us per wave, %.0f waves per launch\n",
+               (double)ck[0] / (double)ck[1] * 0.1, (double)ck[0] / (double)ck[2], (double)ck[1] / (double)ck[2] / 100.0, ck[2] / 5.0);
+    }
+#endif
+#ifdef TK_PLAIN_STAMPS
+    {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st[8];
+        CHECK(hipMemcpyToSymbol(HIP_SYMBOL(tk_plain_stamps), z, sizeof z));
+        launch();
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpyFromSymbol(st, HIP_SYMBOL(tk_plain_stamps), sizeof st));
+        const double w = (double)st[7], it = (double)st[4];
+        printf("stamps (cycles): waves %.0f, iterations %.0f (%.1f per wave); per iteration: stage+fetch %.0f, LDS+MFMA %.0f, "
+               "epilogue+stores %.0f; per wave: in units %.0f (prologues %.0f), kernel %.0f\n",
+               w, it, it / w, st[1] / it, st[2] / it, st[3] / it, st[5] / w, st[0] / w, st[6] / w);
+    }
+#endif
     // ---- check every byte against the host
     std::vector<uint8_t> dist((size_t)nq * cap * 16), mins((size_t)nq * min_stride);
     CHECK(hipMemcpy(dist.data(), d_dist, dist.size(), hipMemcpyDeviceToHost));

@@ -1,0 +1,78 @@
+"""Register / scratch budget of the hot kernels, read from the compiler (no GPU needed).
+
+Round 3 shipped `scan_units2_kernel` with 480 B/lane of scratch: selecting among three by-value
+job descriptors made hipcc copy them to private memory.  This test compiles the kernel files for
+gfx950 with -Rpass-analysis=kernel-resource-usage and pins, for the instantiations the default
+GloVe-shaped batch launches, zero scratch and the occupancy the design counts on.
+"""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "tinyknn_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", "-o", os.devnull]
+
+# (file, substring of the mangled name) -> (max VGPRs, min waves/SIMD)
+PINNED = {
+    # the fused exact launch of the pipelined mode: AVX order, signed tables, per-lane table loads
+    ("adc_scan.hip", "scan_units2_kernelILi1ELb1ELi0EE"): (168, 3),
+    ("adc_scan.hip", "scan_units_kernelILi1ELb1ELi0ELb0EE"): (168, 3),
+    # the plain-sum scan on the matrix cores, M = 52 and M = 32
+    ("plain_scan.hip", "scan_plain_wave_kernelILi26E"): (256, 2),
+    ("plain_scan.hip", "scan_plain_wave_kernelILi16E"): (256, 2),
+    # lane-per-query replay, distinct labels, 64 queries per wave
+    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELb0ELi64EE"): (128, 4),
+    ("rescore.hip", "rescore_staged_kernelILi32EE"): (128, 4),
+}
+
+
+def _usage(fname):
+    r = subprocess.run([HIPCC] + FLAGS + [fname], cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = {}
+    cur = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+@pytest.fixture(scope="module")
+def usage():
+    if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    files = sorted({f for f, _ in PINNED})
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        return dict(zip(files, ex.map(_usage, files)))
+
+
+@pytest.mark.parametrize("key", sorted(PINNED))
+def test_no_scratch_and_occupancy(usage, key):
+    fname, sub = key
+    max_vgpr, min_waves = PINNED[key]
+    hits = {k: v for k, v in usage[fname].items() if sub in k}
+    assert hits, f"no kernel matching {sub} in {fname}: " + ", ".join(sorted(usage[fname]))[:2000]
+    for name, u in hits.items():
+        assert u.get("ScratchSize") == 0, (name, u)
+        assert u.get("VGPRs Spill", 0) == 0 and u.get("SGPRs Spill", 0) == 0, (name, u)
+        assert u["VGPRs"] + u.get("AGPRs", 0) <= max_vgpr, (name, u)
+        assert u["Occupancy"] >= min_waves, (name, u)
+
+
+def test_no_kernel_of_the_scan_files_uses_scratch(usage):
+    """Every instantiation of the scan kernels, not only the default ones."""
+    bad = {k: v["ScratchSize"] for f in ("adc_scan.hip", "plain_scan.hip") for k, v in usage[f].items()
+           if v.get("ScratchSize", 0) != 0}
+    assert not bad, bad

@@ -397,10 +397,7 @@ __device__ __forceinline__ void finish_chunk(uint32_t (&a0)[8], uint4 &o, uint32
 }
 
 #define TK_UNIT_Q 4
-// work counters of the list-major scan: TK_TICKETS ints, 128 bytes apart, behind the
-// (n_lists+1)-entry unit_prefix table in the same allocation
-#define TK_TICKETS 8
-#define TK_TICKET_OFF(n_lists) ((((n_lists) + 1 + 31) / 32 + 1) * 32)
+#include "tickets.h"
 
 // One scan job of the list-major kernel: everything tk_launch_scan_units takes.
 // (kernels.h: struct TkScanJob)
@@ -623,63 +620,6 @@ __device__ __forceinline__ void scan_units_block_lds(
 #define TK_LDS_WAVE_BYTES 9984
 #define TK_LDS_WAVE_BYTES_MAX 13312
 
-// Blocks of 64 consecutive units.  Every wave takes one block statically; the rest are
-// drawn from TK_TICKETS work counters (behind the prefix table, a cache line each, zeroed
-// by the kernel that wrote the table; a wave starts at its home counter and moves on when a
-// range is used up), the draw for the NEXT block being issued before the current block's
-// work.  With other batches' heap replays sharing some SIMDs a static split leaves the
-// kernel waiting for its slowest waves.  One counter would not do: same-address atomics
-// retire at ~60 M/s and this kernel wants 70 M blocks/s.
-// `work(blk)` processes block blk of NB.
-template <typename F>
-__device__ __forceinline__ void ticketed_blocks(int NB, int *ticket, F work)
-{
-    const int NW = gridDim.x * 4 < NB ? gridDim.x * 4 : NB;   // blocks handed out statically
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int dyn = NB - NW;
-    int tried = 0, tk = wid & (TK_TICKETS - 1);
-    // synchronous draw: the search through the other ranges once a wave's range is used up
-    auto draw = [&]() -> int {
-        while (tried < TK_TICKETS) {
-            const int lo = (int)((int64_t)dyn * tk / TK_TICKETS);
-            const int len = (int)((int64_t)dyn * (tk + 1) / TK_TICKETS) - lo;
-            int got = len;
-            if ((threadIdx.x & 63) == 0) {
-                int *t = ticket + tk * 32;
-                if (__atomic_load_n(t, __ATOMIC_RELAXED) < len) got = atomicAdd(t, 1);
-            }
-            got = __builtin_amdgcn_readfirstlane(got);
-            if (got < len) return NW + lo + got;
-            tried++;
-            tk = (tk + 1) & (TK_TICKETS - 1);
-        }
-        return NB;
-    };
-    int blk = wid < NW ? wid : NB;
-    while (blk < NB) {
-        // draw the block after this one now; the answer is looked at after this block's work
-        int nlo = 0, nlen = 0, ngot = 0;
-        const bool drawn = dyn > 0 && tried < TK_TICKETS;
-        if (drawn) {
-            nlo = (int)((int64_t)dyn * tk / TK_TICKETS);
-            nlen = (int)((int64_t)dyn * (tk + 1) / TK_TICKETS) - nlo;
-            if ((threadIdx.x & 63) == 0) ngot = atomicAdd(ticket + tk * 32, 1);
-        }
-        work(__builtin_amdgcn_readfirstlane(blk));   // wave-uniform, and known to be
-        // next block
-        blk = NB;
-        if (!drawn) break;
-        ngot = __builtin_amdgcn_readfirstlane(ngot);
-        if (ngot < nlen) {
-            blk = NW + nlo + ngot;
-            continue;
-        }
-        tried++;
-        tk = (tk + 1) & (TK_TICKETS - 1);
-        blk = draw();
-    }
-}
-
 // COARSE only tags the instantiation used for the coded centres so that profilers
 // list the two launches of a batch separately.  LDS_T: table rows through LDS (gmax > 0).
 // FORM: 0 = table rows by per-lane global loads (3 waves/SIMD), 1 = rows through LDS, rows of
@@ -714,25 +654,39 @@ __global__ __launch_bounds__(256, (FORM == 1 ? 4 : 3)) void scan_units_kernel(
 // Two jobs in one launch, one pool of blocks: the list scan of batch b and the coarse scan
 // of batch b+1 (pipelined mode, api.hip).  Either job may be absent (unit_prefix == NULL).
 // The work counters are those of the first job present.
+// The three jobs arrive as ONE by-value argument, the first one, and are read where they lie — in
+// the kernel-argument segment, through scalar loads at a wave-uniform offset.  (Selecting among
+// three by-value structs, `which == 0 ? a : ...`, made the compiler copy all of them to private
+// memory: 480 B of scratch per lane on every instantiation; tests/test_kernel_resources.py.)
+struct TkScanJobs3 { TkScanJob j[3]; };
+typedef const __attribute__((address_space(4))) TkScanJob tk_kernarg_job;
+
 template <int ORDER, bool SIGNED, int FORM>
-__global__ __launch_bounds__(256, (FORM == 1 ? 4 : 3)) void scan_units2_kernel(TkScanJob a, TkScanJob b, TkScanJob c,
-                                                                int P, int M, int gmax)
+__global__ __launch_bounds__(256, (FORM == 1 ? 4 : 3)) void scan_units2_kernel(TkScanJobs3 jobs_by_value, int P,
+                                                                int M, int gmax)
 {
     extern __shared__ uint4 tk_lds_tables[];
     uint4 *lw = tk_lds_tables + (threadIdx.x >> 6) * (gmax * TK_UNIT_Q * M);
-    const int UA = a.unit_prefix ? a.unit_prefix[a.n_lists] : 0;
-    const int UB = b.unit_prefix ? b.unit_prefix[b.n_lists] : 0;
-    const int UC = c.unit_prefix ? c.unit_prefix[c.n_lists] : 0;
+    (void)jobs_by_value;        // (offset 0 of the kernel-argument segment)
+    tk_kernarg_job *jobs = (tk_kernarg_job *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int *upa = jobs[0].unit_prefix, *upb = jobs[1].unit_prefix, *upc = jobs[2].unit_prefix;
+    const int UA = upa ? upa[jobs[0].n_lists] : 0;
+    const int UB = upb ? upb[jobs[1].n_lists] : 0;
+    const int UC = upc ? upc[jobs[2].n_lists] : 0;
     const int NBA = (UA + 63) >> 6, NBB = (UB + 63) >> 6, NBC = (UC + 63) >> 6;
-    int *ticket = a.unit_prefix ? const_cast<int *>(a.unit_prefix) + TK_TICKET_OFF(a.n_lists)
-                : b.unit_prefix ? const_cast<int *>(b.unit_prefix) + TK_TICKET_OFF(b.n_lists)
-                                : const_cast<int *>(c.unit_prefix) + TK_TICKET_OFF(c.n_lists);
-    ticketed_blocks(NBA + NBB + NBC, ticket, [&](int blk) {
-        // one copy of the block body: the job's fields are picked with wave-uniform selects
+    int *ticket = upa ? const_cast<int *>(upa) + TK_TICKET_OFF(jobs[0].n_lists)
+                : upb ? const_cast<int *>(upb) + TK_TICKET_OFF(jobs[1].n_lists)
+                      : const_cast<int *>(upc) + TK_TICKET_OFF(jobs[2].n_lists);
+    // (captures by VALUE: by reference, `which == 0 ? UA : ...` becomes a select between the addresses
+    // of the closure's members, and the closure goes to scratch)
+    ticketed_blocks(NBA + NBB + NBC, ticket, [=](int blk) {
+        // one copy of the block body; `which` is wave-uniform
         const int which = blk < NBA ? 0 : (blk < NBA + NBB ? 1 : 2);
-        const TkScanJob &j = which == 0 ? a : (which == 1 ? b : c);
-        const int U = which == 0 ? UA : (which == 1 ? UB : UC);
-        const int jb = which == 0 ? blk : (which == 1 ? blk - NBA : blk - NBA - NBB);
+        tk_kernarg_job &j = jobs[which];
+        // (masks, not `which == 0 ? UA : ...`: the compiler turns that into a load through a selected
+        // ADDRESS of the closure's members, which pins the closure in scratch)
+        const int U = (UA & -(int)(which == 0)) | (UB & -(int)(which == 1)) | (UC & -(int)(which == 2));
+        const int jb = blk - (NBA & -(int)(which >= 1)) - (NBB & -(int)(which == 2));
         if (FORM != 0)
             scan_units_block_lds<ORDER, SIGNED, FORM == 1>(j.codes, P, j.tables, M, j.list_chunk_off, j.n_lists,
                                                 j.unit_prefix, j.pair_off, j.pair_q, j.pair_f0, j.dist,
@@ -836,8 +790,52 @@ void tk_launch_unit_pairs(int64_t nq, const int64_t *probes, int S, int64_t n_li
 // -> units of the exact kernel over the first head_chunks chunks of the list.
 struct PairSets {
     int *count[3], *cursor[3], *pair_off[3], *unit_prefix[3], *pair_q[3], *pair_f0[3];
-    int *unit_desc;
+    int *unit_desc;     // set 1: int4 (list, tile, first chunk pair, end chunk pair) per unit
+    int plain_k;        // set 1: chunk pairs per unit (a multiple of 4)
 };
+
+// Units of the plain kernel (plain_scan.hip: one wave per unit): a tile of 32 of a list's pairs
+// times a range of at most K chunk pairs, numbered (list, tile, range) with the range fastest —
+// the waves of a workgroup take neighbouring units, i.e. ranges of ONE tile, and read the same
+// table rows.  unit_prefix[l] = units before list l.
+__device__ __forceinline__ int plain_units_of(int cnt, int C, int K)
+{
+    if (cnt <= 0 || C <= 0) return 0;
+    const int CP = (C + 1) >> 1;
+    return ((cnt + 31) >> 5) * ((CP + K - 1) / K);
+}
+
+__device__ __forceinline__ void plain_desc_fill(const int *__restrict__ unit_prefix,
+                                                const int64_t *__restrict__ list_chunk_off, int n_lists,
+                                                int K, int4 *__restrict__ desc, int u)
+{
+    int lo = 0, hi = n_lists;       // unit_prefix[lo] <= u < unit_prefix[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (unit_prefix[mid] <= u) lo = mid; else hi = mid;
+    }
+    const int local = u - unit_prefix[lo];
+    const int C = (int)(list_chunk_off[lo + 1] - list_chunk_off[lo]);
+    const int CP = (C + 1) >> 1;
+    const int nsub = (CP + K - 1) / K;
+    const int t = local / nsub, sb = local - t * nsub;
+    const int a = sb * K, b = a + K < CP ? a + K : CP;
+    desc[u] = make_int4(lo, t, a, b);
+}
+
+__global__ void plain_desc_kernel(const int *__restrict__ unit_prefix, const int64_t *__restrict__ list_chunk_off,
+                                  int n_lists, int K, int4 *__restrict__ desc)
+{
+    const int U = unit_prefix[n_lists];
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x)
+        plain_desc_fill(unit_prefix, list_chunk_off, n_lists, K, desc, u);
+}
+
+void tk_launch_plain_desc(const TkPairSet &pl, const int64_t *list_chunk_off, int64_t n_lists, hipStream_t s)
+{
+    hipLaunchKernelGGL(plain_desc_kernel, dim3(256), dim3(256), 0, s, pl.unit_prefix, list_chunk_off,
+                       (int)n_lists, pl.plain_k, (int4 *)pl.unit_desc);
+}
 
 __global__ __launch_bounds__(1024) void pairs_scan3_kernel(PairSets ps, const int64_t *__restrict__ list_chunk_off,
                                                            int n_lists, int head_chunks)
@@ -862,7 +860,7 @@ __global__ __launch_bounds__(1024) void pairs_scan3_kernel(PairSets ps, const in
                     unit = groups * (set == 2 && head_chunks < C ? head_chunks : C);
                 } else {
                     rec = cnt;
-                    unit = C > 0 ? (cnt + 31) / 32 : 0;
+                    unit = plain_units_of(cnt, C, ps.plain_k);
                 }
             }
             s_a[threadIdx.x] = rec;
@@ -884,11 +882,6 @@ __global__ __launch_bounds__(1024) void pairs_scan3_kernel(PairSets ps, const in
                 cur_p[l] = 0;
                 if (set != 1)
                     for (int t = cnt; t < rec; t++) pq[off + t] = -1;   // padding records
-                else        // (list, tile) of every unit: the plain kernel looks its unit up in one load
-                    for (int t = 0; t < unit; t++) {
-                        ps.unit_desc[2 * (ubase + t)] = l;
-                        ps.unit_desc[2 * (ubase + t) + 1] = t;
-                    }
             }
             __syncthreads();
             if (threadIdx.x == 1023) {
@@ -901,17 +894,22 @@ __global__ __launch_bounds__(1024) void pairs_scan3_kernel(PairSets ps, const in
             off_p[n_lists] = carry_a;
             unit_p[n_lists] = carry_b;
         }
-        if (set != 1 && threadIdx.x < TK_TICKETS) unit_p[TK_TICKET_OFF(n_lists) + threadIdx.x * 32] = 0;
-        if (set == 1 && threadIdx.x == 0) unit_p[TK_PLAIN_COUNTER_OFF(n_lists)] = 0;
+        if (threadIdx.x < TK_TICKETS) unit_p[TK_TICKET_OFF(n_lists) + threadIdx.x * 32] = 0;
         __syncthreads();
     }
 }
 
 __global__ void pairs_fill3_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
                                    int64_t n_lists, const int *__restrict__ slot_prefix,
-                                   const int *__restrict__ slot_exact, PairSets ps)
+                                   const int *__restrict__ slot_exact, PairSets ps,
+                                   const int64_t *__restrict__ list_chunk_off)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    {   // the plain kernel's unit descriptors (unit_prefix is complete: pairs_scan3_kernel ran before)
+        const int U = ps.unit_prefix[1][n_lists];
+        for (int64_t u = i; u < U; u += (int64_t)gridDim.x * blockDim.x)
+            plain_desc_fill(ps.unit_prefix[1], list_chunk_off, (int)n_lists, ps.plain_k, (int4 *)ps.unit_desc, (int)u);
+    }
     if (i >= nq * S) return;
     const int64_t qi = i / S;
     const int s = (int)(i - qi * S);
@@ -941,6 +939,7 @@ static PairSets pair_sets(const TkPairSet &ex, const TkPairSet &pl, const TkPair
         ps.unit_prefix[i] = sets[i]->unit_prefix; ps.pair_q[i] = sets[i]->pair_q; ps.pair_f0[i] = sets[i]->pair_f0;
     }
     ps.unit_desc = pl.unit_desc;
+    ps.plain_k = pl.plain_k < 4 ? 12 : (pl.plain_k + 3) & ~3;
     return ps;
 }
 
@@ -963,7 +962,7 @@ void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_l
     hipLaunchKernelGGL(pairs_scan3_kernel, dim3(1), dim3(1024), 0, s, ps, list_chunk_off, (int)n_lists,
                        head_chunks);
     hipLaunchKernelGGL(pairs_fill3_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, probes, S,
-                       nq, n_lists, slot_prefix, slot_exact, ps);
+                       nq, n_lists, slot_prefix, slot_exact, ps, list_chunk_off);
 }
 
 void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_lists, int *pair_off,
@@ -1070,9 +1069,12 @@ void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_
 void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
                            hipStream_t s, const TkScanJob *cj)
 {
-    TkScanJob c;
-    memset(&c, 0, sizeof c);
-    if (cj) c = *cj;
+    TkScanJobs3 jobs;
+    memset(&jobs, 0, sizeof jobs);
+    jobs.j[0] = a;
+    jobs.j[1] = b;
+    if (cj) jobs.j[2] = *cj;
+    const TkScanJob &c = jobs.j[2];
     if (!a.unit_prefix && !b.unit_prefix && !c.unit_prefix) return;
     const int P = M / 2;
     int form = g_scan_form;
@@ -1083,8 +1085,8 @@ void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int or
     do {                                                                                          \
         static bool attr_ = false;                                                                \
         if (F_ != 0 && !attr_) { lds_attr(scan_units2_kernel<O, true, F_>); attr_ = true; }       \
-        hipLaunchKernelGGL((scan_units2_kernel<O, true, F_>), dim3(n_blocks), dim3(256), lds, s, a, \
-                           b, c, P, M, gmax);                                                     \
+        hipLaunchKernelGGL((scan_units2_kernel<O, true, F_>), dim3(n_blocks), dim3(256), lds, s,  \
+                           jobs, P, M, gmax);                                                     \
     } while (0)
 #define TK_LAUNCH1(O)                                  \
     do {                                               \

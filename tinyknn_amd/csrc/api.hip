@@ -993,6 +993,24 @@ static bool plain_now(tk_index *ix, const Plan &p)
     }
 }
 
+// Chunk pairs per unit of the plain kernel (one wave per unit): a multiple of 4 — the wave's output
+// tile leaves every fourth chunk pair — of at least 12 (a unit's 26 table-row loads want amortising),
+// more where a batch holds far more than ~6 units per resident wave (long lists: 100M x 128).
+static int plain_k(const tk_index *ix, int64_t nq, const Plan &p)
+{
+    if (!tk_plain_wave_form()) return TK_PLAIN_K_WHOLE;
+    const double iters = (double)nq * p.S / 32.0 * ((double)ix->total_chunks / (double)ix->n_lists) / 2.0;
+    int k = (int)(iters / (2048.0 * 6.0));
+    k = (k + 3) & ~3;
+    return k < 12 ? 12 : (k > 64 ? 64 : k);
+}
+
+static size_t plain_desc_bytes(const tk_index *ix, int64_t nq, const Plan &p)
+{
+    return (size_t)tk_plain_units_bound(nq * p.S, ix->n_lists, ix->total_chunks, ix->max_list_chunks,
+                                        plain_k(ix, nq, p)) * 16;
+}
+
 static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
 {
     const int M = ix->M;
@@ -1043,7 +1061,7 @@ static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
         TRY(w.p_pair_q.ensure(((size_t)nq * p.S + 4) * 4));
         TRY(w.p_pair_f0.ensure(((size_t)nq * p.S + 4) * 4));
         TRY(w.flag_list.ensure(((size_t)nq + 1) * 4));
-        TRY(w.p_unit_desc.ensure(((size_t)nq * p.S / 32 + L + 8) * 8));
+        TRY(w.p_unit_desc.ensure(plain_desc_bytes(ix, nq, p)));
         TRY(w.plain0.ensure((size_t)nq * 4));
         if (!w.flag_host) {
             HIPCHECK(hipHostMalloc((void **)&w.flag_host, 64, hipHostMallocDefault));
@@ -1211,7 +1229,7 @@ static TkScanJob plain_job(const tk_index *ix, const Work &w, const Plan &p)
     j.pair_off = w.p_pair_off.as<int>();
     j.pair_q = w.p_pair_q.as<int>();
     j.pair_f0 = w.p_pair_f0.as<int>();
-    j.unit_desc = w.p_unit_desc.as<int>();
+    j.unit_desc4 = w.p_unit_desc.as<int>();
     return j;
 }
 
@@ -1345,7 +1363,7 @@ static void unit_pairs(tk_index *ix, Work &w, int64_t nq, const Plan &p, bool pl
                  w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>()};
     TkPairSet pl{w.p_count.as<int>(), w.p_cursor.as<int>(), w.p_pair_off.as<int>(),
                  w.p_unit_prefix.as<int>(), w.p_pair_q.as<int>(), w.p_pair_f0.as<int>(),
-                 w.p_unit_desc.as<int>()};
+                 w.p_unit_desc.as<int>(), plain_k(ix, nq, p)};
     TkPairSet hd{w.h_count.as<int>(), w.h_cursor.as<int>(), w.h_pair_off.as<int>(),
                  w.h_unit_prefix.as<int>(), w.h_pair_q.as<int>(), w.h_pair_f0.as<int>()};
     tk_launch_unit_pairs2(nq, w.probes.as<int64_t>(), p.S, ix->n_lists, ix->list_chunk_off.as<int64_t>(),
@@ -2125,7 +2143,7 @@ static int reserve_shard_plain(tk_index *ix, Work &w, int64_t nq, const Plan &p)
     TRY(w.p_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
     TRY(w.p_pair_q.ensure(((size_t)nq * p.S + 4) * 4));
     TRY(w.p_pair_f0.ensure(((size_t)nq * p.S + 4) * 4));
-    TRY(w.p_unit_desc.ensure(((size_t)nq * p.S / 32 + L + 8) * 8));
+    TRY(w.p_unit_desc.ensure(plain_desc_bytes(ix, nq, p)));
     TRY(w.h_cursor.ensure(L * 4));
     TRY(w.h_pair_off.ensure((L + 1) * 4));
     TRY(w.h_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
@@ -2235,10 +2253,11 @@ extern "C" int tk_index_shard_scan_rest_dev(tk_index *ix, int slot, int64_t nq, 
                  w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>()};
     TkPairSet pl{w.p_count.as<int>(), w.p_cursor.as<int>(), w.p_pair_off.as<int>(),
                  w.p_unit_prefix.as<int>(), w.p_pair_q.as<int>(), w.p_pair_f0.as<int>(),
-                 w.p_unit_desc.as<int>()};
+                 w.p_unit_desc.as<int>(), plain_k(ix, nq, p)};
     TkPairSet hd{w.h_count.as<int>(), w.h_cursor.as<int>(), w.h_pair_off.as<int>(),
                  w.h_unit_prefix.as<int>(), w.h_pair_q.as<int>(), w.h_pair_f0.as<int>()};   // (stays empty)
     tk_launch_pairs_scan3(ex, pl, hd, ix->local_chunk_off.as<int64_t>(), ix->n_lists, 0, st);
+    tk_launch_plain_desc(pl, ix->local_chunk_off.as<int64_t>(), ix->n_lists, st);
     tk_launch_shard_pairs_fill(probes, p.S, nq, ix->n_lists, owner, ix->rank, w.spos.as<int>(),
                                w.u_pair_off.as<int>(), w.u_cursor.as<int>(), w.u_pair_q.as<int>(),
                                w.u_pair_f0.as<int>(), st, 1, p.S, w.plain_q.as<uint8_t>(), 0);
@@ -2255,7 +2274,7 @@ extern "C" int tk_index_shard_scan_rest_dev(tk_index *ix, int slot, int64_t nq, 
     pj.pair_off = w.p_pair_off.as<int>();
     pj.pair_q = w.p_pair_q.as<int>();
     pj.pair_f0 = w.p_pair_f0.as<int>();
-    pj.unit_desc = w.p_unit_desc.as<int>();
+    pj.unit_desc4 = w.p_unit_desc.as<int>();
     pj.dist = (uint4 *)send_dev;
     pj.cap = 0;
     pj.mins = w.smins.as<uint8_t>();
@@ -2291,7 +2310,13 @@ extern "C" int tk_index_shard_plain_stats(tk_index *ix, int slot, int64_t *out4)
     HIPCHECK(hipMemcpy(pq.data(), w.plain_q.p, pq.size(), hipMemcpyDeviceToHost));
     int64_t n = 0;
     for (uint8_t b : pq) n += b != 0;
-    out4[0] = v[0]; out4[1] = v[1]; out4[2] = v[2]; out4[3] = n;
+    int64_t tiles = 0;          // (v[1] units = (tile, range of chunk pairs): a tile's first range starts at 0)
+    if (v[1] > 0) {
+        std::vector<int> desc((size_t)v[1] * 4);
+        HIPCHECK(hipMemcpy(desc.data(), w.p_unit_desc.p, desc.size() * 4, hipMemcpyDeviceToHost));
+        for (int u = 0; u < v[1]; u++) tiles += desc[(size_t)4 * u + 2] == 0;
+    }
+    out4[0] = v[0]; out4[1] = tiles; out4[2] = v[2]; out4[3] = n;
     return TK_OK;
 }
 
@@ -3242,17 +3267,17 @@ extern "C" int tk_index_plain_stats(tk_index *ix, int64_t *out8)
     HIPCHECK(hipMemcpy(&v[3], w.h_pair_off.as<int>() + L, 4, hipMemcpyDeviceToHost));
     int flagged = 0;
     HIPCHECK(hipMemcpy(&flagged, w.flag_list.p, 4, hipMemcpyDeviceToHost));
-    out8[0] = v[0]; out8[1] = v[1]; out8[2] = v[2]; out8[3] = v[3]; out8[4] = flagged;
+    out8[1] = v[1]; out8[2] = v[2]; out8[3] = v[3]; out8[4] = flagged;
     if (v[0] > 0) {
-        std::vector<int> desc((size_t)v[0] * 2);
-        std::vector<int64_t> coff((size_t)L + 1);
+        // v[0] units = (tile, range of chunk pairs); a tile's first range starts at chunk pair 0
+        std::vector<int> desc((size_t)v[0] * 4);
         HIPCHECK(hipMemcpy(desc.data(), w.p_unit_desc.p, desc.size() * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(coff.data(), ix->list_chunk_off.p, coff.size() * 8, hipMemcpyDeviceToHost));
-        int64_t cps = 0;
+        int64_t cps = 0, tiles = 0;
         for (int u = 0; u < v[0]; u++) {
-            const int l = desc[(size_t)2 * u];
-            if (l >= 0 && l < L) cps += (coff[(size_t)l + 1] - coff[(size_t)l] + 1) / 2;
+            tiles += desc[(size_t)4 * u + 2] == 0;
+            cps += desc[(size_t)4 * u + 3] - desc[(size_t)4 * u + 2];
         }
+        out8[0] = tiles;
         out8[5] = cps;
     }
     return TK_OK;

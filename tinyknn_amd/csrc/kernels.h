@@ -77,8 +77,8 @@ struct TkScanJob {
     int64_t cap;
     uint8_t *mins;
     int64_t min_stride;
-    const int *unit_desc = nullptr;   // plain kernel: (list, tile) of every unit, 2 ints each
     int max_chunks = 0;               // list-major kernel: only the first max_chunks chunks of a list (0: all)
+    const int *unit_desc4 = nullptr;  // plain kernel: int4 (list, tile, first chunk pair, end chunk pair) of every unit
 };
 // table rows of the list-major kernel: 1 = staged per block in LDS (default), 0 = per-lane
 // global loads (the round-1 form; A/B switch)
@@ -95,7 +95,10 @@ int tk_get_scan_tables(void);
 void tk_launch_table_limits(const uint4 *tables, int M, int order, int64_t nq, int *qlim, hipStream_t s);
 void tk_plain_force_limit(int v);      // debug: cap every query's limit (INT_MAX = off)
 int tk_plain_forced(void);             // ... is such a cap set?
-void tk_plain_set_form(int form);      // 0 = table operand in registers (default), 1 / 2 = read from LDS per MFMA (A/B)
+void tk_plain_set_flush(int on);      // wave form: outputs through an LDS tile, a whole line per query (default on)
+void tk_plain_set_form(int form);
+int tk_plain_wave_form(void);          // the default form (one wave per unit) is selected
+#define TK_PLAIN_K_WHOLE (1 << 20)     // plain_k of the workgroup-per-tile forms: one unit per tile      // 0 = table operand in registers (default), 1 / 2 = read from LDS per MFMA (A/B)
 int tk_plain_fits(int M);
 // TkScanJob with unit_prefix = tiles of 32 pairs before each list (+ the work counter at
 // TK_PLAIN_COUNTER_OFF); pair records are not padded.  Returns -1 for unsupported M.
@@ -103,8 +106,18 @@ int tk_launch_scan_plain(const TkScanJob &j, int M, int order, int n_blocks, hip
 // the second pair set (plain pairs) beside the first in ONE pass: see tk_launch_unit_pairs2
 struct TkPairSet {
     int *count, *cursor, *pair_off, *unit_prefix, *pair_q, *pair_f0;
-    int *unit_desc = nullptr;      // plain set: (list, tile) per unit, 2 ints each (nq * S / 32 + n_lists + 1 units)
+    int *unit_desc = nullptr;      // plain set: int4 (list, tile, first chunk pair, end chunk pair) per unit
+    int plain_k = 12;              // plain set: chunk pairs per unit, a multiple of 4 (tk_plain_units_bound)
 };
+// the plain set's unit descriptors alone (tk_launch_unit_pairs2 writes them itself; callers of
+// tk_launch_pairs_scan3 that fill the records their own way call this behind it)
+void tk_launch_plain_desc(const TkPairSet &pl, const int64_t *list_chunk_off, int64_t n_lists, hipStream_t s);
+// upper bound of the plain set's units for nq * S pairs over n_lists lists
+static inline int64_t tk_plain_units_bound(int64_t pairs, int64_t n_lists, int64_t total_chunks, int max_list_chunks, int K)
+{
+    const int64_t nsub_max = (max_list_chunks / 2 + 1 + K - 1) / K + 1;
+    return (pairs / 32 + 1) * nsub_max + total_chunks / (2 * (int64_t)K) + 2 * n_lists + 8;
+}
 // (query, slot) pairs grouped by list, split at slot_exact[q]: slots below it -> set `ex` (units
 // of the list-major exact kernel), the others -> set `pl` (tiles of the plain kernel)
 // hd (head pairs: the first probed list of a query in head mode, slot_exact[q] == 0): units of the

@@ -40,9 +40,26 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "tickets.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+
+#ifdef TK_PLAIN_CLOCK       // scripts/micro only: the clock the chip holds inside the kernel (s_memtime / s_memrealtime)
+__device__ unsigned long long tk_plain_clock[4];
+#define TK_CLOCK_BEGIN() const unsigned long long ck_t0_ = __builtin_readcyclecounter(), ck_r0_ = __builtin_amdgcn_s_memrealtime()
+#define TK_CLOCK_END()                                                                          \
+    do {                                                                                        \
+        if ((threadIdx.x & 63) == 0) {                                                          \
+            atomicAdd(&tk_plain_clock[0], (unsigned long long)__builtin_readcyclecounter() - ck_t0_);       \
+            atomicAdd(&tk_plain_clock[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - ck_r0_);   \
+            atomicAdd(&tk_plain_clock[2], 1ull);                                                \
+        }                                                                                       \
+    } while (0)
+#else
+#define TK_CLOCK_BEGIN()
+#define TK_CLOCK_END()
+#endif
 
 // ---------------------------------------------------------------------------
 // C of the lemma per query, or TK_PLAIN_NEVER when a chain's negative mass exceeds 128
@@ -150,6 +167,7 @@ template <int PT, bool EXACT>
 __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, int M)
 {
     if (EXACT) P = PT;
+    TK_CLOCK_BEGIN();
     using SH = PlainShape<PT>;
     constexpr int PS = SH::PS, TROW = SH::TROW, TL = SH::TL;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem_plain[];
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
     // (a binary search through unit_prefix here was ten dependent trips to L2 per look-up, three
     // look-ups per unit: longer than the unit's arithmetic)
     auto locate = [&](int u, int &l, int &t) {
-        const int2 d = ((const int2 *)j.unit_desc)[u];
+        const int4 d = ((const int4 *)j.unit_desc4)[u];     // (this form takes whole tiles: plain_k = TK_PLAIN_K_WHOLE)
         l = __builtin_amdgcn_readfirstlane(d.x);
         t = __builtin_amdgcn_readfirstlane(d.y);
     };
@@ -264,17 +282,21 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
             return j.codes[((gc >> 3) * (int64_t)(M >> 1) + lp) * 8 + (gc & 7)];
         };
         __syncthreads();                   // the next unit's pairs are staged
-        int cp = wave;
-        uint4 g0 = fetch(cp), g1 = fetch(cp + 4);
-        for (; cp < CP; cp += 4) {
-            const uint4 g2 = fetch(cp + 8);
-            const uint4 tslice = fetch_slice(buf ^ 1);
+        // Two code groups in flight in two NAMED registers, iterations in pairs, the first pair peeled:
+        // loads and stores retire through one in-order counter, and at a loop header the compiler
+        // merges the counter's state on entry (the two prefetched groups are the youngest operations)
+        // with the back edge's — a rotation by moves (g0 = g1; g1 = g2) and an un-peeled loop made
+        // every iteration wait for the store it had issued a few instructions earlier (vmcnt(1)).
+        auto stage_codes = [&](const uint4 g) {
             if (loader) {
-                st[(lch * 4 + 0) * PS + lp] = g0.x;
-                st[(lch * 4 + 1) * PS + lp] = g0.y;
-                st[(lch * 4 + 2) * PS + lp] = g0.z;
-                st[(lch * 4 + 3) * PS + lp] = g0.w;
+                st[(lch * 4 + 0) * PS + lp] = g.x;
+                st[(lch * 4 + 1) * PS + lp] = g.y;
+                st[(lch * 4 + 2) * PS + lp] = g.z;
+                st[(lch * 4 + 3) * PS + lp] = g.w;
             }
+        };
+        auto chunk_pair = [&](int cp) {
+            const uint4 tslice = fetch_slice(buf ^ 1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // (the staging region is rewritten one iteration later, after this iteration's reads:
@@ -357,8 +379,31 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
                 slice_next();
                 ks++;
             }
-            g0 = g1;
-            g1 = g2;
+        };
+        int cp = wave;
+        uint4 ga = fetch(cp), gb = fetch(cp + 4);
+#define TK_PAIR(cp_)                                  \
+        {                                             \
+            stage_codes(ga);                          \
+            ga = fetch((cp_) + 8);                    \
+            chunk_pair(cp_);                          \
+            stage_codes(gb);                          \
+            gb = fetch((cp_) + 12);                   \
+            chunk_pair((cp_) + 4);                    \
+        }
+        if (cp + 4 < CP) {
+            TK_PAIR(cp)
+            cp += 8;
+#pragma nounroll
+            while (cp + 4 < CP) {
+                TK_PAIR(cp)
+                cp += 8;
+            }
+        }
+#undef TK_PAIR
+        if (cp < CP) {
+            stage_codes(ga);
+            chunk_pair(cp);
         }
         for (; ks < TL; ks++) {
             store_slice(buf ^ 1, fetch_slice(buf ^ 1));
@@ -367,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void scan_plain_kernel(TkScanJob j, int P, 
         u = un;
         buf ^= 1;
     }
+    TK_CLOCK_END();
 }
 
 // ---------------------------------------------------------------------------
@@ -424,7 +470,7 @@ __global__ __launch_bounds__(256, WPS) void scan_plain_lds_kernel(TkScanJob j, i
         __syncthreads();                   // every wave is done with the previous unit's tile
         const int u = s_unit[0];
         if (u >= n_units) break;           // (workgroup-uniform)
-        const int2 d = ((const int2 *)j.unit_desc)[u];
+        const int4 d = ((const int4 *)j.unit_desc4)[u];
         const int l = __builtin_amdgcn_readfirstlane(d.x), t = __builtin_amdgcn_readfirstlane(d.y);
         int nvalid = j.pair_off[l + 1] - j.pair_off[l] - 32 * t;      // >= 1
         nvalid = nvalid < 32 ? nvalid : 32;
@@ -530,10 +576,239 @@ __global__ __launch_bounds__(256, WPS) void scan_plain_lds_kernel(TkScanJob j, i
     }
 }
 
+// ---------------------------------------------------------------------------
+// Round 4: ONE WAVE PER UNIT.  A unit is (list, tile of 32 of its pairs, range of chunk pairs):
+// int4 descriptors written by plain_desc_fill (adc_scan.hip).  What changed against the
+// workgroup-per-tile form above, and why:
+//   * no workgroup barrier and no table tile in LDS: a wave loads the 26 table rows of its lane's
+//     query straight into the B registers (the sub-units of a tile are consecutive units, so the
+//     four waves of a workgroup read the same rows: L1 hits) — 3.8 KB of LDS per workgroup
+//     instead of 58 KB, and a unit's 12 chunk pairs amortise that load, where the four waves of
+//     the old form met at two barriers every ~9 chunk pairs;
+//   * the chunk-pair loop is PEELED twice by hand.  Loads and stores retire through one in-order
+//     counter (vmcnt); at a loop header the compiler merges the counter state of the loop's entry
+//     with that of its back edge, and on entry the two prefetched code groups are the YOUNGEST
+//     operations in flight: the merged wait became vmcnt(1) in every iteration, i.e. each
+//     iteration waited for the 16-byte store it had issued a few instructions earlier (a full
+//     round trip to L2: the 42 % of wave cycles in s_waitcnt of round 3).  Entering the loop from
+//     two peeled copies of its body makes entry and back edge look alike, and the waits count
+//     what they should (vmcnt(5): the loads of two iterations ago).
+//   * units are handed out like the exact kernel's blocks (tickets.h): one statically per wave,
+//     the rest from eight counters.
+// Same outputs, byte for byte, as scan_plain_kernel (tests/test_plain_scan_gpu.py,
+// scripts/micro/mfma_scan.hip).
+
+template <int PT>
+struct PlainWaveShape {
+    static constexpr int PS = (PT + 3) & ~3;
+    // one-hot table | code staging [4 waves][8][PS] dwords | per wave: output tile 32 x 9 x 16 B,
+    // minima 32 x 8 B, row offsets of the tile's pairs 2 x 32 x 8 B
+    static constexpr size_t wave_out = 32 * 9 * 16 + 32 * 8 + 2 * 32 * 8;
+    static constexpr size_t lds = 256 + (size_t)4 * 8 * PS * 4 + 4 * wave_out;
+};
+
+// FLUSH: a lane's 16-byte block of (query, chunk) and its minimum go to an LDS tile [query][chunk
+// slot] and leave every fourth chunk pair as four 16-byte stores whose eight neighbouring lanes
+// write the eight chunks of ONE query (a whole 128-byte line when the row is aligned) — instead of
+// one 16-byte store and one byte store per chunk pair that touch 32 rows each.  The texture path
+// (TA/TD 67 % / 77 % busy under the per-row form, rocprofv3 on scripts/micro/mfma_scan) is what
+// this kernel saturates first.
+template <int PT, bool EXACT, bool FLUSH>
+__global__ __launch_bounds__(256, 2) void scan_plain_wave_kernel(TkScanJob j, int P, int M)
+{
+    if (EXACT) P = PT;          // (P < PT: the block pairs past P get zero table rows)
+    TK_CLOCK_BEGIN();
+    using SH = PlainWaveShape<PT>;
+    constexpr int PS = SH::PS;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem_plain[];
+    uint4 *lut = (uint4 *)smem_plain;                                   // 16 one-hot entries
+    uint32_t *stage = (uint32_t *)(smem_plain + 256);                   // [4 waves][8][PS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char *wout = smem_plain + 256 + 4 * 8 * PS * 4 + wave * SH::wave_out;
+    uint4 *otile = (uint4 *)wout;                                       // [32 pairs][9 slots]
+    uint8_t *omin = wout + 32 * 9 * 16;                                 // [32 pairs][8 slots]
+    long long *orow = (long long *)(wout + 32 * 9 * 16 + 32 * 8);       // [32] uint4 offset of a pair's distance row
+    long long *omrow = orow + 32;                                       // [32] byte offset of its minima row
+    if (threadIdx.x < 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        w[threadIdx.x >> 2] = 1u << (8 * (threadIdx.x & 3));
+        lut[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    const int n_units = j.unit_prefix[j.n_lists];
+    int *ticket = const_cast<int *>(j.unit_prefix) + TK_TICKET_OFF(j.n_lists);
+    const int r = lane & 31, h = lane >> 5;
+    const int rr = r & 15;
+    const uint32_t rot = (uint32_t)(8 * (rr & 3) + 4 * h + 28) & 31u;    // rotate right: nibble -> bits 4..7
+    const uint32_t lut0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_plain;   // 256-byte aligned
+    const bool loader = lane < 2 * P;
+    const int ll = loader ? lane : 2 * P - 1;     // (lanes past the 2P groups clone the last loader)
+    const int lch = ll / P, lp = ll - lch * P;
+    uint32_t *st = stage + wave * 8 * PS;
+    uint32_t *stw = st + (lch * 4) * PS + lp;
+    const uint32_t *rd = st + ((r >> 4) * 4 + (rr >> 2)) * PS;
+
+    ticketed_blocks(n_units, ticket, [&](int u) {
+        const int4 d = ((const int4 *)j.unit_desc4)[u];
+        const int l = __builtin_amdgcn_readfirstlane(d.x), t = __builtin_amdgcn_readfirstlane(d.y);
+        const int cpa = __builtin_amdgcn_readfirstlane(d.z), cpb = __builtin_amdgcn_readfirstlane(d.w);
+        const int po = j.pair_off[l];
+        int nvalid = j.pair_off[l + 1] - po - 32 * t;                     // >= 1
+        nvalid = nvalid < 32 ? nvalid : 32;
+        const int rec = po + 32 * t + (r < nvalid ? r : nvalid - 1);      // (pairs past the last one: the last one)
+        const int qi = j.pair_q[rec], f0 = j.pair_f0[rec];
+        const int64_t c0 = j.list_chunk_off[l];
+        const int C = (int)(j.list_chunk_off[l + 1] - c0);
+        // tiled code layout (kernels.h) relative to the 8-chunk row the list starts in
+        const uint4 *cbase = j.codes + (c0 >> 3) * (int64_t)(8 * P) + lp * 8;
+        const int cin = (int)(c0 & 7);
+        auto fetch = [&](int cp) -> uint4 {        // unconditional (chunks past the list: its last)
+            int c = 2 * cp + lch;
+            c = (c < C ? c : C - 1) + cin;
+            return cbase[(c >> 3) * (8 * P) + (c & 7)];
+        };
+        uint4 ga = fetch(cpa), gb = fetch(cpa + 1);
+        v4i B[PT];
+        {
+            const v4i *brow = (const v4i *)(j.tables + (int64_t)qi * M + h);
+#pragma unroll
+            for (int p = 0; p < PT; p++) B[p] = (EXACT || p < P) ? brow[2 * p] : v4i{0, 0, 0, 0};
+        }
+        uint4 *drow = j.dist + (int64_t)qi * j.cap + f0;
+        uint8_t *mrow = j.mins + (int64_t)qi * j.min_stride + f0;
+        if (FLUSH && h == 0) {
+            orow[r] = (long long)qi * j.cap + f0;
+            omrow[r] = (long long)qi * j.min_stride + f0;
+        }
+        const int c_end = 2 * cpb < C ? 2 * cpb : C;      // chunks this unit owns: [2 cpa, c_end)
+
+        auto stage_codes = [&](const uint4 g) {
+            if (loader) {
+                stw[0 * PS] = g.x;
+                stw[1 * PS] = g.y;
+                stw[2 * PS] = g.z;
+                stw[3 * PS] = g.w;
+            }
+        };
+        // chunks [8 g8, 8 g8 + 8) of the tile's pairs: LDS tile -> rows
+        auto flush = [&](int g8) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int s = lane & 7, chunk = 8 * g8 + s;
+            const bool cok = chunk >= 2 * cpa && chunk < c_end;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int qq = (lane >> 3) + 8 * k;
+                const uint4 v = otile[qq * 9 + s];
+                const uint8_t m = omin[qq * 8 + s];
+                const long long ro = orow[qq], mo = omrow[qq];
+                if (cok && qq < nvalid) {
+                    j.dist[ro + chunk] = v;
+                    j.mins[mo + chunk] = m;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto chunk_pair = [&](int cp) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (the staging region is rewritten one iteration later, after this iteration's reads:
+            // LDS operations of one wave complete in issue order)
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t x[PS];
+#pragma unroll
+            for (int k = 0; k < PS / 4; k++) {
+                const uint4 v = *(const uint4 *)(rd + 4 * k);
+                x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+            }
+            v4i A[PT];
+#pragma unroll
+            for (int p = 0; p < PT; p++) A[p] = one_hot(lut0, x[p], rot);
+#pragma unroll
+            for (int p = 0; p < PT; p++)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[p], B[p], acc, 0, 0, 0);
+            // schedule: the x reads, DEPTH one-hot reads, then one MFMA per further one-hot read
+            constexpr int DEPTH = 6 < PT ? 6 : PT;
+            __builtin_amdgcn_sched_group_barrier(0x100, PS / 4 + DEPTH, 0);
+#pragma unroll
+            for (int p = 0; p < PT - DEPTH; p++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, DEPTH, 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int o[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) o[i] = clamp8(acc[i]);
+            uint32_t X = pack4(o[0], o[1], o[2], o[3]), Y = pack4(o[4], o[5], o[6], o[7]);
+            uint32_t Z = pack4(o[8], o[9], o[10], o[11]), W = pack4(o[12], o[13], o[14], o[15]);
+            uint32_t mA = (uint32_t)min(min(min(o[0], o[1]), min(o[2], o[3])), min(min(o[4], o[5]), min(o[6], o[7])));
+            uint32_t mB = (uint32_t)min(min(min(o[8], o[9]), min(o[10], o[11])), min(min(o[12], o[13]), min(o[14], o[15])));
+            swap_halves(X, Z);
+            swap_halves(Y, W);
+            swap_halves(mA, mB);
+            const int mn = min((int)mA, (int)mB);
+            if (FLUSH) {
+                const int slot = (2 * cp + h) & 7;
+                otile[r * 9 + slot] = make_uint4(X, Z, Y, W);
+                omin[r * 8 + slot] = (uint8_t)mn;
+                if ((cp & 3) == 3) flush(cp >> 2);
+            } else {
+                int cc = 2 * cp + h;
+                cc = cc < C ? cc : C - 1;      // odd list: the second half holds the first chunk again
+                drow[cc] = make_uint4(X, Z, Y, W);
+                mrow[cc] = (uint8_t)mn;
+            }
+        };
+        // Two code groups in flight, in two named registers (no rotation by moves: a move of the
+        // younger group would wait for it); iterations go in pairs, the first pair peeled (see the
+        // header comment), an odd last one on its own.
+#define TK_PAIR(cp_)                                  \
+        {                                             \
+            stage_codes(ga);                          \
+            ga = fetch((cp_) + 2);                    \
+            chunk_pair(cp_);                          \
+            stage_codes(gb);                          \
+            gb = fetch((cp_) + 3);                    \
+            chunk_pair((cp_) + 1);                    \
+        }
+        int cp = cpa;
+        if (cp + 1 < cpb) {
+            TK_PAIR(cp)
+            cp += 2;
+#pragma nounroll
+            while (cp + 1 < cpb) {
+                TK_PAIR(cp)
+                cp += 2;
+            }
+        }
+#undef TK_PAIR
+        if (cp < cpb) {
+            stage_codes(ga);
+            chunk_pair(cp);
+            cp++;
+        }
+        if (FLUSH && (cp & 3) != 0) flush((cp - 1) >> 2);      // (a unit that ends inside a group of four)
+    });
+    TK_CLOCK_END();
+}
+
 int tk_plain_fits(int M) { return M >= 2 && M % 2 == 0 && M / 2 <= 26; }
 
-static int g_plain_form = -1;       // -1: not read yet (environment, default 0)
+static int g_plain_flush = 1;      // wave form: outputs leave through an LDS tile, a whole line per query (A/B: tk_plain_set_flush)
+void tk_plain_set_flush(int on) { g_plain_flush = on; }
+static int g_plain_form = -1;       // -1: not read yet (environment, default 3)
 void tk_plain_set_form(int form) { g_plain_form = form; }
+// 3 (default): one wave per unit; 0 / 1 / 2: the round-3 workgroup-per-tile forms (whole tiles: the
+// descriptors must then be built with plain_k = TK_PLAIN_K_WHOLE — tk_plain_k says which)
+static int plain_form()
+{
+    if (g_plain_form < 0) g_plain_form = getenv("TINYKNN_PLAIN_FORM") ? atoi(getenv("TINYKNN_PLAIN_FORM")) : 3;
+    return g_plain_form;
+}
+int tk_plain_wave_form(void) { return plain_form() == 3; }
 
 // j.unit_prefix: tiles of 32 pairs before each list (n_lists + 1), then the work counter (zeroed
 // by the kernel that wrote the table); P block pairs are summed (AVX order: an odd trailing pair
@@ -544,6 +819,32 @@ int tk_launch_scan_plain(const TkScanJob &j, int M, int order, int n_blocks, hip
     int P = M / 2;
     if (order == TK_ORDER_AVX) P &= ~1;
     if (P < 1 || P > 26) return -1;
+    if (tk_plain_wave_form()) { // one wave per unit (descriptors with chunk-pair ranges)
+#define TK_LAUNCH_W(PT_, EX_)                                                                       \
+    do {                                                                                            \
+        if (g_plain_flush) {                                                                        \
+            static bool attr_ = false;                                                              \
+            if (!attr_) {                                                                           \
+                if (hipFuncSetAttribute((const void *)scan_plain_wave_kernel<PT_, EX_, true>,       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,                 \
+                                        (int)PlainWaveShape<PT_>::lds) != hipSuccess)               \
+                    return -1;                                                                      \
+                attr_ = true;                                                                       \
+            }                                                                                       \
+            hipLaunchKernelGGL((scan_plain_wave_kernel<PT_, EX_, true>), dim3(n_blocks), dim3(256), \
+                               PlainWaveShape<PT_>::lds, s, j, P, M);                               \
+        } else                                                                                      \
+            hipLaunchKernelGGL((scan_plain_wave_kernel<PT_, EX_, false>), dim3(n_blocks), dim3(256), \
+                               PlainWaveShape<PT_>::lds, s, j, P, M);                               \
+    } while (0)
+        if (P == 26) TK_LAUNCH_W(26, true);
+        else if (P == 16) TK_LAUNCH_W(16, true);
+        else if (P <= 8) TK_LAUNCH_W(8, false);
+        else if (P <= 16) TK_LAUNCH_W(16, false);
+        else TK_LAUNCH_W(26, false);
+#undef TK_LAUNCH_W
+        return 0;
+    }
 #define TK_LAUNCH(PT_, EX_)                                                                         \
     do {                                                                                            \
         static bool attr_ = false;                                                                  \
@@ -561,8 +862,7 @@ int tk_launch_scan_plain(const TkScanJob &j, int M, int order, int n_blocks, hip
     if (lean < 0) lean = getenv("TINYKNN_PLAIN_LEAN") ? atoi(getenv("TINYKNN_PLAIN_LEAN")) : 0;
     // A/B: TINYKNN_PLAIN_FORM / tk_plain_set_form: 1 = table operand from LDS per MFMA, four waves per
     // SIMD; 2 = the same at three
-    if (g_plain_form < 0) g_plain_form = getenv("TINYKNN_PLAIN_FORM") ? atoi(getenv("TINYKNN_PLAIN_FORM")) : 0;
-    const int form = g_plain_form;
+    const int form = plain_form();
 #define TK_LAUNCH_L(PT_, WPS_)                                                                      \
     do {                                                                                            \
         static bool attr_ = false;                                                                  \
