@@ -658,6 +658,9 @@ def main():
                          "1 rows through LDS, 4 waves/SIMD; 2 LDS, 3 waves/SIMD")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="replay streams (tk_index_set_pipeline): caller + coarse stream + these = 4 HW queues")
+    ap.add_argument("--coalesce", type=int, default=2, choices=[1, 2],
+                    help="tk_index_set_coalesce: 2 = pairs of consecutive steps run through the pipeline as one "
+                         "batch of 2 x nq queries (same rows out; the latency-bound kernels cost the same for both)")
     ap.add_argument("--workload", choices=["glove", "c5"], default="glove",
                     help="c5: BASELINE configs[4] on one GPU, 100M x 128 generated and built in HBM; "
                          "implies --n 100000000 --d 128 --n-clusters 10000 --metric euclidean unless given")
@@ -795,7 +798,8 @@ def main():
         torch.cuda.set_stream(own_stream)
     stream = torch.cuda.current_stream().cuda_stream
     dev.set_pipeline(args.pipeline)
-    dev.reserve(args.nq, args.k, args.n_probes)
+    dev.set_coalesce(args.coalesce if args.pipeline > 1 else 1)
+    dev.reserve(args.nq * (2 if args.coalesce == 2 and args.pipeline > 1 else 1), args.k, args.n_probes)
     dev.set_heap_mode(args.heap_mode)
     dev.set_scan_mode(args.scan_mode)
     _lib.check(_lib.lib().tk_set_scan_form(args.scan_form))

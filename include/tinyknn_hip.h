@@ -212,6 +212,18 @@ int tk_index_query_batch_dev(tk_index *ix, const float *q_dev, const void *q_pq_
  * needs depth = 1: the pipelined mode hands work to streams outside the capture. */
 int tk_index_set_pipeline(tk_index *ix, int depth);
 int tk_index_join(tk_index *ix, void *stream);
+/* n = 2 (pipelined mode only): two consecutive tk_index_query_batch_dev[_ex] calls with the same
+ * k / n_probes / pass_1 / stream run through the pipeline as ONE batch of nq_a + nq_b queries.
+ * The kernels that leave most of the chip idle (two heap replays of 157 dependent waves per
+ * 10 000 queries, the small kernels of the coarse stage) take as long for 20 000 queries as for
+ * 10 000.  The first call copies its queries into the index's staging rows and returns; the second
+ * appends its rows and enqueues the pair; each call's ids are copied to its own buffers (and its
+ * completion event recorded) behind the pair's last kernel.  Results are those of separate calls
+ * (the same kernels over the same rows).  A held call is launched alone by tk_index_join /
+ * tk_index_quiesce / any tk_index_set_*, or when the next call cannot join it.  n = 1 (default):
+ * every call its own batch.  ivf.py:106-163 answers one query per call; the batch forms here and
+ * everything about their scheduling are this library's. */
+int tk_index_set_coalesce(tk_index *ix, int n);
 /* hipGraph of the pipelined mode: tk_index_quiesce (device-synchronising; forgets the completion
  * events of earlier calls), then capture on a non-NULL stream any number of
  * tk_index_query_batch_dev calls followed by tk_index_join on that stream.  The internal streams

@@ -142,6 +142,7 @@ SIGNATURES = {
     "tk_stream_destroy": (None, [C.c_void_p]),
     "tk_index_knn_brute": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _i64p]),
     "tk_index_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+    "tk_index_set_coalesce": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tk_index_set_heap_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_set_scan_mode": (C.c_int, [C.c_void_p, C.c_int]),

@@ -96,6 +96,18 @@ struct DevBuf {
         if (r_ != TK_OK) return r_;    \
     } while (0)
 
+#define TK_DBG_SYNC(tag)                                                                       \
+    do {                                                                                       \
+        static const int on_ = getenv("TINYKNN_DEBUG_SYNC") ? 1 : 0;                           \
+        if (on_) {                                                                             \
+            fprintf(stderr, "[dbg] %s ...", tag);                                              \
+            fflush(stderr);                                                                    \
+            hipError_t e_ = hipDeviceSynchronize();                                            \
+            fprintf(stderr, " %s\n", hipGetErrorString(e_));                                   \
+            fflush(stderr);                                                                    \
+        }                                                                                      \
+    } while (0)
+
 // ---------------------------------------------------------------------------
 // scratch of the host-pointer entry points
 struct Scratch {
@@ -562,7 +574,8 @@ struct Work {
         c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage, pos_lens, pos_off,
         qlim, slot_exact, p_count, p_cursor, p_pair_off, p_unit_prefix, p_pair_q, p_pair_f0, flag_list, p_unit_desc,
         plain0, h_count, h_cursor, h_pair_off, h_unit_prefix, h_pair_q, h_pair_f0,   // plain_scan.hip
-        plain_q;                                                                       // two-phase sharded scan
+        plain_q,                                                                       // two-phase sharded scan
+        q_stage, qpq_stage, out_stage;                                                 // coalesced calls (tk_index_set_coalesce)
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -571,6 +584,7 @@ struct Work {
     hipEvent_t tables_done = nullptr, coarse_scanned = nullptr, front_done = nullptr,
                scanned = nullptr, done = nullptr;
     bool busy = false;                                 // `done` has been recorded
+    uint64_t td_seq = 0, fd_seq = 0;                   // order in which tables_done / front_done were last recorded
     // plain_scan.hip: how many queries of the workspace's last plain batch were flagged — a
     // page-locked word the device writes and an event behind it, polled (never waited for) when a
     // later call looks at the workspace
@@ -592,7 +606,8 @@ struct Work {
                        &u_pair_q, &u_pair_f0, &c_pair_off, &c_unit_prefix, &c_pair_q, &c_pair_f0,
                        &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage, &pos_lens, &pos_off,
                        &qlim, &slot_exact, &p_count, &p_cursor, &p_pair_off, &p_unit_prefix, &p_pair_q, &p_pair_f0, &flag_list, &p_unit_desc,
-                       &plain0, &h_count, &h_cursor, &h_pair_off, &h_unit_prefix, &h_pair_q, &h_pair_f0};
+                       &plain0, &h_count, &h_cursor, &h_pair_off, &h_unit_prefix, &h_pair_q, &h_pair_f0,
+                       &plain_q, &q_stage, &qpq_stage, &out_stage};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -666,6 +681,12 @@ struct tk_index {
     hipEvent_t ev_front_in = nullptr;        // front stream (input copies) -> the table build's stream
     bool input_on_front = false;             // tk_index_input_stream has handed the front stream out
     std::vector<struct Pending *> pending;   // calls whose list scan is still to be enqueued (<= 2)
+    uint64_t ev_seq = 0;                     // counts the records of tables_done / front_done (pipeline_step's merged wait)
+    int coalesce = 1;                        // 2: two consecutive calls run as ONE batch (tk_index_set_coalesce)
+    struct Pending *held = nullptr;          // ... the first of such a pair, its inputs copied, waiting for the second
+    int held_n_probes = 0, held_pass_1 = 0, held_f64 = 0;
+    int64_t held_rows = 0;                   // rows its staging buffers hold
+    hipStream_t held_stt = nullptr, held_caller = nullptr;
     hipStream_t front_stream = nullptr;      // coarse replays + descriptors of all batches, in order
     hipStream_t front_stream2 = nullptr;     // A/B (TINYKNN_FRONT_STREAMS=2): ... of the odd calls
     // profiling: one set of 8 events per recorded batch, read back on demand
@@ -1515,6 +1536,16 @@ struct Pending {
     hipEvent_t user_ev;     // recorded behind that copy (or NULL)
     Prof pf;
     hipStream_t st, sf, sl;   // scans (+ tables) / coarse replay + descriptors / replay + rescoring
+    // coalesced calls: the batch is the rows of n_subs calls, staged back to back in the workspace;
+    // each call's ids leave from the workspace's output rows to its own buffers
+    struct Sub {
+        int64_t *out_dev;
+        int64_t nq;
+        int64_t *host_out;
+        bool host_out_kernel;
+        hipEvent_t user_ev;
+    } subs[2];
+    int n_subs = 0;
 };
 
 // depth == 1
@@ -1640,7 +1671,11 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         cur->coarse_launched = true;
     }
     if (prev) {
-        if (!desc_s && !(merge && cur && prev->sf == cur->sf))
+        // (the shortcut holds only if front_done(prev) was recorded BEFORE tables_done(cur), which the
+        // three-call distance guarantees — but not a drain of two batches: there the coarse rest of
+        // `prev` was enqueued in the same call as, and behind, the table build of `cur`)
+        const bool covered = merge && cur && prev->sf == cur->sf && prev->w->fd_seq < cur->w->td_seq;
+        if (!desc_s && !covered)
             HIPCHECK(hipStreamWaitEvent(st, prev->w->front_done, 0));
         TRY(prev->pf.mark(st));
     }
@@ -1672,6 +1707,7 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
                                                     ((double)ix->total_chunks / (double)ix->n_lists) : 0.0),
                               st, &hj);
     }
+    TK_DBG_SYNC("step: scans");
     if (prev) {
         // heap replay + rescoring of the previous batch on its stream
         TRY(prev->pf.mark(st));
@@ -1682,6 +1718,7 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         TRY(batch_epilogue(*prev, prev->sl));
         HIPCHECK(hipEventRecord(prev->w->done, prev->sl));
         prev->w->busy = true;
+        TK_DBG_SYNC("step: back");
     }
     if (cur) {
         // rest of the coarse stage + scan descriptors of this batch on its stream (one event
@@ -1703,6 +1740,8 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
             cur->desc_done = true;
         }
         HIPCHECK(hipEventRecord(w.front_done, cur->sf));
+        w.fd_seq = ++ix->ev_seq;
+        TK_DBG_SYNC("step: coarse rest");
     }
     if (desc_s)     // the batch whose coarse stage ran one call ago: its descriptors, behind this call's launch
         for (Pending *m : ix->pending)
@@ -1738,6 +1777,21 @@ static int pipeline_advance(tk_index *ix, bool drain)
 // what the caller of tk_index_query_batch_dev_ex asked for behind a batch's last kernel
 static int batch_epilogue(const Pending &b, hipStream_t st)
 {
+    if (b.n_subs > 0) {
+        int64_t row = 0;
+        for (int i = 0; i < b.n_subs; i++) {
+            const Pending::Sub &u = b.subs[i];
+            const int64_t *src = b.out_dev + row * b.k;
+            tk_launch_copy_words(src, u.nq * b.k, u.out_dev, st);
+            if (u.host_out && u.host_out_kernel)
+                tk_launch_copy_words(src, u.nq * b.k, u.host_out, st);
+            else if (u.host_out)
+                HIPCHECK(hipMemcpyAsync(u.host_out, src, (size_t)u.nq * b.k * 8, hipMemcpyDeviceToHost, st));
+            if (u.user_ev) HIPCHECK(hipEventRecord(u.user_ev, st));
+            row += u.nq;
+        }
+        return TK_OK;
+    }
     if (b.host_out && b.host_out_kernel)
         tk_launch_copy_words(b.out_dev, b.nq * b.k, b.host_out, st);
     else if (b.host_out)
@@ -1746,13 +1800,214 @@ static int batch_epilogue(const Pending &b, hipStream_t st)
     return TK_OK;
 }
 
+static int launch_held(tk_index *ix);
+
 static int flush_pending(tk_index *ix)
 {
     int r = TK_OK;
+    if (ix->held) r = launch_held(ix);
     while (!ix->pending.empty() && r == TK_OK) r = pipeline_advance(ix, true);
     for (Pending *b : ix->pending) delete b;
     ix->pending.clear();
     return r;
+}
+
+// Pipelined mode, first half of enqueuing a batch: internal streams and events exist, the batch has
+// its workspace and streams, and `stt` — the stream its table build will run on — waits for the
+// caller's work so far and for the workspace's previous batch.
+static int pipe_begin(tk_index *ix, Pending &b, hipStream_t caller, hipStream_t &stt_out)
+{
+    Work &w = *b.w;
+    while ((int)ix->lat_streams.size() < ix->depth) {
+        hipStream_t st;
+        // A/B: TINYKNN_REPLAY_CUS=n confines the replay + rescoring streams to the first n
+        // bits of the CU mask (so that the rest of the chip scans undisturbed)
+        static const int cus = getenv("TINYKNN_REPLAY_CUS") ? atoi(getenv("TINYKNN_REPLAY_CUS")) : 0;
+        if (cus > 0 && cus < 256) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < cus; i++) mask[i >> 5] |= 1u << (i & 31);
+            HIPCHECK(hipExtStreamCreateWithCUMask(&st, 8, mask));
+        } else {
+            HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        }
+        ix->lat_streams.push_back(st);
+    }
+    if (!ix->front_stream) {
+        // A/B: TINYKNN_FRONT_PRIO=1 creates the front stream at the highest queue priority (its
+        // small kernels — coarse replay, descriptors — sit on the cycle's critical loop and are
+        // placed late beside the persistent scan grids)
+        static const int fp = getenv("TINYKNN_FRONT_PRIO") ? atoi(getenv("TINYKNN_FRONT_PRIO")) : 0;
+        int lo = 0, hi = 0;
+        if (fp && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+            HIPCHECK(hipStreamCreateWithPriority(&ix->front_stream, hipStreamNonBlocking, hi));
+        else
+            HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking));
+    }
+    b.sf = ix->front_stream;
+    // A/B: two front streams, batches alternate (a batch's tables and the rest of its coarse stage
+    // stay on ONE stream; the events the scan launch merges belong to calls c-1 and c-3: same parity)
+    if (front_streams() == 2) {
+        if (!ix->front_stream2)
+            HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream2, hipStreamNonBlocking));
+        if (ix->calls & 1) b.sf = ix->front_stream2;
+    }
+    b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
+    ix->calls++;
+    hipEvent_t *evs[] = {&w.tables_done, &w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
+    for (hipEvent_t *e : evs)
+        if (!*e) HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (!ix->ev_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_in, hipEventDisableTiming));
+    // the table build of this call goes to the front stream now (after the caller's work
+    // so far — its inputs — and once the workspace is free); its coarse scan rides in the
+    // NEXT call's launch, its list scan in the launch three calls later
+    // A/B (TINYKNN_TABLES_STREAM=1): the table build on the batch's REPLAY stream instead.
+    // The front stream carries, per batch, the tables of call c and the coarse replay /
+    // rescoring / descriptors of call c-1 — within a tenth of the scan launch it must keep
+    // ahead of; the replay streams are a third busy, and a table build has a whole call's
+    // time before its coarse scan is launched.
+    hipStream_t stt = b.sf;
+    if (tables_stream_mode() == 1) stt = b.sl;
+    else if (tables_stream_mode() == 2) stt = ix->lat_streams[ix->calls % (uint64_t)ix->depth];   // (calls is already c + 1)
+    else if (tables_stream_mode() == 3) stt = caller;      // the scan chain itself (it has the slack since the LDS-operand plain kernel)
+    if (stt != caller) {
+        HIPCHECK(hipEventRecord(ix->ev_in, caller));
+        HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
+    }
+    if (stt != b.sf && ix->input_on_front) {      // input copies arrive on the front stream (tk_index_input_stream)
+        if (!ix->ev_front_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_front_in, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(ix->ev_front_in, b.sf));
+        HIPCHECK(hipStreamWaitEvent(stt, ix->ev_front_in, 0));
+    }
+    if (w.busy) HIPCHECK(hipStreamWaitEvent(stt, w.done, 0));
+    stt_out = stt;
+    return TK_OK;
+}
+
+// ... second half: workspace sized, tables built, this call's launch enqueued, the batch pending
+static int pipe_launch(tk_index *ix, Pending &b, const void *qpq, int q_pq_is_f64, hipStream_t stt)
+{
+    Work &w = *b.w;
+    const int64_t sub = b.nq;
+    const int k = b.k;
+    const Plan &p = b.p;
+    TRY(reserve(ix, w, sub, k, p));
+    TRY(prof_begin(ix, w, b.nq, p, b.sl, b.pf));
+    b.units = use_units(ix, b.nq, p);
+    b.plain = b.units && plain_now(ix, p);
+    w.last_plain = b.plain;
+    TK_DBG_SYNC("launch: reserved");
+    TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, stt, b.pf, b.plain));
+    HIPCHECK(hipEventRecord(w.tables_done, stt));
+    w.td_seq = ++ix->ev_seq;
+    TK_DBG_SYNC("launch: tables");
+    // this call's launch: list scan of call c-3 + coarse scan of call c-1
+    TRY(pipeline_advance(ix, false));
+    ix->pending.push_back(new Pending(b));
+    return TK_OK;
+}
+
+// ---- two consecutive calls as ONE batch (tk_index_set_coalesce(ix, 2), pipelined mode) ----
+// The kernels that leave most of the chip idle — the two heap replays (157 waves of 64 queries for
+// 10 000 queries, a dependent chain per wave), the nine small kernels of the front stream — take as
+// long for 20 000 queries as for 10 000, and the plain kernel's tiles fill better with twice the
+// pairs per list.  The first call of a pair only copies its queries into the workspace's staging
+// rows (on the stream its table build would have run on) and is HELD; the second call appends its
+// rows and the pair runs through the pipeline as one batch of nq_a + nq_b queries, whose result
+// rows are copied out to each call's own buffers (and completion event) behind the last kernel.
+// Same kernels on the same rows: results do not change.  A held call is launched alone by
+// tk_index_join / quiesce / set_* and when the next call cannot join it (other k / n_probes /
+// pass_1 / stream, or too many rows).
+static int stage_inputs(tk_index *ix, Work &w, int64_t row0, const float *q_dev, const void *q_pq_dev,
+                        int q_pq_is_f64, int64_t nq, hipStream_t stt)
+{
+    const size_t esz = q_pq_is_f64 ? 8 : 4;
+    float *qdst = w.q_stage.as<float>() + row0 * ix->d;
+    if (((nq * ix->d) & 1) == 0 && ((uintptr_t)qdst & 7) == 0 && ((uintptr_t)q_dev & 7) == 0)
+        tk_launch_copy_words(q_dev, nq * ix->d / 2, qdst, stt);      // (8-byte words, by a kernel: no copy-engine command between dispatches)
+    else
+        HIPCHECK(hipMemcpyAsync(qdst, q_dev, (size_t)nq * ix->d * 4, hipMemcpyDeviceToDevice, stt));
+    const size_t qb = (size_t)nq * ix->dq * esz;      // (dq is even: a multiple of 8 bytes)
+    TK_DBG_SYNC("stage_inputs q");
+    tk_launch_copy_words(q_pq_dev, (int64_t)(qb / 8), (char *)w.qpq_stage.p + (size_t)row0 * ix->dq * esz, stt);
+    TK_DBG_SYNC("stage_inputs qpq");
+    return TK_OK;
+}
+
+static int launch_held(tk_index *ix)
+{
+    Pending *h = ix->held;
+    ix->held = nullptr;
+    if (!h) return TK_OK;
+    Pending b = *h;
+    delete h;
+    int64_t rows = 0;
+    for (int i = 0; i < b.n_subs; i++) rows += b.subs[i].nq;
+    b.nq = rows;
+    b.q_dev = b.w->q_stage.as<float>();
+    TRY(b.w->out_stage.ensure((size_t)rows * b.k * 8));
+    b.out_dev = b.w->out_stage.as<int64_t>();
+    TK_DBG_SYNC("launch_held");
+    int r_ = pipe_launch(ix, b, b.w->qpq_stage.p, ix->held_f64, ix->held_stt);
+    TK_DBG_SYNC("launch_held done");
+    return r_;
+}
+
+static int coalesce_call(tk_index *ix, const Plan &p, const float *q_dev, const void *q_pq_dev, int q_pq_is_f64,
+                         int64_t nq, int k, int n_probes, int pass_1, int64_t *out_ids_dev,
+                         int64_t *out_ids_pinned, hipEvent_t done_ev, hipStream_t caller)
+{
+    const Pending::Sub sub{out_ids_dev, nq, out_ids_pinned, ix->host_out_kernel, done_ev};
+    if (ix->held) {
+        Pending &h = *ix->held;
+        const bool joins = h.k == k && ix->held_n_probes == n_probes && ix->held_pass_1 == pass_1 &&
+                           ix->held_f64 == q_pq_is_f64 && ix->held_caller == caller &&
+                           h.subs[0].nq + nq <= ix->held_rows;
+        if (joins) {
+            hipStream_t stt = ix->held_stt;
+            if (stt != caller) {            // the second call's inputs: the caller's work so far
+                HIPCHECK(hipEventRecord(ix->ev_in, caller));
+                HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
+            }
+            TRY(stage_inputs(ix, *h.w, h.subs[0].nq, q_dev, q_pq_dev, q_pq_is_f64, nq, stt));
+            h.subs[1] = sub;
+            h.n_subs = 2;
+            return launch_held(ix);
+        }
+        TRY(launch_held(ix));
+    }
+    // first of a pair: workspace, streams, inputs staged; rows for a second call of the same size
+    Work &w = ix->works[ix->calls % ix->works.size()];
+    Pending b;
+    b.w = &w;
+    b.q_dev = nullptr;
+    b.nq = nq;
+    b.k = k;
+    b.p = p;
+    b.out_dev = nullptr;
+    b.units = b.plain = b.coarse_launched = false;
+    b.host_out = nullptr;
+    b.host_out_kernel = false;
+    b.user_ev = nullptr;
+    b.st = b.sf = b.sl = caller;
+    b.subs[0] = sub;
+    b.n_subs = 1;
+    hipStream_t stt = nullptr;
+    TRY(pipe_begin(ix, b, caller, stt));
+    const size_t esz = q_pq_is_f64 ? 8 : 4;
+    const int64_t ms = sub_batch(p);
+    const int64_t rows = 2 * nq <= ms ? 2 * nq : nq;
+    TRY(w.q_stage.ensure((size_t)rows * ix->d * 4 + 8));
+    TRY(w.qpq_stage.ensure((size_t)rows * ix->dq * esz + 8));
+    TRY(stage_inputs(ix, w, 0, q_dev, q_pq_dev, q_pq_is_f64, nq, stt));
+    ix->held = new Pending(b);
+    ix->held_n_probes = n_probes;
+    ix->held_pass_1 = pass_1;
+    ix->held_f64 = q_pq_is_f64;
+    ix->held_rows = rows;
+    ix->held_stt = stt;
+    ix->held_caller = caller;
+    if (rows == nq) return launch_held(ix);     // (no room for a second call: alone, at once)
+    return TK_OK;
 }
 
 static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_pq_dev,
@@ -1775,6 +2030,10 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
     const int64_t ms = sub_batch(p);
     ARGCHECK(!(out_ids_pinned || done_ev) || (nq >= 1 && nq <= ms),
              "a completion event / host copy belongs to ONE sub-batch (tk_index_max_sub_batch)");
+    if (ix->depth > 1 && ix->coalesce == 2 && nq >= 1 && nq <= ms)
+        return coalesce_call(ix, p, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, out_ids_dev,
+                             out_ids_pinned, done_ev, caller);
+    if (ix->held) TRY(launch_held(ix));
     for (int64_t o = 0; o < nq; o += ms) {
         int64_t sub = nq - o < ms ? nq - o : ms;
         Work &w = ix->works[ix->calls % ix->works.size()];
@@ -1799,77 +2058,9 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
             TRY(run_batch_inline(ix, b, qpq, q_pq_is_f64));
             continue;
         }
-        while ((int)ix->lat_streams.size() < ix->depth) {
-            hipStream_t st;
-            // A/B: TINYKNN_REPLAY_CUS=n confines the replay + rescoring streams to the first n
-            // bits of the CU mask (so that the rest of the chip scans undisturbed)
-            static const int cus = getenv("TINYKNN_REPLAY_CUS") ? atoi(getenv("TINYKNN_REPLAY_CUS")) : 0;
-            if (cus > 0 && cus < 256) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < cus; i++) mask[i >> 5] |= 1u << (i & 31);
-                HIPCHECK(hipExtStreamCreateWithCUMask(&st, 8, mask));
-            } else {
-                HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            }
-            ix->lat_streams.push_back(st);
-        }
-        if (!ix->front_stream) {
-            // A/B: TINYKNN_FRONT_PRIO=1 creates the front stream at the highest queue priority (its
-            // small kernels — coarse replay, descriptors — sit on the cycle's critical loop and are
-            // placed late beside the persistent scan grids)
-            static const int fp = getenv("TINYKNN_FRONT_PRIO") ? atoi(getenv("TINYKNN_FRONT_PRIO")) : 0;
-            int lo = 0, hi = 0;
-            if (fp && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
-                HIPCHECK(hipStreamCreateWithPriority(&ix->front_stream, hipStreamNonBlocking, hi));
-            else
-                HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking));
-        }
-        b.sf = ix->front_stream;
-        // A/B: two front streams, batches alternate (a batch's tables and the rest of its coarse stage
-        // stay on ONE stream; the events the scan launch merges belong to calls c-1 and c-3: same parity)
-        if (front_streams() == 2) {
-            if (!ix->front_stream2)
-                HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream2, hipStreamNonBlocking));
-            if (ix->calls & 1) b.sf = ix->front_stream2;
-        }
-        b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
-        ix->calls++;
-        hipEvent_t *evs[] = {&w.tables_done, &w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
-        for (hipEvent_t *e : evs)
-            if (!*e) HIPCHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        if (!ix->ev_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_in, hipEventDisableTiming));
-        // the table build of this call goes to the front stream now (after the caller's work
-        // so far — its inputs — and once the workspace is free); its coarse scan rides in the
-        // NEXT call's launch, its list scan in the launch three calls later
-        // A/B (TINYKNN_TABLES_STREAM=1): the table build on the batch's REPLAY stream instead.
-        // The front stream carries, per batch, the tables of call c and the coarse replay /
-        // rescoring / descriptors of call c-1 — within a tenth of the scan launch it must keep
-        // ahead of; the replay streams are a third busy, and a table build has a whole call's
-        // time before its coarse scan is launched.
-        hipStream_t stt = b.sf;
-        if (tables_stream_mode() == 1) stt = b.sl;
-        else if (tables_stream_mode() == 2) stt = ix->lat_streams[ix->calls % (uint64_t)ix->depth];   // (calls is already c + 1)
-        else if (tables_stream_mode() == 3) stt = caller;      // the scan chain itself (it has the slack since the LDS-operand plain kernel)
-        if (stt != caller) {
-            HIPCHECK(hipEventRecord(ix->ev_in, caller));
-            HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
-        }
-        if (stt != b.sf && ix->input_on_front) {      // input copies arrive on the front stream (tk_index_input_stream)
-            if (!ix->ev_front_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_front_in, hipEventDisableTiming));
-            HIPCHECK(hipEventRecord(ix->ev_front_in, b.sf));
-            HIPCHECK(hipStreamWaitEvent(stt, ix->ev_front_in, 0));
-        }
-        if (w.busy) HIPCHECK(hipStreamWaitEvent(stt, w.done, 0));
-        TRY(reserve(ix, w, sub, k, p));
-        TRY(prof_begin(ix, w, b.nq, p, b.sl, b.pf));
-        b.units = use_units(ix, b.nq, p);
-        b.plain = b.units && plain_now(ix, p);
-        w.last_plain = b.plain;
-        TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, stt, b.pf, b.plain));
-        HIPCHECK(hipEventRecord(w.tables_done, stt));
-        // this call's launch: list scan of call c-3 + coarse scan of call c-1
-        TRY(pipeline_advance(ix, false));
-        ix->pending.push_back(new Pending(b));
+        hipStream_t stt = nullptr;
+        TRY(pipe_begin(ix, b, caller, stt));
+        TRY(pipe_launch(ix, b, qpq, q_pq_is_f64, stt));
     }
     return TK_OK;
 }
@@ -1924,7 +2115,14 @@ extern "C" void *tk_index_input_stream(tk_index *ix)
     return ix->front_stream;
 }
 
-extern "C" int tk_index_pending(tk_index *ix) { return ix ? (int)ix->pending.size() : 0; }
+// calls whose last stage has not been enqueued yet
+extern "C" int tk_index_pending(tk_index *ix)
+{
+    if (!ix) return 0;
+    int n = ix->held ? ix->held->n_subs : 0;
+    for (const Pending *b : ix->pending) n += b->n_subs > 0 ? b->n_subs : 1;
+    return n;
+}
 
 extern "C" int tk_index_info(tk_index *ix, int64_t *info8)
 {
@@ -3116,6 +3314,16 @@ extern "C" int tk_index_set_pipeline(tk_index *ix, int depth)
     for (Work &w : ix->works) w.busy = false;
     ix->depth = depth;
     ix->calls = 0;
+    return TK_OK;
+}
+
+extern "C" int tk_index_set_coalesce(tk_index *ix, int n)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix, "null index");
+    ARGCHECK(n == 1 || n == 2, "1 (every call its own batch) or 2 (pairs of calls as one batch)");
+    TRY(flush_pending(ix));
+    ix->coalesce = n;
     return TK_OK;
 }
 

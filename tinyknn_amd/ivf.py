@@ -513,6 +513,10 @@ class DeviceIndex:
         """Number of batches in flight for query_batch_dev (see tinyknn_hip.h)."""
         _lib.check(_lib.lib().tk_index_set_pipeline(self._h, int(depth)))
 
+    def set_coalesce(self, n):
+        """2: pairs of consecutive query_batch_dev calls run as one batch (tk_index_set_coalesce)."""
+        _lib.check(_lib.lib().tk_index_set_coalesce(self._h, int(n)))
+
     def join(self, stream=0):
         _lib.check(_lib.lib().tk_index_join(self._h, stream))
 
