@@ -52,6 +52,8 @@ def synth(n, nq, d, seed, n_centres=300, sigma=0.7, kind="glove-like"):
         m = min(step, n - i)
         if kind == "sift-like":      # SURVEY §8d C3 stand-in
             X[i:i + m] = np.clip(np.abs(rng.randn(m, d)) * 40, 0, 218).round()
+        elif kind == "sift-clustered":   # the same value range with structure: 300 clusters, so that recall means something
+            X[i:i + m] = np.clip(np.abs(cent[rng.randint(n_centres, size=m)]) * 40 + 12.0 * rng.randn(m, d), 0, 218).round()
         else:
             X[i:i + m] = cent[rng.randint(n_centres, size=m)] + sigma * rng.randn(m, d)
     return X, cent
@@ -62,6 +64,8 @@ def synth_queries(cent, nq, seed, sigma=0.7, kind="glove-like"):
     d = cent.shape[1]
     if kind == "sift-like":
         return np.clip(np.abs(rng.randn(nq, d)) * 40, 0, 218).round().astype(np.float32)
+    if kind == "sift-clustered":
+        return np.clip(np.abs(cent[rng.randint(len(cent), size=nq)]) * 40 + 12.0 * rng.randn(nq, d), 0, 218).round().astype(np.float32)
     return (cent[rng.randint(len(cent), size=nq)] + sigma * rng.randn(nq, d)).astype(np.float32)
 
 
@@ -404,7 +408,8 @@ def raw_stream_leg(args, dev, qs, out_dev, device, world):
     # index (distance rows of a sub-batch stay under ~4 GiB: long lists mean fewer queries)
     piece = min(args.nq, dev.max_sub_batch(args.k, args.n_probes))
     cuts = list(range(0, args.nq, piece))
-    slots = 8 * len(cuts)
+    # (pairs of submits run as one batch when the index coalesces: twice the tickets keep as many batches in flight)
+    slots = 8 * len(cuts) * launch_batches(args)
     st = dev.stream(piece, args.k, args.n_probes, slots=min(slots, 64))
     nbuf = max(2, min(slots, 64) // len(cuts))
     outs = [np.full((args.nq, args.k), -1, dtype=np.int64) for _ in range(nbuf)]
@@ -497,7 +502,9 @@ def hbm_scale_leg(device):
             hbm = -(-nq // 4) * n * (M // 2) + nq * n if nq >= 4 else alg     # bytes that must cross HBM
             res["cases"].append({"kernel": "scan_units_kernel (list-major)" if nq >= 4 else "scan_flat_kernel (query-major)",
                                  "nq": nq, "ms": ms, "algorithmic_GBps": alg / ms / 1e6,
-                                 "min_hbm_GBps": hbm / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBPS})
+                                 "min_hbm_GBps": hbm / ms / 1e6,
+                                 # a fraction of the HBM peak only from bytes that must cross HBM
+                                 "frac": hbm / ms / 1e6 / HBM_PEAK_GBPS})
             del out
     finally:
         L.tk_codes_free(h)
@@ -506,6 +513,67 @@ def hbm_scale_leg(device):
     res["note"] = ("GBps/frac: nq = 1, where every code byte is fetched from HBM exactly once per launch "
                    "(algorithmic = real traffic); HIP events on the launch stream")
     return res
+
+
+def launch_batches(args):
+    """Steps whose queries ONE scan launch of the timed region covers (tk_index_set_coalesce)."""
+    return 2 if (args.coalesce == 2 and args.pipeline > 1) else 1
+
+
+def kernel_stats_child(args, plain_on=True):
+    """Per-kernel durations of the TIMED configuration: a child run of this script's timed region under
+    `rocprofv3 --kernel-trace --stats` (same workload, pipeline depth and coalescing; 50 steps per
+    window).  Returns {kernel name: {"calls", "avg_us"}} and the path of the kept CSV."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    me = os.path.abspath(__file__)
+    tmp = tempfile.mkdtemp(prefix="tk_kt_")
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "--", sys.executable, me,
+           "--steps", "50", "--warmup", "5", "--profile-only", "--shard", "none", "--traffic", "none", "--no-hbm-leg",
+           "--no-cpu", "--cache-dir", args.cache_dir, "--pipeline", str(args.pipeline), "--coalesce", str(args.coalesce),
+           "--workload", args.workload, "--n", str(args.n), "--d", str(args.d),
+           "--n-clusters", str(args.n_clusters), "--nq", str(args.nq), "--k", str(args.k),
+           "--n-probes", str(args.n_probes), "--metric", args.metric, "--data", args.data,
+           "--build-probes", str(args.build_probes), "--seed", str(args.seed)]
+    try:
+        cp = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL, timeout=900, check=True, text=True)
+        fs = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if not fs:
+            return None, "no kernel_stats.csv in the child run"
+        out = {}
+        try:        # the child's own line: its step time and HIP-event kernel time UNDER the profiler
+            cj = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
+            kernel_stats_child.own = {"ms_per_step": cj.get("ms_per_step"), "plain_kernel_ms_hip_events": cj.get("plain_kernel_ms")}
+        except Exception:      # noqa: BLE001
+            kernel_stats_child.own = None
+        for r in csv.DictReader(open(fs[0])):
+            out[r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                              "pct": float(r["Percentage"])}
+        keep = os.path.join(ROOT, "gpurun_out", "bench")
+        os.makedirs(keep, exist_ok=True)
+        kept = os.path.join(keep, "rocprofv3_kernel_stats_timed_region.csv")
+        shutil.copy(fs[0], kept)
+        return out, os.path.relpath(kept, ROOT)
+    except Exception as e:     # noqa: BLE001 - profiling is an extra
+        return None, f"kernel-trace child run failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pick_kernel(stats, sub):
+    """(name, entry) of the busiest kernel whose name contains `sub`."""
+    if not stats:
+        return None, None
+    hits = [(n, e) for n, e in stats.items() if sub in n]
+    if not hits:
+        return None, None
+    return max(hits, key=lambda t: t[1]["calls"] * t[1]["avg_us"])
 
 
 def measure_traffic(args, plain_on=True):
@@ -529,7 +597,7 @@ def measure_traffic(args, plain_on=True):
                "--steps", "3", "--warmup", "1", "--warmup-seconds", "0", "--windows", "1", "--pipeline", "1",
                "--profile-only", "--shard", "none", "--cache-dir", args.cache_dir,
                "--workload", args.workload, "--n", str(args.n), "--d", str(args.d),
-               "--n-clusters", str(args.n_clusters), "--nq", str(args.nq), "--k", str(args.k),
+               "--n-clusters", str(args.n_clusters), "--nq", str(args.nq * launch_batches(args)), "--k", str(args.k),
                "--n-probes", str(args.n_probes), "--metric", args.metric, "--data", args.data,
                "--build-probes", str(args.build_probes), "--seed", str(args.seed)]
         try:
@@ -544,7 +612,7 @@ def measure_traffic(args, plain_on=True):
                     name = r["Kernel_Name"]
                     # the scan launches of one batch in flight: the plain kernel (matrix cores), the
                     # exact list-major launch (heads + whole lists), the coarse scan
-                    key = ("plain" if "scan_plain_kernel" in name else
+                    key = ("plain" if "scan_plain" in name else
                            "units2" if "scan_units2_kernel" in name else
                            "units" if "scan_units_kernel" in name else None)
                     if r["Counter_Name"] == c and key:
@@ -579,7 +647,7 @@ VALU_RATE_PER_SIMD = 0.52e9      # wave-instructions/s/SIMD of the scan's VOP3/V
 I8_MFMA_PEAK_TOPS = 5000.0      # dense int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores)
 
 
-def plain_roofline(st, M, nq, scan_ms=None, iso_scan_ms=None):
+def plain_roofline(st, M, nq):
     """The plain-sum scan (plain_scan.hip): its matrix-core work per batch.  A unit = 32 pairs x a
     list's chunk pairs; per chunk pair M/2 v_mfma_i32_32x32x32_i8 = M/2 x 32768 multiply-adds
     (one-hot(code) x table: 15 of 16 products are by zero — this is matrix-core OCCUPANCY, the
@@ -590,11 +658,6 @@ def plain_roofline(st, M, nq, scan_ms=None, iso_scan_ms=None):
     floor = mfma * 32 / (1024 * 2.4e9) * 1e3
     return dict(st, mfma_instructions_per_batch=mfma, int8_ops_per_batch=mfma * 2 * 32768,
                 mfma_floor_ms=floor,
-                # the scan STAGE = plain kernel + the exact launch behind it (heads of the first lists,
-                # and in the timed region the coarse scan of a later batch): lower bounds of the
-                # plain kernel's own fraction of the matrix-core ceiling
-                mfma_floor_over_scan_stage_isolated=(floor / iso_scan_ms if iso_scan_ms else None),
-                mfma_floor_over_scan_stage_timed_region=(floor / scan_ms if scan_ms else None),
                 peak_unit="TOP/s int8 dense",
                 peak=I8_MFMA_PEAK_TOPS, tile_fill=st["plain_pairs"] / (32.0 * st["plain_units"]),
                 flagged_fraction=st["flagged_queries"] / float(nq),
@@ -603,30 +666,201 @@ def plain_roofline(st, M, nq, scan_ms=None, iso_scan_ms=None):
                      "was above the table's limit (scanned again exactly, replayed again)")
 
 
-def valu_roofline(scan_ms, iso_stages, plain_on=False):
-    """The bound the EXACT scan kernel runs against (profiles/r02_scan_forms.md): VALU issue.
-    floor = SQ_INSTS_VALU of the list + coarse scan (PMC child run of this script, in this run) /
-    (1024 SIMDs x the measured issue rate of the kernel's instruction mix)."""
-    n = getattr(measure_traffic, "valu_insts", None)
-    if not n:
-        return None
-    if plain_on:
-        # the issue rate above was measured on the exact kernel's VOP3/VOP3P mix (v_perm, packed adds:
-        # 4.0-4.6 cycles each); most of a batch's scan now runs in the plain kernel, whose VALU work
-        # (one v_alignbit per one-hot operand, clamps, packs) issues at the plain VOP2 rate and is
-        # not what bounds it (MFMA + LDS round trips: `plain_scan`).  The count stays, the floor goes.
-        return {"wave_instructions_per_launch": n, "floor_ms": None, "frac_isolated": None,
-                "frac_timed_region": None,
-                "note": "SQ_INSTS_VALU of plain kernel + exact launch + coarse scan (PMC child run); the "
-                        "issue-rate floor of round 2 applies to the exact kernel's instruction mix only and is "
-                        "not computed while the plain path carries the batch: see roofline.plain_scan"}
-    floor_ms = n / (1024 * VALU_RATE_PER_SIMD) * 1e3
-    iso = iso_stages["scan"] + iso_stages["coarse_scan"]
-    return {"wave_instructions_per_launch": n, "issue_rate_per_simd": VALU_RATE_PER_SIMD,
-            "floor_ms": floor_ms, "frac_isolated": floor_ms / iso if iso > 0 else None,
-            "frac_timed_region": floor_ms / scan_ms if scan_ms > 0 else None,
-            "note": "fraction of the VALU issue ceiling: list scan + coarse scan, one batch in flight "
-                    "(isolated) / the fused launch of the timed region"}
+def timed_rate(dev, batches, qp_is_f64, nq, k, n_probes, stream, pipeline, coalesce, steps=20, windows=4):
+    """queries/s of the pipelined mode for one (index, n_probes): one continuous run of `windows` x
+    `steps` steps, every window closed by the completion event of its last batch; the median window
+    behind the first (the protocol of the headline figure, shorter)."""
+    import torch
+    dev.set_pipeline(pipeline)
+    dev.set_coalesce(coalesce if pipeline > 1 else 1)
+    dev.reserve(nq * (2 if coalesce == 2 and pipeline > 1 else 1), k, n_probes)
+    n = [0]
+
+    def step(ev=None):
+        b = batches[n[0] % len(batches)]
+        n[0] += 1
+        dev.query_batch_dev(b["q_dev"].data_ptr(), b["qp_dev"].data_ptr(), qp_is_f64, nq, k, n_probes,
+                            b["out"].data_ptr(), stream=stream, done_event=ev)
+
+    for _ in range(16):
+        step()
+    dev.join(stream)
+    torch.cuda.synchronize()
+    n[0] = 0
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(windows + 1)]
+    for e in evs:
+        e.record()
+    torch.cuda.synchronize()
+    evs[0].record()
+    for w in range(windows):
+        for i in range(steps):
+            step(evs[w + 1].cuda_event if i == steps - 1 else None)
+    dev.join(stream)
+    torch.cuda.synchronize()
+    ms = sorted(evs[w].elapsed_time(evs[w + 1]) for w in range(1, windows))
+    per_step = ms[len(ms) // 2] / steps
+    return {"queries_per_s": nq / (per_step * 1e-3), "ms_per_step": per_step, "steps_per_window": steps,
+            "windows": windows}
+
+
+def sweep_leg(args, ivf, dev, batches, qp_is_f64, stream, device, cent):
+    """BASELINE configs[3] and the reference's own sweep (examples/bench.py:108-139) in front of the
+    driver: n_probes 1 / 5 / 20 / 50 on the headline index, then the reference's default build
+    (IVF.build(n_probes=2), ivf.py:53) and the SIFT-shaped stand-in of configs[2] at n_probes 10 — each
+    with its rate (timed_rate) and >= 500 result rows compared with the CPU oracle."""
+    import torch
+    rows = 500
+    out = {"protocol": "pipelined mode, %d steps x 4 windows per point, median window behind the first; parity: the "
+                       "first %d rows of batch 0 against oracle/tinyknn_oracle.c" % (20, rows), "points": []}
+
+    def point(label, ivf_, dev_, batches_, f64, n_probes, extra=None):
+        e = {"config": label, "n_probes": n_probes}
+        try:
+            e.update(timed_rate(dev_, batches_, f64, args.nq, args.k, n_probes, stream, args.pipeline, args.coalesce))
+            torch.cuda.synchronize()
+            got = batches_[0]["out"].cpu().numpy()[:rows]
+            ox = oracle_index(ivf_)
+            tc = time.perf_counter()
+            want = ox.query_batch(batches_[0]["qn"][:rows], args.k, n_probes)
+            e["cpu_oracle_queries_per_s"] = rows / (time.perf_counter() - tc)
+            e["parity_vs_oracle"] = {"queries_checked": rows, "identical_rows": int((want == got).all(axis=1).sum())}
+            if extra:
+                e.update(extra(dev_))
+        except Exception as ex:     # noqa: BLE001 - a sweep point must not lose the line
+            e["error"] = repr(ex)
+        out["points"].append(e)
+
+    for np_ in (1, 5, 20, 50):
+        point("headline index", ivf, dev, batches, qp_is_f64, np_)
+    dev.set_pipeline(1)
+
+    def other_index(label, **over):
+        a2 = argparse.Namespace(**dict(vars(args), **over))
+        t0 = time.perf_counter()
+        ivf2, cent2 = build_index(a2, device)
+        dev2 = ivf2.device_index()
+        bs = []
+        for b in range(2):
+            qs_b = synth_queries(cent2, a2.nq, a2.seed + 100 + 1000 * b, kind=a2.data)
+            qn_b, qp_b = ivf2._prepare(qs_b.copy())
+            bs.append(dict(qn=qn_b, q_dev=torch.from_numpy(qn_b).to(device),
+                           qp_dev=torch.from_numpy(np.ascontiguousarray(qp_b)).to(device),
+                           out=torch.full((a2.nq, a2.k), -1, dtype=torch.int64, device=device)))
+        f64 = qp_b.dtype != np.float32
+        point(label + " (fit + build %.0f s)" % (time.perf_counter() - t0), ivf2, dev2, bs, f64, 10,
+              extra=lambda d_: {"plain_scan_state": (d_.plain_stats() or {}).get("state")})
+        dev2.set_pipeline(1)
+        dev2.close()
+
+    try:
+        other_index("IVF.build(n_probes=2): the reference's default build (ivf.py:53), every point in two lists",
+                    build_probes=2)
+        other_index("sift-clustered euclidean 1M x 128 (BASELINE configs[2] stand-in: SIFT's value range, 300 clusters), "
+                    "n_clusters 1000, PQ rotated to 64 dims (M = 32, float64 tables)",
+                    data="sift-clustered", metric="euclidean", d=128, n=1000000, n_clusters=1000)
+    except Exception as ex:     # noqa: BLE001
+        out["error"] = repr(ex)
+    return out
+
+
+def roofline_entry(args, M, pst, plain_ms, stages, iso_stages, scan_bytes, n_prof, traffic, traffic_src,
+                   kstats, kstats_src, copy_gbps, read_gbps):
+    """The roofline of the dominant kernel of the timed region, with the resource that binds it.
+
+    Plain path on (the default batch): `scan_plain_wave_kernel` — one-hot(code) x table on
+    v_mfma_i32_32x32x32_i8.  Its bound is matrix-core issue: `achieved` = int8 operations per launch /
+    the kernel's duration, `peak` = the dense int8 MFMA peak (2 x bf16, MI355X_MICROARCH.md), `frac` =
+    their ratio = (MFMA instructions x 32 cycles / (1024 SIMDs x 2.4 GHz)) / duration.  The duration is
+    measured twice and both are printed: HIP events around the kernel on the stream it is launched on, in
+    the timed region (`kernel_ms`, what `achieved` uses), and the rocprofv3 --kernel-trace --stats
+    average of a child run of the same command (`kernel_ms_rocprofv3`; CSV kept under gpurun_out/bench/,
+    committed as profiles/r04/).  HBM is the bound by contract only: the contractual
+    algorithmic rate stays as `algorithmic_GBps`, and what the fabric really carried is
+    `hbm_frac_measured` = PMC traffic / duration / 8 TB/s.  Plain path off: the exact launch against its
+    VALU-issue floor (profiles/r02_scan_forms.md)."""
+    lb = launch_batches(args)
+    scan_ms = stages["scan"]
+    ex_name, ex = pick_kernel(kstats, "scan_units2_kernel") if args.pipeline > 1 else pick_kernel(kstats, "scan_units_kernel")
+    valu_parts = (getattr(measure_traffic, "parts", {}) or {}).get("SQ_INSTS_VALU") or {}
+    exact_valu = sum(v for k_, v in valu_parts.items() if k_.startswith("units"))
+    exact = None
+    if exact_valu:
+        floor_ms = exact_valu / (1024 * VALU_RATE_PER_SIMD) * 1e3
+        exact = {"kernel": ex_name, "bound": "valu-issue", "wave_instructions_per_launch": exact_valu,
+                 "issue_rate_per_simd": VALU_RATE_PER_SIMD, "floor_ms": floor_ms,
+                 "kernel_ms_rocprofv3": None if not ex else ex["avg_us"] / 1e3,
+                 "frac": None if not ex else floor_ms / (ex["avg_us"] / 1e3),
+                 "note": "SQ_INSTS_VALU (PMC child run, one batch in flight, %d queries) of the exact launches — heads of "
+                         "the first lists + whole lists of the queries that stay exact + the coarse scan — at the issue "
+                         "rate measured for this instruction mix (profiles/r02_valu_issue_rate_microbench.txt)"
+                         % (args.nq * lb)}
+    common = {"traffic_source": traffic_src, "device_copy_GBps_measured": copy_gbps,
+              "device_read_GBps_measured": read_gbps, "launches_timed": n_prof,
+              "launch_covers": "%d step(s) = %d queries" % (lb, args.nq * lb),
+              "algorithmic_bytes_per_launch": scan_bytes,
+              "scan_stage_ms": scan_ms,
+              "algorithmic_GBps": scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else None,
+              "algorithmic_note": "SURVEY 8d's contractual figure: one code byte per (query, stored code) pair (+ table + "
+                                  "heap bytes) of the batch over its scan stage (plain kernel + exact launch, HIP "
+                                  "events on the scan stream).  It exceeds what HBM carries by the reuse factor (32 "
+                                  "queries share each fetched tile; codes sit in L2 / Infinity Cache), so NO fraction "
+                                  "of the HBM peak is formed from it",
+              "exact_launch": exact,
+              "kernel_stats_rocprofv3": None if not kstats else
+              {n[:96]: e for n, e in sorted(kstats.items(), key=lambda t: -t[1]["calls"] * t[1]["avg_us"])[:12]},
+              "kernel_stats_csv": kstats_src}
+    if pst and pst.get("plain_units") and plain_ms > 0:
+        pr = plain_roofline(pst, M, args.nq * lb)
+        name, e = pick_kernel(kstats, "scan_plain")
+        ops = pr["int8_ops_per_batch"]
+        achieved = ops / (plain_ms * 1e-3) / 1e12
+        ptraffic = None
+        parts = getattr(measure_traffic, "parts", {}) or {}
+        if traffic is not None and "plain" in (parts.get("FETCH_SIZE") or {}):
+            ptraffic = (2 * parts["FETCH_SIZE"]["plain"] + parts["WRITE_SIZE"].get("plain", 0.0)) * 1024
+        return dict(common, bound="mfma",
+                    bound_measured="matrix-core issue of the plain-sum kernel (one MFMA per block pair and 32 x 32 tile; "
+                                   "beside it the CU's texture path — table-row loads and output stores — is 67-77 % busy: "
+                                   "profiles/r04/pmc_plain_kernel_micro.txt); the exact launch: VALU issue (`exact_launch`); "
+                                   "hbm by contract only (`algorithmic_GBps`, `hbm_frac_measured`)",
+                    kernel=name or "scan_plain_wave_kernel",
+                    achieved=(achieved if not e else ops / (e["avg_us"] * 1e-6) / 1e12), peak=I8_MFMA_PEAK_TOPS,
+                    unit="TOP/s",
+                    frac=(achieved if not e else ops / (e["avg_us"] * 1e-6) / 1e12) / I8_MFMA_PEAK_TOPS,
+                    frac_is="int8 operations of one launch / the kernel's average duration in the rocprofv3 "
+                            "--kernel-trace --stats child run of this command (`kernel_ms_rocprofv3`, the kept CSV) / "
+                            "peak = mfma_floor_ms / kernel_ms_rocprofv3.  `frac_hip_events_timed_region` is the same "
+                            "ratio with the HIP-event duration of the un-profiled timed region (`kernel_ms`): there the "
+                            "host enqueues faster, more kernels run beside the scan and each is longer; `child_run` "
+                            "gives the profiled run's own HIP-event time — inside one run events and rocprofv3 agree",
+                    kernel_ms=plain_ms, kernel_ms_source="HIP events in front of and behind the kernel on the scan stream, "
+                                                         "timed region, every 4th batch (tk_index_last_profile)",
+                    frac_hip_events_timed_region=achieved / I8_MFMA_PEAK_TOPS,
+                    kernel_ms_rocprofv3=None if not e else e["avg_us"] / 1e3,
+                    child_run=getattr(kernel_stats_child, "own", None),
+                    mfma_floor_ms=pr["mfma_floor_ms"],
+                    mfma_floor_note="MFMA instructions of the launch x 32 cycles / (1024 SIMDs x 2.4 GHz): the spec clock; "
+                                    "inside this kernel the chip holds 1.8-2.1 GHz (s_memtime / s_memrealtime, "
+                                    "profiles/r04/plain_kernel_clock.txt), at which the floor is 15-25 % higher",
+                    traffic=ptraffic,
+                    traffic_note="HBM bytes of ONE plain-kernel launch (PMC child run, FETCH x2 + WRITE, one batch of "
+                                 "launch_covers queries in flight)",
+                    hbm_frac_measured=None if ptraffic is None else ptraffic / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    all_scan_launches_traffic=traffic,
+                    plain_scan=pr)
+    # plain path off: the exact launch is the dominant scan kernel
+    if exact and exact["frac"]:
+        return dict(common, bound="valu", bound_measured="VALU issue of the exact scan's v_perm / packed-add mix "
+                                                         "(profiles/r02_scan_forms.md); hbm by contract only",
+                    kernel=ex_name, achieved=exact_valu / (exact["kernel_ms_rocprofv3"] * 1e-3) / 1e9,
+                    peak=1024 * VALU_RATE_PER_SIMD / 1e9, unit="G wave-instructions/s", frac=exact["frac"],
+                    kernel_ms=exact["kernel_ms_rocprofv3"], traffic=traffic,
+                    hbm_frac_measured=None if traffic is None else
+                    traffic / (exact["kernel_ms_rocprofv3"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+    ach = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    return dict(common, bound="hbm", bound_measured="not measured in this run (no rocprofv3 child run): the contractual "
+                                                    "algorithmic rate only", kernel="scan launches of a batch",
+                achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s (algorithmic)", frac=None, traffic=traffic)
 
 
 def main():
@@ -649,7 +883,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--build-probes", type=int, default=1, help="lists per point (ivf.py:53)")
     ap.add_argument("--metric", choices=["angular", "euclidean"], default="angular")
-    ap.add_argument("--data", choices=["glove-like", "sift-like"], default="glove-like",
+    ap.add_argument("--data", choices=["glove-like", "sift-like", "sift-clustered"], default="glove-like",
                     help="synthetic stand-in: Gaussian clusters, or |N(0,1)|*40 clipped to [0,218]")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
@@ -661,6 +895,9 @@ def main():
     ap.add_argument("--coalesce", type=int, default=2, choices=[1, 2],
                     help="tk_index_set_coalesce: 2 = pairs of consecutive steps run through the pipeline as one "
                          "batch of 2 x nq queries (same rows out; the latency-bound kernels cost the same for both)")
+    ap.add_argument("--sweep", choices=["auto", "none"], default="auto",
+                    help="auto: n_probes 1/5/20/50, build_probes=2 and the SIFT-shaped index beside the headline "
+                         "(default workload at N = 1 only)")
     ap.add_argument("--workload", choices=["glove", "c5"], default="glove",
                     help="c5: BASELINE configs[4] on one GPU, 100M x 128 generated and built in HBM; "
                          "implies --n 100000000 --d 128 --n-clusters 10000 --metric euclidean unless given")
@@ -859,6 +1096,8 @@ def main():
     steady = sorted(win_ms[1:]) if n_win > 1 else win_ms
     elapsed = steady[len(steady) // 2] * 1e-3        # seconds per --steps steps: the median window
     stages, scan_bytes, n_prof = dev.last_profile()
+    plain_ms_timed = getattr(dev, "last_plain_kernel_ms", 0.0)      # HIP events around the plain kernel alone
+    plain_stats_timed = dev.plain_stats()       # of the last batch of the timed region (a pair of steps when coalescing)
     raw_leg = None if args.profile_only else raw_stream_leg(args, dev, qs, out_dev, device, world)
     # the same kernels with ONE batch in flight (no co-running batches), for reference
     dev.set_pipeline(1)
@@ -877,7 +1116,7 @@ def main():
             print(json.dumps({"profile_only": True, "ms_per_step": elapsed / args.steps * 1e3,
                               "host_enqueue_ms_per_step": host_enqueue / (n_win * K) * 1e3,
                               "ms_per_step_drained": region / (n_win * K) * 1e3, "windows_ms": win_ms,
-                              "stage_ms": stages, "isolated_stage_ms": iso_stages,
+                              "stage_ms": stages, "isolated_stage_ms": iso_stages, "plain_kernel_ms": plain_ms_timed,
                               "scan_bytes": scan_bytes, "iso_scan_bytes": iso_bytes}), flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -1009,8 +1248,11 @@ def main():
     default_wl = (args.workload, args.n, args.d, args.n_clusters, args.nq, args.n_probes, args.metric,
                   args.data, args.build_probes) == ("glove", 1183514, 100, 1087, 10000, 10, "angular",
                                                     "glove-like", 1)
+    kstats, kstats_src = None, "not run"
+    plain_on_timed = bool(plain_stats_timed and plain_stats_timed.get("plain_units"))
     if args.traffic == "auto" and (default_wl or args.workload == "c5") and world == 1 and not args.data_file:
-        traffic, traffic_src = measure_traffic(args, bool(plain_stats and plain_stats.get("plain_units")))
+        traffic, traffic_src = measure_traffic(args, plain_on_timed)
+        kstats, kstats_src = kernel_stats_child(args, plain_on_timed)
     hbm_leg = None
     if not args.no_hbm_leg and world == 1:
         try:
@@ -1119,6 +1361,12 @@ def main():
         cpu["note"] = ("value = C batch loop of the port (no per-query Python overhead: the STRONGER "
                        "baseline); python_loop = the reference's own measurement protocol")
 
+    sweep = None
+    if args.sweep == "auto" and default_wl and world == 1 and not args.data_file:
+        try:
+            sweep = sweep_leg(args, ivf, dev, batches, qp_is_f64, stream, device, cent)
+        except Exception as e:      # noqa: BLE001 - an extra leg must not lose the line
+            sweep = {"error": repr(e)}
     line = {
         "metric": f"queries/sec at Recall10@10 on GloVe-100 angular (synthetic stand-in), IVF+4-bit PQ, build_probes={args.build_probes}"
                   if (args.workload, args.data, args.metric, args.d) == ("glove", "glove-like", "angular", 100) else
@@ -1159,37 +1407,17 @@ def main():
                                            f"in {truth_s * 1e3:.0f} ms"),
                    "parallelism": f"replica x{world} (queries sharded)",
                    "batches_in_flight": args.pipeline},
-        "roofline": {"bound": "hbm",
-                     "bound_measured": ("plain kernel: matrix-core issue + LDS round trips of the one-hot operands "
-                                        "(`plain_scan`: its MFMA floor, DESIGN 3.1b), exact launches: VALU issue "
-                                        "(profiles/r02_scan_forms.md); hbm by contract"
-                                        if plain_stats and plain_stats.get("plain_units") else
-                                        "valu-issue (measured: profiles/r02_scan_forms.md; see `valu`); hbm by contract"),
-                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "achieved_is": "ALGORITHMIC GB/s (one code byte per (query, code) pair); the fabric "
-                                    "carries `traffic` bytes per launch: four queries share each fetched "
-                                    "code byte and the code set sits in L2/Infinity Cache",
-                     "device_copy_GBps_measured": copy_gbps, "device_read_GBps_measured": read_gbps,
-                     "kernel": ("scan_plain_kernel<26> + scan_units2_kernel<AVX,signed>: the two scan launches of a batch, "
-                                "back to back on the scan stream, timed as one (plain sums on the matrix cores for the "
-                                "lists behind the first; exact kernel for the heads of the first lists + the coarse "
-                                "scan of a later batch)"
-                                if plain_stats and plain_stats.get("plain_units") and args.pipeline > 1 else
-                                "scan_probes_kernel<AVX,signed>" if args.scan_mode == 1 else
-                                "scan_units_kernel<AVX,signed>" if args.pipeline == 1 else
-                                "scan_units2_kernel<AVX,signed> (one launch: list scan of a batch + coarse scan "
-                                "of a later one)"),
-                     "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": scan_ms,
-                     "launches_timed": n_prof, "valu": valu_roofline(scan_ms, iso_stages, bool(plain_stats and plain_stats.get("plain_units"))),
-                     "plain_scan": plain_roofline(plain_stats, M, args.nq, scan_ms, iso_stages.get("scan"))},
+        "roofline": roofline_entry(args, M, plain_stats_timed, plain_ms_timed, stages, iso_stages, scan_bytes, n_prof,
+                                   traffic, traffic_src, kstats, kstats_src, copy_gbps, read_gbps),
         "raw_in_ids_out": raw_leg,
         "roofline_hbm_scale": hbm_leg,
         "stage_ms": stages,
         "isolated": {"note": "same batch with one batch in flight (5 steps after the timed region)",
                      "stage_ms": iso_stages, "ms_per_step": sum(iso_stages.values()),
-                     "scan_kernel_GBps": iso_bytes / (iso_stages["scan"] * 1e-3) / 1e9,
-                     "scan_kernel_frac_of_hbm_peak": iso_bytes / (iso_stages["scan"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                     "scan_stage_algorithmic_GBps": iso_bytes / (iso_stages["scan"] * 1e-3) / 1e9,
+                     "scan_stage_note": "algorithmic bytes (one code byte per (query, code) pair) over the isolated scan "
+                                        "stage; NOT HBM traffic (32 queries share each fetched tile, the code set sits in "
+                                        "L2 / Infinity Cache): no fraction of the HBM peak is formed from it"},
         "hipgraph": graph,
         "host_boundary": {"queries_per_s": host_qps,
                           "note": "tk_index_query_batch with host buffers: H2D queries + pipeline + D2H ids, "
@@ -1207,6 +1435,7 @@ def main():
                            "rows": args.nq},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
+        "sweep": sweep,
     }
     if do_shard:
         # the replica line above is complete: a list-sharded leg that gets stuck (it is the

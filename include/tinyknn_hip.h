@@ -301,12 +301,13 @@ int tk_set_plain_form(int form);
  * around the stages (no synchronisation in the query call; 1 = every batch).
  * tk_index_last_profile synchronises that stream and returns the mean
  * milliseconds per stage over the batches recorded since the last read
- * [tables, coarse_scan, coarse_heap, coarse_rescore+slots, scan, heap, rescore],
- * their count, and the algorithmic bytes the list-scan kernel streamed for the
+ * [tables, coarse_scan, coarse_heap, coarse_rescore+slots, scan, heap, rescore, plain kernel alone
+ * (HIP events in front of and behind scan_plain_wave_kernel on the stream it is launched on; 0 when
+ * no recorded batch ran it)], their count, and the algorithmic bytes the list-scan kernel streamed for the
  * most recent batch (code bytes + table + heap per query; with depth > 1 the
  * timed launch also carries the next batch's coarse scan, whose bytes are included). */
 int tk_index_set_profiling(tk_index *ix, int on);
-int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches);
+int tk_index_last_profile(tk_index *ix, float *ms8, double *scan_bytes, int *batches);
 
 /* measurement plumbing (bench.py): GB/s of a kernel that only reads `bytes` of HBM, every byte
  * once with the flat scan's access pattern — the streaming-read ceiling of the box */

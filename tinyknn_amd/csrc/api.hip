@@ -694,6 +694,7 @@ struct tk_index {
     uint64_t prof_seen = 0;
     std::vector<hipEvent_t> evs;   // 8 per set
     std::vector<hipStream_t> ev_streams;
+    std::vector<char> ev_plain;    // the set's batch ran the plain kernel (events 8, 9 recorded)
     size_t ev_used = 0;            // sets recorded since the last read
     int last_S = 0, last_R = 0, last_work = 0;
     int64_t last_nq = 0;
@@ -1141,13 +1142,24 @@ extern "C" int tk_index_reserve(tk_index *ix, int64_t nq, int k, int n_probes, i
 }
 
 // stage timers of one batch (tk_index_set_profiling)
+#define TK_PROF_EVENTS 10     // per recorded batch: 8 stage marks + 2 around the plain kernel alone
 struct Prof {
     const std::vector<hipEvent_t> *evs = nullptr;   // the index's event pool (it may grow)
     size_t base = 0;
     int evi = 0;
+    int set = -1;
+    bool plain_marked = false;
     int mark(hipStream_t st)
     {
         if (evs) HIPCHECK(hipEventRecord((*evs)[base + (size_t)evi++], st));
+        return TK_OK;
+    }
+    int mark_plain(int which, hipStream_t st)       // 0: in front of the plain kernel, 1: behind it
+    {
+        if (evs) {
+            HIPCHECK(hipEventRecord((*evs)[base + 8 + (size_t)which], st));
+            plain_marked = true;
+        }
         return TK_OK;
     }
 };
@@ -1157,15 +1169,18 @@ static int prof_begin(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStrea
     // profiling = n: every n-th batch is timed (1 = every batch)
     if (ix->profiling == 0 || ix->ev_used >= 4096 || (ix->prof_seen++ % (uint64_t)ix->profiling) != 0)
         return TK_OK;
-    while (ix->evs.size() < (ix->ev_used + 1) * 8) {
+    while (ix->evs.size() < (ix->ev_used + 1) * TK_PROF_EVENTS) {
         hipEvent_t e;
         HIPCHECK(hipEventCreate(&e));
         ix->evs.push_back(e);
     }
     pf.evs = &ix->evs;
-    pf.base = ix->ev_used * 8;
+    pf.base = ix->ev_used * TK_PROF_EVENTS;
     if (ix->ev_streams.size() <= ix->ev_used) ix->ev_streams.resize(ix->ev_used + 1);
+    if (ix->ev_plain.size() <= ix->ev_used) ix->ev_plain.resize(ix->ev_used + 1);
     ix->ev_streams[ix->ev_used] = st;
+    ix->ev_plain[ix->ev_used] = 0;
+    pf.set = (int)ix->ev_used;
     ix->ev_used++;
     ix->last_S = p.S; ix->last_R = p.R; ix->last_nq = nq;
     ix->last_work = (int)(&w - &ix->works[0]);
@@ -1567,8 +1582,11 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
     TRY(b.pf.mark(st));
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
     // (plain first: the exact kernel then overwrites the head chunks of the lists in head mode)
+    if (b.plain) TRY(b.pf.mark_plain(0, st));
     if (b.plain && tk_launch_scan_plain(plain_job(ix, w, p), M, ix->order, plain_blocks(), st))
         return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
+    if (b.plain) TRY(b.pf.mark_plain(1, st));
+    if (b.plain && b.pf.evs && b.pf.set >= 0) ix->ev_plain[(size_t)b.pf.set] = 1;
     if (b.plain) {
         TkScanJob none;
         memset(&none, 0, sizeof none);
@@ -1693,9 +1711,12 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
 #else
     constexpr int dbg_skip_scan = 0;
 #endif
+    if (prev && prev->plain) TRY(prev->pf.mark_plain(0, st));
     if (prev && prev->plain && !(dbg_skip_scan & 16) &&
         tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order, plain_blocks(), st))
         return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
+    if (prev && prev->plain) TRY(prev->pf.mark_plain(1, st));
+    if (prev && prev->plain && prev->pf.evs && prev->pf.set >= 0) ix->ev_plain[(size_t)prev->pf.set] = 1;
     if (fuse_prev || fuse_cur) {
         TkScanJob none;
         memset(&none, 0, sizeof none);
@@ -2030,7 +2051,10 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
     const int64_t ms = sub_batch(p);
     ARGCHECK(!(out_ids_pinned || done_ev) || (nq >= 1 && nq <= ms),
              "a completion event / host copy belongs to ONE sub-batch (tk_index_max_sub_batch)");
-    if (ix->depth > 1 && ix->coalesce == 2 && nq >= 1 && nq <= ms)
+    // (repeating labels — IVF.build(n_probes >= 2) — run the duplicate-test replay: 32 queries and 70 KB
+    //  of LDS per wave, two waves per CU; a doubled batch would not fit the chip in one round of waves:
+    //  5.1 M queries/s paired against 7.7 M alone, profiles/r04/bench_full_first.json)
+    if (ix->depth > 1 && ix->coalesce == 2 && ix->ids_unique && nq >= 1 && nq <= ms)
         return coalesce_call(ix, p, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, out_ids_dev,
                              out_ids_pinned, done_ev, caller);
     if (ix->held) TRY(launch_held(ix));
@@ -3507,11 +3531,12 @@ extern "C" int tk_index_set_profiling(tk_index *ix, int on)
     return TK_OK;
 }
 
-extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_bytes, int *batches)
+extern "C" int tk_index_last_profile(tk_index *ix, float *ms8, double *scan_bytes, int *batches)
 {
     IXLOCK(ix);
     ARGCHECK(ix, "null index");
-    for (int i = 0; i < 7; i++) ms7[i] = 0;
+    float *ms7 = ms8;
+    for (int i = 0; i < 8; i++) ms8[i] = 0;
     *scan_bytes = 0;
     TRY(flush_pending(ix));
     *batches = (int)ix->ev_used;
@@ -3520,9 +3545,20 @@ extern "C" int tk_index_last_profile(tk_index *ix, float *ms7, double *scan_byte
     for (size_t b = 0; b < ix->ev_used; b++)
         for (int i = 0; i < 7; i++) {
             float ms = 0;
-            HIPCHECK(hipEventElapsedTime(&ms, ix->evs[b * 8 + i], ix->evs[b * 8 + i + 1]));
+            HIPCHECK(hipEventElapsedTime(&ms, ix->evs[b * TK_PROF_EVENTS + i], ix->evs[b * TK_PROF_EVENTS + i + 1]));
             ms7[i] += ms / (float)ix->ev_used;
         }
+    {   // the plain kernel alone (events on the stream it is launched on), over the sets that ran it
+        int n_plain = 0;
+        for (size_t b = 0; b < ix->ev_used; b++)
+            if (b < ix->ev_plain.size() && ix->ev_plain[b]) {
+                float ms = 0;
+                HIPCHECK(hipEventElapsedTime(&ms, ix->evs[b * TK_PROF_EVENTS + 8], ix->evs[b * TK_PROF_EVENTS + 9]));
+                ms8[7] += ms;
+                n_plain++;
+            }
+        if (n_plain) ms8[7] /= (float)n_plain;
+    }
     // algorithmic bytes of the list scan of the most recent sub-batch:
     // per query  sum over probed lists ceil(n/16)*M*8  +  16*M (table)  +  12*R (heap)
     const int S = ix->last_S;

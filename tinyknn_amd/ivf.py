@@ -554,12 +554,13 @@ class DeviceIndex:
         _lib.check(_lib.lib().tk_index_set_profiling(self._h, int(on)))
 
     def last_profile(self):
-        ms = (C.c_float * 7)()
+        ms = (C.c_float * 8)()
         b = C.c_double()
         n = C.c_int32()
         _lib.check(_lib.lib().tk_index_last_profile(self._h, ms, C.byref(b), C.byref(n)))
         names = ["tables", "coarse_scan", "coarse_heap", "coarse_rescore", "scan", "heap", "rescore"]
-        return dict(zip(names, list(ms))), b.value, n.value
+        self.last_plain_kernel_ms = float(ms[7])      # the plain kernel alone (0: no recorded batch ran it)
+        return dict(zip(names, list(ms)[:7])), b.value, n.value
 
 
 class IVF:
