@@ -603,7 +603,7 @@ def measure_traffic(args, plain_on=True):
         try:
             # the child answers 4 batches: too few for the plain path to prove itself (probe, wait, on).
             # It runs in the state the parent's timed region settled in — always plain, or never.
-            mode = {"TINYKNN_PLAIN_ADAPT": "0"} if plain_on else {"TINYKNN_PLAIN_SCAN": "0"}
+            mode = {"TINYKNN_PLAIN_SCAN": "2"} if plain_on else {"TINYKNN_PLAIN_SCAN": "0"}
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", **mode), stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=600, check=True)
             acc = {}
@@ -888,7 +888,7 @@ def main():
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
     ap.add_argument("--scan-form", type=int, default=0,
-                    help="tk_set_scan_form (A/B): 0 table rows by per-lane global loads (default, fastest); "
+                    help="tk_index_set_option TK_OPT_SCAN_FORM (A/B): 0 table rows by per-lane global loads (default, fastest); "
                          "1 rows through LDS, 4 waves/SIMD; 2 LDS, 3 waves/SIMD")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="replay streams (tk_index_set_pipeline): caller + coarse stream + these = 4 HW queues")
@@ -1039,7 +1039,7 @@ def main():
     dev.reserve(args.nq * (2 if args.coalesce == 2 and args.pipeline > 1 else 1), args.k, args.n_probes)
     dev.set_heap_mode(args.heap_mode)
     dev.set_scan_mode(args.scan_mode)
-    _lib.check(_lib.lib().tk_set_scan_form(args.scan_form))
+    dev.set_option(_lib.OPT_SCAN_FORM, args.scan_form)
     n_step = [0]
 
     def step(done_event=None):

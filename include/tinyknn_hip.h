@@ -273,29 +273,21 @@ int tk_index_set_plain_scan(tk_index *ix, int mode);
  * re-scan, sum over the plain units of the list's chunk pairs, state of mode 0 (0 probe next,
  * 1 waiting for the probe's count, 2 on, 3 paused), batches left of the pause. */
 int tk_index_plain_stats(tk_index *ix, int64_t *out8);
-/* Debug/test hook: caps every query's limit C (INT_MAX = off; -128 sends every query with a
- * plain slot through the re-scan path). */
-int tk_debug_plain_limit(int limit);
-
-/* Form of the list-major scan kernel (process-wide; A/B timing, identical outputs).
- * 1 = the table rows a 64-unit block needs are staged once per block in the wave's
- * LDS region and read with ds_read_b128, one query's rows live at a time (4 waves per SIMD);
- * 2 = rows through LDS, 3 waves per SIMD; 0 = per-lane global loads of the rows (round-1
- * form; DEFAULT: measured faster, profiles/r02_scan_forms.md).  Tables with more than 156 blocks
- * fall back to 0. */
-int tk_set_scan_form(int form);
-/* Form of the exact rescoring kernel for float32 vectors with d % 4 == 0, d <= 256 (process-wide;
- * identical outputs — the summation order of every row is numpy's in each form): 2 = candidate rows
- * read by the wave as one stream of 16-byte pieces and staged through LDS in tiles of 32 rows
- * (DEFAULT), 1 = tiles of 64 rows, 0 = every lane walks its own row (the only form for float64
- * operands and other d).  Environment TINYKNN_RESCORE_STAGED sets the initial value. */
-int tk_set_rescore_form(int form);
-/* Form of the plain-sum kernel for M = 52 and M = 32 (process-wide; identical outputs): 0 = the table
- * operand of a unit's 32 queries held in registers (212 per lane, two waves per SIMD; DEFAULT),
- * 1 = read from LDS for every MFMA (128 registers, 31 KB per workgroup, four waves per SIMD: the same
- * speed alone and per batch, half the stretch beside the replays — profiles/r03/ab_pipeline_knobs.txt),
- * 2 = the same at three waves per SIMD.  Environment TINYKNN_PLAIN_FORM sets the initial value. */
-int tk_set_plain_form(int form);
+/* Per-index options (no process-wide state: the reference's entry points carry none either,
+ * _fast_pq.pyx:101-307 are nogil and re-entrant).  Results never depend on an option; they exist for
+ * A/B measurements and for the tests.
+ *   TK_OPT_SCAN_FORM     table rows of the exact list-major kernel: 0 = per-lane global loads (DEFAULT;
+ *                        fastest, profiles/r02_scan_forms.md), 1 / 2 = staged per block in LDS
+ *   TK_OPT_RESCORE_FORM  candidate rows of the rescoring: 2 = staged through LDS in tiles of 32 rows
+ *                        (DEFAULT), 1 = tiles of 64, 0 = every lane walks its own row (always for float64
+ *                        operands and d % 4 != 0)
+ *   TK_OPT_PLAIN_LIMIT   a cap on every query's table limit C (plain_scan.hip's lemma; INT_MAX = none):
+ *                        -128 sends EVERY query of a plain batch through the exact re-scan + second
+ *                        replay (tests/test_plain_scan_gpu.py) */
+#define TK_OPT_SCAN_FORM 1
+#define TK_OPT_RESCORE_FORM 2
+#define TK_OPT_PLAIN_LIMIT 3
+int tk_index_set_option(tk_index *ix, int option, int value);
 
 /* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
  * around the stages (no synchronisation in the query call; 1 = every batch).

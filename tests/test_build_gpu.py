@@ -134,6 +134,7 @@ def test_device_build_equals_host_build(metric, d, rot, probes):
     """IVF.build(device=True) == IVF.build(device=False): same lists, ids, codes."""
     from tinyknn_amd import IVF, FastPQ
     rng = np.random.RandomState(1)
+    np.random.seed(7)       # sklearn's KMeans and FastPQ.fit draw from numpy's global generator: the same fit every run
     n = 20037
     cent = rng.randn(60, d)
     X = (cent[rng.randint(60, size=n)] + 0.6 * rng.randn(n, d)).astype(np.float32)

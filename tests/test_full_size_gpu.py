@@ -37,22 +37,25 @@ def test_full_size_index_all_modes_vs_oracle(full):
     qn, qp = ivf._prepare(qs.copy())
     L = _lib.lib()
     try:
-        for n_probes in (1, 10, 50):
+        for n_probes in (1, 5, 10, 20, 50):
             want = ox.query_batch(qn, 10, n_probes)
-            for scan_mode, heap_mode, form, depth in ((0, 0, 0, 1), (1, 0, 0, 1), (2, 1, 0, 1), (2, 2, 0, 1),
-                                                      (2, 0, 1, 1), (2, 0, 2, 1), (0, 0, 0, 2)):
+            modes = ((0, 0, 0, 1), (1, 0, 0, 1), (2, 1, 0, 1), (2, 2, 0, 1), (2, 0, 1, 1), (2, 0, 2, 1), (0, 0, 0, 2))
+            if n_probes in (5, 20):     # the sweep's other points: default path, one batch and pipelined + paired
+                modes = ((0, 0, 0, 1), (0, 0, 0, 2))
+            for scan_mode, heap_mode, form, depth in modes:
                 dev.set_pipeline(depth)
+                dev.set_coalesce(2 if depth > 1 else 1)
                 dev.set_scan_mode(scan_mode)
                 dev.set_heap_mode(heap_mode)
-                _lib.check(L.tk_set_scan_form(form))
+                dev.set_option(_lib.OPT_SCAN_FORM, form)
                 got = dev.query_batch(qn, qp, 10, n_probes)
                 bad = np.flatnonzero((got != want).any(axis=1))
                 assert bad.size == 0, (n_probes, scan_mode, heap_mode, form, depth, bad[:5])
         # raw queries through the exact streamed front end
         np.testing.assert_array_equal(ivf.query_batch(qs, 10, n_probes=10), ox.query_batch(qn, 10, 10))
     finally:
-        dev.set_pipeline(1); dev.set_scan_mode(0); dev.set_heap_mode(0)
-        _lib.check(L.tk_set_scan_form(0))
+        dev.set_pipeline(1); dev.set_coalesce(1); dev.set_scan_mode(0); dev.set_heap_mode(0)
+        dev.set_option(_lib.OPT_SCAN_FORM, 0)
 
 
 def test_flat_top_two_pass_at_1m_codes(full, oracle):

@@ -328,11 +328,11 @@ def test_ivf_query_golden(tk, tag):
         from tinyknn_amd import _lib
         try:
             for form in (0, 1, 2):
-                _lib.check(_lib.lib().tk_set_rescore_form(form))
+                dev.set_option(_lib.OPT_RESCORE_FORM, form)
                 np.testing.assert_array_equal(dev.query_batch(g["qn"], g["qpq"], k, n_probes),
                                               g[f"ids_p{n_probes}"])
         finally:
-            _lib.check(_lib.lib().tk_set_rescore_form(2))
+            dev.set_option(_lib.OPT_RESCORE_FORM, 2)
         dev.set_scan_mode(0)
         out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
         np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])

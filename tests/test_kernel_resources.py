@@ -25,10 +25,10 @@ PINNED = {
     ("adc_scan.hip", "scan_units2_kernelILi1ELb1ELi0EE"): (168, 3),
     ("adc_scan.hip", "scan_units_kernelILi1ELb1ELi0ELb0EE"): (168, 3),
     # the plain-sum scan on the matrix cores, M = 52 and M = 32
-    ("plain_scan.hip", "scan_plain_wave_kernelILi26E"): (256, 2),
-    ("plain_scan.hip", "scan_plain_wave_kernelILi16E"): (256, 2),
+    ("plain_scan.hip", "scan_plain_wave_kernelILi26ELb1E"): (256, 2),
+    ("plain_scan.hip", "scan_plain_wave_kernelILi16ELb1E"): (256, 2),
     # lane-per-query replay, distinct labels, 64 queries per wave
-    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELb0ELi64EE"): (128, 4),
+    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64EE"): (128, 4),
     ("rescore.hip", "rescore_staged_kernelILi32EE"): (128, 4),
 }
 

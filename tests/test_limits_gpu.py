@@ -107,6 +107,26 @@ def test_assign_lists_up_to_nine_lists_per_row(k, y64):
         np.testing.assert_array_equal(out, O.assign(X, Y, k, metric))
 
 
+def test_device_assignment_defers_to_this_hosts_numpy_for_k_above_two(monkeypatch):
+    """The ORDER of argpartition's first k is numpy's implementation detail (ascending on the fixture
+    host).  IVF.build(device=True) checks the device's k > 2 assignment against this host's numpy on
+    sampled chunks and falls back to numpy when they differ — simulated here by a numpy that returns
+    the columns in another order."""
+    import tinyknn_amd
+    from tinyknn_amd import ivf as ivf_mod
+    from tinyknn_amd.utils import knn_brute as real
+    rng = np.random.RandomState(4)
+    X = rng.randn(3000, 32).astype(np.float32)
+    index = tinyknn_amd.IVF("euclidean", 40, tinyknn_amd.FastPQ(2))
+    index.all_centers = X[:40].copy()
+    got = index._nearest_on_device(X, 3)
+    np.testing.assert_array_equal(got, real(X, index.all_centers, k=3, metric="euclidean"))      # this host: ascending
+    monkeypatch.setattr(ivf_mod, "knn_brute", lambda *a, **k: real(*a, **k)[:, ::-1].copy())
+    with pytest.warns(UserWarning, match="falls back to numpy"):
+        got = index._nearest_on_device(X, 3)
+    np.testing.assert_array_equal(got, real(X, index.all_centers, k=3, metric="euclidean")[:, ::-1])
+
+
 def test_one_handle_from_several_threads_is_serialised(small):
     """The reference's entry points are nogil and re-entrant; a tk_index handle is not — its entry
     points take a per-handle lock, so concurrent callers are serialised instead of corrupting

@@ -30,6 +30,9 @@ _f32p = C.POINTER(C.c_float)
 _f64p = C.POINTER(C.c_double)
 
 # name -> (restype, argtypes); mirrors include/tinyknn_hip.h one to one
+# tk_index_set_option
+OPT_SCAN_FORM, OPT_RESCORE_FORM, OPT_PLAIN_LIMIT = 1, 2, 3
+
 SIGNATURES = {
     "tk_last_error": (C.c_char_p, []),
     "tk_version": (C.c_int, []),
@@ -149,10 +152,7 @@ SIGNATURES = {
     "tk_index_set_plain_scan": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_quiesce": (C.c_int, [C.c_void_p]),
     "tk_index_plain_stats": (C.c_int, [C.c_void_p, _i64p]),
-    "tk_debug_plain_limit": (C.c_int, [C.c_int]),
-    "tk_set_scan_form": (C.c_int, [C.c_int]),
-    "tk_set_rescore_form": (C.c_int, [C.c_int]),
-    "tk_set_plain_form": (C.c_int, [C.c_int]),
+    "tk_index_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "tk_index_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "tk_index_last_profile": (C.c_int, [C.c_void_p, _f32p, _f64p, _i32p]),
 }

@@ -1002,10 +1002,8 @@ void tk_launch_identity_pairs(int64_t nq, int chunks, int *pair_off, int *unit_p
                        nq, chunks, pair_off, unit_prefix, pair_q, pair_f0);
 }
 
-// form of the list-major kernel (tk_set_scan_tables: A/B switch; see scan_units_kernel)
-static int g_scan_form = 0;   // measured (profiles/r02_scan_forms.md): the global-load form wins
-void tk_set_scan_tables(int form) { g_scan_form = form < 0 || form > 2 ? 0 : form; }
-int tk_get_scan_tables(void) { return g_scan_form; }
+// (form of the list-major kernel — tk_index_set_option(TK_OPT_SCAN_FORM): 0 = per-lane global loads of
+//  the table rows, the default: profiles/r02_scan_forms.md; 1 / 2 = rows staged per block in LDS)
 
 template <typename K>
 static void lds_attr(K kern)
@@ -1029,12 +1027,12 @@ void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_
                           int64_t n_lists, const int64_t *list_chunk_off, const int *pair_off,
                           const int *unit_prefix, const int *pair_q, const int *pair_f0,
                           uint4 *dist, int64_t cap, uint8_t *mins, int64_t min_stride, int signd,
-                          int order, int n_blocks, hipStream_t s)
+                          int order, int n_blocks, hipStream_t s, int form)
 {
     if (nq == 0 || S == 0) return;
     const int P = M / 2;
     const bool coarse = n_lists == 1 && S == 1;
-    int form = g_scan_form;
+    form = form < 0 || form > 2 ? 0 : form;
     const int gmax = scan_form_gmax(M, form);
     const size_t lds = (size_t)4 * gmax * TK_UNIT_Q * M * 16;
 #define TK_LAUNCH3(O, S_, F_, C_)                                                                \
@@ -1067,7 +1065,7 @@ void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_
 }
 
 void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
-                           hipStream_t s, const TkScanJob *cj)
+                           hipStream_t s, const TkScanJob *cj, int form)
 {
     TkScanJobs3 jobs;
     memset(&jobs, 0, sizeof jobs);
@@ -1077,8 +1075,8 @@ void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int or
     const TkScanJob &c = jobs.j[2];
     if (!a.unit_prefix && !b.unit_prefix && !c.unit_prefix) return;
     const int P = M / 2;
-    int form = g_scan_form;
-    if (a.max_chunks || b.max_chunks || c.max_chunks) form = 0;      // (only the global-load form knows heads)
+    form = form < 0 || form > 2 ? 0 : form;
+    if (a.max_chunks || b.max_chunks || c.max_chunks) form = 0;      // (only the global-load form, the default, knows heads)
     const int gmax = scan_form_gmax(M, form);
     const size_t lds = (size_t)4 * gmax * TK_UNIT_Q * M * 16;
 #define TK_LAUNCH(O, F_)                                                                          \

@@ -663,9 +663,14 @@ struct tk_index {
     // index-static descriptors of the coarse stage, staging buffers of the host API
     DevBuf cslots_i, cslots_l, c_chunk_off, q, qpq, stage;
     int scan_mode = 0;         // 0 auto, 1 query-major kernel, 2 list-major (units) kernel
+    // tk_index_set_option
+    int opt_scan_form = 0;             // exact list-major kernel: 0 per-lane table-row loads, 1 / 2 rows staged in LDS
+    int opt_rescore_form = 2;          // rescoring: 2 / 1 rows staged through LDS in tiles of 32 / 64, 0 lane per row
+    int opt_plain_limit = 0x7fffffff;  // a cap on every query's table limit (tests: provokes the re-scan path)
     int plain_state = 0;       // PLAIN_PROBE .. PLAIN_OFF (see plain_poll)
     int plain_skip = 0;        // OFF: batches left before the next probe
-    int plain_backoff = 128;   // OFF: length of the next pause (doubled by a failed probe)
+    int plain_backoff = 256;   // OFF: length of the next pause (doubled by a failed probe, up to 4096)
+    int plain_wait = 0;        // WAIT: batches seen while no verdict is pending (a probe that was abandoned)
     bool capturing = false;    // the current call is being captured into a hipGraph: no event queries
     int plain_mode = 0;        // 0 auto: probed lists behind the first ones as plain sums on the matrix
                                // cores where the lemma of plain_scan.hip allows AND few queries need the
@@ -678,8 +683,6 @@ struct tk_index {
     uint64_t calls = 0;
     std::vector<hipStream_t> lat_streams;    // `depth` of them (pipelined mode)
     hipEvent_t ev_in = nullptr;              // caller's stream -> a batch's stream
-    hipEvent_t ev_front_in = nullptr;        // front stream (input copies) -> the table build's stream
-    bool input_on_front = false;             // tk_index_input_stream has handed the front stream out
     std::vector<struct Pending *> pending;   // calls whose list scan is still to be enqueued (<= 2)
     uint64_t ev_seq = 0;                     // counts the records of tables_done / front_done (pipeline_step's merged wait)
     int coalesce = 1;                        // 2: two consecutive calls run as ONE batch (tk_index_set_coalesce)
@@ -688,7 +691,6 @@ struct tk_index {
     int64_t held_rows = 0;                   // rows its staging buffers hold
     hipStream_t held_stt = nullptr, held_caller = nullptr;
     hipStream_t front_stream = nullptr;      // coarse replays + descriptors of all batches, in order
-    hipStream_t front_stream2 = nullptr;     // A/B (TINYKNN_FRONT_STREAMS=2): ... of the odd calls
     // profiling: one set of 8 events per recorded batch, read back on demand
     int profiling = 0;
     uint64_t prof_seen = 0;
@@ -725,9 +727,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
     for (Work &w : ix->works) w.release();
     for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
     if (ix->front_stream) (void)hipStreamDestroy(ix->front_stream);
-    if (ix->front_stream2) (void)hipStreamDestroy(ix->front_stream2);
     if (ix->ev_in) (void)hipEventDestroy(ix->ev_in);
-    if (ix->ev_front_in) (void)hipEventDestroy(ix->ev_front_in);
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -970,14 +970,12 @@ static bool plain_possible(const tk_index *ix, const Plan &p)
 //     ON       plain for every batch; any completed batch above 1 % -> OFF
 //     OFF      exact kernel only for `plain_backoff` batches (256, doubling up to 4096 on every
 //              failed probe in a row), then -> PROBE
-// tk_index_set_plain_scan(ix, 2) / TINYKNN_PLAIN_ADAPT=0: always plain (A/B, the tests' forced
-// re-scans).  Results never depend on any of this.
+// tk_index_set_plain_scan(ix, 2): always plain (A/B, the tests' forced re-scans).  Results never
+// depend on any of this.
 enum { PLAIN_PROBE = 0, PLAIN_WAIT = 1, PLAIN_ON = 2, PLAIN_OFF = 3 };
 static bool plain_adaptive(const tk_index *ix)
 {
-    static int adapt = -1;
-    if (adapt < 0) adapt = !(getenv("TINYKNN_PLAIN_ADAPT") && getenv("TINYKNN_PLAIN_ADAPT")[0] == '0');
-    return adapt && ix->plain_mode == 0 && !tk_plain_forced();
+    return ix->plain_mode == 0 && ix->opt_plain_limit == 0x7fffffff;
 }
 static void plain_poll(tk_index *ix)
 {
@@ -993,7 +991,7 @@ static void plain_poll(tk_index *ix)
                 ix->plain_state = PLAIN_OFF;
             } else if (ix->plain_state == PLAIN_WAIT) {
                 ix->plain_state = PLAIN_ON;
-                ix->plain_backoff = 128;
+                ix->plain_backoff = 256;
             }
         }
     (void)hipGetLastError();       // (hipErrorNotReady of a query is not an error)
@@ -1007,8 +1005,19 @@ static bool plain_now(tk_index *ix, const Plan &p)
     plain_poll(ix);
     switch (ix->plain_state) {
     case PLAIN_ON: return true;
-    case PLAIN_PROBE: ix->plain_state = PLAIN_WAIT; return true;
-    case PLAIN_WAIT: return false;
+    case PLAIN_PROBE:
+        ix->plain_state = PLAIN_WAIT;
+        ix->plain_wait = 0;
+        return true;
+    case PLAIN_WAIT: {
+        // the probe's verdict is recorded behind its replay, up to three calls after this point; a
+        // probe batch that was abandoned before that (a failed reserve, a HIP error) never reports:
+        // after 16 batches with no verdict pending anywhere, probe again
+        bool pending = !ix->pending.empty() || ix->held != nullptr;      // (a batch not yet replayed may be the probe)
+        for (const Work &w : ix->works) pending |= w.plain_pending;
+        if (!pending && ++ix->plain_wait >= 16) ix->plain_state = PLAIN_PROBE;
+        return false;
+    }
     default:
         if (--ix->plain_skip <= 0) ix->plain_state = PLAIN_PROBE;
         return false;
@@ -1020,7 +1029,6 @@ static bool plain_now(tk_index *ix, const Plan &p)
 // more where a batch holds far more than ~6 units per resident wave (long lists: 100M x 128).
 static int plain_k(const tk_index *ix, int64_t nq, const Plan &p)
 {
-    if (!tk_plain_wave_form()) return TK_PLAIN_K_WHOLE;
     const double iters = (double)nq * p.S / 32.0 * ((double)ix->total_chunks / (double)ix->n_lists) / 2.0;
     int k = (int)(iters / (2048.0 * 6.0));
     k = (k + 3) & ~3;
@@ -1211,7 +1219,7 @@ static int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64,
                            qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>(), w.shift.p,
                            w.scale.as<double>(), st);
     if (plain)      // per query: below which value clamp(plain sum) is the saturated value
-        tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st);
+        tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st, ix->opt_plain_limit);
     if (coarse_units(ix, nq))
         // every query scans the one list of coded centres: list-major, no idle lanes
         tk_launch_identity_pairs(nq, (int)ix->center_chunks, w.c_pair_off.as<int>(),
@@ -1274,17 +1282,10 @@ static TkScanJob plain_job(const tk_index *ix, const Work &w, const Plan &p)
 // distinct (a flagged query is then re-played by the packed kernel without the duplicate test:
 // ~0.15 ms of one wave), 4 where they repeat (build_probes >= 2: with 2 about one query in 10 000
 // was still flagged, and ONE flagged query costs its batch a 0.9 ms wave-per-query replay with
-// the duplicate test; with 4 none in the bench batches).  A/B: TINYKNN_PLAIN_HEAD.
+// the duplicate test; with 4 none in the bench batches).
 static int head_rows(const tk_index *ix, const Plan &p)
 {
-    static double forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("TINYKNN_PLAIN_HEAD");
-        forced = e ? atof(e) : 0.0;
-        forced = forced < 0.0 ? 0.0 : forced;
-    }
-    const double mult = forced >= 1.0 ? forced : (ix->ids_unique ? 2.0 : 4.0);
-    return (int)(mult * p.R);
+    return (ix->ids_unique ? 2 : 4) * p.R;
 }
 // head pairs: the first ceil(head_rows / 16) chunks of the first probed list of a query in head mode
 static int head_chunks(const tk_index *ix, const Plan &p) { return (head_rows(ix, p) + 15) >> 4; }
@@ -1301,16 +1302,7 @@ static TkScanJob head_job(const tk_index *ix, const Work &w, const Plan &p)
 }
 
 // persistent workgroups of the plain kernel: two per CU (58 KB of LDS, 256 registers per lane)
-static int plain_blocks()
-{
-    static int n = -1;
-    if (n < 0) {
-        const char *e = getenv("TINYKNN_PLAIN_BLOCKS");
-        n = e ? atoi(e) : 512;
-        n = n < 1 ? 512 : n;
-    }
-    return n;
-}
+static int plain_blocks() { return 512; }
 
 // 2a. coarse scan = the scan of dtable.top(centers)          ivf.py:131, fast_pq.py:284-312
 static void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st,
@@ -1365,7 +1357,7 @@ static int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64
     }
     TRY(pf.mark(st));
     tk_launch_rescore(q_dev, 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
-                      w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0, probes_out, nullptr, st);
+                      w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0, probes_out, nullptr, st, ix->opt_rescore_form);
     return TK_OK;
 }
 
@@ -1448,15 +1440,7 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     // (a list may then be scanned twice) re-run with the duplicate test.  Repeating labels
     // (build n_probes >= 2): the packed wave kernel with the duplicate test for everybody.
     const bool packed_ok = ix->heap_mode != 1 && p.cap * 16 <= 0xffffff;
-    // timing experiments (profiles/r02_scan_grid.md) skip stages and give WRONG results: only a
-    // library built with -DTK_TIMING_EXPERIMENTS reads the switch
-#ifdef TK_TIMING_EXPERIMENTS
-    static const int dbg_skip = getenv("TINYKNN_DEBUG_SKIP") ? atoi(getenv("TINYKNN_DEBUG_SKIP")) : 0;
-#else
-    constexpr int dbg_skip = 0;
-#endif
-    if (dbg_skip & 1) {             // timing experiments only (wrong results): no main replay
-    } else if (packed_ok && ix->ids_unique) {
+    if (packed_ok && ix->ids_unique) {
         const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
         if (!lanes)
             tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
@@ -1508,10 +1492,8 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     }
     TRY(pf.mark(st));
     // 4. strip sentinels, exact rescoring                   ivf.py:154-163
-    if (!(dbg_skip & 2))
-    tk_launch_rescore(q_dev, 0, ix->d, ix->data.p, ix->data_is_f64, ix->N,
-                      w.heap_idx.as<int64_t>(), p.R, nq, k, 1 | ((dbg_skip & 4) ? 0x100 : 0) | ((dbg_skip & 8) ? 0x200 : 0),
-                      out_dev, nullptr, st);
+    tk_launch_rescore(q_dev, 0, ix->d, ix->data.p, ix->data_is_f64, ix->N, w.heap_idx.as<int64_t>(), p.R, nq, k, 1,
+                      out_dev, nullptr, st, ix->opt_rescore_form);
     TRY(pf.mark(st));
     return TK_OK;
 }
@@ -1545,7 +1527,6 @@ struct Pending {
     bool units;
     bool plain;             // probed lists behind the first ones by the plain kernel (plain_scan.hip)
     bool coarse_launched;   // its coarse scan has been enqueued
-    bool desc_done = false; // (TINYKNN_DESC_STREAM=1) its slot descriptors and pair lists have been enqueued
     int64_t *host_out;      // pinned host copy of the ids, enqueued behind the rescoring (or NULL)
     bool host_out_kernel;   // ... written by copy_words_kernel instead of the copy engine
     hipEvent_t user_ev;     // recorded behind that copy (or NULL)
@@ -1591,15 +1572,13 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
         TkScanJob none;
         memset(&none, 0, sizeof none);
         const TkScanJob hj = head_job(ix, w, p);
-        tk_launch_scan_units2(list_job(ix, w, p), none, M, ix->order,
-                              getenv("TINYKNN_SCAN_BLOCKS_ISO") ? atoi(getenv("TINYKNN_SCAN_BLOCKS_ISO")) : 768, st, &hj);
+        tk_launch_scan_units2(list_job(ix, w, p), none, M, ix->order, 768, st, &hj, ix->opt_scan_form);
     } else if (b.units)
         tk_launch_scan_units(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), b.nq, p.S, ix->n_lists,
                              ix->list_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                              w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(),
                              w.u_pair_f0.as<int>(), w.dist.as<uint4>(), p.cap,
-                             w.mins.as<uint8_t>(), p.cap_min, 1, ix->order,
-                             getenv("TINYKNN_SCAN_BLOCKS_ISO") ? atoi(getenv("TINYKNN_SCAN_BLOCKS_ISO")) : 768, st);
+                             w.mins.as<uint8_t>(), p.cap_min, 1, ix->order, 768, st, ix->opt_scan_form);
     else
         tk_launch_scan_probes(ix->codes.as<uint4>(), M, w.tables.as<uint4>(), b.nq,
                               w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), p.S,
@@ -1618,72 +1597,23 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
 // replay wave (120+ VGPRs) has no room for a third scan workgroup, which then waits for a slot
 // while its share of the work is drawn by others — measured per 10 000 queries: 768 -> 0.705 ms,
 // 640 -> 0.703, 576 -> 0.682, 512 -> 0.657, 448 -> 0.678, 384 -> 0.743 (profiles/r02_scan_grid.md).
-// A/B: TINYKNN_SCAN_BLOCKS.
 // Long launches (100M x 128: 15 M units, 3 ms) amortise that wait and prefer more resident
 // waves: 512 -> 4.15 ms per batch, 576 -> 3.95, 640 -> 3.89, 704 -> 3.84, 768 -> 4.03
 // (profiles/r02_scan_grid.md), so the grid is 704 above ~6 M estimated units.
-static int scan_blocks_pipelined(double est_units)
-{
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("TINYKNN_SCAN_BLOCKS");
-        forced = e ? atoi(e) : 0;
-        forced = forced < 64 ? 0 : forced;
-    }
-    if (forced) return forced;
-    return est_units > 6.0e6 ? 704 : 512;
-}
+static int scan_blocks_pipelined(double est_units) { return est_units > 6.0e6 ? 704 : 512; }
 
 // depth > 1: the launch on the caller's stream that carries the list scan of `prev` (may be
-// NULL) and the coarse scan of `cur` (may be NULL), and what follows each on its stream
-// 0: front stream (default); 1: the batch's own replay stream; 2: the other replay stream
-static int tables_stream_mode()
-{
-    static const int m = getenv("TINYKNN_TABLES_STREAM") ? atoi(getenv("TINYKNN_TABLES_STREAM")) : 0;
-    return m;
-}
-static bool tables_on_replay_stream() { return tables_stream_mode() != 0; }
-
-static int front_streams()
-{
-    static const int n = getenv("TINYKNN_FRONT_STREAMS") ? atoi(getenv("TINYKNN_FRONT_STREAMS")) : 1;
-    return n == 2 ? 2 : 1;
-}
-
-// A/B (TINYKNN_DESC_STREAM=1): the slot descriptors and pair lists of a batch are built on the SCAN
-// stream, one call after its coarse stage ran on the front stream — behind the launch of that call,
-// in front of the launch that scans the batch, in order on one stream: no event in between.  The
-// front stream then carries the table build + coarse replay + coarse rescoring only (the cycle is
-// bound by what that stream executes serially: DESIGN 3.5).
-static int desc_on_scan_stream()
-{
-    static const int m = getenv("TINYKNN_DESC_STREAM") ? atoi(getenv("TINYKNN_DESC_STREAM")) : 0;
-    return m == 1;
-}
-
-static int make_descriptors(tk_index *ix, Pending &b, hipStream_t st)
-{
-    Work &w = *b.w;
-    HIPCHECK(hipStreamWaitEvent(st, w.front_done, 0));       // (here: the batch's probe lists exist)
-    coarse_slots(ix, w, w.probes.as<int64_t>(), b.nq, b.p, b.units ? w.u_count.as<int>() : nullptr, nullptr, 0,
-                 st, b.plain);
-    if (b.units) unit_pairs(ix, w, b.nq, b.p, b.plain, st);
-    b.desc_done = true;
-    return TK_OK;
-}
-
+// NULL) and the coarse scan of `cur` (may be NULL), and what follows each on its stream.
+// (Measured and dropped in rounds 2-3, profiles/HISTORY.md: table builds on a replay stream or on the
+// scan stream, two front streams, descriptors on the scan stream, a high-priority front stream, replay
+// streams confined to a CU mask — none moved the batch.)
 static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
 {
     const int M = ix->M;
     hipStream_t st = prev ? prev->st : cur->st;
-    const bool desc_s = desc_on_scan_stream();
-    // (start-up and drain: the batch about to be scanned has no descriptors yet)
-    if (desc_s && prev && !prev->desc_done) TRY(make_descriptors(ix, *prev, st));
     // what the launch waits for lives on the front stream, in order: ..., front_done(c-3),
     // tables_done(c-1), ... — the later event covers the earlier one, and every hand-over
     // between streams is a barrier packet the command processor spends microseconds on
-    static const bool merge = !(getenv("TINYKNN_MERGE_EVENTS") && getenv("TINYKNN_MERGE_EVENTS")[0] == '0') &&
-                              !tables_on_replay_stream();     // (the events are then on different streams)
     if (cur) {
         HIPCHECK(hipStreamWaitEvent(st, cur->w->tables_done, 0));
         cur->coarse_launched = true;
@@ -1692,9 +1622,8 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         // (the shortcut holds only if front_done(prev) was recorded BEFORE tables_done(cur), which the
         // three-call distance guarantees — but not a drain of two batches: there the coarse rest of
         // `prev` was enqueued in the same call as, and behind, the table build of `cur`)
-        const bool covered = merge && cur && prev->sf == cur->sf && prev->w->fd_seq < cur->w->td_seq;
-        if (!desc_s && !covered)
-            HIPCHECK(hipStreamWaitEvent(st, prev->w->front_done, 0));
+        const bool covered = cur && prev->sf == cur->sf && prev->w->fd_seq < cur->w->td_seq;
+        if (!covered) HIPCHECK(hipStreamWaitEvent(st, prev->w->front_done, 0));
         TRY(prev->pf.mark(st));
     }
     const bool fuse_prev = prev && prev->units;
@@ -1706,17 +1635,13 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
                               prev->w->mins.as<uint8_t>(), prev->p.cap_min, 1, ix->order, st);
     if (cur && !fuse_cur) launch_coarse_scan(ix, *cur->w, cur->nq, cur->p, st);
     // (plain first: the exact kernel then overwrites the head chunks of the lists in head mode)
-#ifdef TK_TIMING_EXPERIMENTS      // (wrong results on purpose: what does the batch cost without this kernel?)
-    static const int dbg_skip_scan = getenv("TINYKNN_DEBUG_SKIP") ? atoi(getenv("TINYKNN_DEBUG_SKIP")) : 0;
-#else
-    constexpr int dbg_skip_scan = 0;
-#endif
-    if (prev && prev->plain) TRY(prev->pf.mark_plain(0, st));
-    if (prev && prev->plain && !(dbg_skip_scan & 16) &&
-        tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order, plain_blocks(), st))
-        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
-    if (prev && prev->plain) TRY(prev->pf.mark_plain(1, st));
-    if (prev && prev->plain && prev->pf.evs && prev->pf.set >= 0) ix->ev_plain[(size_t)prev->pf.set] = 1;
+    if (prev && prev->plain) {
+        TRY(prev->pf.mark_plain(0, st));
+        if (tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order, plain_blocks(), st))
+            return fail(TK_ERR_HIP, "scan_plain_wave_kernel: LDS attribute / unsupported M");
+        TRY(prev->pf.mark_plain(1, st));
+        if (prev->pf.evs && prev->pf.set >= 0) ix->ev_plain[(size_t)prev->pf.set] = 1;
+    }
     if (fuse_prev || fuse_cur) {
         TkScanJob none;
         memset(&none, 0, sizeof none);
@@ -1726,7 +1651,7 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
                               fuse_cur ? coarse_job(ix, *cur->w, cur->p) : none, M, ix->order,
                               scan_blocks_pipelined(fuse_prev ? (double)prev->nq * prev->p.S / 4.0 *
                                                     ((double)ix->total_chunks / (double)ix->n_lists) : 0.0),
-                              st, &hj);
+                              st, &hj, ix->opt_scan_form);
     }
     TK_DBG_SYNC("step: scans");
     if (prev) {
@@ -1745,31 +1670,19 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         // rest of the coarse stage + scan descriptors of this batch on its stream (one event
         // behind the launch serves both consumers)
         Work &w = *cur->w;
-        if (merge && prev) {
+        if (prev) {
             HIPCHECK(hipStreamWaitEvent(cur->sf, prev->w->scanned, 0));
         } else {
             HIPCHECK(hipEventRecord(w.coarse_scanned, st));
             HIPCHECK(hipStreamWaitEvent(cur->sf, w.coarse_scanned, 0));
         }
-        if (desc_s) {
-            TRY(coarse_replay_probes(ix, w, cur->q_dev, cur->nq, cur->p, w.probes.as<int64_t>(), cur->sf, cur->pf));
-        } else {
-            TRY(stage_coarse_rest(ix, w, cur->q_dev, cur->nq, cur->p,
-                                  cur->units ? w.u_count.as<int>() : nullptr, nullptr, 0, cur->sf,
-                                  cur->pf, cur->plain));
-            if (cur->units) unit_pairs(ix, w, cur->nq, cur->p, cur->plain, cur->sf);
-            cur->desc_done = true;
-        }
+        TRY(stage_coarse_rest(ix, w, cur->q_dev, cur->nq, cur->p, cur->units ? w.u_count.as<int>() : nullptr,
+                              nullptr, 0, cur->sf, cur->pf, cur->plain));
+        if (cur->units) unit_pairs(ix, w, cur->nq, cur->p, cur->plain, cur->sf);
         HIPCHECK(hipEventRecord(w.front_done, cur->sf));
         w.fd_seq = ++ix->ev_seq;
         TK_DBG_SYNC("step: coarse rest");
     }
-    if (desc_s)     // the batch whose coarse stage ran one call ago: its descriptors, behind this call's launch
-        for (Pending *m : ix->pending)
-            if (m != prev && m != cur && m->coarse_launched && !m->desc_done) {
-                TRY(make_descriptors(ix, *m, st));
-                break;
-            }
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
@@ -1841,37 +1754,11 @@ static int pipe_begin(tk_index *ix, Pending &b, hipStream_t caller, hipStream_t 
     Work &w = *b.w;
     while ((int)ix->lat_streams.size() < ix->depth) {
         hipStream_t st;
-        // A/B: TINYKNN_REPLAY_CUS=n confines the replay + rescoring streams to the first n
-        // bits of the CU mask (so that the rest of the chip scans undisturbed)
-        static const int cus = getenv("TINYKNN_REPLAY_CUS") ? atoi(getenv("TINYKNN_REPLAY_CUS")) : 0;
-        if (cus > 0 && cus < 256) {
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < cus; i++) mask[i >> 5] |= 1u << (i & 31);
-            HIPCHECK(hipExtStreamCreateWithCUMask(&st, 8, mask));
-        } else {
-            HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        }
+        HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         ix->lat_streams.push_back(st);
     }
-    if (!ix->front_stream) {
-        // A/B: TINYKNN_FRONT_PRIO=1 creates the front stream at the highest queue priority (its
-        // small kernels — coarse replay, descriptors — sit on the cycle's critical loop and are
-        // placed late beside the persistent scan grids)
-        static const int fp = getenv("TINYKNN_FRONT_PRIO") ? atoi(getenv("TINYKNN_FRONT_PRIO")) : 0;
-        int lo = 0, hi = 0;
-        if (fp && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
-            HIPCHECK(hipStreamCreateWithPriority(&ix->front_stream, hipStreamNonBlocking, hi));
-        else
-            HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking));
-    }
+    if (!ix->front_stream) HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking));
     b.sf = ix->front_stream;
-    // A/B: two front streams, batches alternate (a batch's tables and the rest of its coarse stage
-    // stay on ONE stream; the events the scan launch merges belong to calls c-1 and c-3: same parity)
-    if (front_streams() == 2) {
-        if (!ix->front_stream2)
-            HIPCHECK(hipStreamCreateWithFlags(&ix->front_stream2, hipStreamNonBlocking));
-        if (ix->calls & 1) b.sf = ix->front_stream2;
-    }
     b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
     ix->calls++;
     hipEvent_t *evs[] = {&w.tables_done, &w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
@@ -1881,23 +1768,10 @@ static int pipe_begin(tk_index *ix, Pending &b, hipStream_t caller, hipStream_t 
     // the table build of this call goes to the front stream now (after the caller's work
     // so far — its inputs — and once the workspace is free); its coarse scan rides in the
     // NEXT call's launch, its list scan in the launch three calls later
-    // A/B (TINYKNN_TABLES_STREAM=1): the table build on the batch's REPLAY stream instead.
-    // The front stream carries, per batch, the tables of call c and the coarse replay /
-    // rescoring / descriptors of call c-1 — within a tenth of the scan launch it must keep
-    // ahead of; the replay streams are a third busy, and a table build has a whole call's
-    // time before its coarse scan is launched.
     hipStream_t stt = b.sf;
-    if (tables_stream_mode() == 1) stt = b.sl;
-    else if (tables_stream_mode() == 2) stt = ix->lat_streams[ix->calls % (uint64_t)ix->depth];   // (calls is already c + 1)
-    else if (tables_stream_mode() == 3) stt = caller;      // the scan chain itself (it has the slack since the LDS-operand plain kernel)
     if (stt != caller) {
         HIPCHECK(hipEventRecord(ix->ev_in, caller));
         HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
-    }
-    if (stt != b.sf && ix->input_on_front) {      // input copies arrive on the front stream (tk_index_input_stream)
-        if (!ix->ev_front_in) HIPCHECK(hipEventCreateWithFlags(&ix->ev_front_in, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(ix->ev_front_in, b.sf));
-        HIPCHECK(hipStreamWaitEvent(stt, ix->ev_front_in, 0));
     }
     if (w.busy) HIPCHECK(hipStreamWaitEvent(stt, w.done, 0));
     stt_out = stt;
@@ -2129,13 +2003,6 @@ extern "C" void *tk_index_input_stream(tk_index *ix)
     if (!ix->front_stream &&
         hipStreamCreateWithFlags(&ix->front_stream, hipStreamNonBlocking) != hipSuccess)
         return nullptr;
-    ix->input_on_front = true;
-    if (front_streams() == 2 && (ix->calls & 1)) {      // (the stream the NEXT call's tables go to)
-        if (!ix->front_stream2 &&
-            hipStreamCreateWithFlags(&ix->front_stream2, hipStreamNonBlocking) != hipSuccess)
-            return nullptr;
-        return ix->front_stream2;
-    }
     return ix->front_stream;
 }
 
@@ -2405,7 +2272,7 @@ extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float
         probes = w.probes.as<int64_t>();
     }
     // the limits C of all nq tables (built by _shard_coarse_dev or just above)
-    tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st);
+    tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st, ix->opt_plain_limit);
     {
         const int64_t n1 = nq * p.S + (int64_t)ix->world * qh * p.S + 1;
         ARGCHECK(n1 < (1ll << 31), "too many (query, list) entries for one sharded batch");
@@ -3429,25 +3296,26 @@ extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
     return TK_OK;
 }
 
-extern "C" int tk_set_plain_form(int form)
+extern "C" int tk_index_set_option(tk_index *ix, int option, int value)
 {
-    ARGCHECK(form >= 0 && form <= 2, "form must be 0, 1 or 2");
-    tk_plain_set_form(form);
-    return TK_OK;
-}
-
-extern "C" int tk_set_rescore_form(int form)
-{
-    ARGCHECK(form >= 0 && form <= 2, "form must be 0, 1 or 2");
-    tk_set_rescore_staged(form);
-    return TK_OK;
-}
-
-extern "C" int tk_set_scan_form(int form)
-{
-    ARGCHECK(form >= 0 && form <= 2, "form must be 0, 1 or 2");
-    tk_set_scan_tables(form);
-    return TK_OK;
+    IXLOCK(ix);
+    ARGCHECK(ix, "null index");
+    TRY(flush_pending(ix));
+    switch (option) {
+    case TK_OPT_SCAN_FORM:
+        ARGCHECK(value >= 0 && value <= 2, "TK_OPT_SCAN_FORM: 0, 1 or 2");
+        ix->opt_scan_form = value;
+        return TK_OK;
+    case TK_OPT_RESCORE_FORM:
+        ARGCHECK(value >= 0 && value <= 2, "TK_OPT_RESCORE_FORM: 0, 1 or 2");
+        ix->opt_rescore_form = value;
+        return TK_OK;
+    case TK_OPT_PLAIN_LIMIT:
+        ix->opt_plain_limit = value;
+        return TK_OK;
+    default:
+        return fail(TK_ERR_ARG, "bad argument: unknown option");
+    }
 }
 
 extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
@@ -3469,7 +3337,7 @@ extern "C" int tk_index_set_plain_scan(tk_index *ix, int mode)
     ix->plain_mode = mode;
     ix->plain_state = PLAIN_PROBE;
     ix->plain_skip = 0;
-    ix->plain_backoff = 128;
+    ix->plain_backoff = 256;
     return TK_OK;
 }
 
@@ -3512,12 +3380,6 @@ extern "C" int tk_index_plain_stats(tk_index *ix, int64_t *out8)
         out8[0] = tiles;
         out8[5] = cps;
     }
-    return TK_OK;
-}
-
-extern "C" int tk_debug_plain_limit(int limit)
-{
-    tk_plain_force_limit(limit);
     return TK_OK;
 }
 

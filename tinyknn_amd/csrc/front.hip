@@ -282,16 +282,8 @@ extern "C" int tk_prepare_queries_host(const float *q_raw, int64_t nq, int d, in
 //   1  (default) kernels that read / write the page-locked buffers directly over PCIe: one
 //      ingest launch (copy + pad1 in one pass) and one egress launch, so that a stream never
 //      alternates between copy-engine commands and kernel dispatches
-// env TINYKNN_STREAM_COPY; A/B in profiles/r02_raw_stream_ab.md
-static int stream_copy_mode()
-{
-    static int mode = -1;
-    if (mode < 0) {
-        const char *e = getenv("TINYKNN_STREAM_COPY");
-        mode = (e && e[0] == '0') ? 0 : 1;
-    }
-    return mode;
-}
+// A/B in profiles/r02_raw_stream_ab.md
+static int stream_copy_mode() { return 1; }     // (0, the copy-engine form, was measured slower: profiles/r02_raw_stream_ab.md)
 
 // rows of page-locked host memory -> q (nq, d) and, when dq > d, the zero-padded table-build
 // rows (nq, dq) (fast_pq.py:202 pad1), 16 bytes per lane and load where the row length allows
@@ -430,11 +422,7 @@ extern "C" tk_stream *tk_stream_create(tk_index *ix, int64_t max_nq, int k, int 
     // a stream of our own would be a fifth whenever anything in the process has touched the
     // NULL stream (torch does), and was seen to land on the queue of a replay stream, which
     // serialised the two replays: 1.03 ms per batch instead of 0.7 (profiles/r02_raw_stream_ab.md).
-    // TINYKNN_STREAM_OWN_STREAM=1 creates one anyway (a caller that keeps the NULL stream busy).
     bool ok = true;
-    const char *own = getenv("TINYKNN_STREAM_OWN_STREAM");
-    if (own && own[0] == '1')
-        ok = hipStreamCreateWithFlags(&s->comp_st, hipStreamNonBlocking) == hipSuccess;
     for (StreamSlot &x : s->slots) {
         if (!ok) break;
         ok = hipHostMalloc((void **)&x.h_q, (size_t)max_nq * d * 4, hipHostMallocDefault) == hipSuccess &&

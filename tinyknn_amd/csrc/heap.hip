@@ -409,7 +409,7 @@ __global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq
 // a SLOT, LAB[slot][lane] holds the slot's 32-bit label, `insert` first scans LAB for
 // the candidate's label (the reference's duplicate test, _fast_pq.pyx:284-287) and a
 // new entry inherits the slot of the root it evicts.  labels32 = the ids as int32.
-template <bool SIGNED, bool DEDUPE, bool PRED, int LW>
+template <bool SIGNED, bool DEDUPE, int LW>
 __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
@@ -419,18 +419,6 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     int64_t cap_min, const int32_t *__restrict__ labels32, unsigned long long *__restrict__ dbg,
     int prio, int wave_lds, const int *__restrict__ plain0_arr, const int *__restrict__ qlim)
 {
-    // dbg != NULL (tk_debug_replay_timers): cycle counters of the wave's phases, 8 per workgroup:
-    // total, block search, insert (all of it), LDS sift levels, rounds, LDS iterations, search
-    // iterations, segments
-#ifdef TK_REPLAY_TIMERS
-#define TK_TICK() (dbg ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
-#define TK_DBG(x) x
-#else        // the production build carries no timer code (it cost 10 % even when disarmed)
-#define TK_TICK() 0ull
-#define TK_DBG(x)
-#endif
-    unsigned long long d_search = 0, d_ins = 0, d_lds = 0, d_rounds = 0, d_ldsit = 0, d_sit = 0;
-    const unsigned long long d_t0 = TK_TICK();
     // the replay is a chain of dependent LDS round trips on 157 waves; when it shares SIMDs
     // with other batches' VALU-bound scan waves, let the arbiter issue its instructions first
     if ((prio & 0xff) >= 3) __builtin_amdgcn_s_setprio(3);
@@ -530,49 +518,29 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const int last_blk = (int)(cap > 0 ? cap - 1 : 0);
     const int last_m = (int)(cap_min / 16) - 1;
     uint4 nx[16];
-    uint4 mins_nx = make_uint4(0, 0, 0, 0), mins_n2 = make_uint4(0, 0, 0, 0);
-    uint32_t pf = 0xffffu;          // PRED: blocks of the pending segment that were fetched
+    uint4 mins_nx = make_uint4(0, 0, 0, 0);
 #define TK_MINS_ROW(g_) mrow[(g_) < last_m ? (g_) : (last_m > 0 ? last_m : 0)]
-#define TK_FETCH_BLOCKS(g_, mask_)                                                \
+#define TK_FETCH_BLOCKS(g_)                                                       \
     {                                                                             \
-        _Pragma("unroll") for (int k = 0; k < 16; k++)                            \
-            if (!PRED || ((mask_) & (1u << k))) {                                 \
-                int blk_ = 16 * (g_) + k;                                         \
-                blk_ = blk_ < last_blk ? blk_ : last_blk;                         \
-                nx[k] = drow[blk_];                                               \
-            }                                                                     \
+        _Pragma("unroll") for (int k = 0; k < 16; k++) {                          \
+            int blk_ = 16 * (g_) + k;                                             \
+            blk_ = blk_ < last_blk ? blk_ : last_blk;                             \
+            nx[k] = drow[blk_];                                                   \
+        }                                                                         \
     }
-    auto seg_mask = [&](int g_) {         // blocks of segment g_ that exist in this lane's row
-        int km = total - 16 * g_;
-        km = km < 0 ? 0 : (km > 16 ? 16 : km);
-        return km >= 16 ? 0xffffu : ((1u << km) - 1u);
-    };
 #pragma unroll
     for (int k = 0; k < 16; k++) nx[k] = make_uint4(0, 0, 0, 0);
     if (max_nseg > 0) {
         mins_nx = TK_MINS_ROW(0);
-        if (PRED && max_nseg > 1) mins_n2 = TK_MINS_ROW(1);
-        if (PRED) pf = mask_lt16_swar<SIGNED>(mins_nx, bb) & seg_mask(0);
-        TK_FETCH_BLOCKS(0, pf)
+        TK_FETCH_BLOCKS(0)
     }
     for (int g = 0; g < max_nseg; g++) {
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (!PRED || (pf & (1u << k))) ST[k * LW + lane] = nx[k];
+        for (int k = 0; k < 16; k++) ST[k * LW + lane] = nx[k];
         const uint4 mins_cur = mins_nx;
-        // PRED: only the blocks of the next segment whose minimum is below the bound known NOW
-        // are fetched (the bound only decreases: a superset of the blocks that will be entered);
-        // that needs the minima one segment earlier than the blocks
-        if (PRED) {
-            mins_nx = mins_n2;
-            if (g + 2 < max_nseg) mins_n2 = TK_MINS_ROW(g + 2);
-            if (g + 1 < max_nseg) {
-                pf = mask_lt16_swar<SIGNED>(mins_nx, bb) & seg_mask(g + 1);
-                TK_FETCH_BLOCKS(g + 1, pf)
-            }
-        } else if (g + 1 < max_nseg) {
+        if (g + 1 < max_nseg) {
             mins_nx = TK_MINS_ROW(g + 1);
-            TK_FETCH_BLOCKS(g + 1, 0xffffu)
+            TK_FETCH_BLOCKS(g + 1)
         }
         const int buf = 0;
         int kmax = total - 16 * g;
@@ -588,9 +556,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
         int lab_base = 0;             //         labels32 index of row 0 of the current block
         for (;;) {
             // next block of this segment with a byte below the live bound
-            const unsigned long long d_ts = TK_TICK();
             while (bits == 0 && hit) {
-                TK_DBG(if (dbg) d_sit++;)
                 const int k = __builtin_ctz(hit);
                 hit &= hit - 1;
                 dd = ST[(buf * 16 + k) * LW + lane];
@@ -605,10 +571,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                     lab_next = (uint32_t)labels32[(int64_t)lab_base + __builtin_ctz(bits)];
                 }
             }
-            const unsigned long long d_ti = TK_TICK();
-            d_search += d_ti - d_ts;
             if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
-            TK_DBG(if (dbg) d_rounds++;)
             if (bits) {   // one insert per lane with a pending candidate
                 const int r = __builtin_ctz(bits);
                 bits &= bits - 1;
@@ -635,7 +598,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                     dup = (x1.x == label) | (x1.y == label) | (x1.z == label) | (x1.w == label) |
                           (x2.x == label) | (x2.y == label) | (x2.z == label) | (x2.w == label) |
                           (sh0 == label) | (sh1 == label) | (sh2 == label) | (sh3 == label);
-                    if (tb_ovf && !(prio & 0x100)) {
+                    if (tb_ovf) {
 #pragma unroll 4
                         for (int g = 0; g < R4; g++) {
                             const uint4 lv = ((const uint4 *)LAB)[g * LW + lane];
@@ -699,9 +662,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                         if (ca | cb) {   // node 3..6, children in LDS
                             int j = (c2 ? 5 : 3) + (cb ? 1 : 0);
                             bool first = true, go = true;
-                            const unsigned long long d_tl = TK_TICK();
                             do {
-                                TK_DBG(if (dbg) d_ldsit++;)
                                 const int l = 2 * j + 1;
                                 const int lc = l < R ? l : R;
                                 const uint32_t el = H[lc * LW + lane];
@@ -724,7 +685,6 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                                 go = nxt != j;
                                 j = nxt;
                             } while (go);
-                            d_lds += TK_TICK() - d_tl;
                         }
                     }
                 }
@@ -734,19 +694,10 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                     b_plain = cur < plain0 ? bound : b_plain;
                 }
             }
-            d_ins += TK_TICK() - d_ti;
         }
     }
 #undef TK_FETCH_BLOCKS
 #undef TK_MINS_ROW
-    TK_DBG(if (dbg && lane == 0) {
-        unsigned long long *o = dbg + (size_t)blockIdx.x * 8;
-        o[0] = TK_TICK() - d_t0; o[1] = d_search; o[2] = d_ins; o[3] = d_lds;
-        o[4] = d_rounds; o[5] = d_ldsit; o[6] = d_sit; o[7] = (unsigned long long)max_nseg;
-    })
-    (void)d_search; (void)d_ins; (void)d_lds; (void)d_rounds; (void)d_ldsit; (void)d_sit; (void)d_t0;
-#undef TK_TICK
-#undef TK_DBG
     // registers back to their heap rows
     if (R > 0) H[0 * LW + lane] = h0;
     if (R > 1) H[1 * LW + lane] = h1;
@@ -976,39 +927,6 @@ int tk_lanes_dedupe_fits(int R, int S)
     return R <= TK_LANES_MAX_R_DEDUPE && tk_lanes_fixed_lds(R, S, 1) + 16384 <= 160 * 1024;
 }
 
-// phase timers of the lane kernel (debug tooling, scripts/replay_timers.py; the kernel carries
-// the timer code only when the library is built with -DTK_REPLAY_TIMERS): while armed, every
-// launch with at least `min_nq` queries writes 8 counters per workgroup
-#define TK_REPLAY_DBG_WG 4096
-static unsigned long long *g_replay_dbg = nullptr;
-static int64_t g_replay_dbg_min_nq = 0;
-static int g_replay_dbg_wgs = 0;
-
-extern "C" int tk_debug_replay_timers(int arm, int64_t min_nq, unsigned long long *sums8, int *workgroups)
-{
-    if (arm) {
-        if (!g_replay_dbg &&
-            hipMalloc((void **)&g_replay_dbg, (size_t)TK_REPLAY_DBG_WG * 8 * 8) != hipSuccess)
-            return -2;
-        (void)hipMemset(g_replay_dbg, 0, (size_t)TK_REPLAY_DBG_WG * 8 * 8);
-        g_replay_dbg_min_nq = min_nq;
-        g_replay_dbg_wgs = 0;
-        return 0;
-    }
-    if (!g_replay_dbg) return -1;
-    (void)hipDeviceSynchronize();
-    unsigned long long *h = (unsigned long long *)malloc((size_t)TK_REPLAY_DBG_WG * 8 * 8);
-    (void)hipMemcpy(h, g_replay_dbg, (size_t)TK_REPLAY_DBG_WG * 8 * 8, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 8; i++) sums8[i] = 0;
-    for (int w = 0; w < g_replay_dbg_wgs; w++)
-        for (int i = 0; i < 8; i++) sums8[i] += h[(size_t)w * 8 + i];
-    free(h);
-    *workgroups = g_replay_dbg_wgs;
-    (void)hipFree(g_replay_dbg);
-    g_replay_dbg = nullptr;
-    return 0;
-}
-
 int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                 const int *slot_n, const int64_t *slot_label_off, int S,
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
@@ -1019,50 +937,23 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     if (nq == 0 || R == 0) return 0;
     if (!plain0 || !qlim || !skip || !signd) plain0 = qlim = nullptr;
     const int dedupe = labels32 != nullptr;
-    // Queries per wave.  With the duplicate test a 64-query wave needs 140+ KB of LDS at
-    // R = 111: one workgroup per CU, and the two replay kernels of the pipelined mode (2 x 157
-    // workgroups on 256 CUs) then wait for each other's CUs — 1.6 ms alone became 2.9 ms in the
-    // pipeline.  Half-filled waves (32 queries, lanes 32..63 exit at once) halve every per-lane
-    // column: two workgroups per CU.  A/B: TINYKNN_REPLAY_LANES=64.
-    static int lanes_dedupe = -1;
-    if (lanes_dedupe < 0) {
-        const char *e = getenv("TINYKNN_REPLAY_LANES");
-        lanes_dedupe = (e && atoi(e) == 64) ? 64 : (e && atoi(e) == 16) ? 16 : 32;
-    }
-    static int lanes_plain = -1;      // distinct labels: 64 (A/B: TINYKNN_REPLAY_LANES_PLAIN=32)
-    if (lanes_plain < 0) {
-        const char *e = getenv("TINYKNN_REPLAY_LANES_PLAIN");
-        lanes_plain = (e && atoi(e) == 32) ? 32 : (e && atoi(e) == 16) ? 16 : 64;
-    }
-    static int lanes_coarse = -1;     // the coarse replay (one list, small heap) alone (A/B: TINYKNN_REPLAY_LANES_COARSE=32 / 16)
-    if (lanes_coarse < 0) {
-        const char *e = getenv("TINYKNN_REPLAY_LANES_COARSE");
-        lanes_coarse = (e && (atoi(e) == 32 || atoi(e) == 16)) ? atoi(e) : 0;
-    }
-    const int LWr = dedupe ? lanes_dedupe : (slots_uniform && lanes_coarse) ? lanes_coarse : lanes_plain;
-    // heap columns (+ label slots) + 16 staged blocks per lane, scaled to the columns in use
-    const size_t fixed = tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64;
-    // one staged segment (16 blocks x LW lanes x 16 B); the next one waits in registers
-    const int nbuf = 1;
-    size_t lds = fixed + (size_t)16384 * LWr / 64;
+    // Queries per wave: 64, or 32 with the duplicate test — a 64-query wave then needs 140+ KB of
+    // LDS at R = 111: one workgroup per CU, and the two replay kernels of the pipelined mode (2 x 157
+    // workgroups on 256 CUs) waited for each other's CUs (1.6 ms alone became 2.9 ms in the
+    // pipeline); half-filled waves (lanes 32..63 exit at once) halve every per-lane column: two
+    // workgroups per CU.  (Measured and dropped, profiles/HISTORY.md: 32- and 16-query waves for
+    // distinct labels and for the coarse replay, 2-4 query-waves per workgroup, blocks fetched only
+    // where their minimum passes, s_setprio below 3.)
+    const int LWr = dedupe ? 32 : 64;
+    // heap columns (+ label slots) + one staged segment (16 blocks x LW lanes x 16 B; the next one
+    // waits in registers), scaled to the columns in use
+    const size_t lds = tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64 + (size_t)16384 * LWr / 64;
     static bool attr_set = false;
     if (!attr_set) {
-        const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false, false, 64>,
-                             (const void *)heap_replay_lanes_kernel<false, false, false, 64>,
-                             (const void *)heap_replay_lanes_kernel<true, true, false, 64>,
-                             (const void *)heap_replay_lanes_kernel<false, true, false, 64>,
-                             (const void *)heap_replay_lanes_kernel<true, false, true, 64>,
-                             (const void *)heap_replay_lanes_kernel<false, false, true, 64>,
-                             (const void *)heap_replay_lanes_kernel<true, true, true, 64>,
-                             (const void *)heap_replay_lanes_kernel<false, true, true, 64>,
-                             (const void *)heap_replay_lanes_kernel<true, true, false, 32>,
-                             (const void *)heap_replay_lanes_kernel<false, true, false, 32>,
-                             (const void *)heap_replay_lanes_kernel<true, false, false, 32>,
-                             (const void *)heap_replay_lanes_kernel<false, false, false, 32>,
-                             (const void *)heap_replay_lanes_kernel<true, true, false, 16>,
-                             (const void *)heap_replay_lanes_kernel<false, true, false, 16>,
-                             (const void *)heap_replay_lanes_kernel<true, false, false, 16>,
-                             (const void *)heap_replay_lanes_kernel<false, false, false, 16>};
+        const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false, 64>,
+                             (const void *)heap_replay_lanes_kernel<false, false, 64>,
+                             (const void *)heap_replay_lanes_kernel<true, true, 32>,
+                             (const void *)heap_replay_lanes_kernel<false, true, 32>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
@@ -1079,64 +970,20 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
             hipLaunchKernelGGL(pad_fix_kernel<false>, dim3(pg), dim3(256), 0, s, (uint4 *)dist, cap, nq,
                                slot_prefix, slot_n, S, slots_uniform, (uint8_t *)mins, cap_min);
     }
-    // query-waves per workgroup: a replay wave needs 130+ VGPRs, so a CU that hosts one cannot
-    // hold the third workgroup of the persistent scan kernel beside it; packing the replay's
-    // 157 waves into workgroups keeps them on fewer CUs (A/B: TINYKNN_REPLAY_WAVES)
-    static int wpw = -1;
-    if (wpw < 0) {
-        const char *e = getenv("TINYKNN_REPLAY_WAVES");
-        wpw = e ? atoi(e) : 1;
-        wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);
-    }
-    // (the short coarse replay, one list against a small heap, stays one wave per workgroup:
-    // multi-wave workgroups are placed only when a whole CU has room, which next to the
-    // persistent scan kernel means at its launch boundaries)
-    int waves = slots_uniform ? 1 : wpw;
-    while (waves > 1 && lds * waves > 160 * 1024) waves--;
+    // one query-wave per workgroup (multi-wave workgroups are placed only when a whole CU has room,
+    // which next to the persistent scan kernels means at their launch boundaries)
     const int wave_lds = (int)lds;
     const int64_t n_waves = (nq + LWr - 1) / LWr;
-    dim3 grid((unsigned)((n_waves + waves - 1) / waves));
-    const size_t lds_wg = lds * waves;
-    static int prio = -1;       // s_setprio of the replay waves (A/B: TINYKNN_REPLAY_PRIO)
-    if (prio < 0) {
-        const char *e = getenv("TINYKNN_REPLAY_PRIO");
-        prio = e ? atoi(e) : 3;
-#ifdef TK_TIMING_EXPERIMENTS
-        if (getenv("TINYKNN_DEBUG_NOSCAN")) prio |= 0x100;      // wrong results: timing only
-#endif
-    }
-    unsigned long long *dbg = nullptr;
-    if (g_replay_dbg && nq >= g_replay_dbg_min_nq && grid.x <= TK_REPLAY_DBG_WG) {
-        dbg = g_replay_dbg;
-        g_replay_dbg_wgs = (int)grid.x;
-    }
-    static int pred = -1;       // fetch only blocks whose minimum passes (A/B: TINYKNN_REPLAY_PRED)
-    if (pred < 0) {
-        const char *e = getenv("TINYKNN_REPLAY_PRED");
-        pred = e ? atoi(e) : 0;
-    }
-#define TK_LAUNCH3(S_, D_, P_, L_)                                                              \
-    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, P_, L_>), grid, dim3(64 * waves), lds_wg, s, dist, cap, nq, \
+    dim3 grid((unsigned)n_waves);
+    const int prio = 3;         // s_setprio of the replay waves: they share SIMDs with issue-bound scan waves
+#define TK_LAUNCH3(S_, D_, L_)                                                                    \
+    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, L_>), grid, dim3(64), lds, s, dist, cap, nq,  \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
-                       slots_uniform, skip, nbuf, mins, cap_min, labels32, dbg, prio, wave_lds,   \
+                       slots_uniform, skip, 1, mins, cap_min, labels32, nullptr, prio, wave_lds,  \
                        plain0, qlim)
-    if (LWr == 32) {
-        if (dedupe) { if (signd) TK_LAUNCH3(true, true, false, 32); else TK_LAUNCH3(false, true, false, 32); }
-        else { if (signd) TK_LAUNCH3(true, false, false, 32); else TK_LAUNCH3(false, false, false, 32); }
-        return 0;
-    }
-    if (LWr == 16) {     // (A/B: a quarter-filled wave per 16 queries — four times the waves, a quarter of the LDS each)
-        if (dedupe) { if (signd) TK_LAUNCH3(true, true, false, 16); else TK_LAUNCH3(false, true, false, 16); }
-        else { if (signd) TK_LAUNCH3(true, false, false, 16); else TK_LAUNCH3(false, false, false, 16); }
-        return 0;
-    }
-#define TK_LAUNCH2(S_, D_, P_) TK_LAUNCH3(S_, D_, P_, 64)
-#define TK_LAUNCH(S_, D_) { if (pred) TK_LAUNCH2(S_, D_, true); else TK_LAUNCH2(S_, D_, false); }
-    if (signd) { if (dedupe) TK_LAUNCH(true, true) else TK_LAUNCH(true, false) }
-    else { if (dedupe) TK_LAUNCH(false, true) else TK_LAUNCH(false, false) }
-#undef TK_LAUNCH
+    if (dedupe) { if (signd) TK_LAUNCH3(true, true, 32); else TK_LAUNCH3(false, true, 32); }
+    else { if (signd) TK_LAUNCH3(true, false, 64); else TK_LAUNCH3(false, false, 64); }
 #undef TK_LAUNCH3
-#undef TK_LAUNCH2
     return 0;
 }
 

@@ -80,25 +80,14 @@ struct TkScanJob {
     int max_chunks = 0;               // list-major kernel: only the first max_chunks chunks of a list (0: all)
     const int *unit_desc4 = nullptr;  // plain kernel: int4 (list, tile, first chunk pair, end chunk pair) of every unit
 };
-// table rows of the list-major kernel: 1 = staged per block in LDS (default), 0 = per-lane
-// global loads (the round-1 form; A/B switch)
-void tk_set_scan_tables(int lds);
-// rescoring: 0 = a lane walks its own row, 1 / 2 = rows staged through LDS in tiles of 64 / 32 (default 2)
-void tk_set_rescore_staged(int mode);
-int tk_get_rescore_staged(void);
-int tk_get_scan_tables(void);
 // ---- plain-sum scan on the int8 matrix cores (plain_scan.hip) ----
 // qlim[q]: the bound below which clamp(plain sum) IS the reference's saturated value for query q
 // (C of the lemma in plain_scan.hip), or TK_PLAIN_NEVER when the query's table rules it out
 #define TK_PLAIN_NEVER (-(1 << 30))
 #define TK_PLAIN_COUNTER_OFF(n_lists) ((((n_lists) + 1 + 31) / 32 + 1) * 32)
-void tk_launch_table_limits(const uint4 *tables, int M, int order, int64_t nq, int *qlim, hipStream_t s);
-void tk_plain_force_limit(int v);      // debug: cap every query's limit (INT_MAX = off)
-int tk_plain_forced(void);             // ... is such a cap set?
-void tk_plain_set_flush(int on);      // wave form: outputs through an LDS tile, a whole line per query (default on)
-void tk_plain_set_form(int form);
-int tk_plain_wave_form(void);          // the default form (one wave per unit) is selected
-#define TK_PLAIN_K_WHOLE (1 << 20)     // plain_k of the workgroup-per-tile forms: one unit per tile      // 0 = table operand in registers (default), 1 / 2 = read from LDS per MFMA (A/B)
+// force: a cap on every query's limit (the tests' way to provoke the re-scan path); INT_MAX = none
+void tk_launch_table_limits(const uint4 *tables, int M, int order, int64_t nq, int *qlim, hipStream_t s,
+                            int force = 0x7fffffff);
 int tk_plain_fits(int M);
 // TkScanJob with unit_prefix = tiles of 32 pairs before each list (+ the work counter at
 // TK_PLAIN_COUNTER_OFF); pair records are not padded.  Returns -1 for unsupported M.
@@ -130,12 +119,12 @@ void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_l
 // two jobs in ONE launch sharing one pool of 64-unit blocks (pipelined mode: the list scan
 // of one batch and the coarse scan of the next); signed tables
 void tk_launch_scan_units2(const TkScanJob &a, const TkScanJob &b, int M, int order, int n_blocks,
-                           hipStream_t s, const TkScanJob *c = nullptr);
+                           hipStream_t s, const TkScanJob *c = nullptr, int form = 0);
 void tk_launch_scan_units(const uint4 *codes, int M, const uint4 *tables, int64_t nq, int S,
                           int64_t n_lists, const int64_t *list_chunk_off, const int *pair_off,
                           const int *unit_prefix, const int *pair_q, const int *pair_f0,
                           uint4 *dist, int64_t cap, uint8_t *mins, int64_t min_stride, int signd,
-                          int order, int n_blocks, hipStream_t s);
+                          int order, int n_blocks, hipStream_t s, int form = 0);
 
 // Exact replay of the reference's sequential heap over precomputed distances.
 // One wave per query.  slot_n: true rows per slot; slot_label_off: offset into
@@ -203,7 +192,7 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
 // q / rows: float32 or float64 (flags); float64 arithmetic if either is float64.
 void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
                        int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
-                       int64_t *out, int *out_count, hipStream_t s);
+                       int64_t *out, int *out_count, hipStream_t s, int form = 2);
 
 // probes (nq, kc) list ids -> per-slot scan descriptors; pair_count (n_lists, zeroed, or
 // NULL) receives the number of (query, slot) pairs per list — with `owner` (n_lists ranks,

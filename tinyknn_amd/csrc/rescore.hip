@@ -244,13 +244,9 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
     if (tid == 0 && out_count) out_count[qi] = k;
 }
 
-static int g_rescore_staged = -1;      // -1: not read yet (environment, default 2)
-void tk_set_rescore_staged(int mode) { g_rescore_staged = mode; }
-int tk_get_rescore_staged(void) { return g_rescore_staged; }
-
 void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
                        int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
-                       int64_t *out, int *out_count, hipStream_t s)
+                       int64_t *out, int *out_count, hipStream_t s, int form)
 {
     if (nq == 0 || k == 0) return;
     const bool dbl = q_is_f64 || rows_is_f64;   // numpy promotes `Y - x` to float64
@@ -258,23 +254,18 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
     // one wave is enough for the coarse stage's 2 * n_probes + 10 candidates: the second wave of
     // a 128-thread workgroup only waited at the barriers and took a wave slot beside the scan
     dim3 grid((unsigned)nq), block(R <= 64 ? 64 : 128);
-    // Rows staged through LDS in tiles of 32 (mode 2, DEFAULT) / 64 (mode 1) rows, or every lane
-    // walking its own row (mode 0); tk_set_rescore_staged / TINYKNN_RESCORE_STAGED.  Round 2
+    // Rows staged through LDS in tiles of 32 (form 2, DEFAULT) / 64 (form 1) rows, or every lane
+    // walking its own row (form 0); tk_index_set_option(TK_OPT_RESCORE_FORM).  Round 2
     // (profiles/r02_scan_grid.md): the 32-row form was the fastest alone (0.118 ms per 10 000
     // queries against 0.135) but lost in the pipeline — its workgroups (15-29 KB of LDS) were
     // placed late next to the exact scan's persistent grid: 0.68-0.70 ms per batch against 0.656.
     // Round 3, next to the plain kernel (two 58 KB workgroups per CU leave 44 KB): 0.495 ms per
     // batch against 0.543 (profiles/r03/ab_pipeline_knobs.txt) — the 64 lines a wave touches per
     // load in mode 0 were costing the scans beside it more than its own time.
-    if (g_rescore_staged < 0) {
-        const char *e = getenv("TINYKNN_RESCORE_STAGED");
-        g_rescore_staged = e ? atoi(e) : 2;
-        if (g_rescore_staged < 0 || g_rescore_staged > 2) g_rescore_staged = 2;
-    }
-    const int staged = g_rescore_staged;
+    const int staged = form < 0 || form > 2 ? 2 : form;
     // (heaps beyond 256 entries: a 64-lane workgroup walks 16+ tiles one after the other — n_probes 50,
     //  R = 511: 3.18 M queries/s staged against 3.85 M with the 128-lane lane-per-row kernel)
-    if (!dbl && staged && d % 4 == 0 && d <= 256 && R <= 256 && !(strip & 0x300)) {
+    if (!dbl && staged && d % 4 == 0 && d <= 256 && R <= 256 ) {
         const int stride4 = (d / 4) | 1;                      // odd number of 16-byte pieces
         const int tile_rows = staged == 2 ? 32 : 64;
         const size_t slds = (((size_t)R * 8 + 15) & ~(size_t)15) +

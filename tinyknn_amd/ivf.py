@@ -513,6 +513,11 @@ class DeviceIndex:
         """Number of batches in flight for query_batch_dev (see tinyknn_hip.h)."""
         _lib.check(_lib.lib().tk_index_set_pipeline(self._h, int(depth)))
 
+    def set_option(self, option, value):
+        """Per-index A/B and test options (tk_index_set_option): _lib.OPT_SCAN_FORM,
+        _lib.OPT_RESCORE_FORM, _lib.OPT_PLAIN_LIMIT."""
+        _lib.check(_lib.lib().tk_index_set_option(self._h, int(option), int(value)))
+
     def set_coalesce(self, n):
         """2: pairs of consecutive query_batch_dev calls run as one batch (tk_index_set_coalesce)."""
         _lib.check(_lib.lib().tk_index_set_coalesce(self._h, int(n)))
@@ -668,7 +673,31 @@ class IVF:
             _lib.ptr(out, _lib._i64p)))
         if full < n:
             out[full:] = knn_brute(data[full:], self.all_centers, k=n_probes, metric=self.metric)
+        if n_probes > 2 and full > 0 and not self._assign_order_holds(data, out, n_probes, full):
+            # numpy's argpartition leaves the ORDER of the first k unspecified; the device writes them
+            # ascending by (value, index), which is what this host's numpy was seen to return — but that
+            # is an implementation detail of its argselect (x86-simd-sort on AVX-512; other on AVX2, ARM,
+            # older numpy).  Column order decides list order (group_data_by_indices appends column by
+            # column): where this host's numpy orders differently, numpy's answer is the reference's.
+            import warnings
+            warnings.warn("tinyknn_amd: numpy.argpartition on this host does not return the first k ascending "
+                          "(k = %d); list assignment falls back to numpy's knn_brute" % n_probes)
+            return knn_brute(data, self.all_centers, k=n_probes, metric=self.metric)
         return out
+
+    def _assign_order_holds(self, data, nearest, n_probes, full, chunks=24):
+        """Self-check of the k > 2 device assignment against THIS host's numpy: whole 100-row chunks of
+        knn_brute (utils.py:81-85 works in chunks of 100), spread over the data."""
+        n_chunks = full // 100
+        if n_chunks == 0:
+            return True
+        pick = np.unique(np.linspace(0, n_chunks - 1, min(chunks, n_chunks)).astype(np.int64))
+        for c in pick:
+            rows = slice(100 * int(c), 100 * int(c) + 100)
+            want = knn_brute(data[rows], self.all_centers, k=n_probes, metric=self.metric)
+            if not np.array_equal(want, nearest[rows]):
+                return False
+        return True
 
     def _encode_lists_on_device(self, data, nearest, n_active):
         """ivf.py:98-102 with ONE pass over the points: a row's code does not depend on the
@@ -799,6 +828,19 @@ class IVF:
         with timer(verbose, "Generating vectors in HBM..."):
             dev = DeviceIndex.resident(self, N, d)
             dev.synth_data(seed, centres, sigma)
+        if n_probes > 2:
+            # no host fallback here: refuse k > 2 unless this host's numpy orders argpartition's first k
+            # the way the device does (see _nearest_on_device), checked on generated rows
+            probe = IVF(self.metric, self.n_clusters, FastPQ(self.pq.dims_per_block))
+            probe.all_centers = self.all_centers
+            rows = dev.read_rows(np.arange(min(N - N % 100, 2400), dtype=np.int64))
+            if self.metric == "angular":
+                rows = rows / np.linalg.norm(rows, axis=1, keepdims=True)
+            got = probe._nearest_on_device(np.ascontiguousarray(rows, dtype=np.float32), n_probes)
+            if len(rows) and not np.array_equal(got, knn_brute(rows, self.all_centers, k=n_probes, metric=self.metric)):
+                raise RuntimeError("build_resident(n_probes=%d): numpy.argpartition on this host does not return the "
+                                   "first k ascending, which the device assignment assumes for k > 2; build with "
+                                   "n_probes <= 2 or on the host (IVF.build)" % n_probes)
         with timer(verbose, "Building lists on the device..."):
             L = dev.build_dev(self.all_centers, n_probes)
         self.active_centers, cc = dev.export_centers()

@@ -675,7 +675,10 @@ class ListShardedIndex:
             if (g[:, -1] & 2).any():
                 raise RuntimeError("filtered exchange: a record outside the home rank's rows")
             need = self._usage(slot)
-            rec_need, _ = self._take_rec_need()
+            # (the device-side maximum is shared by every batch since the last look: batches still in
+            #  flight from submit(), possibly with another (nq, n_probes), are credited with it too —
+            #  an over-estimate for them, never a lost count)
+            rec_need, rec_keys = self._take_rec_need()
             key = (nq, n_probes)
             if not g[:, -1].any():
                 # trim only on the evidence of SEVERAL batches (their longest stream, +35 %): one
@@ -687,7 +690,7 @@ class ListShardedIndex:
                     if len(seen) >= 2 and int(1.35 * max(seen)) + 64 < 0.8 * cap:
                         self.capacity[key] = int(1.35 * max(seen)) + 64
                 if rec_need is not None:
-                    self._note_region([key], rec_need)
+                    self._note_region(set(rec_keys) | {key}, rec_need)
                 return g[:, :-1].reshape(self.world * qh, k)[:nq]
             if rec_need is not None and rec_need > self._region(nq, n_probes, cap):
                 # the record regions were too small (counts="device"); the streams may have fitted
