@@ -160,10 +160,10 @@ int main(int argc, char **argv)
     TkScanJob j;
     j.codes = d_codes; j.tables = d_tables; j.list_chunk_off = d_coff; j.n_lists = n_lists;
     j.unit_prefix = d_up; j.pair_off = d_po; j.pair_q = d_pq; j.pair_f0 = d_pf;
-    j.unit_desc = d_ud;
     j.dist = d_dist; j.cap = cap; j.mins = d_mins; j.min_stride = min_stride;
-    if (variant >= 1) { j.unit_desc4 = d_ud4; j.unit_prefix = d_up4; }
-    tk_plain_set_flush(variant == 2);      // 1: a store per chunk pair, 2: through the LDS tile, a line per query
+    j.unit_desc4 = d_ud4;       // (list, tile, chunk pairs [a, b)): one wave per unit
+    j.unit_prefix = d_up4;
+    (void)variant;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));

@@ -38,12 +38,11 @@ def test_golden_ids_and_heaps(tk, tag, mode, limit_hook):
     dev.set_plain_scan("always" if mode != "off" else False)
     if mode == "rescan-all":
         limit_hook(dev, -128)       # no bound is <= -128 ... every query with a plain slot is redone
+    plain_seen = 0
     for n_probes in g["probes_list"]:
         n_probes = int(n_probes)
         out, dbg = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, debug=True)
-        if mode != "off" and n_probes >= 2:
-            # the matrix-core kernel really ran on the fixture (not everything stayed "head" / exact)
-            assert dev.plain_stats()["plain_units"] > 0, (tag, n_probes, dev.plain_stats())
+        plain_seen = max(plain_seen, dev.plain_stats()["plain_units"])
         np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
         np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])
         np.testing.assert_array_equal(dbg["heap_val"], g[f"heap_val_p{n_probes}"])
@@ -51,12 +50,16 @@ def test_golden_ids_and_heaps(tk, tag, mode, limit_hook):
         # small heaps make more slots plain (they are full after fewer rows)
         for pass_1 in (3, 17):
             a, da = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1, debug=True)
+            plain_seen = max(plain_seen, dev.plain_stats()["plain_units"])
             dev.set_plain_scan(False)
             b, db = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1, debug=True)
             dev.set_plain_scan("always" if mode != "off" else False)
             np.testing.assert_array_equal(da["heap_idx"], db["heap_idx"])
             np.testing.assert_array_equal(da["heap_val"], db["heap_val"])
             np.testing.assert_array_equal(a, b)
+    # the matrix-core kernel really ran on this fixture (the lists are ~45 rows: with the default heaps most
+    # slots stay "head" / exact; the small heaps above leave rows to the plain kernel)
+    assert mode == "off" or plain_seen > 0, (tag, mode)
 
 
 def test_pipelined_batches_vs_oracle(tk, oracle):
@@ -163,3 +166,42 @@ def test_every_register_shape_of_the_plain_kernel(tk, d, metric):
         np.testing.assert_array_equal(dg["heap_idx"], dw["heap_idx"])
         np.testing.assert_array_equal(dg["heap_val"], dw["heap_val"])
         np.testing.assert_array_equal(got, want)
+
+
+def test_automatic_mode_cycle_on_off_probe_on(tk):
+    """Mode 0 end to end: probe -> on (clustered queries), a batch of queries far from every row
+    (their bound never falls to the table's limit: > 1 % flagged) -> paused, the pause runs out ->
+    probe -> on again.  Every batch returns the rows of mode "off"."""
+    from tinyknn_amd import IVF, FastPQ
+    np.random.seed(21)
+    n, d, nq = 30000, 64, 400
+    cent = np.random.randn(150, d)
+    X = (cent[np.random.randint(150, size=n)] + 0.4 * np.random.randn(n, d)).astype(np.float32)
+    near = (cent[np.random.randint(150, size=nq)] + 0.4 * np.random.randn(nq, d)).astype(np.float32)
+    far = (6.0 * np.random.randn(nq, d)).astype(np.float32)
+    ivf = IVF("euclidean", 120, FastPQ(2))
+    ivf.fit(X[:12000]).build(X, n_probes=1)
+    dev = ivf.device_index()
+    dev.set_scan_mode(2)
+    qa, pa = ivf._prepare(near.copy())
+    qb, pb = ivf._prepare(far.copy())
+    dev.set_plain_scan(False)
+    want_a, want_b = dev.query_batch(qa, pa, 10, 8), dev.query_batch(qb, pb, 10, 8)
+    dev.set_plain_scan(True)
+    assert dev.plain_stats()["state"] == "probe"
+    np.testing.assert_array_equal(dev.query_batch(qa, pa, 10, 8), want_a)
+    assert dev.plain_stats()["state"] == "on"
+    np.testing.assert_array_equal(dev.query_batch(qb, pb, 10, 8), want_b)
+    st = dev.plain_stats()
+    assert st["state"] == "paused" and st["flagged_queries"] * 100 > nq and st["pause_left"] >= 256, st
+    left = st["pause_left"]
+    for i in range(left + 2):           # the pause runs out on small batches
+        got = dev.query_batch(qa[:32], pa[:32], 10, 8)
+        if i % 64 == 0:
+            np.testing.assert_array_equal(got, want_a[:32])
+        if dev.plain_stats()["state"] != "paused":
+            break
+    assert dev.plain_stats()["state"] in ("probe", "wait", "on"), dev.plain_stats()
+    np.testing.assert_array_equal(dev.query_batch(qa, pa, 10, 8), want_a)
+    np.testing.assert_array_equal(dev.query_batch(qa, pa, 10, 8), want_a)
+    assert dev.plain_stats()["state"] == "on", dev.plain_stats()

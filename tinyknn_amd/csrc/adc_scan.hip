@@ -993,6 +993,44 @@ __global__ void pairs_identity_kernel(int64_t nq, int chunks, int *__restrict__ 
     }
 }
 
+// The same for the plain kernel (one wave per unit): the one list, pair i = query i, tiles of 32
+// consecutive queries x ranges of K chunk pairs (the range fastest).
+__global__ void plain_identity_kernel(int64_t nq, int chunks, int K, int *__restrict__ pair_off,
+                                      int *__restrict__ unit_prefix, int *__restrict__ pair_q,
+                                      int *__restrict__ pair_f0, int4 *__restrict__ desc)
+{
+    const int CP = (chunks + 1) >> 1;
+    const int nsub = (CP + K - 1) / K;
+    const int64_t U = ((nq + 31) / 32) * nsub;
+    const int64_t nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (U > nq ? U : nq); i += nt) {
+        if (i < nq) {
+            pair_q[i] = (int)i;
+            pair_f0[i] = 0;
+        }
+        if (i < U) {
+            const int t = (int)(i / nsub), sb = (int)(i - (int64_t)t * nsub);
+            const int a = sb * K, b = a + K < CP ? a + K : CP;
+            desc[i] = make_int4(0, t, a, b);
+        }
+        if (i == 0) {
+            pair_off[0] = 0;
+            pair_off[1] = (int)nq;
+            unit_prefix[0] = 0;
+            unit_prefix[1] = (int)U;
+            for (int t = 0; t < TK_TICKETS; t++) unit_prefix[TK_TICKET_OFF(1) + t * 32] = 0;
+        }
+    }
+}
+
+void tk_launch_plain_identity(int64_t nq, int chunks, const TkPairSet &pl, hipStream_t s)
+{
+    if (nq == 0 || chunks == 0) return;
+    const int K = pl.plain_k < 4 ? 12 : (pl.plain_k + 3) & ~3;
+    hipLaunchKernelGGL(plain_identity_kernel, dim3(256), dim3(256), 0, s, nq, chunks, K, pl.pair_off,
+                       pl.unit_prefix, pl.pair_q, pl.pair_f0, (int4 *)pl.unit_desc);
+}
+
 void tk_launch_identity_pairs(int64_t nq, int chunks, int *pair_off, int *unit_prefix, int *pair_q,
                               int *pair_f0, hipStream_t s)
 {

@@ -667,6 +667,7 @@ struct tk_index {
     int opt_scan_form = 0;             // exact list-major kernel: 0 per-lane table-row loads, 1 / 2 rows staged in LDS
     int opt_rescore_form = 2;          // rescoring: 2 / 1 rows staged through LDS in tiles of 32 / 64, 0 lane per row
     int opt_plain_limit = 0x7fffffff;  // a cap on every query's table limit (tests: provokes the re-scan path)
+    bool flat_plain_ok = true;         // tk_index_top_centers: the plain path has not failed on this index
     int plain_state = 0;       // PLAIN_PROBE .. PLAIN_OFF (see plain_poll)
     int plain_skip = 0;        // OFF: batches left before the next probe
     int plain_backoff = 256;   // OFF: length of the next pause (doubled by a failed probe, up to 4096)
@@ -3126,6 +3127,12 @@ extern "C" int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int 
 // the exact distances of those candidates, k best in ascending order — the coarse stage of
 // IVF.query (ivf.py:131) is exactly this call, so the same three kernels run.  Host buffers;
 // queries are processed in chunks whose distance rows fit one workspace.
+// Rows far longer than the heap (n >= 2^16 rows): the scan runs on the matrix cores (plain_scan.hip)
+// behind an exact HEAD — the first n/64 rows — after which the heap is full of real values and its
+// bound far below the table's limit C; the lane replay checks exactly that per query (bound at the
+// first plain block <= C) and fetches only the blocks whose minimum passes its bound (LAZY).  A chunk
+// of queries in which any query fails the check is answered again by the exact kernel alone, and an
+// index on which more than 1 % fail (rows without structure) stays on the exact kernel.
 extern "C" int tk_index_top_centers(tk_index *ix, const float *q, const void *q_pq, int q_pq_is_f64,
                                     int64_t nq, int k, int64_t *out_ids)
 {
@@ -3147,6 +3154,12 @@ extern "C" int tk_index_top_centers(tk_index *ix, const float *q, const void *q_
     Work &w = ix->works[0];
     const int M = ix->M;
     const size_t esz = q_pq_is_f64 ? 8 : 4;
+    const bool lanes = ix->heap_mode == 0 && ix->center_chunks * 16 <= 0xffffff && p.rescore <= TK_LANES_MAX_R;
+    const bool lazy = lanes && ix->center_chunks >= 1024;
+    const int hc = (int)(ix->center_chunks / 64 < 16 ? 16 : ix->center_chunks / 64);     // exact head, in chunks
+    bool flat_plain = lanes && ix->plain_mode != 1 && plain_env_on() && tk_plain_fits(M) && ix->flat_plain_ok &&
+                      ix->center_chunks >= 4096 && coarse_units(ix, chunk);
+    TkPairSet pl;
     TRY(w.tables.ensure((size_t)chunk * M * 16));
     TRY(w.shift.ensure((size_t)chunk * 8));
     TRY(w.scale.ensure((size_t)chunk * 8));
@@ -3161,17 +3174,86 @@ extern "C" int tk_index_top_centers(tk_index *ix, const float *q, const void *q_
     TRY(w.c_pair_f0.ensure(((size_t)chunk + 4) * 4));
     TRY(ix->q.ensure((size_t)chunk * ix->d * 4));
     TRY(ix->qpq.ensure((size_t)chunk * ix->dq * esz));
+    if (flat_plain) {
+        const int K = 64;
+        const int64_t nsub = ((ix->center_chunks + 1) / 2 + K - 1) / K;
+        TRY(w.qlim.ensure((size_t)chunk * 4));
+        TRY(w.plain0.ensure((size_t)chunk * 4));
+        TRY(w.repeat_flag.ensure((size_t)chunk));
+        TRY(w.flag_list.ensure(((size_t)chunk + 1) * 4));
+        TRY(w.p_pair_off.ensure(8));
+        TRY(w.p_unit_prefix.ensure(tk_unit_prefix_ints(1) * 4));
+        TRY(w.p_pair_q.ensure(((size_t)chunk + 4) * 4));
+        TRY(w.p_pair_f0.ensure(((size_t)chunk + 4) * 4));
+        TRY(w.p_unit_desc.ensure((size_t)((chunk + 31) / 32) * nsub * 16 + 64));
+        if (!w.flag_host) {
+            HIPCHECK(hipHostMalloc((void **)&w.flag_host, 64, hipHostMallocDefault));
+            *w.flag_host = 0;
+        }
+        pl = TkPairSet{nullptr, nullptr, w.p_pair_off.as<int>(), w.p_unit_prefix.as<int>(), w.p_pair_q.as<int>(),
+                       w.p_pair_f0.as<int>(), w.p_unit_desc.as<int>(), K};
+        std::vector<int> h((size_t)chunk, hc);      // every query: plain sums from flat chunk hc on
+        HIPCHECK(hipMemcpy(w.plain0.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    }
+    // heap replay over the centre rows (fresh heap, positions as labels) + exact rescoring -> w.probes
+    auto replay_rescore = [&](int64_t m, bool plain) -> int {
+        if (!lanes) {
+            Prof pf;
+            return coarse_replay_probes(ix, w, ix->q.as<float>(), m, p, w.probes.as<int64_t>(), nullptr, pf);
+        }
+        if (tk_launch_heap_replay_lanes(w.cdist.as<uint4>(), ix->center_chunks, m, ix->cslots_i.as<int>(),
+                                        ix->cslots_i.as<int>() + 2, ix->cslots_l.as<int64_t>(), 1, nullptr,
+                                        w.cheap_idx.as<int64_t>(), w.cheap_val.as<int32_t>(), p.rescore, 1, 1,
+                                        plain ? w.repeat_flag.as<unsigned char>() : nullptr, w.cmins.as<uint8_t>(),
+                                        p.ccap_min, nullptr, nullptr, plain ? w.plain0.as<int>() : nullptr,
+                                        plain ? w.qlim.as<int>() : nullptr, lazy ? 1 : 0))
+            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
+        tk_launch_rescore(ix->q.as<float>(), 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
+                          w.cheap_idx.as<int64_t>(), p.rescore, m, p.kc, 0, w.probes.as<int64_t>(), nullptr, nullptr,
+                          ix->opt_rescore_form);
+        return TK_OK;
+    };
     for (int64_t o = 0; o < nq; o += chunk) {
         const int64_t m = nq - o < chunk ? nq - o : chunk;
         HIPCHECK(hipMemcpy(ix->q.p, q + o * ix->d, (size_t)m * ix->d * 4, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(ix->qpq.p, (const char *)q_pq + (size_t)o * ix->dq * esz, (size_t)m * ix->dq * esz,
                            hipMemcpyHostToDevice));
         Prof pf;
-        TRY(stage_tables(ix, w, ix->qpq.p, q_pq_is_f64, m, nullptr, pf));
-        launch_coarse_scan(ix, w, m, p, nullptr);
-        TRY(coarse_replay_probes(ix, w, ix->q.as<float>(), m, p, w.probes.as<int64_t>(), nullptr, pf));
-        HIPCHECK(hipGetLastError());
-        HIPCHECK(hipDeviceSynchronize());
+        bool exact = !flat_plain;
+        if (flat_plain) {
+            TRY(stage_tables(ix, w, ix->qpq.p, q_pq_is_f64, m, nullptr, pf, true));
+            HIPCHECK(hipMemsetAsync(w.repeat_flag.p, 0, (size_t)m, nullptr));
+            // plain sums of every row first; the exact kernel then overwrites the head chunks
+            tk_launch_plain_identity(m, (int)ix->center_chunks, pl, nullptr);
+            TkScanJob pj = coarse_job(ix, w, p);
+            pj.unit_prefix = pl.unit_prefix; pj.pair_off = pl.pair_off; pj.pair_q = pl.pair_q; pj.pair_f0 = pl.pair_f0;
+            pj.unit_desc4 = pl.unit_desc;
+            if (tk_launch_scan_plain(pj, M, ix->order, plain_blocks(), nullptr))
+                return fail(TK_ERR_HIP, "scan_plain_wave_kernel: LDS attribute / unsupported M");
+            tk_launch_identity_pairs(m, hc, w.c_pair_off.as<int>(), w.c_unit_prefix.as<int>(),
+                                     w.c_pair_q.as<int>(), w.c_pair_f0.as<int>(), nullptr);
+            TkScanJob hj = coarse_job(ix, w, p), none;
+            memset(&none, 0, sizeof none);
+            hj.max_chunks = hc;
+            tk_launch_scan_units2(hj, none, M, ix->order, 768, nullptr, nullptr, 0);
+            TRY(replay_rescore(m, true));
+            tk_launch_flagged_list(w.repeat_flag.as<unsigned char>(), m, w.flag_list.as<int>(), nullptr, w.flag_host);
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipDeviceSynchronize());
+            const int flagged = *w.flag_host;
+            if (flagged > 0) exact = true;                       // (this chunk again, exactly)
+            if ((double)flagged > 0.01 * (double)m) {            // rows without structure: not again on this index
+                ix->flat_plain_ok = false;
+                flat_plain = false;
+            }
+        }
+        if (exact) {
+            TRY(stage_tables(ix, w, ix->qpq.p, q_pq_is_f64, m, nullptr, pf));
+            launch_coarse_scan(ix, w, m, p, nullptr);
+            TRY(replay_rescore(m, false));
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipDeviceSynchronize());
+        }
         if (p.kc == k) {
             HIPCHECK(hipMemcpy(out_ids + o * k, w.probes.p, (size_t)m * k * 8, hipMemcpyDeviceToHost));
         } else {    // fewer rows than k: rows of kc ids into rows of k, padded with -1

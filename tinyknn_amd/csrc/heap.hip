@@ -409,7 +409,12 @@ __global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq
 // a SLOT, LAB[slot][lane] holds the slot's 32-bit label, `insert` first scans LAB for
 // the candidate's label (the reference's duplicate test, _fast_pq.pyx:284-287) and a
 // new entry inherits the slot of the root it evicts.  labels32 = the ids as int32.
-template <bool SIGNED, bool DEDUPE, int LW>
+// LAZY (rows far longer than the heap: _FastDistanceTable.top over a whole data set, 62 500 blocks per
+// query at 1M rows): nothing is staged — a lane reads its row's block minima, 16 at a time and one
+// segment ahead, and fetches a block from global memory only when its minimum passes the bound.
+// A handful of blocks in 4 000 segments pass once the heap is warm; staging every block cost 16
+// row-per-lane loads and 16 LDS writes per segment and lane (55 of the 90 ms per 10 000 queries).
+template <bool SIGNED, bool DEDUPE, int LW, bool LAZY = false>
 __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
@@ -532,15 +537,17 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     for (int k = 0; k < 16; k++) nx[k] = make_uint4(0, 0, 0, 0);
     if (max_nseg > 0) {
         mins_nx = TK_MINS_ROW(0);
-        TK_FETCH_BLOCKS(0)
+        if (!LAZY) TK_FETCH_BLOCKS(0)
     }
     for (int g = 0; g < max_nseg; g++) {
+        if (!LAZY) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) ST[k * LW + lane] = nx[k];
+            for (int k = 0; k < 16; k++) ST[k * LW + lane] = nx[k];
+        }
         const uint4 mins_cur = mins_nx;
         if (g + 1 < max_nseg) {
             mins_nx = TK_MINS_ROW(g + 1);
-            TK_FETCH_BLOCKS(g + 1)
+            if (!LAZY) TK_FETCH_BLOCKS(g + 1)
         }
         const int buf = 0;
         int kmax = total - 16 * g;
@@ -559,8 +566,8 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
             while (bits == 0 && hit) {
                 const int k = __builtin_ctz(hit);
                 hit &= hit - 1;
-                dd = ST[(buf * 16 + k) * LW + lane];
                 cur = 16 * g + k;
+                dd = LAZY ? drow[cur < last_blk ? cur : last_blk] : ST[(buf * 16 + k) * LW + lane];
                 // `pos < n` (:111): the rows that pad a list's last chunk were set to the largest
                 // value by pad_fix_kernel and can never be below a bound — no row count, and
                 // with distinct labels no slot cursor at all, is needed here
@@ -932,7 +939,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
-                                hipStream_t s, const int *plain0, const int *qlim)
+                                hipStream_t s, const int *plain0, const int *qlim, int lazy)
 {
     if (nq == 0 || R == 0) return 0;
     if (!plain0 || !qlim || !skip || !signd) plain0 = qlim = nullptr;
@@ -953,7 +960,9 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
         const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false, 64>,
                              (const void *)heap_replay_lanes_kernel<false, false, 64>,
                              (const void *)heap_replay_lanes_kernel<true, true, 32>,
-                             (const void *)heap_replay_lanes_kernel<false, true, 32>};
+                             (const void *)heap_replay_lanes_kernel<false, true, 32>,
+                             (const void *)heap_replay_lanes_kernel<true, false, 64, true>,
+                             (const void *)heap_replay_lanes_kernel<false, false, 64, true>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
@@ -982,7 +991,15 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                        slots_uniform, skip, 1, mins, cap_min, labels32, nullptr, prio, wave_lds,  \
                        plain0, qlim)
     if (dedupe) { if (signd) TK_LAUNCH3(true, true, 32); else TK_LAUNCH3(false, true, 32); }
-    else { if (signd) TK_LAUNCH3(true, false, 64); else TK_LAUNCH3(false, false, 64); }
+    else if (lazy) {
+#define TK_LAUNCH_LAZY(S_)                                                                        \
+    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, false, 64, true>), grid, dim3(64), lds, s, dist, cap, nq, \
+                       slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
+                       slots_uniform, skip, 1, mins, cap_min, labels32, nullptr, prio, wave_lds,  \
+                       plain0, qlim)
+        if (signd) TK_LAUNCH_LAZY(true); else TK_LAUNCH_LAZY(false);
+#undef TK_LAUNCH_LAZY
+    } else { if (signd) TK_LAUNCH3(true, false, 64); else TK_LAUNCH3(false, false, 64); }
 #undef TK_LAUNCH3
     return 0;
 }

@@ -98,6 +98,9 @@ struct TkPairSet {
     int *unit_desc = nullptr;      // plain set: int4 (list, tile, first chunk pair, end chunk pair) per unit
     int plain_k = 12;              // plain set: chunk pairs per unit, a multiple of 4 (tk_plain_units_bound)
 };
+// descriptors of the plain kernel for ONE list scanned by every query (pair i = query i, row offset 0):
+// pair_off / unit_prefix of one list, pair_q / pair_f0: nq ints, unit_desc: ceil(nq/32) * ceil(CP/K) int4
+void tk_launch_plain_identity(int64_t nq, int chunks, const TkPairSet &pl, hipStream_t s);
 // the plain set's unit descriptors alone (tk_launch_unit_pairs2 writes them itself; callers of
 // tk_launch_pairs_scan3 that fill the records their own way call this behind it)
 void tk_launch_plain_desc(const TkPairSet &pl, const int64_t *list_chunk_off, int64_t n_lists, hipStream_t s);
@@ -160,7 +163,9 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
-                                hipStream_t s, const int *plain0 = nullptr, const int *qlim = nullptr);
+                                hipStream_t s, const int *plain0 = nullptr, const int *qlim = nullptr,
+                                int lazy = 0);
+// lazy: blocks are fetched only where their minimum passes (rows far longer than the heap; distinct labels)
 
 // Wave-per-query replay on packed 32-bit entries from FRESH heaps (R*4 B of LDS, or
 // R*12 with `dedupe`: int64 labels per slot + the reference's duplicate-label test,
