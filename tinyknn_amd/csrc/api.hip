@@ -1117,7 +1117,7 @@ static const int64_t MAX_SUB = 32768;  // gridDim.y limit of the scan kernels is
 static const int64_t MAX_SHARD_BATCH = 131072;
 
 // Queries per sub-batch: the distance buffer is nq * cap * 17 bytes (16 int8 + 1 minimum
-// per chunk, cap = n_probes * longest list); one workspace keeps it under 12 GB (env
+// per chunk, cap = n_probes * longest list); one workspace keeps it under 16 GB (env
 // TINYKNN_WORKSPACE_GB; up to depth + 5 workspaces exist — sized for 288 GB of HBM: at
 // 100M x 128 with 10 000 lists a 4 GB workspace cut a batch of 10 000 queries in two, and the
 // list-major scan then found 5 instead of 10 queries per list to share a fetched chunk).
@@ -1127,7 +1127,7 @@ static double workspace_bytes()
     if (b == 0) {
         const char *e = getenv("TINYKNN_WORKSPACE_GB");
         const double g = e ? atof(e) : 0.0;
-        b = (g >= 0.25 ? g : 12.0) * 1.0e9;
+        b = (g >= 0.25 ? g : 16.0) * 1.0e9;
     }
     return b;
 }
