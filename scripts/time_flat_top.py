@@ -64,6 +64,7 @@ print(json.dumps({"batched": {"api": "tinyknn_amd.fast_pq.FlatTop.top (tk_index_
                   "code_bytes": int(td.packed.nbytes), "algorithmic_GBps_incl_host": td.packed.nbytes / t_gpu / 1e9,
                   "oracle_ms_per_query_1_core": t_cpu * 1e3, "identical_results": same, "queries": nq,
                   "encode_s": t_enc,
-                  "note": "per call: numpy table build on the host + tk_codes_query (table H2D, flat scan + "
-                          "wave-per-query heap replay, heap D2H) + numpy rescoring; latency-bound, one query "
-                          "at a time as the reference's example does"}}))
+                  "note": "per call: table build + tk_codes_query (table copy from pinned memory, flat scan, ONE "
+                          "launch that replays with the heap in registers: head, compaction by block minima, tail; "
+                          "heap written to pinned memory) + rescoring; latency-bound, one query at a time as the "
+                          "reference's example does"}}))

@@ -70,3 +70,41 @@ def test_flat_top_long_rows_on_the_matrix_cores(oracle, d, structured):
         for i in (1, 50, 199):
             np.testing.assert_array_equal(got[i], pq.distance_table(qs[i]).top(td, X, k=k))
     ft.close()
+
+
+@pytest.mark.parametrize("signd", [True, False])
+@pytest.mark.parametrize("chunks,n_off,R", [(4096, 0, 30), (6000, -7, 30), (6000, -16 * 5000, 12), (5000, 0, 2000),
+                                            (70000, -3, 30), (4500, 40, 1), (5000, -1, 64), (5000, -1, 65)])
+def test_query_pq_long_rows_fresh_heap_compacts_candidates(oracle, signd, chunks, n_off, R):
+    """Per-query `query_pq` over >= 4096 blocks with a fresh heap of at most 64 entries: one launch
+    replays the first ~sqrt(R chunks) blocks with the heap in registers, compacts the later blocks whose
+    minimum is below the bound reached there, and replays those (heap.hip, flat_top_one_kernel).  Same
+    heap arrays as the oracle — with n short of (or beyond) the padded rows, signed and unsigned, heaps
+    on either side of the 64-entry limit (R = 65, 2000: the general kernel), and a second call that
+    continues from the heap of the first (general kernel)."""
+    from tinyknn_amd import _fast_pq_avx as F
+    from tinyknn_amd import _fast_pq as P
+    rng = np.random.RandomState(chunks + R)
+    M = 16
+    data = rng.randint(0, 2 ** 63, size=(chunks, M), dtype=np.int64).astype(np.uint64)
+    data |= rng.randint(0, 2, size=(chunks, M)).astype(np.uint64) << np.uint64(63)
+    lo, hi = (-8, 8) if signd else (0, 16)
+    t8 = rng.randint(lo, hi, size=(M * 16,)).astype(np.int8 if signd else np.uint8)
+    t8[rng.randint(0, M * 16, size=40)] = 7 if signd else 15
+    tables = t8.view(np.uint64).copy()
+    n = 16 * chunks + n_off
+    gi, gv = np.zeros(R, np.int64), np.zeros(R, np.int32)
+    wi, wv = np.zeros(R, np.int64), np.zeros(R, np.int32)
+    P.init_heap(gi, gv, signd)
+    oracle.init_heap(wi, wv, signd)
+    F.query_pq_avx(data, n, tables, gi, gv, signd)
+    oracle.query_pq(data, n, tables, wi, wv, signd, None, oracle.ORDER_AVX)
+    np.testing.assert_array_equal(gi, wi)
+    np.testing.assert_array_equal(gv, wv)
+    assert (gi < max(n, 0)).all()
+    # continue from that heap (not fresh: the general path), other tables
+    tables2 = np.roll(t8, 5).view(np.uint64).copy()
+    F.query_pq_avx(data, n, tables2, gi, gv, signd)
+    oracle.query_pq(data, n, tables2, wi, wv, signd, None, oracle.ORDER_AVX)
+    np.testing.assert_array_equal(gi, wi)
+    np.testing.assert_array_equal(gv, wv)

@@ -4,6 +4,7 @@
 // resident and only enqueue kernels.  There is no CPU implementation behind any of
 // these calls.
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -214,21 +215,19 @@ extern "C" int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t 
     return TK_OK;
 }
 
+// init_heap (_fast_pq.pyx:311-315): two HOST arrays filled with constants — nothing for the device to
+// do (a fill kernel plus two copies back cost 45 us per call); like every entry point it still refuses
+// to run on a machine without a GPU
 extern "C" int tk_init_heap(int64_t *indices, int32_t *vals, int R, int signd)
 {
-    TRY(require_gpu());
+    static const int have_gpu = tk_device_count();
+    if (have_gpu <= 0) return require_gpu();
     ARGCHECK(R >= 0, "R");
-    if (R == 0) return TK_OK;
-    Scratch &S = scratch();
-    std::lock_guard<std::mutex> lk(S.mu);
-    hipStream_t st = 0;
-    TRY(S.hidx.ensure((size_t)R * 8));
-    TRY(S.hval.ensure((size_t)R * 4));
-    tk_launch_heap_fill(S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R, signd ? 127 : 255, st);
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(indices, S.hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipMemcpyAsync(vals, S.hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipStreamSynchronize(st));
+    ARGCHECK(R == 0 || (indices && vals), "null heap");
+    for (int i = 0; i < R; i++) {
+        indices[i] = -1;
+        vals[i] = signd ? 127 : 255;
+    }
     return TK_OK;
 }
 
@@ -337,7 +336,8 @@ struct tk_codes {
     int M = 0;
     // scratch of the calls on this array
     DevBuf tables, out, hidx, hval, labels, slots_i, slots_l, pair_off, unit_prefix, pair_q,
-        pair_f0, chunk_off, mins;
+        pair_f0, chunk_off, mins, cdist, cblock;
+    void *pin = nullptr;   // 64 KiB of pinned host memory: tables in, heap out, of the one-launch replay
 };
 
 extern "C" tk_codes *tk_codes_upload(const uint64_t *data, int64_t chunks, int M)
@@ -376,8 +376,9 @@ extern "C" void tk_codes_free(tk_codes *c)
     if (!c) return;
     DevBuf *b[] = {&c->tiled, &c->tables, &c->out, &c->hidx, &c->hval, &c->labels, &c->slots_i,
                    &c->slots_l, &c->pair_off, &c->unit_prefix, &c->pair_q, &c->pair_f0,
-                   &c->chunk_off, &c->mins};
+                   &c->chunk_off, &c->mins, &c->cdist, &c->cblock};
     for (DevBuf *x : b) x->release();
+    if (c->pin) (void)hipHostFree(c->pin);
     delete c;
 }
 
@@ -446,6 +447,44 @@ extern "C" int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, in
     hipStream_t st = 0;
     TRY(c->tables.ensure((size_t)c->M * 16));
     TRY(c->out.ensure((size_t)chunks * 16));
+    const int64_t cap_min = (chunks + 15) / 16 * 16;
+    TRY(c->mins.ensure((size_t)cap_min));
+    // Rows far longer than a FRESH heap of at most 64 entries (top() of one query over a whole data
+    // set): one table copy from pinned memory, the scan, ONE launch that replays with the heap in
+    // registers and writes it to pinned memory (heap.hip, flat_top_one_kernel).  The head is
+    // ~sqrt(R chunks) blocks: about as many again pass its bound.
+    bool fresh = !labels && chunks >= 4096 && R <= 64 && (size_t)c->M * 16 <= 32 * 1024;
+    for (int i = 0; i < R && fresh; i++) fresh = indices[i] == -1 && vals[i] == (signd ? 127 : 255);
+    if (fresh) {
+        if (!c->pin) HIPCHECK(hipHostMalloc(&c->pin, 64 * 1024, hipHostMallocDefault));
+        TRY(c->cdist.ensure((size_t)chunks * 16));
+        TRY(c->cblock.ensure((size_t)chunks * 5));
+        unsigned char *pin = (unsigned char *)c->pin;
+        int64_t *pidx = (int64_t *)(pin + 32 * 1024);
+        int32_t *pval = (int32_t *)(pin + 32 * 1024 + 64 * 8);
+        memcpy(pin, tables, (size_t)c->M * 16);
+        HIPCHECK(hipMemcpyAsync(c->tables.p, pin, (size_t)c->M * 16, hipMemcpyHostToDevice, st));
+        tk_launch_scan_flat(c->tiled.as<uint4>(), chunks, c->M, c->tables.as<uint4>(), 1,
+                            c->out.as<uint4>(), chunks, c->mins.as<uint8_t>(), cap_min, signd, order, st);
+        int64_t h = ((int64_t)std::sqrt((double)R * (double)chunks) + 63) / 64 * 64;
+        h = h < 64 ? 64 : (h > chunks / 16 * 16 ? chunks / 16 * 16 : h);
+        const int64_t nn = n < 0 ? 0 : n;
+        tk_launch_flat_top_one(c->out.as<uint4>(), c->mins.as<uint8_t>(), (int)chunks, (int)h, nn, R, signd,
+                               c->cdist.as<uint4>(), c->cblock.as<int>(), pidx, pval, st);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(st));
+        memcpy(indices, pidx, (size_t)R * 8);
+        memcpy(vals, pval, (size_t)R * 4);
+#ifdef TK_FLAT_CLOCK
+        {
+            const int64_t *g = pidx + 1024;
+            fprintf(stderr, "flat clock: head %lld cyc %.1f us | compact %lld cyc %.1f us | tail %lld cyc %.1f us | kept %lld h %lld\n",
+                    (long long)(g[2] - g[0]), (g[3] - g[1]) / 100.0, (long long)(g[4] - g[2]), (g[5] - g[3]) / 100.0,
+                    (long long)(g[6] - g[4]), (g[7] - g[5]) / 100.0, (long long)g[8], (long long)h);
+        }
+#endif
+        return TK_OK;
+    }
     TRY(c->hidx.ensure((size_t)R * 8));
     TRY(c->hval.ensure((size_t)R * 4));
     TRY(c->slots_i.ensure(3 * sizeof(int)));
@@ -465,8 +504,6 @@ extern "C" int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, in
     HIPCHECK(hipMemcpyAsync(c->slots_i.p, si, sizeof si, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(c->slots_l.p, sl, sizeof sl, hipMemcpyHostToDevice, st));
     // the scan also writes each block's minimum: the replay walks 1024 blocks per step on them
-    const int64_t cap_min = (chunks + 15) / 16 * 16;
-    TRY(c->mins.ensure((size_t)cap_min));
     tk_launch_scan_flat(c->tiled.as<uint4>(), chunks, c->M, c->tables.as<uint4>(), 1,
                         c->out.as<uint4>(), chunks, c->mins.as<uint8_t>(), cap_min, signd, order, st);
     tk_launch_heap_replay(c->out.as<uint4>(), chunks, 1, c->slots_i.as<int>(),

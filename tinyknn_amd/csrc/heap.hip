@@ -287,6 +287,256 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 }
 
 // ---------------------------------------------------------------------------
+// One query over rows far longer than its heap (`_FastDistanceTable.top` per query, fast_pq.py:297-302:
+// 62 500 blocks at 1M rows against a heap of 2k+10 entries), ONE launch of ONE workgroup.
+//
+// What one such call costs in the general kernel above is latency, not work: ~300 inserts whose sift
+// goes through LDS round trips, and a dependent global load for every group of blocks that can hold a
+// row.  Here
+//   * the heap (R <= 64) lives in three VGPRs across the lanes of wave 0 — entry t in lane t — and
+//     `insert` (_fast_pq.pyx:274-307) runs on the scalar unit with v_readlane and a one-lane select;
+//   * wave 0 replays the first `h` blocks (256 per batch of loads);
+//   * the bound never rises from block to block while the array is a heap (every insert of a block is
+//     below the bound captured at the block's start, _fast_pq_256.pyx:73-123), so a later block whose
+//     minimum (written by the scan) is not below the bound reached after the head can never insert a
+//     row: all 16 waves compact the others, in order, into `cdist` with their block numbers;
+//   * wave 0 replays the compact array — same blocks in the same order as the reference's loop would
+//     have entered, positions recovered from the block numbers, `pos < n` as there.
+// The heap starts fresh (the caller checked): nothing is read from the caller's arrays.
+struct RegHeap {
+    int32_t v;        // lane t: vals[t]
+    uint32_t lo, hi;  // lane t: indices[t]
+};
+
+// `insert` (_fast_pq.pyx:274-307) without its loop.  The sift goes down the heap's MAX-CHILD path —
+// at node j the larger child (the left one on a tie: `vl > v`, then `vr > nxt_val`), as long as that
+// child is above v — and that path does not depend on v: lane t knows from its sibling whether it is
+// the larger child of its parent, one ballot makes that a mask, and a node is on the path when every
+// ancestor is.  Values never rise along the path (it is a heap), so the nodes the loop would have
+// passed are the root and the path nodes above v; each takes its path child's entry, the last of them
+// takes (label, v).  Five cross-lane reads and ~80 vector instructions instead of five dependent
+// scalar rounds.
+struct RegHeapLane {   // what lane t knows about node t of a heap of R entries; fixed for the launch
+    uint64_t anc;      // bits of t and its ancestors below the root
+    int a_next, a_prev, odd, last, root, in_heap, has_child, l, lsh;
+};
+__device__ __forceinline__ RegHeapLane reg_heap_lane(int lane, int R)
+{
+    RegHeapLane K;
+    K.anc = 0;
+    for (int t = lane; t > 0; t = (t - 1) >> 1) K.anc |= 1ull << t;
+    K.a_next = 4 * (lane < 63 ? lane + 1 : 63);
+    K.a_prev = 4 * (lane > 0 ? lane - 1 : 0);
+    K.odd = lane & 1;
+    K.last = lane + 1 >= R;
+    K.root = lane == 0;
+    K.in_heap = lane < R;
+    K.l = 2 * lane + 1;
+    K.has_child = K.l < R;
+    K.lsh = K.l & 63;
+    return K;
+}
+
+__device__ __forceinline__ void reg_heap_insert(RegHeap &H, const RegHeapLane &K, int64_t label, int32_t v)
+{
+    const uint32_t llo = (uint32_t)label, lhi = (uint32_t)((uint64_t)label >> 32);
+    if (__builtin_amdgcn_ballot_w64((K.in_heap & (int)(H.lo == llo) & (int)(H.hi == lhi)) != 0)) return;  // :284-287
+    const int32_t next = __builtin_amdgcn_ds_bpermute(K.a_next, H.v);   // vals[t + 1]
+    const int32_t prev = __builtin_amdgcn_ds_bpermute(K.a_prev, H.v);   // vals[t - 1]
+    const int larger = K.odd ? (K.last | (int)(H.v >= next)) : (K.root | (int)(H.v > prev));
+    const uint64_t M = __builtin_amdgcn_ballot_w64((larger & K.in_heap) != 0);
+    const int onp = (~M & K.anc) == 0;                        // every node from t up to the root's child is the larger child
+    const int c = K.l + 1 - (int)((M >> K.lsh) & 1);          // the larger child (a lone left child is one)
+    const int ca = (c & 63) << 2;
+    const int32_t cv = __builtin_amdgcn_ds_bpermute(ca, H.v);
+    const uint32_t clo = (uint32_t)__builtin_amdgcn_ds_bpermute(ca, (int)H.lo);
+    const uint32_t chi = (uint32_t)__builtin_amdgcn_ds_bpermute(ca, (int)H.hi);
+    const int passed = onp & (K.root | (int)(H.v > v));
+    const int up = passed & K.has_child & (int)(cv > v);
+    H.v = up ? cv : passed ? v : H.v;
+    H.lo = up ? clo : passed ? llo : H.lo;
+    H.hi = up ? chi : passed ? lhi : H.hi;
+}
+
+// blocks d[0 .. nb) in order, mn[i] the minimum of block i (written by the scan); block i is block
+// bmap[i] of the original array (identity without bmap)
+template <bool SIGNED>
+__device__ __forceinline__ void reg_heap_span(RegHeap &H, const RegHeapLane &K, uint32_t &bound, const uint4 *d, const uint8_t *mn,
+                                              int nb, const int *bmap, int64_t n, int lane)
+{
+    for (int s0 = 0; s0 < nb; s0 += 256) {
+        uint4 dd4[4];
+        int bm4[4];
+        uint32_t mn4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int b = s0 + 64 * i + lane;
+            dd4[i] = make_uint4(0, 0, 0, 0);
+            bm4[i] = b;
+            mn4[i] = SIGNED ? 0x7fu : 0xffu;   // never below a bound
+            if (b < nb) {
+                dd4[i] = d[b];
+                mn4[i] = mn[b];
+                if (bmap) bm4[i] = bmap[b];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 dd = dd4[i];
+            uint64_t mask = __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn4[i], bound));
+            while (mask) {
+                const int j = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint32_t d0 = __builtin_amdgcn_readlane(dd.x, j);
+                const uint32_t d1 = __builtin_amdgcn_readlane(dd.y, j);
+                const uint32_t d2 = __builtin_amdgcn_readlane(dd.z, j);
+                const uint32_t d3 = __builtin_amdgcn_readlane(dd.w, j);
+                const int64_t pos0 = 16 * (int64_t)__builtin_amdgcn_readlane(bm4[i], j);
+                // the reference's cmp_mask of this block against the live bound: row r in lane r
+                const uint32_t wr = lane < 4 ? d0 : lane < 8 ? d1 : lane < 12 ? d2 : d3;
+                const uint32_t myb = (wr >> (8 * (lane & 3))) & 0xffu;
+                uint32_t bits = (uint32_t)__builtin_amdgcn_ballot_w64(lane < 16 && byte_lt<SIGNED>(myb, bound));
+                while (bits) {
+                    const int r = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const int64_t pos = pos0 + r;
+                    if (pos < n) {   // _fast_pq_256.pyx:111
+                        const uint32_t w = r < 4 ? d0 : r < 8 ? d1 : r < 12 ? d2 : d3;
+                        const uint32_t by = (w >> (8 * (r & 3))) & 0xffu;
+                        reg_heap_insert(H, K, pos, SIGNED ? (int32_t)(int8_t)by : (int32_t)by);
+                    }
+                }
+                bound = (uint32_t)__builtin_amdgcn_readlane(H.v, 0) & 0xffu;   // :123
+                if (mask) mask &= __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn4[i], bound));
+            }
+        }
+    }
+}
+
+template <bool SIGNED>
+__global__ __launch_bounds__(1024) void flat_top_one_kernel(const uint4 *__restrict__ dist,
+                                                            const uint8_t *__restrict__ mins, int chunks, int h,
+                                                            int64_t n, int R, uint4 *__restrict__ cdist,
+                                                            int *__restrict__ cblock, int64_t *__restrict__ out_idx,
+                                                            int32_t *__restrict__ out_val)
+{
+#ifdef TK_FLAT_CLOCK
+    int64_t *dbg = (int64_t *)(out_idx + 1024);
+    int n_ins = 0;
+#define CLK(i) if (tid == 0) { dbg[2 * (i)] = __builtin_readcyclecounter(); dbg[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define CLK(i)
+#endif
+    __shared__ uint32_t s_bound;
+    __shared__ int s_wave[16], s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RegHeap H = {SIGNED ? 127 : 255, 0xffffffffu, 0xffffffffu};   // init_heap (_fast_pq.pyx:311-315)
+    uint32_t bound = SIGNED ? 127u : 255u;
+    const RegHeapLane K = reg_heap_lane(lane, R);
+    const int rest = chunks - h;
+    const int per = ((rest + 1023) / 1024 + 15) & ~15;
+    const int b_lo = h + tid * per;
+    uint4 pm[4];   // minima of the thread's first 64 blocks for the compaction: in flight during the head replay
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int b0 = b_lo + 16 * g;
+        pm[g] = make_uint4(0, 0, 0, 0);
+        if (16 * g < per && b0 < chunks) pm[g] = *(const uint4 *)(mins + b0);
+    }
+    CLK(0)
+    if (wave == 0) {
+        reg_heap_span<SIGNED>(H, K, bound, dist, mins, h, nullptr, n, lane);
+        if (lane == 0) s_bound = bound;
+    }
+    CLK(1)
+    __syncthreads();
+    const uint32_t hb = s_bound;
+    uint8_t *cmin = (uint8_t *)(cblock + chunks);   // the kept blocks' minima, behind their numbers
+    // compaction: thread t owns blocks [h + t per, + per), per a multiple of 16 (h is one too); the
+    // minima of its first 64 were loaded before the head replay
+    uint64_t keep = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t w[4] = {pm[g].x, pm[g].y, pm[g].z, pm[g].w};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            keep |= (uint64_t)byte_lt<SIGNED>((w[k >> 2] >> (8 * (k & 3))) & 0xffu, hb) << (16 * g + k);
+    }
+    {   // blocks past the thread's range or the array's end
+        int valid = per < 64 ? per : 64;
+        if (b_lo + valid > chunks) valid = chunks - b_lo;
+        keep = valid <= 0 ? 0 : valid >= 64 ? keep : keep & ((1ull << valid) - 1ull);
+    }
+    int cnt = __builtin_popcountll(keep);
+    for (int g = 64; g < per; g += 16) {   // more than 64 blocks per thread: above 2^16 + h blocks
+        const int b0 = b_lo + g;
+        if (b0 >= chunks) break;
+        const uint4 m16 = *(const uint4 *)(mins + b0);
+        const uint32_t w[4] = {m16.x, m16.y, m16.z, m16.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            cnt += (b0 + k < chunks) && byte_lt<SIGNED>((w[k >> 2] >> (8 * (k & 3))) & 0xffu, hb);
+    }
+    int inc = cnt;   // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int at = inc - cnt;
+    for (int w = 0; w < wave; w++) at += s_wave[w];
+    if (tid == 1023) s_total = at + cnt;
+    while (keep) {
+        const int b = b_lo + __builtin_ctzll(keep);
+        keep &= keep - 1;
+        cdist[at] = dist[b];
+        cblock[at] = b;
+        cmin[at] = mins[b];
+        at++;
+    }
+    for (int g = 64; g < per; g += 16) {
+        const int b0 = b_lo + g;
+        if (b0 >= chunks) break;
+        const uint4 m16 = *(const uint4 *)(mins + b0);
+        const uint32_t w[4] = {m16.x, m16.y, m16.z, m16.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if ((b0 + k < chunks) && byte_lt<SIGNED>((w[k >> 2] >> (8 * (k & 3))) & 0xffu, hb)) {
+                cdist[at] = dist[b0 + k];
+                cblock[at] = b0 + k;
+                cmin[at] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                at++;
+            }
+    }
+    __threadfence();
+    __syncthreads();
+    if (wave != 0) return;
+    CLK(2)
+    reg_heap_span<SIGNED>(H, K, bound, cdist, cmin, s_total, cblock, n, lane);
+    CLK(3)
+#ifdef TK_FLAT_CLOCK
+    if (tid == 0) dbg[8] = s_total;
+#endif
+    if (lane < R) {
+        out_idx[lane] = (int64_t)(((uint64_t)H.hi << 32) | H.lo);
+        out_val[lane] = H.v;
+    }
+}
+
+void tk_launch_flat_top_one(const uint4 *dist, const uint8_t *mins, int chunks, int h, int64_t n, int R, int signd,
+                            uint4 *cdist, int *cblock, int64_t *out_idx, int32_t *out_val, hipStream_t s)
+{
+    if (signd)
+        hipLaunchKernelGGL(flat_top_one_kernel<true>, dim3(1), dim3(1024), 0, s, dist, mins, chunks, h, n, R, cdist,
+                           cblock, out_idx, out_val);
+    else
+        hipLaunchKernelGGL(flat_top_one_kernel<false>, dim3(1), dim3(1024), 0, s, dist, mins, chunks, h, n, R, cdist,
+                           cblock, out_idx, out_val);
+}
+
+// ---------------------------------------------------------------------------
 // Lane-per-query replay (the throughput path of IVF.query batches).
 //
 // The wave-per-query kernel above spends 64 lanes on one scalar heap.  When

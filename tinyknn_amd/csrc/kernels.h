@@ -143,6 +143,13 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 // mins (optional): the scan's per-block minima, (nq, cap_min) bytes, cap_min a multiple of 16:
 // slots that start at a multiple of 16 blocks are then walked 1024 blocks per step
 
+// one query, a FRESH heap of R <= 64 entries, rows far longer than it: one workgroup — head of h blocks
+// (a multiple of 16) replayed with the heap in registers, the later blocks whose minimum is below the
+// bound reached there compacted in order, those replayed; the heap goes to out_idx / out_val (which may
+// be pinned host memory).  cdist: chunks uint4, cblock: chunks int + chunks bytes.  See heap.hip
+void tk_launch_flat_top_one(const uint4 *dist, const uint8_t *mins, int chunks, int h, int64_t n, int R, int signd,
+                            uint4 *cdist, int *cblock, int64_t *out_idx, int32_t *out_val, hipStream_t s);
+
 // Lane-per-query form of the same replay: 64 queries per wave.  Preconditions
 // (checked by the caller): heaps start fresh (-1 / 127|255), no label can repeat
 // among a query's lists (so `insert`'s duplicate test cannot fire), R*256 B of LDS
