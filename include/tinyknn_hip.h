@@ -216,9 +216,10 @@ int tk_index_join(tk_index *ix, void *stream);
  * k / n_probes / pass_1 / stream run through the pipeline as ONE batch of nq_a + nq_b queries.
  * The kernels that leave most of the chip idle (two heap replays of 157 dependent waves per
  * 10 000 queries, the small kernels of the coarse stage) take as long for 20 000 queries as for
- * 10 000.  The first call copies its queries into the index's staging rows and returns; the second
- * appends its rows and enqueues the pair; each call's ids are copied to its own buffers (and its
- * completion event recorded) behind the pair's last kernel.  Results are those of separate calls
+ * 10 000.  The first call is held and returns; the second joins it and enqueues the pair.  Nothing is
+ * copied: the kernels read each call's queries from, and write its ids to, the call's own buffers
+ * (which stay the library's until tk_index_join, as above); each call's completion event is recorded
+ * behind the pair's last kernel.  Results are those of separate calls
  * (the same kernels over the same rows).  A held call is launched alone by tk_index_join /
  * tk_index_quiesce / any tk_index_set_*, or when the next call cannot join it.  n = 1 (default):
  * every call its own batch.  ivf.py:106-163 answers one query per call; the batch forms here and

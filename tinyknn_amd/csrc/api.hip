@@ -611,8 +611,7 @@ struct Work {
         c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage, pos_lens, pos_off,
         qlim, slot_exact, p_count, p_cursor, p_pair_off, p_unit_prefix, p_pair_q, p_pair_f0, flag_list, p_unit_desc,
         plain0, h_count, h_cursor, h_pair_off, h_unit_prefix, h_pair_q, h_pair_f0,   // plain_scan.hip
-        plain_q,                                                                       // two-phase sharded scan
-        q_stage, qpq_stage, out_stage;                                                 // coalesced calls (tk_index_set_coalesce)
+        plain_q;                                                                       // two-phase sharded scan
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -644,7 +643,7 @@ struct Work {
                        &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage, &pos_lens, &pos_off,
                        &qlim, &slot_exact, &p_count, &p_cursor, &p_pair_off, &p_unit_prefix, &p_pair_q, &p_pair_f0, &flag_list, &p_unit_desc,
                        &plain0, &h_count, &h_cursor, &h_pair_off, &h_unit_prefix, &h_pair_q, &h_pair_f0,
-                       &plain_q, &q_stage, &qpq_stage, &out_stage};
+                       &plain_q};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -1249,13 +1248,13 @@ static bool coarse_units(const tk_index *ix, int64_t nq)
 }
 
 static int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_t nq,
-                        hipStream_t st, Prof &pf, bool plain = false)
+                        hipStream_t st, Prof &pf, bool plain = false, TkSecond qpq2 = TkSecond())
 {
     TRY(pf.mark(st));
     // 1. distance tables                                   fast_pq.py:186-222
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
                            qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>(), w.shift.p,
-                           w.scale.as<double>(), st);
+                           w.scale.as<double>(), st, qpq2);
     if (plain)      // per query: below which value clamp(plain sum) is the saturated value
         tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st, ix->opt_plain_limit);
     if (coarse_units(ix, nq))
@@ -1365,7 +1364,7 @@ static void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p,
 // (or NULL); with `owner` only the lists owned by `me` are counted (list-sharded index).
 // `probes_out`: (nq, kc) int64, the probe lists (ivf.py:131) — w.probes, or a caller's buffer.
 static int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
-                                int64_t *probes_out, hipStream_t st, Prof &pf)
+                                int64_t *probes_out, hipStream_t st, Prof &pf, TkSecond q2 = TkSecond())
 {
     TRY(pf.mark(st));
     // positions of one list against a fresh heap are distinct labels: lane-per-query
@@ -1395,7 +1394,7 @@ static int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64
     }
     TRY(pf.mark(st));
     tk_launch_rescore(q_dev, 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
-                      w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0, probes_out, nullptr, st, ix->opt_rescore_form);
+                      w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0, probes_out, nullptr, st, ix->opt_rescore_form, q2);
     return TK_OK;
 }
 
@@ -1438,9 +1437,9 @@ static void unit_pairs(tk_index *ix, Work &w, int64_t nq, const Plan &p, bool pl
 
 static int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
                              int *pair_count, const int *owner, int me, hipStream_t st, Prof &pf,
-                             bool plain = false)
+                             bool plain = false, TkSecond q2 = TkSecond())
 {
-    TRY(coarse_replay_probes(ix, w, q_dev, nq, p, w.probes.as<int64_t>(), st, pf));
+    TRY(coarse_replay_probes(ix, w, q_dev, nq, p, w.probes.as<int64_t>(), st, pf, q2));
     coarse_slots(ix, w, w.probes.as<int64_t>(), nq, p, pair_count, owner, me, st, plain);
     return TK_OK;
 }
@@ -1465,7 +1464,8 @@ static void rescan_flagged(tk_index *ix, Work &w, int64_t q0, int64_t nq, const 
 }
 
 static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq, int k,
-                      const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf, bool plain = false)
+                      const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf, bool plain = false,
+                      TkSecond q2 = TkSecond(), TkSecond out2 = TkSecond())
 {
     const int *slot_exact = plain ? w.plain0.as<int>() + q0 : nullptr;     // (first plain chunk per query)
     const int *qlim = plain ? w.qlim.as<int>() + q0 : nullptr;
@@ -1531,7 +1531,7 @@ static int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int
     TRY(pf.mark(st));
     // 4. strip sentinels, exact rescoring                   ivf.py:154-163
     tk_launch_rescore(q_dev, 0, ix->d, ix->data.p, ix->data_is_f64, ix->N, w.heap_idx.as<int64_t>(), p.R, nq, k, 1,
-                      out_dev, nullptr, st, ix->opt_rescore_form);
+                      out_dev, nullptr, st, ix->opt_rescore_form, q2, out2);
     TRY(pf.mark(st));
     return TK_OK;
 }
@@ -1570,16 +1570,19 @@ struct Pending {
     hipEvent_t user_ev;     // recorded behind that copy (or NULL)
     Prof pf;
     hipStream_t st, sf, sl;   // scans (+ tables) / coarse replay + descriptors / replay + rescoring
-    // coalesced calls: the batch is the rows of n_subs calls, staged back to back in the workspace;
-    // each call's ids leave from the workspace's output rows to its own buffers
+    // coalesced calls: the batch is the rows of n_subs calls, each read from and written to the call's
+    // OWN buffers (no staging copies: the three kernels that touch them take a second base pointer)
     struct Sub {
         int64_t *out_dev;
         int64_t nq;
         int64_t *host_out;
         bool host_out_kernel;
         hipEvent_t user_ev;
+        const float *q_dev;
+        const void *qpq_dev;
     } subs[2];
     int n_subs = 0;
+    TkSecond q2, qpq2, out2;   // rows of the second call (empty: one call)
 };
 
 // depth == 1
@@ -1593,10 +1596,10 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
     b.units = use_units(ix, b.nq, p);
     b.plain = b.units && plain_now(ix, p);
     w.last_plain = b.plain;
-    TRY(stage_tables(ix, w, qpq_dev, qpq_f64, b.nq, st, b.pf, b.plain));
+    TRY(stage_tables(ix, w, qpq_dev, qpq_f64, b.nq, st, b.pf, b.plain, b.qpq2));
     launch_coarse_scan(ix, w, b.nq, p, st);
     TRY(stage_coarse_rest(ix, w, b.q_dev, b.nq, p, b.units ? w.u_count.as<int>() : nullptr, nullptr,
-                          0, st, b.pf, b.plain));
+                          0, st, b.pf, b.plain, b.q2));
     if (b.units) unit_pairs(ix, w, b.nq, p, b.plain, st);
     TRY(b.pf.mark(st));
     // 3. probed lists through ONE heap, in probe order      ivf.py:135-150
@@ -1623,7 +1626,7 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
                               (int)p.cap, w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(),
                               p.cap_min, 1, ix->order, st);
     TRY(b.pf.mark(st));
-    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf, b.plain));
+    TRY(stage_back(ix, w, b.q_dev, 0, b.nq, b.k, p, b.out_dev, st, b.pf, b.plain, b.q2, b.out2));
     TRY(batch_epilogue(b, st));
     HIPCHECK(hipGetLastError());
     return TK_OK;
@@ -1698,7 +1701,7 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
         HIPCHECK(hipEventRecord(prev->w->scanned, st));
         HIPCHECK(hipStreamWaitEvent(prev->sl, prev->w->scanned, 0));
         TRY(stage_back(ix, *prev->w, prev->q_dev, 0, prev->nq, prev->k, prev->p, prev->out_dev,
-                       prev->sl, prev->pf, prev->plain));
+                       prev->sl, prev->pf, prev->plain, prev->q2, prev->out2));
         TRY(batch_epilogue(*prev, prev->sl));
         HIPCHECK(hipEventRecord(prev->w->done, prev->sl));
         prev->w->busy = true;
@@ -1715,7 +1718,7 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
             HIPCHECK(hipStreamWaitEvent(cur->sf, w.coarse_scanned, 0));
         }
         TRY(stage_coarse_rest(ix, w, cur->q_dev, cur->nq, cur->p, cur->units ? w.u_count.as<int>() : nullptr,
-                              nullptr, 0, cur->sf, cur->pf, cur->plain));
+                              nullptr, 0, cur->sf, cur->pf, cur->plain, cur->q2));
         if (cur->units) unit_pairs(ix, w, cur->nq, cur->p, cur->plain, cur->sf);
         HIPCHECK(hipEventRecord(w.front_done, cur->sf));
         w.fd_seq = ++ix->ev_seq;
@@ -1750,17 +1753,13 @@ static int pipeline_advance(tk_index *ix, bool drain)
 static int batch_epilogue(const Pending &b, hipStream_t st)
 {
     if (b.n_subs > 0) {
-        int64_t row = 0;
-        for (int i = 0; i < b.n_subs; i++) {
+        for (int i = 0; i < b.n_subs; i++) {      // (the rescoring wrote each call's ids to its own buffer)
             const Pending::Sub &u = b.subs[i];
-            const int64_t *src = b.out_dev + row * b.k;
-            tk_launch_copy_words(src, u.nq * b.k, u.out_dev, st);
             if (u.host_out && u.host_out_kernel)
-                tk_launch_copy_words(src, u.nq * b.k, u.host_out, st);
+                tk_launch_copy_words(u.out_dev, u.nq * b.k, u.host_out, st);
             else if (u.host_out)
-                HIPCHECK(hipMemcpyAsync(u.host_out, src, (size_t)u.nq * b.k * 8, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipMemcpyAsync(u.host_out, u.out_dev, (size_t)u.nq * b.k * 8, hipMemcpyDeviceToHost, st));
             if (u.user_ev) HIPCHECK(hipEventRecord(u.user_ev, st));
-            row += u.nq;
         }
         return TK_OK;
     }
@@ -1829,7 +1828,7 @@ static int pipe_launch(tk_index *ix, Pending &b, const void *qpq, int q_pq_is_f6
     b.plain = b.units && plain_now(ix, p);
     w.last_plain = b.plain;
     TK_DBG_SYNC("launch: reserved");
-    TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, stt, b.pf, b.plain));
+    TRY(stage_tables(ix, w, qpq, q_pq_is_f64, b.nq, stt, b.pf, b.plain, b.qpq2));
     HIPCHECK(hipEventRecord(w.tables_done, stt));
     w.td_seq = ++ix->ev_seq;
     TK_DBG_SYNC("launch: tables");
@@ -1843,29 +1842,15 @@ static int pipe_launch(tk_index *ix, Pending &b, const void *qpq, int q_pq_is_f6
 // The kernels that leave most of the chip idle — the two heap replays (157 waves of 64 queries for
 // 10 000 queries, a dependent chain per wave), the nine small kernels of the front stream — take as
 // long for 20 000 queries as for 10 000, and the plain kernel's tiles fill better with twice the
-// pairs per list.  The first call of a pair only copies its queries into the workspace's staging
-// rows (on the stream its table build would have run on) and is HELD; the second call appends its
-// rows and the pair runs through the pipeline as one batch of nq_a + nq_b queries, whose result
-// rows are copied out to each call's own buffers (and completion event) behind the last kernel.
+// pairs per list.  The first call of a pair is only HELD; the second call joins it and the pair runs
+// through the pipeline as one batch of nq_a + nq_b queries.  Nothing is copied: the three kernels
+// that touch the callers' buffers (table build, the two rescorings) take a second base pointer for
+// the rows of the second call, and each call's ids are written straight to its own buffer (its
+// pinned copy and completion event follow behind the last kernel).  The buffers of a call are the
+// caller's until tk_index_join, as in the pipelined mode without pairs (tinyknn_hip.h).
 // Same kernels on the same rows: results do not change.  A held call is launched alone by
 // tk_index_join / quiesce / set_* and when the next call cannot join it (other k / n_probes /
 // pass_1 / stream, or too many rows).
-static int stage_inputs(tk_index *ix, Work &w, int64_t row0, const float *q_dev, const void *q_pq_dev,
-                        int q_pq_is_f64, int64_t nq, hipStream_t stt)
-{
-    const size_t esz = q_pq_is_f64 ? 8 : 4;
-    float *qdst = w.q_stage.as<float>() + row0 * ix->d;
-    if (((nq * ix->d) & 1) == 0 && ((uintptr_t)qdst & 7) == 0 && ((uintptr_t)q_dev & 7) == 0)
-        tk_launch_copy_words(q_dev, nq * ix->d / 2, qdst, stt);      // (8-byte words, by a kernel: no copy-engine command between dispatches)
-    else
-        HIPCHECK(hipMemcpyAsync(qdst, q_dev, (size_t)nq * ix->d * 4, hipMemcpyDeviceToDevice, stt));
-    const size_t qb = (size_t)nq * ix->dq * esz;      // (dq is even: a multiple of 8 bytes)
-    TK_DBG_SYNC("stage_inputs q");
-    tk_launch_copy_words(q_pq_dev, (int64_t)(qb / 8), (char *)w.qpq_stage.p + (size_t)row0 * ix->dq * esz, stt);
-    TK_DBG_SYNC("stage_inputs qpq");
-    return TK_OK;
-}
-
 static int launch_held(tk_index *ix)
 {
     Pending *h = ix->held;
@@ -1876,11 +1861,16 @@ static int launch_held(tk_index *ix)
     int64_t rows = 0;
     for (int i = 0; i < b.n_subs; i++) rows += b.subs[i].nq;
     b.nq = rows;
-    b.q_dev = b.w->q_stage.as<float>();
-    TRY(b.w->out_stage.ensure((size_t)rows * b.k * 8));
-    b.out_dev = b.w->out_stage.as<int64_t>();
+    b.q_dev = b.subs[0].q_dev;
+    b.out_dev = b.subs[0].out_dev;
+    if (b.n_subs == 2) {
+        const int64_t n_a = b.subs[0].nq;
+        b.q2 = TkSecond{b.subs[1].q_dev, n_a};
+        b.qpq2 = TkSecond{b.subs[1].qpq_dev, n_a};
+        b.out2 = TkSecond{b.subs[1].out_dev, n_a};
+    }
     TK_DBG_SYNC("launch_held");
-    int r_ = pipe_launch(ix, b, b.w->qpq_stage.p, ix->held_f64, ix->held_stt);
+    int r_ = pipe_launch(ix, b, b.subs[0].qpq_dev, ix->held_f64, ix->held_stt);
     TK_DBG_SYNC("launch_held done");
     return r_;
 }
@@ -1889,7 +1879,7 @@ static int coalesce_call(tk_index *ix, const Plan &p, const float *q_dev, const 
                          int64_t nq, int k, int n_probes, int pass_1, int64_t *out_ids_dev,
                          int64_t *out_ids_pinned, hipEvent_t done_ev, hipStream_t caller)
 {
-    const Pending::Sub sub{out_ids_dev, nq, out_ids_pinned, ix->host_out_kernel, done_ev};
+    const Pending::Sub sub{out_ids_dev, nq, out_ids_pinned, ix->host_out_kernel, done_ev, q_dev, q_pq_dev};
     if (ix->held) {
         Pending &h = *ix->held;
         const bool joins = h.k == k && ix->held_n_probes == n_probes && ix->held_pass_1 == pass_1 &&
@@ -1901,7 +1891,6 @@ static int coalesce_call(tk_index *ix, const Plan &p, const float *q_dev, const 
                 HIPCHECK(hipEventRecord(ix->ev_in, caller));
                 HIPCHECK(hipStreamWaitEvent(stt, ix->ev_in, 0));
             }
-            TRY(stage_inputs(ix, *h.w, h.subs[0].nq, q_dev, q_pq_dev, q_pq_is_f64, nq, stt));
             h.subs[1] = sub;
             h.n_subs = 2;
             return launch_held(ix);
@@ -1926,12 +1915,8 @@ static int coalesce_call(tk_index *ix, const Plan &p, const float *q_dev, const 
     b.n_subs = 1;
     hipStream_t stt = nullptr;
     TRY(pipe_begin(ix, b, caller, stt));
-    const size_t esz = q_pq_is_f64 ? 8 : 4;
     const int64_t ms = sub_batch(p);
     const int64_t rows = 2 * nq <= ms ? 2 * nq : nq;
-    TRY(w.q_stage.ensure((size_t)rows * ix->d * 4 + 8));
-    TRY(w.qpq_stage.ensure((size_t)rows * ix->dq * esz + 8));
-    TRY(stage_inputs(ix, w, 0, q_dev, q_pq_dev, q_pq_is_f64, nq, stt));
     ix->held = new Pending(b);
     ix->held_n_probes = n_probes;
     ix->held_pass_1 = pass_1;

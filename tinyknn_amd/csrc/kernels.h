@@ -191,9 +191,16 @@ void tk_launch_heap_insert(int64_t *heap_idx, int32_t *heap_val, int R, int64_t 
                            int is, hipStream_t s);
 
 // Distance tables (fast_pq.py:186-252).  q: (nq, dq) float or double.
+// Rows of a batch made of two calls (tk_index_set_coalesce): rows [n_a, nq) live in a second buffer
+// whose row 0 is row n_a of the batch.  Empty (b == nullptr): one buffer.
+struct TkSecond {
+    const void *b = nullptr;
+    int64_t n_a = 0;
+};
+
 void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, const void *q,
                             int q_is_f64, int64_t nq, double aux0, double aux1, int signd,
-                            uint8_t *tables, void *shift, double *scale, hipStream_t s);
+                            uint8_t *tables, void *shift, double *scale, hipStream_t s, TkSecond q2 = TkSecond());
 
 // Exact rescoring + ascending top-k.
 // cand: (nq, R) int64 candidate ids (heap order).  strip: drop -1 entries first
@@ -204,7 +211,8 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
 // q / rows: float32 or float64 (flags); float64 arithmetic if either is float64.
 void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
                        int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
-                       int64_t *out, int *out_count, hipStream_t s, int form = 2);
+                       int64_t *out, int *out_count, hipStream_t s, int form = 2, TkSecond q2 = TkSecond(),
+                       TkSecond out2 = TkSecond());
 
 // probes (nq, kc) list ids -> per-slot scan descriptors; pair_count (n_lists, zeroed, or
 // NULL) receives the number of (query, slot) pairs per list — with `owner` (n_lists ranks,

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(128) void rescore_kernel(const TX *__restrict__ q, 
                                                       int64_t n_rows,
                                                       const int64_t *__restrict__ cand, int R,
                                                       int k, int strip, int64_t *__restrict__ out,
-                                                      int *__restrict__ out_count)
+                                                      int *__restrict__ out_count, const TX *__restrict__ q_b,
+                                                      int64_t q_na, int64_t *__restrict__ out_b, int64_t out_na)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int64_t *cs = (int64_t *)smem;
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(128) void rescore_kernel(const TX *__restrict__ q, 
     const int64_t qi = blockIdx.x;
     const int64_t *c = cand + qi * R;
 
-    for (int t = tid; t < d; t += blockDim.x) xs[t] = (T)q[qi * d + t];
+    const TX *qrow = (q_b && qi >= q_na) ? q_b + (qi - q_na) * d : q + qi * d;   // second call of a pair
+    for (int t = tid; t < d; t += blockDim.x) xs[t] = (T)qrow[t];
     // ordered compaction of the candidate ids (ivf.py:154-155 drops -1)
     if (tid < 64) {
         int base = 0;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(128) void rescore_kernel(const TX *__restrict__ q, 
     }
     __syncthreads();
     const int nc = s_count;
-    int64_t *o = out + qi * k;
+    int64_t *o = (out_b && qi >= out_na) ? out_b + (qi - out_na) * k : out + qi * k;
     if (nc <= k) {  // ivf.py:158-159 / fast_pq.py:307-308: heap order, no rescoring
         for (int t = tid; t < k; t += blockDim.x) o[t] = t < nc ? cs[t] : -1;
         if (tid == 0 && out_count) out_count[qi] = nc;
@@ -173,7 +175,9 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
                                                             int64_t n_rows,
                                                             const int64_t *__restrict__ cand, int R,
                                                             int k, int strip, int64_t *__restrict__ out,
-                                                            int *__restrict__ out_count, int stride4)
+                                                            int *__restrict__ out_count, int stride4,
+                                                            const float *__restrict__ q_b, int64_t q_na,
+                                                            int64_t *__restrict__ out_b, int64_t out_na)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int64_t *cs = (int64_t *)smem;
@@ -183,7 +187,8 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.x;
     const int64_t *c = cand + qi * R;
-    for (int t = tid; t < d; t += 64) xs[t] = q[qi * d + t];
+    const float *qrow = (q_b && qi >= q_na) ? q_b + (qi - q_na) * d : q + qi * d;   // second call of a pair
+    for (int t = tid; t < d; t += 64) xs[t] = qrow[t];
     // ordered compaction of the candidate ids (ivf.py:154-155 drops -1)
     int nc = 0;
     for (int t0 = 0; t0 < R; t0 += 64) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
         nc += __builtin_popcountll(m);
     }
     __syncthreads();
-    int64_t *o = out + qi * k;
+    int64_t *o = (out_b && qi >= out_na) ? out_b + (qi - out_na) * k : out + qi * k;
     if (nc <= k) {  // ivf.py:158-159 / fast_pq.py:307-308: heap order, no rescoring
         for (int t = tid; t < k; t += 64) o[t] = t < nc ? cs[t] : -1;
         if (tid == 0 && out_count) out_count[qi] = nc;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
 
 void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
                        int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
-                       int64_t *out, int *out_count, hipStream_t s, int form)
+                       int64_t *out, int *out_count, hipStream_t s, int form, TkSecond q2, TkSecond out2)
 {
     if (nq == 0 || k == 0) return;
     const bool dbl = q_is_f64 || rows_is_f64;   // numpy promotes `Y - x` to float64
@@ -273,29 +278,31 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
         if (slds <= 64 * 1024) {
             if (tile_rows == 32)
                 hipLaunchKernelGGL(rescore_staged_kernel<32>, grid, dim3(64), slds, s, (const float *)q, d,
-                                   (const float *)rows, n_rows, cand, R, k, strip, out, out_count, stride4);
+                                   (const float *)rows, n_rows, cand, R, k, strip, out, out_count, stride4,
+                                   (const float *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
             else
                 hipLaunchKernelGGL(rescore_staged_kernel<64>, grid, dim3(64), slds, s, (const float *)q, d,
-                                   (const float *)rows, n_rows, cand, R, k, strip, out, out_count, stride4);
+                                   (const float *)rows, n_rows, cand, R, k, strip, out, out_count, stride4,
+                                   (const float *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
             return;
         }
     }
     if (!dbl)
         hipLaunchKernelGGL((rescore_kernel<float, float, float>), grid, block, lds, s,
                            (const float *)q, d, (const float *)rows, n_rows, cand, R, k, strip, out,
-                           out_count);
+                           out_count, (const float *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
     else if (rows_is_f64 && q_is_f64)
         hipLaunchKernelGGL((rescore_kernel<double, double, double>), grid, block, lds, s,
                            (const double *)q, d, (const double *)rows, n_rows, cand, R, k, strip,
-                           out, out_count);
+                           out, out_count, (const double *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
     else if (rows_is_f64)
         hipLaunchKernelGGL((rescore_kernel<double, double, float>), grid, block, lds, s,
                            (const float *)q, d, (const double *)rows, n_rows, cand, R, k, strip, out,
-                           out_count);
+                           out_count, (const float *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
     else
         hipLaunchKernelGGL((rescore_kernel<double, float, double>), grid, block, lds, s,
                            (const double *)q, d, (const float *)rows, n_rows, cand, R, k, strip, out,
-                           out_count);
+                           out_count, (const double *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
 }
 
 // ---------------------------------------------------------------------------

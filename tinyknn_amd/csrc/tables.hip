@@ -112,7 +112,8 @@ template <typename T, bool SIGNED>
 __global__ __launch_bounds__(256) void build_tables_kernel(
     const float *__restrict__ centers, int dq, int dpb, int f_order, const T *__restrict__ qs,
     double aux0, double aux1, uint8_t *__restrict__ tables, T *__restrict__ shift_out,
-    double *__restrict__ scale_out, int64_t nq, int wave_lds, const PwProgram pw)
+    double *__restrict__ scale_out, int64_t nq, int wave_lds, const PwProgram pw,
+    const T *__restrict__ qs_b, int64_t n_a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
     const int64_t qraw = (int64_t)blockIdx.x * waves + wave;
     if (qraw >= nq) return;                     // (no workgroup barrier below)
     const int64_t qi = qraw;
-    const T *q = qs + qi * dq;
+    const T *q = (qs_b && qi >= n_a) ? qs_b + (qi - n_a) * dq : qs + qi * dq;   // second call of a pair
     constexpr int MAXDPB = 32;
     T diff[MAXDPB];
 
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
 
 void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, const void *q,
                             int q_is_f64, int64_t nq, double aux0, double aux1, int signd,
-                            uint8_t *tables, void *shift, double *scale, hipStream_t s)
+                            uint8_t *tables, void *shift, double *scale, hipStream_t s, TkSecond q2)
 {
     if (nq == 0) return;
     const int M = dq / dpb;
@@ -271,19 +272,22 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
         if (signd)
             hipLaunchKernelGGL((build_tables_kernel<double, true>), grid, block, lds, s, centers, dq,
                                pdpb, f_order, (const double *)q, aux0, aux1, tables,
-                               (double *)shift, scale, nq, wave_lds, pw);
+                               (double *)shift, scale, nq, wave_lds, pw,
+                               (const double *)q2.b, q2.n_a);
         else
             hipLaunchKernelGGL((build_tables_kernel<double, false>), grid, block, lds, s, centers,
                                dq, pdpb, f_order, (const double *)q, aux0, aux1, tables,
-                               (double *)shift, scale, nq, wave_lds, pw);
+                               (double *)shift, scale, nq, wave_lds, pw,
+                               (const double *)q2.b, q2.n_a);
     } else {
         if (signd)
             hipLaunchKernelGGL((build_tables_kernel<float, true>), grid, block, lds, s, centers, dq,
-                               pdpb, f_order, (const float *)q, aux0, aux1, tables, (float *)shift,
-                               scale, nq, wave_lds, pw);
+                               pdpb, f_order, (const float *)q, aux0, aux1, tables, (float *)shift, scale, nq, wave_lds, pw,
+                               (const float *)q2.b, q2.n_a);
         else
             hipLaunchKernelGGL((build_tables_kernel<float, false>), grid, block, lds, s, centers,
                                dq, pdpb, f_order, (const float *)q, aux0, aux1, tables,
-                               (float *)shift, scale, nq, wave_lds, pw);
+                               (float *)shift, scale, nq, wave_lds, pw,
+                               (const float *)q2.b, q2.n_a);
     }
 }
