@@ -28,7 +28,9 @@ PINNED = {
     ("plain_scan.hip", "scan_plain_wave_kernelILi26ELb1E"): (256, 2),
     ("plain_scan.hip", "scan_plain_wave_kernelILi16ELb1E"): (256, 2),
     # lane-per-query replay, distinct labels, 64 queries per wave
-    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64EE"): (128, 4),
+    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb0EE"): (128, 4),
+    # one query over a long array: one workgroup of 16 waves, heap in registers
+    ("heap.hip", "flat_top_one_kernelILb1EE"): (128, 4),
     ("rescore.hip", "rescore_staged_kernelILi32EE"): (128, 4),
 }
 
