@@ -201,10 +201,10 @@ int main(int argc, char **argv)
         launch();
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpyFromSymbol(st, HIP_SYMBOL(tk_plain_stamps), sizeof st));
-        const double w = (double)st[7], it = (double)st[4];
-        printf("stamps (cycles): waves %.0f, iterations %.0f (%.1f per wave); per iteration: stage+fetch %.0f, LDS+MFMA %.0f, "
-               "epilogue+stores %.0f; per wave: in units %.0f (prologues %.0f), kernel %.0f\n",
-               w, it, it / w, st[1] / it, st[2] / it, st[3] / it, st[5] / w, st[0] / w, st[6] / w);
+        const double it = (double)st[6], w = 2048.0;
+        printf("stamps, cycles per chunk pair and wave (%.0f chunk pairs, %.1f per wave): staging + fetch %.0f | LDS reads + MFMA chain + clamp %.0f | "
+               "pack + swaps + LDS tile %.0f | flush %.0f | unit prologue %.0f | between units %.0f || per wave: kernel %.0f\n",
+               it, it / w, st[1] / it, st[2] / it, st[3] / it, st[4] / it, st[0] / it, st[5] / it, st[7] / w);
     }
 #endif
     // ---- check every byte against the host

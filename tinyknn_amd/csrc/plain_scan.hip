@@ -62,6 +62,17 @@ __device__ unsigned long long tk_plain_clock[4];
 #define TK_CLOCK_BEGIN()
 #define TK_CLOCK_END()
 #endif
+#ifdef TK_PLAIN_STAMPS      // scripts/micro only: where a wave's cycles go (s_memtime between the phases)
+__device__ unsigned long long tk_plain_stamps[8];
+#define TK_STAMP(i)                                                   \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        stamp_acc[i] += now_ - stamp_last;                            \
+        stamp_last = now_;                                            \
+    } while (0)
+#else
+#define TK_STAMP(i)
+#endif
 
 // ---------------------------------------------------------------------------
 // C of the lemma per query, or TK_PLAIN_NEVER when a chain's negative mass exceeds 128
@@ -159,6 +170,10 @@ __global__ __launch_bounds__(256, 2) void scan_plain_wave_kernel(TkScanJob j, in
 {
     if (EXACT) P = PT;          // (P < PT: the block pairs past P get zero table rows)
     TK_CLOCK_BEGIN();
+#ifdef TK_PLAIN_STAMPS
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_readcyclecounter(), stamp_it = 0;
+    const unsigned long long stamp_k0 = stamp_last;
+#endif
     using SH = PlainWaveShape<PT>;
     constexpr int PS = SH::PS;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem_plain[];
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void scan_plain_wave_kernel(TkScanJob j, in
     const uint32_t *rd = st + ((r >> 4) * 4 + (rr >> 2)) * PS;
 
     ticketed_blocks(n_units, ticket, [&](int u) {
+        TK_STAMP(5);        // between units: ticket
         const int4 d = ((const int4 *)j.unit_desc4)[u];
         const int l = __builtin_amdgcn_readfirstlane(d.x), t = __builtin_amdgcn_readfirstlane(d.y);
         const int cpa = __builtin_amdgcn_readfirstlane(d.z), cpb = __builtin_amdgcn_readfirstlane(d.w);
@@ -249,7 +265,9 @@ __global__ __launch_bounds__(256, 2) void scan_plain_wave_kernel(TkScanJob j, in
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
+        TK_STAMP(0);        // unit prologue: descriptor, pair records, table rows, first code groups
         auto chunk_pair = [&](int cp) {
+            TK_STAMP(1);    // staging stores + next fetch issued
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // (the staging region is rewritten one iteration later, after this iteration's reads:
@@ -281,6 +299,11 @@ __global__ __launch_bounds__(256, 2) void scan_plain_wave_kernel(TkScanJob j, in
             int o[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) o[i] = clamp8(acc[i]);
+#ifdef TK_PLAIN_STAMPS
+            asm volatile("s_nop 0" ::"v"(o[15]));
+            TK_STAMP(2);    // LDS reads + MFMA chain + clamp
+            stamp_it++;
+#endif
             uint32_t X = pack4(o[0], o[1], o[2], o[3]), Y = pack4(o[4], o[5], o[6], o[7]);
             uint32_t Z = pack4(o[8], o[9], o[10], o[11]), W = pack4(o[12], o[13], o[14], o[15]);
             uint32_t mA = (uint32_t)min(min(min(o[0], o[1]), min(o[2], o[3])), min(min(o[4], o[5]), min(o[6], o[7])));
@@ -294,7 +317,9 @@ __global__ __launch_bounds__(256, 2) void scan_plain_wave_kernel(TkScanJob j, in
             const int slot = (2 * cp + h) & 7;
             otile[r * 9 + slot] = make_uint4(X, Z, Y, W);
             omin[r * 8 + slot] = (uint8_t)mn;
+            TK_STAMP(3);    // pack, swaps, LDS tile
             if ((cp & 3) == 3) flush(cp >> 2);
+            TK_STAMP(4);    // flush (every fourth)
         };
         // Two code groups in flight, in two named registers (no rotation by moves: a move of the
         // younger group would wait for it); iterations go in pairs, the first pair peeled (see the
@@ -325,8 +350,16 @@ __global__ __launch_bounds__(256, 2) void scan_plain_wave_kernel(TkScanJob j, in
             cp++;
         }
         if ((cp & 3) != 0) flush((cp - 1) >> 2);      // (a unit that ends inside a group of four)
+        TK_STAMP(4);
     });
     TK_CLOCK_END();
+#ifdef TK_PLAIN_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd(&tk_plain_stamps[i], stamp_acc[i]);
+        atomicAdd(&tk_plain_stamps[6], stamp_it);
+        atomicAdd(&tk_plain_stamps[7], (unsigned long long)__builtin_readcyclecounter() - stamp_k0);
+    }
+#endif
 }
 
 int tk_plain_fits(int M) { return M >= 2 && M % 2 == 0 && M / 2 <= 26; }
