@@ -150,7 +150,7 @@ class OracleShardEngine:
         buf = scan_buf.numpy().reshape(self.world, capacity * 16)
         b = bound.numpy()
         qh = -(-len(qn) // self.world)
-        cap = probes.shape[1] * int(self.chunks.max())                  # Plan.cap (api.hip make_plan)
+        cap = probes.shape[1] * int(self.chunks.max())                  # Plan.cap (api_index.hip make_plan)
         prefix = np.concatenate([np.zeros((len(qn), 1), np.int64),
                                  np.cumsum(self.chunks[probes], axis=1)], axis=1)
         per_home = [[] for _ in range(self.world)]
