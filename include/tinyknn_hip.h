@@ -278,7 +278,9 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
  * _fast_pq.pyx:101-307 are nogil and re-entrant).  Results never depend on an option; they exist for
  * A/B measurements and for the tests.
  *   TK_OPT_SCAN_FORM     table rows of the exact list-major kernel: 0 = per-lane global loads (DEFAULT;
- *                        fastest, profiles/r02_scan_forms.md), 1 / 2 = staged per block in LDS
+ *                        fastest, profiles/r02_scan_forms.md), 1 / 2 = staged per block in LDS (a launch
+ *                        that carries the exact heads of a plain batch always runs form 0: only that
+ *                        form knows row limits)
  *   TK_OPT_RESCORE_FORM  candidate rows of the rescoring: 2 = staged through LDS in tiles of 32 rows
  *                        (DEFAULT), 1 = tiles of 64, 0 = every lane walks its own row (always for float64
  *                        operands and d % 4 != 0)
