@@ -335,6 +335,17 @@ class ListShardedIndex:
         # by batch: what a sharded batch costs beyond the unsharded one is its own kernels (positions,
         # unpack, the exact scan of every list), not the stream structure.  Off by default;
         # TINYKNN_SHARD_ROLES=1 selects it.
+        # One communicator per batch in flight.  torch runs every collective of a process group on that
+        # group's ONE internal RCCL stream, in call order: with a single group the probe all-gather of
+        # batch b+1 queues behind the id all-gather of batch b, which waits for b's replay and rescoring
+        # — the batches "in flight" ran one after the other.  A group per slot lets their exchanges
+        # overlap; every rank issues the same sequence on each group.
+        self._slot_groups = None
+        self._cg = group
+        if (on and depth > 1 and self.backend == "nccl" and (self.world > 1 or self.force) and
+                os.environ.get("TINYKNN_SHARD_COMMS", "1") != "0"):
+            ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+            self._slot_groups = [dist.new_group(ranks=ranks, backend="nccl") for _ in range(depth)]
         self._roles = None
         if self._streams is not None and os.environ.get("TINYKNN_SHARD_ROLES", "0") == "1":
             self._roles = dict(front=torch.cuda.Stream(), scan=torch.cuda.Stream(),
@@ -392,30 +403,30 @@ class ListShardedIndex:
         if self.world == 1 and not self.force:
             recv.copy_(send)
         elif self.backend == "nccl" or self.device == "cpu":
-            self.dist.all_to_all_single(recv, send, group=self.group)
+            self.dist.all_to_all_single(recv, send, group=self._cg)
         else:
             r, s_ = self.torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
-            self.dist.all_to_all_single(r, s_, group=self.group)
+            self.dist.all_to_all_single(r, s_, group=self._cg)
             recv.copy_(r)
 
     def _all_gather(self, out, inp):
         if self.world == 1 and not self.force:
             out.copy_(inp)
         elif self.backend == "nccl" or self.device == "cpu":
-            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+            self.dist.all_gather_into_tensor(out, inp, group=self._cg)
         else:
             o = self.torch.empty(out.shape, dtype=out.dtype)
-            self.dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            self.dist.all_gather_into_tensor(o, inp.cpu(), group=self._cg)
             out.copy_(o)
 
     def _all_reduce_min(self, t_):
         if self.world == 1 and not self.force:
             return
         if self.backend == "nccl" or self.device == "cpu":
-            self.dist.all_reduce(t_, op=self.dist.ReduceOp.MIN, group=self.group)
+            self.dist.all_reduce(t_, op=self.dist.ReduceOp.MIN, group=self._cg)
         else:
             h = t_.cpu()
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN, group=self.group)
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN, group=self._cg)
             t_.copy_(h)
 
     def _all_to_all_rows(self, recv, send, rsplit, ssplit):
@@ -423,10 +434,10 @@ class ListShardedIndex:
         if self.world == 1 and not self.force:
             recv.copy_(send)
         elif self.backend == "nccl" or self.device == "cpu":
-            self.dist.all_to_all_single(recv, send, rsplit, ssplit, group=self.group)
+            self.dist.all_to_all_single(recv, send, rsplit, ssplit, group=self._cg)
         else:
             r = self.torch.empty(recv.shape, dtype=recv.dtype)
-            self.dist.all_to_all_single(r, send.cpu(), rsplit, ssplit, group=self.group)
+            self.dist.all_to_all_single(r, send.cpu(), rsplit, ssplit, group=self._cg)
             recv.copy_(r)
 
     def _filtered_buffers(self, slot, nq, capacity, region=0):
@@ -588,6 +599,7 @@ class ListShardedIndex:
         nq = qn.shape[0]
         slot = self._calls % self.depth
         self._calls += 1
+        self._cg = self._slot_groups[slot] if self._slot_groups else self.group
         b = self._buffers(slot, nq, k, capacity)
         qh = -(-nq // self.world)
         b["flag"].zero_()
@@ -631,6 +643,7 @@ class ListShardedIndex:
 
     def _enqueue_back(self, st):
         if st["f"] is not None:
+            self._cg = self._slot_groups[st["slot"]] if self._slot_groups else self.group
             b, qn, k = st["b"], st["qn"], st["k"]
             qh = -(-qn.shape[0] // self.world)
             rrec, n_r = self._filtered_back(qn, st["f"])
@@ -775,6 +788,7 @@ class ListShardedIndex:
         slot = self._calls % self.depth
         n = self._calls
         self._calls += 1
+        self._cg = self._slot_groups[slot] if self._slot_groups else self.group
         b = self._buffers(slot, nq, k, cap)
         qh = -(-nq // self.world)
         cur = t.cuda.current_stream()
