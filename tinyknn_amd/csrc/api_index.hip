@@ -603,7 +603,8 @@ void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStr
 // (or NULL); with `owner` only the lists owned by `me` are counted (list-sharded index).
 // `probes_out`: (nq, kc) int64, the probe lists (ivf.py:131) — w.probes, or a caller's buffer.
 int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
-                                int64_t *probes_out, hipStream_t st, Prof &pf, TkSecond q2)
+                                int64_t *probes_out, hipStream_t st, Prof &pf, TkSecond q2,
+                                const TkSlotsOut *slots, int *slots_written)
 {
     TRY(pf.mark(st));
     // positions of one list against a fresh heap are distinct labels: lane-per-query
@@ -632,22 +633,50 @@ int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64_t nq, 
                               w.cheap_val.as<int32_t>(), p.rescore, 1, 1, nullptr, st);
     }
     TRY(pf.mark(st));
-    tk_launch_rescore(q_dev, 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
-                      w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0, probes_out, nullptr, st, ix->opt_rescore_form, q2);
+    const int fused = tk_launch_rescore(q_dev, 0, ix->d, ix->active_centers.p, 0, ix->n_lists,
+                                        w.cheap_idx.as<int64_t>(), p.rescore, nq, p.kc, 0, probes_out, nullptr, st,
+                                        ix->opt_rescore_form, q2, TkSecond(), slots);
+    if (slots_written) *slots_written = fused;
     return TK_OK;
 }
 
 // per-slot descriptors of the probed lists of `nq` queries
+// (the same arguments as a structure: the coarse rescoring writes the descriptors itself where it can)
+static TkSlotsOut slots_out(tk_index *ix, Work &w, const Plan &p, int *pair_count, const int *owner, int me,
+                            bool plain)
+{
+    TkSlotsOut so;
+    memset(&so, 0, sizeof so);        // (compared byte by byte with the workspace's device copy)
+    so.n_lists = ix->n_lists;
+    so.list_chunk_off = ix->list_chunk_off.as<int64_t>();
+    so.list_n = ix->list_n.as<int64_t>();
+    so.ids_off = ix->ids_off.as<int64_t>();
+    so.slot_prefix = w.slot_prefix.as<int>();
+    so.slot_chunk0 = w.slot_chunk0.as<int64_t>();
+    so.slot_n = w.slot_n.as<int>();
+    so.slot_label_off = w.slot_loff.as<int64_t>();
+    so.repeat_flag = w.repeat_flag.as<unsigned char>();
+    so.pair_count = pair_count;
+    so.owner = owner;
+    so.me = me;
+    so.qlim = plain ? w.qlim.as<int>() : nullptr;
+    so.R = head_rows(ix, p);
+    so.slot_exact = plain ? w.slot_exact.as<int>() : nullptr;
+    so.pair_count2 = plain ? w.p_count.as<int>() : nullptr;
+    so.plain0 = plain ? w.plain0.as<int>() : nullptr;
+    so.pair_count3 = plain ? w.h_count.as<int>() : nullptr;
+    if (!so.qlim || !so.pair_count2 || !so.plain0 || !so.pair_count3) so.slot_exact = nullptr;
+    return so;
+}
+
 void coarse_slots(tk_index *ix, Work &w, const int64_t *probes, int64_t nq, const Plan &p,
                          int *pair_count, const int *owner, int me, hipStream_t st, bool plain)
 {
-    tk_launch_make_slots(probes, nullptr, p.S, nq, ix->n_lists, ix->list_chunk_off.as<int64_t>(),
-                         ix->list_n.as<int64_t>(), ix->ids_off.as<int64_t>(),
-                         w.slot_prefix.as<int>(), w.slot_chunk0.as<int64_t>(), w.slot_n.as<int>(),
-                         w.slot_loff.as<int64_t>(), w.repeat_flag.as<unsigned char>(), pair_count,
-                         owner, me, st, plain ? w.qlim.as<int>() : nullptr, head_rows(ix, p),
-                         plain ? w.slot_exact.as<int>() : nullptr, plain ? w.p_count.as<int>() : nullptr,
-                         plain ? w.plain0.as<int>() : nullptr, plain ? w.h_count.as<int>() : nullptr);
+    const TkSlotsOut so = slots_out(ix, w, p, pair_count, owner, me, plain);
+    tk_launch_make_slots(probes, nullptr, p.S, nq, so.n_lists, so.list_chunk_off, so.list_n, so.ids_off,
+                         so.slot_prefix, so.slot_chunk0, so.slot_n, so.slot_label_off, so.repeat_flag,
+                         so.pair_count, so.owner, so.me, st, so.qlim, so.R, so.slot_exact, so.pair_count2,
+                         so.plain0, so.pair_count3);
 }
 
 // the pair lists of a batch: one set for the exact list-major kernel, with `plain` a second one
@@ -678,8 +707,23 @@ int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, con
                              int *pair_count, const int *owner, int me, hipStream_t st, Prof &pf,
                              bool plain, TkSecond q2)
 {
-    TRY(coarse_replay_probes(ix, w, q_dev, nq, p, w.probes.as<int64_t>(), st, pf, q2));
-    coarse_slots(ix, w, w.probes.as<int64_t>(), nq, p, pair_count, owner, me, st, plain);
+    // the slot descriptors: written by the coarse rescoring's own waves where that kernel can (p.S == p.kc)
+    const TkSlotsOut so = slots_out(ix, w, p, pair_count, owner, me, plain);
+    const TkSlotsOut *so_dev = nullptr;
+    if (p.S == p.kc && p.kc <= 64) {      // (same box: 0.415 -> 0.408 ms per 10 000 queries, profiles/r04/ab_fused_slots.txt)
+        // the structure lives in device memory (it is the same from batch to batch of a workspace:
+        // uploaded when it changes, on the stream that uses it)
+        if (!w.slots_valid || memcmp(&so, &w.slots_host, sizeof so) != 0) {
+            TRY(w.slots_desc.ensure(sizeof so));
+            HIPCHECK(hipMemcpyAsync(w.slots_desc.p, &so, sizeof so, hipMemcpyHostToDevice, st));
+            w.slots_host = so;
+            w.slots_valid = true;
+        }
+        so_dev = w.slots_desc.as<TkSlotsOut>();
+    }
+    int written = 0;
+    TRY(coarse_replay_probes(ix, w, q_dev, nq, p, w.probes.as<int64_t>(), st, pf, q2, so_dev, &written));
+    if (!written) coarse_slots(ix, w, w.probes.as<int64_t>(), nq, p, pair_count, owner, me, st, plain);
     return TK_OK;
 }
 

@@ -87,7 +87,10 @@ struct Work {
         c_pair_f0, spos, rpos, smins, pair_cnt, pair_off, scan_tmp, tally, usage, pos_lens, pos_off,
         qlim, slot_exact, p_count, p_cursor, p_pair_off, p_unit_prefix, p_pair_q, p_pair_f0, flag_list, p_unit_desc,
         plain0, h_count, h_cursor, h_pair_off, h_unit_prefix, h_pair_q, h_pair_f0,   // plain_scan.hip
-        plain_q;                                                                       // two-phase sharded scan
+        plain_q,                                                                       // two-phase sharded scan
+        slots_desc;        // TkSlotsOut of this workspace for the coarse rescoring's epilogue (device copy)
+    TkSlotsOut slots_host;      // ... what slots_desc holds
+    bool slots_valid = false;
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -112,6 +115,7 @@ struct Work {
         if (plain_ev) (void)hipEventDestroy(plain_ev);
         plain_ev = nullptr;
         plain_pending = false;
+        slots_valid = false;
         DevBuf *b[] = {&tables, &shift, &scale, &cdist, &cheap_idx, &cheap_val, &probes,
                        &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
@@ -119,7 +123,7 @@ struct Work {
                        &spos, &rpos, &smins, &pair_cnt, &pair_off, &scan_tmp, &tally, &usage, &pos_lens, &pos_off,
                        &qlim, &slot_exact, &p_count, &p_cursor, &p_pair_off, &p_unit_prefix, &p_pair_q, &p_pair_f0, &flag_list, &p_unit_desc,
                        &plain0, &h_count, &h_cursor, &h_pair_off, &h_unit_prefix, &h_pair_q, &h_pair_f0,
-                       &plain_q};
+                       &plain_q, &slots_desc};
         for (DevBuf *x : b) x->release();
         hipEvent_t *evs[] = {&tables_done, &coarse_scanned, &front_done, &scanned, &done};
         for (hipEvent_t *e : evs) {
@@ -263,7 +267,8 @@ int plain_blocks();
 void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st,
                         const uint4 *tables = nullptr);
 int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
-                         int64_t *probes_out, hipStream_t st, Prof &pf, TkSecond q2 = TkSecond());
+                         int64_t *probes_out, hipStream_t st, Prof &pf, TkSecond q2 = TkSecond(),
+                         const TkSlotsOut *slots = nullptr, int *slots_written = nullptr);
 void coarse_slots(tk_index *ix, Work &w, const int64_t *probes, int64_t nq, const Plan &p,
                   int *pair_count, const int *owner, int me, hipStream_t st, bool plain = false);
 int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,

@@ -209,10 +209,31 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
 // order (ivf.py:158-159 / fast_pq.py:307-308).  out: (nq, k) padded with -1;
 // out_count (nq,) optional.
 // q / rows: float32 or float64 (flags); float64 arithmetic if either is float64.
-void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
-                       int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
-                       int64_t *out, int *out_count, hipStream_t s, int form = 2, TkSecond q2 = TkSecond(),
-                       TkSecond out2 = TkSecond());
+// make_slots (below) as the epilogue of the coarse rescoring: the wave that ranked a query's probed
+// lists writes their scan descriptors and counts the (query, list) pairs — one kernel less on the
+// stream whose chain of short kernels the pipelined mode waits for.  Arguments as tk_launch_make_slots.
+struct TkSlotsOut {
+    int64_t n_lists;
+    const int64_t *list_chunk_off, *list_n, *ids_off;
+    int *slot_prefix;
+    int64_t *slot_chunk0;
+    int *slot_n;
+    int64_t *slot_label_off;
+    unsigned char *repeat_flag;
+    int *pair_count;
+    const int *owner;
+    int me;
+    const int *qlim;
+    int R;
+    int *slot_exact, *pair_count2, *plain0, *pair_count3;
+};
+// `slots`: a copy of the structure in DEVICE memory (17 pointers as kernel arguments would sit in scalar
+// registers for the whole kernel).  Returns 1 if it was given AND written by the rescoring kernel
+// (float32 operands staged through LDS, k <= 64), else 0: the caller then launches tk_launch_make_slots
+int tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
+                      int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
+                      int64_t *out, int *out_count, hipStream_t s, int form = 2, TkSecond q2 = TkSecond(),
+                      TkSecond out2 = TkSecond(), const TkSlotsOut *slots = nullptr);
 
 // probes (nq, kc) list ids -> per-slot scan descriptors; pair_count (n_lists, zeroed, or
 // NULL) receives the number of (query, slot) pairs per list — with `owner` (n_lists ranks,

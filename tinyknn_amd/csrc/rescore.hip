@@ -14,6 +14,7 @@
 // lower candidate position first) — the order numpy's argpartition yields on the
 // fixture host for these sizes; a rank-by-counting pass in LDS does the ordering.
 #include <stdlib.h>
+#include <string.h>
 
 #include "kernels.h"
 
@@ -160,6 +161,67 @@ __device__ __forceinline__ float sqdist_row_lds(const float4 *__restrict__ y4, c
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
+// make_slots_kernel's work for ONE query by the wave that ranked its probed lists (S <= 64): lane s
+// holds the id of slot s.  Same outputs, same atomics.
+__device__ __forceinline__ void slots_epilogue(const TkSlotsOut &so, int64_t qi, int S, int lane, int64_t cl)
+{
+    const bool act = lane < S;
+    bool wr = false;
+    if (act && cl < 0) { cl += so.n_lists; wr = true; }
+    const bool wrapped = __builtin_amdgcn_ballot_w64(wr) != 0;
+    int64_t c0 = 0, rows = 0, loff = 0;
+    int len = 0, n = 0;
+    if (act) {
+        c0 = so.list_chunk_off[cl];
+        len = (int)(so.list_chunk_off[cl + 1] - c0);
+        const int64_t ln = so.list_n[cl];
+        n = (int)ln;
+        rows = ln;
+        loff = so.ids_off[cl];
+    }
+    int acc = len;              // inclusive scans over the slots
+    int64_t racc = rows;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ua = __shfl_up(acc, o, 64);
+        const int64_t ur = __shfl_up(racc, o, 64);
+        if (lane >= o) { acc += ua; racc += ur; }
+    }
+    if (lane == 0) so.slot_prefix[qi * (S + 1)] = 0;
+    if (act) {
+        so.slot_prefix[qi * (S + 1) + lane + 1] = acc;
+        so.slot_chunk0[qi * S + lane] = c0;
+        so.slot_n[qi * S + lane] = n;
+        so.slot_label_off[qi * S + lane] = loff;
+    }
+    // leading slots that stay exact: until the lists scanned so far hold R rows
+    const uint64_t full = __builtin_amdgcn_ballot_w64(act && racc >= (int64_t)so.R);
+    int e = full ? __builtin_ctzll(full) + 1 : S;
+    const bool plain_ok = so.slot_exact && !wrapped && so.qlim[qi] != TK_PLAIN_NEVER;
+    const int e_walk = e;
+    if (!plain_ok) e = S;
+    bool head = false;
+    if (so.slot_exact) {
+        const int E = (so.R + 15) >> 4;
+        const int first_len = __shfl(acc, 0, 64);
+        head = plain_ok && e_walk == 1 && first_len > E;
+        const int at_e = e > 0 ? __shfl(acc, e - 1, 64) : 0;
+        if (lane == 0) {
+            so.slot_exact[qi] = head ? 0 : e;
+            so.plain0[qi] = head ? E : at_e;
+        }
+    }
+    if (so.pair_count && act && !(so.owner && so.owner[cl] != so.me)) {
+        if (head && lane == 0) {
+            atomicAdd(&so.pair_count3[cl], 1);
+            atomicAdd(&so.pair_count2[cl], 1);
+        } else {
+            atomicAdd(lane < e ? &so.pair_count[cl] : &so.pair_count2[cl], 1);
+        }
+    }
+    if (lane == 0 && so.repeat_flag) so.repeat_flag[qi] = wrapped;
+}
+
 // The same for float32 vectors and queries with d % 4 == 0, rows staged through LDS: in the
 // kernel above a lane walks its own row, so every load instruction of a wave touches 64
 // different lines — 2775 line visits per query at R = 111, d = 100 — and that address traffic
@@ -177,8 +239,10 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
                                                             int k, int strip, int64_t *__restrict__ out,
                                                             int *__restrict__ out_count, int stride4,
                                                             const float *__restrict__ q_b, int64_t q_na,
-                                                            int64_t *__restrict__ out_b, int64_t out_na)
+                                                            int64_t *__restrict__ out_b, int64_t out_na,
+                                                            const TkSlotsOut *__restrict__ so_dev)
 {
+    const bool have_slots = so_dev != nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int64_t *cs = (int64_t *)smem;
     float *ds = (float *)(smem + (((size_t)R * 8 + 15) & ~(size_t)15));
@@ -205,6 +269,7 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
     if (nc <= k) {  // ivf.py:158-159 / fast_pq.py:307-308: heap order, no rescoring
         for (int t = tid; t < k; t += 64) o[t] = t < nc ? cs[t] : -1;
         if (tid == 0 && out_count) out_count[qi] = nc;
+        if (have_slots) slots_epilogue(*so_dev, qi, k, tid, tid < nc ? cs[tid < k ? tid : 0] : -1);
         return;
     }
     const int d4 = d >> 2;
@@ -237,6 +302,7 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
         if (tid < nt) ds[t0 + tid] = sqdist_row_lds(tile + tid * stride4, xs, d);
         __syncthreads();
     }
+    int64_t *ps = (int64_t *)(tile + (TILE + 1) * stride4);      // have_slots: the k results in order
     for (int t = tid; t < nc; t += 64) {
         const float dv = ds[t];
         int rank = 0;
@@ -244,16 +310,24 @@ __global__ __launch_bounds__(64) void rescore_staged_kernel(const float *__restr
             const float du = ds[u];
             rank += (du < dv) || (du == dv && u < t);
         }
-        if (rank < k) o[rank] = cs[t];
+        if (rank < k) {
+            o[rank] = cs[t];
+            if (have_slots) ps[rank] = cs[t];
+        }
     }
     if (tid == 0 && out_count) out_count[qi] = k;
+    if (have_slots) {
+        __syncthreads();
+        slots_epilogue(*so_dev, qi, k, tid, tid < k ? ps[tid] : -1);
+    }
 }
 
-void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
-                       int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
-                       int64_t *out, int *out_count, hipStream_t s, int form, TkSecond q2, TkSecond out2)
+int tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int rows_is_f64,
+                      int64_t n_rows, const int64_t *cand, int R, int64_t nq, int k, int strip,
+                      int64_t *out, int *out_count, hipStream_t s, int form, TkSecond q2, TkSecond out2,
+                      const TkSlotsOut *slots)
 {
-    if (nq == 0 || k == 0) return;
+    if (nq == 0 || k == 0) return 0;
     const bool dbl = q_is_f64 || rows_is_f64;   // numpy promotes `Y - x` to float64
     size_t lds = (size_t)R * 8 + ((size_t)R + d) * (dbl ? 8 : 4) + 16;
     // one wave is enough for the coarse stage's 2 * n_probes + 10 candidates: the second wave of
@@ -273,18 +347,21 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
     if (!dbl && staged && d % 4 == 0 && d <= 256 && R <= 256 ) {
         const int stride4 = (d / 4) | 1;                      // odd number of 16-byte pieces
         const int tile_rows = staged == 2 ? 32 : 64;
+        const bool fuse = slots != nullptr && k <= 64;
+        const TkSlotsOut *so = fuse ? slots : nullptr;      // (a DEVICE copy of the structure)
         const size_t slds = (((size_t)R * 8 + 15) & ~(size_t)15) +
-                            (size_t)(((R + 3) & ~3) + ((d + 3) & ~3)) * 4 + (size_t)(tile_rows + 1) * stride4 * 16;
+                            (size_t)(((R + 3) & ~3) + ((d + 3) & ~3)) * 4 + (size_t)(tile_rows + 1) * stride4 * 16 +
+                            (fuse ? (size_t)k * 8 : 0);
         if (slds <= 64 * 1024) {
             if (tile_rows == 32)
                 hipLaunchKernelGGL(rescore_staged_kernel<32>, grid, dim3(64), slds, s, (const float *)q, d,
                                    (const float *)rows, n_rows, cand, R, k, strip, out, out_count, stride4,
-                                   (const float *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
+                                   (const float *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a, so);
             else
                 hipLaunchKernelGGL(rescore_staged_kernel<64>, grid, dim3(64), slds, s, (const float *)q, d,
                                    (const float *)rows, n_rows, cand, R, k, strip, out, out_count, stride4,
-                                   (const float *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
-            return;
+                                   (const float *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a, so);
+            return fuse ? 1 : 0;
         }
     }
     if (!dbl)
@@ -303,6 +380,7 @@ void tk_launch_rescore(const void *q, int q_is_f64, int d, const void *rows, int
         hipLaunchKernelGGL((rescore_kernel<double, float, double>), grid, block, lds, s,
                            (const double *)q, d, (const float *)rows, n_rows, cand, R, k, strip, out,
                            out_count, (const double *)q2.b, q2.n_a, (int64_t *)out2.b, out2.n_a);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------
