@@ -667,7 +667,7 @@ def plain_roofline(st, M, nq):
                      "was above the table's limit (scanned again exactly, replayed again)")
 
 
-def timed_rate(dev, batches, qp_is_f64, nq, k, n_probes, stream, pipeline, coalesce, steps=20, windows=4):
+def timed_rate(dev, batches, qp_is_f64, nq, k, n_probes, stream, pipeline, coalesce, steps=40, windows=4):
     """queries/s of the pipelined mode for one (index, n_probes): one continuous run of `windows` x
     `steps` steps, every window closed by the completion event of its last batch; the median window
     behind the first (the protocol of the headline figure, shorter)."""
@@ -683,7 +683,7 @@ def timed_rate(dev, batches, qp_is_f64, nq, k, n_probes, stream, pipeline, coale
         dev.query_batch_dev(b["q_dev"].data_ptr(), b["qp_dev"].data_ptr(), qp_is_f64, nq, k, n_probes,
                             b["out"].data_ptr(), stream=stream, done_event=ev)
 
-    for _ in range(16):
+    for _ in range(48):      # (clocks and every workspace of the pipeline settle)
         step()
     dev.join(stream)
     torch.cuda.synchronize()
@@ -712,7 +712,7 @@ def sweep_leg(args, ivf, dev, batches, qp_is_f64, stream, device, cent):
     import torch
     rows = 500
     out = {"protocol": "pipelined mode, %d steps x 4 windows per point, median window behind the first; parity: the "
-                       "first %d rows of batch 0 against oracle/tinyknn_oracle.c" % (20, rows), "points": []}
+                       "first %d rows of batch 0 against oracle/tinyknn_oracle.c" % (40, rows), "points": []}
 
     def point(label, ivf_, dev_, batches_, f64, n_probes, extra=None):
         e = {"config": label, "n_probes": n_probes}
