@@ -401,7 +401,11 @@ class DeviceIndex:
                         pass_1=None, stream=0, done_event=None):
         """Device pointers in, device pointer out, enqueued on `stream` (no sync).
         done_event: a hipEvent_t (integer handle) recorded behind the batch's last kernel, on
-        whichever internal stream that runs (tk_index_query_batch_dev_ex)."""
+        whichever internal stream that runs (tk_index_query_batch_dev_ex).
+        With set_pipeline(depth > 1) the kernels of a call run up to three calls later, and with
+        set_coalesce(2) they read the queries from, and write the ids to, these very buffers (no
+        staging copy): all three buffers belong to the library until join() — or the call's
+        done_event — as include/tinyknn_hip.h says for tk_index_set_pipeline."""
         if done_event is None:
             _lib.check(_lib.lib().tk_index_query_batch_dev(
                 self._h, qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
@@ -519,7 +523,8 @@ class DeviceIndex:
         _lib.check(_lib.lib().tk_index_set_option(self._h, int(option), int(value)))
 
     def set_coalesce(self, n):
-        """2: pairs of consecutive query_batch_dev calls run as one batch (tk_index_set_coalesce)."""
+        """2: pairs of consecutive query_batch_dev calls run as one batch (tk_index_set_coalesce);
+        the first call of a pair is held until the second arrives (join() launches it alone)."""
         _lib.check(_lib.lib().tk_index_set_coalesce(self._h, int(n)))
 
     def join(self, stream=0):
