@@ -18,6 +18,7 @@
 // One wave per query (four per workgroup); the 16*M distances sit in LDS.  The
 // pairwise mean is evaluated in numpy's exact order with the 8 accumulators of
 // every <=128-element leaf spread over the lanes; only the leaf combine is serial.
+#include <stdlib.h>
 #include "kernels.h"
 #include "np_order.h"
 
@@ -115,6 +116,11 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
     double *__restrict__ scale_out, int64_t nq, int wave_lds, const PwProgram pw,
     const T *__restrict__ qs_b, int64_t n_a)
 {
+    // a wave = one query's chain of dependent LDS round trips; in the pipelined mode it shares its SIMD
+    // with the scans of earlier batches and heads the stream the launches wait for: its instructions
+    // first (same box: 0.406 -> 0.401 ms per 10 000 queries, profiles/r04/ab_tables_prio.txt; the
+    // same on the rescoring kernels: no gain coarse, a loss final)
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int waves = blockDim.x >> 6;
