@@ -937,6 +937,7 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 with --shard lists: a one-rank nccl process group, the sharded leg's "
                          "exchanges through RCCL instead of device copies (rehearsal of the N > 1 code path)")
+    ap.add_argument("--graph-steps", type=int, default=32, help="steps captured in the hipGraph of the pipelined mode")
     ap.add_argument("--batches", type=int, default=4,
                     help="distinct query batches rotated through the timed loop")
     ap.add_argument("--warmup-seconds", type=float, default=0.5,
@@ -1148,7 +1149,7 @@ def main():
                                          "identical_to_stream_launch": bool((gout.cpu().numpy() == out_dev.cpu().numpy()).all())}}
         del g
         # (b)
-        gsteps = 32
+        gsteps = args.graph_steps
         dev.set_profiling(False)
         dev.set_pipeline(args.pipeline)
         dev.reserve(args.nq, args.k, args.n_probes)
