@@ -35,3 +35,16 @@ for nq in (1, 8, 64, 512, 4096, 10000):
     t = (time.perf_counter() - t0) / reps
     out.append({"nq": nq, "ms_per_call": t * 1e3, "queries_per_s": nq / t})
 print(json.dumps({"query_batch_by_size": out}))
+# one query per call with the other replay kernels (tk_index_set_heap_mode: 0 lane-per-query, 2 packed wave-per-query, 1 general)
+res = {}
+dev = ivf.device_index()
+for mode in (0, 2, 1, 0):
+    dev.set_heap_mode(mode)
+    for q in qs[:30]:
+        ivf.query(q.copy(), 10, 10)
+    t0 = time.perf_counter()
+    for q in qs[:600]:
+        ivf.query(q.copy(), 10, 10)
+    res.setdefault(str(mode), []).append((time.perf_counter() - t0) / 600 * 1e3)
+dev.set_heap_mode(0)
+print(json.dumps({"per_query_ms_by_heap_mode": res}))
