@@ -888,6 +888,7 @@ def main():
                     help="synthetic stand-in: Gaussian clusters, or |N(0,1)|*40 clipped to [0,218]")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
+    ap.add_argument("--rescore-form", type=int, default=2, help="TK_OPT_RESCORE_FORM (A/B): 2 = 32-row tiles, 1 = 64-row, 0 = row per lane")
     ap.add_argument("--scan-form", type=int, default=0,
                     help="tk_index_set_option TK_OPT_SCAN_FORM (A/B): 0 table rows by per-lane global loads (default, fastest); "
                          "1 rows through LDS, 4 waves/SIMD; 2 LDS, 3 waves/SIMD")
@@ -1043,6 +1044,7 @@ def main():
     dev.set_heap_mode(args.heap_mode)
     dev.set_scan_mode(args.scan_mode)
     dev.set_option(_lib.OPT_SCAN_FORM, args.scan_form)
+    dev.set_option(_lib.OPT_RESCORE_FORM, args.rescore_form)
     n_step = [0]
 
     def step(done_event=None):
