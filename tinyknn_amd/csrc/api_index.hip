@@ -33,8 +33,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->br_cand, &ix->br_count, &ix->br_out, &ix->br_q, &ix->br_sample};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
-    for (hipStream_t st : ix->lat_streams) (void)hipStreamDestroy(st);
-    if (ix->front_stream) (void)hipStreamDestroy(ix->front_stream);
+    // (the internal streams belong to the process: shared_streams below)
     if (ix->ev_in) (void)hipEventDestroy(ix->ev_in);
     for (auto &e : ix->evs) (void)hipEventDestroy(e);
     delete ix;
@@ -1066,16 +1065,57 @@ int flush_pending(tk_index *ix)
     return r;
 }
 
-// The front stream's chain (table build, coarse replay + rescoring, descriptors: ten short kernels per
-// batch, each waiting for the one before) is the pipeline's critical path once the scans overlap: its
-// kernels go first when CU slots free up.  Same box, ms per 10 000 queries: 0.430 default priority,
-// 0.417 high, 0.443 low; the replay streams high as well: 0.425 (profiles/r04/ab_front_prio.txt)
-static hipError_t make_front_stream(hipStream_t *st)
+// The internal streams of the pipelined mode — one "front" stream and up to eight replay streams — belong
+// to the PROCESS (per device), not to an index.  HIP maps streams onto its four hardware queues in creation
+// order: the streams a second index created for itself landed on the queues of the first one's — its
+// front stream on the caller's queue — and that index ran 10 % slower than alone (the sweep points of
+// bench.py behind the headline index: 7.2 against 8.0 M queries/s, scripts/r04_b2_sweep_check.py).  Shared
+// streams are in-order, so indexes used in turn or from several threads only see extra ordering.
+//
+// The front stream's chain (table build, coarse replay + rescoring, descriptors: short kernels each
+// waiting for the one before) is the pipeline's critical path once the scans overlap: its kernels go
+// first when CU slots free up.  Same box, ms per 10 000 queries: 0.430 default priority, 0.417 high,
+// 0.443 low; the replay streams high as well: 0.425 (profiles/r04/ab_front_prio.txt)
+struct SharedStreams {
+    hipStream_t front = nullptr;
+    std::vector<hipStream_t> lat;
+};
+static std::mutex g_streams_mu;
+static SharedStreams g_streams[64];     // by device ordinal
+
+static hipError_t shared_front_stream(hipStream_t *st)
 {
-    int lo = 0, hi = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    SharedStreams &S = g_streams[dev & 63];
+    if (!S.front) {
+        int lo = 0, hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e != hipSuccess) return e;
+        e = hipStreamCreateWithPriority(&S.front, hipStreamNonBlocking, hi);
+        if (e != hipSuccess) return e;
+    }
+    *st = S.front;
+    return hipSuccess;
+}
+
+static hipError_t shared_replay_stream(int i, hipStream_t *st)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    SharedStreams &S = g_streams[dev & 63];
+    while ((int)S.lat.size() <= i) {
+        hipStream_t n;
+        e = hipStreamCreateWithFlags(&n, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        S.lat.push_back(n);
+    }
+    *st = S.lat[(size_t)i];
+    return hipSuccess;
 }
 
 // Pipelined mode, first half of enqueuing a batch: internal streams and events exist, the batch has
@@ -1086,10 +1126,10 @@ static int pipe_begin(tk_index *ix, Pending &b, hipStream_t caller, hipStream_t 
     Work &w = *b.w;
     while ((int)ix->lat_streams.size() < ix->depth) {
         hipStream_t st;
-        HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHECK(shared_replay_stream((int)ix->lat_streams.size(), &st));
         ix->lat_streams.push_back(st);
     }
-    if (!ix->front_stream) HIPCHECK(make_front_stream(&ix->front_stream));
+    if (!ix->front_stream) HIPCHECK(shared_front_stream(&ix->front_stream));
     b.sf = ix->front_stream;
     b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
     ix->calls++;
@@ -1318,7 +1358,7 @@ extern "C" void *tk_index_input_stream(tk_index *ix)
 {
     IXLOCK(ix);
     if (!ix || ix->depth <= 1) return nullptr;
-    if (!ix->front_stream && make_front_stream(&ix->front_stream) != hipSuccess) return nullptr;
+    if (!ix->front_stream && shared_front_stream(&ix->front_stream) != hipSuccess) return nullptr;
     return ix->front_stream;
 }
 
