@@ -128,3 +128,32 @@ def test_drain_of_few_batches(setup, n_calls):
         for o in outs:
             np.testing.assert_array_equal(o.cpu().numpy(), want)
     dev.set_pipeline(1)
+
+
+@pytest.mark.parametrize("n_probes", [1, 64, 65, 100])
+def test_slot_descriptors_by_the_coarse_rescoring_or_by_their_own_kernel(setup, n_probes):
+    """Up to 64 probed lists the wave that ranked a query's lists writes their scan descriptors and counts the
+    pairs (rescore.hip: slots_epilogue); above, make_slots_kernel does, as a launch of its own.  Pairs of calls
+    of unequal sizes through the pipeline on either side of the limit: the oracle's rows."""
+    torch, fx = setup
+    ivf, ox, qn, qp = fx["an100"]
+    dev = ivf.device_index()
+    dev.set_pipeline(2)
+    dev.set_coalesce(2)
+    st = torch.cuda.current_stream().cuda_stream
+    nq = 600
+    want = ox.query_batch(qn[:nq], 10, n_probes)
+    q_dev, qp_dev = torch.from_numpy(qn[:nq]).cuda(), torch.from_numpy(qp[:nq]).cuda()
+    dq = qp.shape[1]
+    outs = []
+    for a, b in ((0, 250), (250, 600), (0, 600)):
+        o = torch.full((b - a, 10), -1, dtype=torch.int64, device="cuda")
+        outs.append(((a, b), o))
+        dev.query_batch_dev(q_dev.data_ptr() + a * qn.shape[1] * 4, qp_dev.data_ptr() + a * dq * 4, False, b - a,
+                            10, n_probes, o.data_ptr(), stream=st)
+    dev.join(st)
+    torch.cuda.synchronize()
+    for (a, b), o in outs:
+        np.testing.assert_array_equal(o.cpu().numpy(), want[a:b])
+    dev.set_coalesce(1)
+    dev.set_pipeline(1)
