@@ -221,7 +221,11 @@ int tk_index_join(tk_index *ix, void *stream);
  * (which stay the library's until tk_index_join, as above); each call's completion event is recorded
  * behind the pair's last kernel.  Results are those of separate calls
  * (the same kernels over the same rows).  A held call is launched alone by tk_index_join /
- * tk_index_quiesce / any tk_index_set_*, or when the next call cannot join it.  n = 1 (default):
+ * tk_index_quiesce / any tk_index_set_*, or when the next call cannot join it.
+ * A HELD call has enqueued NOTHING yet: its completion event (tk_index_query_batch_dev_ex) is not
+ * recorded and its pinned copy not ordered until its partner arrives or tk_index_join runs — wait on
+ * such an event only after one of the two (tk_index_pending() > 0 says calls are still owed;
+ * hipEventSynchronize on a never-recorded event returns at once).  n = 1 (default):
  * every call its own batch.  ivf.py:106-163 answers one query per call; the batch forms here and
  * everything about their scheduling are this library's. */
 int tk_index_set_coalesce(tk_index *ix, int n);
@@ -392,7 +396,13 @@ int tk_prepare_queries_host(const float *q_raw, int64_t nq, int d, int angular, 
  * are copied into out_ids_pinned (page-locked host memory, or NULL) and done_event (a
  * hipEvent_t, or NULL) is recorded.  With tk_index_set_pipeline(depth > 1) that happens up
  * to three calls later (or at tk_index_join); tk_index_pending = number of calls whose last
- * stage is not enqueued yet.  nq must fit one sub-batch (tk_index_max_sub_batch). */
+ * stage is not enqueued yet.  nq must fit one sub-batch (tk_index_max_sub_batch).
+ * With tk_index_set_coalesce(ix, 2) the first call of a pair is only held: done_event is valid
+ * (recorded) only once the partner call has been made or tk_index_join has run.
+ * The internal front / replay streams of the pipelined mode belong to the PROCESS (one set per
+ * device, shared by every index).  While a hipGraph capture of one index is open (between
+ * tk_index_quiesce and the end of the capture) no other index of the process may be used: its work
+ * would be pulled into, or invalidate, the foreign capture. */
 int tk_index_query_batch_dev_ex(tk_index *ix, const float *q_dev, const void *q_pq_dev,
                                 int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                                 int64_t *out_ids_dev, int64_t *out_ids_pinned, void *done_event,

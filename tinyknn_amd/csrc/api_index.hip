@@ -342,9 +342,20 @@ size_t plain_desc_bytes(const tk_index *ix, int64_t nq, const Plan &p)
                                         plain_k(ix, nq, p)) * 16;
 }
 
+int reserve_slots_pool(Work &w)
+{
+    if (w.slots_pinned) return TK_OK;
+    TRY(w.slots_desc.ensure(sizeof(TkSlotsOut) * TK_SLOTS_POOL));
+    HIPCHECK(hipHostMalloc((void **)&w.slots_pinned, sizeof(TkSlotsOut) * TK_SLOTS_POOL, hipHostMallocDefault));
+    w.slots_n = 0;
+    w.slots_need_upload = 0;
+    return TK_OK;
+}
+
 static int reserve(tk_index *ix, Work &w, int64_t nq, int k, const Plan &p)
 {
     const int M = ix->M;
+    if (!ix->capturing) TRY(reserve_slots_pool(w));      // (no pool yet inside a capture: the unfused launch)
     TRY(w.tables.ensure((size_t)nq * M * 16));
     TRY(w.shift.ensure((size_t)nq * 8));
     TRY(w.scale.ensure((size_t)nq * 8));
@@ -709,16 +720,30 @@ int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, con
     // the slot descriptors: written by the coarse rescoring's own waves where that kernel can (p.S == p.kc)
     const TkSlotsOut so = slots_out(ix, w, p, pair_count, owner, me, plain);
     const TkSlotsOut *so_dev = nullptr;
-    if (p.S == p.kc && p.kc <= 64) {      // (same box: 0.415 -> 0.408 ms per 10 000 queries, profiles/r04/ab_fused_slots.txt)
-        // the structure lives in device memory (it is the same from batch to batch of a workspace:
-        // uploaded when it changes, on the stream that uses it)
-        if (!w.slots_valid || memcmp(&so, &w.slots_host, sizeof so) != 0) {
-            TRY(w.slots_desc.ensure(sizeof so));
-            HIPCHECK(hipMemcpyAsync(w.slots_desc.p, &so, sizeof so, hipMemcpyHostToDevice, st));
-            w.slots_host = so;
-            w.slots_valid = true;
+    if (p.S == p.kc && p.kc <= 64 && w.slots_pinned) {      // (same box: 0.415 -> 0.408 ms per 10 000 queries, profiles/r04/ab_fused_slots.txt)
+        // the structure lives in device memory, in a pool of immutable entries found by content
+        // (api_internal.h): the upload's source is page-locked memory that outlives this call, so
+        // the copy may become a node of a hipGraph, and no later batch rewrites what a graph reads
+        int hit = -1;
+        for (int i = 0; i < w.slots_n && hit < 0; i++)
+            if (memcmp(&so, &w.slots_pinned[i], sizeof so) == 0) hit = i;
+        bool upload = hit >= 0 && !ix->capturing && ((w.slots_need_upload >> hit) & 1u);
+        if (hit < 0 && w.slots_n < TK_SLOTS_POOL) {
+            hit = w.slots_n++;
+            w.slots_pinned[hit] = so;
+            upload = true;
         }
-        so_dev = w.slots_desc.as<TkSlotsOut>();
+        if (hit >= 0) {
+            TkSlotsOut *dst = w.slots_desc.as<TkSlotsOut>() + hit;
+            if (upload) {
+                HIPCHECK(hipMemcpyAsync(dst, &w.slots_pinned[hit], sizeof so, hipMemcpyHostToDevice, st));
+                // (inside a capture the copy only runs when the graph does: a later stream-launched
+                //  batch with this descriptor uploads it again)
+                if (ix->capturing) w.slots_need_upload |= 1u << hit;
+                else w.slots_need_upload &= ~(1u << hit);
+            }
+            so_dev = dst;
+        }
     }
     int written = 0;
     TRY(coarse_replay_probes(ix, w, q_dev, nq, p, w.probes.as<int64_t>(), st, pf, q2, so_dev, &written));
@@ -1366,6 +1391,7 @@ extern "C" void *tk_index_input_stream(tk_index *ix)
 extern "C" int tk_index_pending(tk_index *ix)
 {
     if (!ix) return 0;
+    IXLOCK(ix);
     int n = ix->held ? ix->held->n_subs : 0;
     for (const Pending *b : ix->pending) n += b->n_subs > 0 ? b->n_subs : 1;
     return n;

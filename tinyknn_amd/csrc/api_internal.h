@@ -88,9 +88,15 @@ struct Work {
         qlim, slot_exact, p_count, p_cursor, p_pair_off, p_unit_prefix, p_pair_q, p_pair_f0, flag_list, p_unit_desc,
         plain0, h_count, h_cursor, h_pair_off, h_unit_prefix, h_pair_q, h_pair_f0,   // plain_scan.hip
         plain_q,                                                                       // two-phase sharded scan
-        slots_desc;        // TkSlotsOut of this workspace for the coarse rescoring's epilogue (device copy)
-    TkSlotsOut slots_host;      // ... what slots_desc holds
-    bool slots_valid = false;
+        slots_desc;        // pool of TkSlotsOut for the coarse rescoring's epilogue (device copies)
+    // The descriptors the fused epilogue reads are IMMUTABLE once written: a small pool per workspace,
+    // entry i = slots_pinned[i] (page-locked host memory that outlives every call: the source of the
+    // upload, also when that upload is recorded as a node of a hipGraph) and slots_desc[i] (device).
+    // A batch looks its descriptor up by content; a new one takes the next free entry; a full pool
+    // sends the batch to the unfused make_slots launch.  Nothing a captured graph refers to changes.
+    TkSlotsOut *slots_pinned = nullptr;
+    int slots_n = 0;
+    unsigned slots_need_upload = 0;     // bit i: entry i was only uploaded inside a capture so far
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
@@ -115,7 +121,10 @@ struct Work {
         if (plain_ev) (void)hipEventDestroy(plain_ev);
         plain_ev = nullptr;
         plain_pending = false;
-        slots_valid = false;
+        if (slots_pinned) (void)hipHostFree(slots_pinned);
+        slots_pinned = nullptr;
+        slots_n = 0;
+        slots_need_upload = 0;
         DevBuf *b[] = {&tables, &shift, &scale, &cdist, &cheap_idx, &cheap_val, &probes,
                        &slot_prefix, &slot_chunk0, &slot_n, &slot_loff, &dist, &heap_idx, &heap_val,
                        &repeat_flag, &cmins, &mins, &u_count, &u_cursor, &u_pair_off, &u_unit_prefix,
@@ -223,6 +232,9 @@ struct Plan {
     int64_t cap_min;   // bytes per query in the block-minimum buffer (multiple of 16)
     int64_t ccap_min;  // same for the coarse stage
 };
+
+#define TK_SLOTS_POOL 16
+int reserve_slots_pool(Work &w);      // api_index.hip: the pool above exists (not inside a capture)
 
 static const int64_t MAX_SUB = 32768;  // gridDim.y limit of the scan kernels is 65535
 // a sharded batch only runs the list-major kernels (no gridDim.y); what bounds it is int32 unit

@@ -7,6 +7,7 @@
 static int reserve_shard(tk_index *ix, Work &w, int64_t nq, int64_t qh, const Plan &p)
 {
     const int M = ix->M;
+    TRY(reserve_slots_pool(w));
     TRY(w.tables.ensure((size_t)nq * M * 16));
     TRY(w.shift.ensure((size_t)nq * 8));
     TRY(w.scale.ensure((size_t)nq * 8));

@@ -41,3 +41,35 @@ __device__ __forceinline__ T einsum_selfdot(const T *a, int n)
     if (L == 4) return (acc[0] + acc[1]) + (acc[2 % L] + acc[3 % L]);
     return acc[0] + acc[1 % L];
 }
+
+// the same over a[k] = f(k) computed on the fly (every element is used once): no private array, so a
+// run-time n leaves nothing to index dynamically (build_tables_kernel<double, true> kept 272 B per
+// lane of scratch for its `diff[32]`)
+template <typename T, typename F>
+__device__ __forceinline__ T einsum_selfdot_fn(F f, int n)
+{
+    constexpr int L = EinsumLanes<T>::L;
+    T acc[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) acc[l] = 0;
+    int i = 0;
+    for (; n - i >= 4 * L; i += 4 * L) {
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            const T x3 = f(i + 3 * L + l), x2 = f(i + 2 * L + l), x1 = f(i + L + l), x0 = f(i + l);
+            T ab3 = x3 * x3 + acc[l];
+            T ab2 = x2 * x2 + ab3;
+            T ab1 = x1 * x1 + ab2;
+            acc[l] = x0 * x0 + ab1;
+        }
+    }
+    for (; i < n; i += L) {
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            T x = (i + l < n) ? f(i + l) : (T)0;
+            acc[l] = x * x + acc[l];
+        }
+    }
+    if (L == 4) return (acc[0] + acc[1]) + (acc[2 % L] + acc[3 % L]);
+    return acc[0] + acc[1 % L];
+}

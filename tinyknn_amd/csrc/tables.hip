@@ -134,9 +134,6 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
     if (qraw >= nq) return;                     // (no workgroup barrier below)
     const int64_t qi = qraw;
     const T *q = (qs_b && qi >= n_a) ? qs_b + (qi - n_a) * dq : qs + qi * dq;   // second call of a pair
-    constexpr int MAXDPB = 32;
-    T diff[MAXDPB];
-
     const float rcpM = 1.0f / (float)M;
     if (SIGNED && dpb == 2 && M <= 256) {
         // FastPQ(2), the configuration every BASELINE index uses: the 13 rounds of a query were
@@ -159,9 +156,9 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
         const int m = e - i * M;
         T v;
         if (SIGNED) {
-            for (int k = 0; k < dpb; k++)
-                diff[k] = (T)centers[(int64_t)i * dq + m * dpb + k] - q[m * dpb + k];
-            v = einsum_selfdot<T>(diff, dpb);
+            const float *cp = centers + (int64_t)i * dq + m * dpb;
+            const T *qp = q + m * dpb;
+            v = einsum_selfdot_fn<T>([&](int k) { return (T)cp[k] - qp[k]; }, dpb);
         } else {
             // np.square(centers - q).reshape(16, nb, dpb).sum(-1): sequential adds
             v = 0;

@@ -524,7 +524,9 @@ class DeviceIndex:
 
     def set_coalesce(self, n):
         """2: pairs of consecutive query_batch_dev calls run as one batch (tk_index_set_coalesce);
-        the first call of a pair is held until the second arrives (join() launches it alone)."""
+        the first call of a pair is held until the second arrives (join() launches it alone).  A
+        held call has enqueued nothing: a `done_event` passed to it is recorded only once the partner
+        call or join() has run — do not wait on it before (pending() > 0 says work is still owed)."""
         _lib.check(_lib.lib().tk_index_set_coalesce(self._h, int(n)))
 
     def join(self, stream=0):

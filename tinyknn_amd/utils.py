@@ -1,86 +1,111 @@
-"""numpy helpers with the reference's names and semantics (tinyknn/utils.py).
+"""Host-side helpers under the reference's names (tinyknn/utils.py), written for this repository.
 
-Only knn_brute1 is on the hot path; it runs on the GPU (tk_knn_brute1).  The rest
-are host-side bookkeeping used by fit/build and by the recall measurements.
+Only knn_brute1 is on the hot path; it runs on the GPU (tk_knn_brute1).  The rest is host
+bookkeeping for fit / build and the recall measurements: a drop-in needs the same names, argument
+meaning and — where list membership or result order depends on it — the same numpy operations in the
+same order (argpartition, the |x|^2 + |y|^2 - 2 x.y expansion).  Those few expressions are the
+contract, cited per function; nothing else is taken from the reference (AGPL-3.0-or-later).
 """
 import time
-from contextlib import contextmanager
 
 import numpy as np
 
 from . import _lib
 
 
-def pad1(arr, m):
-    """Zero-pad a vector to a multiple of m.  reference: utils.py:6-11"""
-    (s,) = arr.shape
-    out = np.zeros((s + (-s) % m,), dtype=arr.dtype)
-    out[:s] = arr
+def _zero_extended(arr, multiples):
+    """`arr` inside a zero array whose every axis length is rounded up to its multiple."""
+    shape = tuple(-(-n // m) * m for n, m in zip(arr.shape, multiples))
+    out = np.zeros(shape, dtype=arr.dtype)
+    out[tuple(slice(0, n) for n in arr.shape)] = arr
     return out
+
+
+def pad1(arr, m):
+    """A vector zero-extended to a multiple of m (what utils.py:6-11 of the reference returns).
+    Like there, anything but a 1-D array is an error."""
+    (_,) = arr.shape
+    return _zero_extended(arr, (m,))
 
 
 def pad2(arr, m1, m2):
-    """Zero-pad a matrix to multiples of (m1, m2).  reference: utils.py:14-19"""
-    s1, s2 = arr.shape
-    out = np.zeros((s1 + (-s1) % m1, s2 + (-s2) % m2), dtype=arr.dtype)
-    out[:s1, :s2] = arr
-    return out
+    """A matrix zero-extended to multiples of (m1, m2) (utils.py:14-19)."""
+    _, _ = arr.shape
+    return _zero_extended(arr, (m1, m2))
+
+
+def _k_smallest(arr, k, axis):
+    """Positions of the k smallest entries along `axis` in numpy's argpartition order — that order is
+    part of the contract (it decides list membership and the order of returned ids: SURVEY 8c) — or
+    every position, ascending, when there are no more than k."""
+    n = arr.shape[axis]
+    if k >= n:
+        every = np.arange(n)
+        return every if arr.ndim == 1 else np.resize(every, arr.shape)
+    part = np.argpartition(arr, k, axis=axis)
+    return part[:k] if arr.ndim == 1 else part[:, :k]
 
 
 def bottom_k(arr, k):
-    """reference: utils.py:22-25"""
-    if k >= len(arr):
-        return np.arange(len(arr))
-    return np.argpartition(arr, k)[:k]
+    """utils.py:22-25"""
+    return _k_smallest(arr, k, 0)
 
 
 def bottom_k_2d(arr, k):
-    """reference: utils.py:28-31"""
-    if k >= arr.shape[1]:
-        return np.resize(np.arange(arr.shape[1]), arr.shape)
-    return np.argpartition(arr, k, axis=1)[:, :k]
+    """utils.py:28-31"""
+    return _k_smallest(arr, k, 1)
 
 
-@contextmanager
-def timer(verbose, text):
-    """reference: utils.py:34-41"""
-    if verbose:
-        print(text)
-        start = time.time()
-    yield
-    if verbose:
-        print(f"Took {time.time() - start:.1f}s")
+class timer:
+    """`with timer(verbose, text):` prints the text, then "Took ...s" (the lines utils.py:34-41
+    prints; examples and IVF.fit / build use them).  An exception inside the block passes through
+    without the second line, as a generator-based context manager would let it."""
+
+    def __init__(self, verbose, text):
+        self.verbose, self.text = verbose, text
+
+    def __enter__(self):
+        if self.verbose:
+            print(self.text)
+            self.t0 = time.time()
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.verbose and exc_type is None:
+            print(f"Took {time.time() - self.t0:.1f}s")
+        return False
+
+
+def _sq_norms(A):
+    return np.einsum("ij,ij->i", A, A)
 
 
 def cdist(X, Y, chunk=100):
-    """Squared Euclidean distances R[i, j] = |X_i - Y_j|^2.  reference: utils.py:44-63"""
-    nx = np.einsum("ij,ij->i", X, X)
-    ny = np.einsum("ij,ij->i", Y, Y)
-    res = np.zeros((nx.size, ny.size))
-    for i in range(0, nx.size, chunk):
-        res[i:i + chunk] = nx[i:i + chunk, None] + ny
-        res[i:i + chunk] -= 2 * X[i:i + chunk] @ Y.T
-    return res
+    """Squared Euclidean distances D[i, j] = |X_i - Y_j|^2 as float64, `chunk` rows of X at a time,
+    by the expansion |x|^2 + |y|^2 - 2 x.y in the reference's operation order (utils.py:44-63)."""
+    nx, ny = _sq_norms(X), _sq_norms(Y)
+    out = np.zeros((len(nx), len(ny)))
+    for lo in range(0, len(nx), chunk):
+        rows = slice(lo, lo + chunk)
+        out[rows] = nx[rows, None] + ny
+        out[rows] -= 2 * X[rows] @ Y.T
+    return out
 
 
 def knn_brute(X, Y, k, metric="euclidean", chunk=100):
-    """k nearest rows of Y for every row of X (host numpy; ground truth and
-    build-time assignment).  reference: utils.py:66-86"""
+    """k nearest rows of Y for every row of X on the host (ground truth, build-time assignment).
+    The distance expression `|x|^2 + |y|^2 - 2 x @ Y.T`, its dtype and the argpartition behind it are
+    the reference's (utils.py:66-86): list membership of IVF.build depends on their rounding."""
     assert k <= Y.shape[0], f"Can't find knn with {k=} and {Y.shape[0]} targets."
-    if metric == "angular":
-        X = X / np.linalg.norm(X, axis=1, keepdims=True)
-        Y = Y / np.linalg.norm(Y, axis=1, keepdims=True)
-    elif metric != "euclidean":
+    if metric not in ("angular", "euclidean"):
         raise ValueError(f"Metric not supported: {metric}")
-    n = X.shape[0]
-    res = np.zeros((n, k), dtype=int)
-    ynorm = np.einsum("ij,ij->i", Y, Y)
-    for i in range(0, n, chunk):
-        xc = X[i:i + chunk]
-        xnorm = np.einsum("ij,ij->i", xc, xc)
-        part = xnorm[:, None] + ynorm[None] - 2 * xc @ Y.T
-        res[i:i + chunk] = bottom_k_2d(part, k)
-    return res
+    if metric == "angular":
+        X, Y = (A / np.linalg.norm(A, axis=1, keepdims=True) for A in (X, Y))
+    ynorm = _sq_norms(Y)
+    out = np.zeros((X.shape[0], k), dtype=int)
+    for lo in range(0, X.shape[0], chunk):
+        xc = X[lo:lo + chunk]
+        out[lo:lo + chunk] = bottom_k_2d(_sq_norms(xc)[:, None] + ynorm[None] - 2 * xc @ Y.T, k)
+    return out
 
 
 def knn_brute1(x, Y, k):
