@@ -256,12 +256,9 @@ def oracle_index(ivf):
                          [ivf.ids[i] for i in range(L)], ivf.data)
 
 
-def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
-    """Strong-scaling leg: ONE batch of args.nq queries per step, shared by all ranks;
-    lists sharded by cluster id.  Returns a dict (rank 0 reports it)."""
+def shard_inputs(args, ivf, cent, dev, device):
+    """The shared batch of the sharded legs on the device + the unsharded index's rows for it."""
     import torch
-    import torch.distributed as dist
-    from tinyknn_amd.multi_gpu import ListShardedIndex
     qs = synth_queries(cent, args.nq, args.seed + 100, kind=args.data)     # rank 0's batch
     qn, qp = ivf._prepare(qs.copy())
     qn_t = torch.from_numpy(qn).to(device)
@@ -269,13 +266,23 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     want = torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)
     dev.query_batch_dev(qn_t.data_ptr(), qp_t.data_ptr(), qp.dtype != np.float32, args.nq, args.k,
                         args.n_probes, want.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    dev.join(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    want = want.cpu().numpy()
+    return qn_t, qp_t, want.cpu().numpy()
+
+
+def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
+    """Strong-scaling leg: ONE batch of args.nq queries per step, shared by all ranks;
+    lists sharded by cluster id.  Returns a dict (rank 0 reports it)."""
+    import torch
+    import torch.distributed as dist
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+    qn_t, qp_t, want = shard_inputs(args, ivf, cent, dev, device)
     co = args.shard_coalesce if args.shard_coalesce > 0 else max(3, world)    # auto: a rank's home share = one batch
     co = max(1, min(co, 131072 // args.nq))
     idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co,
                            force_collectives=args.force_collectives, counts=args.shard_counts,
-                           plain=bool(args.shard_plain))
+                           plain={0: False, 1: True, 2: "two-phase"}[args.shard_plain])
     if args.shard_exchange == "auto":
         idx.exchange = "auto"          # ListShardedIndex._exchange_kind: filtered where lists are long
         kinds = [idx._exchange_kind(args.k, args.n_probes, None)]
@@ -302,17 +309,65 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     res["streams"] = ("by role: front (coarse stages, probe all-gather) / scan (every scan, in order) / two replay "
                       "streams (exchange, replay, rescoring, id gather)" if idx._roles is not None and kinds[0] == "dense"
                       else "one stream per batch in flight")
+    if world == 1 and args.rank_share > 1 and getattr(ivf, "pq_transformed_points", 0) is not None:
+        # (a resident index was sharded IN PLACE by the leg above: main() runs its rank share first)
+        del idx
+        torch.cuda.empty_cache()
+        try:
+            res["rank_share_W%d" % args.rank_share] = rank_share_leg(args, ivf, device, qn_t, qp_t, want, args.rank_share)
+        except Exception as e:      # noqa: BLE001 - an extra leg must not lose the line
+            res["rank_share_W%d" % args.rank_share] = {"error": repr(e)}
     return res
 
 
-def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind):
+def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8):
+    """What ONE GPU can prove about W ranks: the time of ONE rank's share of a W-rank list partition —
+    its 1/W of the lists for all queries of the shared batches, the coarse stage, replay and rescoring
+    of its home queries, every exchange buffer filled locally with what the other W - 1 ranks
+    contribute (recorded from clone shards on this device: multi_gpu.SimulatedPeers; a device copy
+    stands in for the bytes the links would land in this rank's HBM).  W consecutive steps are answered
+    as one sharded batch (a rank's home share is then one batch of --nq queries), as the N > 1 leg does."""
+    import torch
+    from tinyknn_amd.multi_gpu import ListShardedIndex, SimulatedPeers
+    peers = SimulatedPeers(ivf, world=W, rank=0)
+    try:
+        co = max(1, min(W, 131072 // args.nq))
+        idx = ListShardedIndex(ivf, simulate=peers, depth=args.shard_depth, coarse="home", coalesce=co,
+                               counts="device", plain={0: False, 1: True, 2: "two-phase"}[args.shard_plain],
+                               exchange="auto")
+        kind = idx._exchange_kind(args.k, args.n_probes, None)
+        idx.exchange = kind
+        r = _list_sharded_run(args, idx, device, 1, 0, qn_t, qp_t, want, co, kind, sim=peers)
+        out = {k_: r[k_] for k_ in ("ms_per_step", "identical_rows_vs_replica", "rows", "windows_ms", "exchange", "scan",
+                                    "code_chunks_per_rank", "batches_in_flight", "steps_coalesced_per_exchange")}
+        out.update(world=W, rank=0,
+                   what="ONE rank's share of a W-rank partition on this GPU, the peers' contributions recorded and "
+                        "copied in (no links): per step of --nq shared queries")
+        return out
+    finally:
+        peers.close()
+
+
+def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind, sim=None):
     import torch
     import torch.distributed as dist
-    got = idx.query_prepared(qn_t, qp_t, args.k, args.n_probes)     # also settles the capacity
-    same = int((got == want).all(axis=1).sum())
+    lo_h, hi_h = (0, args.nq) if sim is None else sim.home_range(args.nq)
+    # three looks per batch shape: the capacities and record regions are trimmed on the evidence of three
+    # batches (multi_gpu.py) and are then final — nothing is re-sized inside the timed windows.
+    # Rows checked against the unsharded answer: all of them (a simulated rank: its home rows).
+    bad = 0
+    for _ in range(3):
+        got = idx.query_prepared(qn_t, qp_t, args.k, args.n_probes)
+        bad = max(bad, int((got[lo_h:hi_h] != want[lo_h:hi_h]).any(axis=1).sum()))
     if co > 1:      # the coalesced batch: settles its capacity, and its rows must repeat `want`
-        gotc = idx.query_prepared(torch.cat([qn_t] * co), torch.cat([qp_t] * co), args.k, args.n_probes)
-        same = min(same, *[int((gotc[j * args.nq:(j + 1) * args.nq] == want).all(axis=1).sum()) for j in range(co)])
+        qn_c, qp_c = torch.cat([qn_t] * co), torch.cat([qp_t] * co)
+        wc = np.concatenate([want] * co)
+        lo_c, hi_c = (0, co * args.nq) if sim is None else sim.home_range(co * args.nq)
+        for _ in range(3):
+            gotc = idx.query_prepared(qn_c, qp_c, args.k, args.n_probes)
+            bad = max(bad, int((gotc[lo_c:hi_c] != wc[lo_c:hi_c]).any(axis=1).sum()))
+    rows_checked = (hi_h - lo_h) if co == 1 else (hi_c - lo_c)
+    same = rows_checked - bad
     # every workspace slot must have seen a batch of the timed size before the clock starts: a slot
     # that grows inside the timed region pays hipMalloc/hipFree of gigabytes there (seen as a 4x
     # slower leg whenever the untimed calls above had left slot 0 at the single-batch size)
@@ -327,10 +382,10 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
                 torch.cuda.synchronize()
                 return attempt
             except RuntimeError as e:
-                if "overflowed" not in str(e):
+                if "submit the batches again" not in str(e):
                     raise
                 log(f"[bench] rank {rank}: {e}")
-        raise RuntimeError("list-sharded leg: exchange regions overflowed four times in a row")
+        raise RuntimeError("list-sharded leg: batches had to be repeated four times in a row")
 
     run(-(-max(args.warmup, args.shard_depth * co) // co) * co)
     if world > 1:
@@ -355,7 +410,8 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
     el = wins[len(wins) // 2]
     cap = idx.capacity[(args.nq * co, args.n_probes)] if (args.nq * co, args.n_probes) in idx.capacity \
         else idx.capacity[(args.nq, args.n_probes)]
-    load = np.bincount(idx.owner, weights=(idx.list_sizes + 15) // 16, minlength=world)
+    W_ix = idx.world            # (a simulated rank: the partition's world, not the process group's)
+    load = np.bincount(idx.owner, weights=(idx.list_sizes + 15) // 16, minlength=W_ix)
     filt = {"kind": "dense (whole segments at fixed positions, no host synchronisation)"}
     if kind == "filtered":
         # measured in the timed steps, this rank: records (20 B per block that travels) + bounds +
@@ -374,18 +430,23 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
             filt["records_held_bytes_per_rank_per_step"] = int(20 * idx.records_sent // (args.steps * n_win))
     return {"queries_per_s": args.nq * args.steps / el, "ms_per_step": el / args.steps * 1e3,
             "scaling": "strong (one shared batch of %d queries per step)" % args.nq,
-            "identical_rows_vs_replica": same, "rows": args.nq,
+            "identical_rows_vs_replica": same, "rows": rows_checked,
             "windows_ms": [w_ * 1e3 for w_ in wins], "windows_repeated_after_overflow": repeats,
-            "exchange": {**filt, "all_to_all_bytes_per_rank_per_step": int(world * cap * 16 // co),
+            "exchange": {**filt, "all_to_all_bytes_per_rank_per_step": int(W_ix * cap * 16 // co),
                          "region_capacity_uint4": int(cap),
                          "probe_all_gather_bytes_per_rank_per_step":
-                             int(-(-args.nq // world) * min(args.n_probes, len(idx.list_sizes)) * 8)
+                             int(-(-args.nq // W_ix) * min(args.n_probes, len(idx.list_sizes)) * 8)
                              if args.shard_coarse == "home" else 0,
-                         "all_gather_bytes_per_rank_per_step": int((-(-args.nq // world) * args.k + 1) * 8)},
+                         "all_gather_bytes_per_rank_per_step": int((-(-args.nq // W_ix) * args.k + 1) * 8)},
             "coarse_stage": args.shard_coarse + (" (tables for all queries, coarse scan/replay/rescoring of the "
                                                  "rank's nq/W home queries, probe lists all-gathered)"
                                                  if args.shard_coarse == "home" else " on every rank"),
-            "scan": ({"form": "two-phase: first probed lists exactly, bound min-reduced over the ranks, the lists behind "
+            "scan": ({"form": "one phase, as the unsharded pipeline: heads of the first lists exactly, everything else on "
+                              "the int8 matrix cores, the home replay checks the lemma per query and flags the batch "
+                              "(tk_index_shard_scan_plain_dev); no bound exchange",
+                      "arguments_switched_to_two_phase": [list(map(str, a)) for a in sorted(idx._plain_failed, key=str)]}
+                     if idx._one_phase_now(args.k, args.n_probes, None) else
+                     {"form": "two-phase: first probed lists exactly, bound min-reduced over the ranks, the lists behind "
                               "them on the int8 matrix cores where the bound allows (tk_index_shard_scan_first_dev / _rest_dev)",
                       "last_batch_this_rank": idx.engine.dev.shard_plain_stats((idx._calls - 1) % idx.depth)}
                      if idx._use_plain(args.k, args.n_probes, None) else
@@ -931,8 +992,12 @@ def main():
     ap.add_argument("--shard-counts", default="device", choices=["device", "host"],
                     help="filtered exchange: record counts read on the device (fixed regions, no host "
                          "synchronisation) or on the host (variable splits)")
-    ap.add_argument("--shard-plain", type=int, default=1,
-                    help="list-sharded leg: 1 = two-phase scan with the matrix-core kernel (default), 0 = exact kernel only")
+    ap.add_argument("--shard-plain", type=int, default=1, choices=[0, 1, 2],
+                    help="list-sharded leg: 1 = the matrix-core kernel, one phase for the dense exchange / two phases for "
+                         "the filtered one (default); 2 = two phases for both (A/B); 0 = exact kernel only")
+    ap.add_argument("--rank-share", type=int, default=8,
+                    help="N = 1: after the list-sharded leg, time ONE rank's share of a partition over this many ranks "
+                         "(peers simulated on this GPU); 0 = skip")
     ap.add_argument("--shard-limit", type=float, default=240.0,
                     help="seconds after which a stuck list-sharded leg is abandoned")
     ap.add_argument("--force-collectives", action="store_true",
@@ -1449,6 +1514,24 @@ def main():
         "parity_vs_oracle": parity,
         "sweep": sweep,
     }
+    if args.workload == "c5" and world == 1 and args.rank_share > 1 and not do_shard:
+        # configs[4] is the workload north_star shards: one rank's share of a W-rank partition of THIS index
+        # (the resident index stays unsharded: the simulated ranks are clone shards that borrow its arrays)
+        try:
+            dev.set_pipeline(1)
+            qn_s, qp_s, want_s = shard_inputs(args, ivf, cent, dev, device)
+            rs = rank_share_leg(args, ivf, device, qn_s, qp_s, want_s, args.rank_share)
+            W = rs["world"]
+            rs["unsharded_ms_per_step_over_W"] = line["ms_per_step"] / W
+            rs["target_ms_per_step_at_0.7_efficiency"] = line["ms_per_step"] / (0.7 * W)
+            rs["implied_strong_scaling_efficiency_without_links"] = line["ms_per_step"] / W / rs["ms_per_step"]
+            line["rank_share_W%d" % W] = rs
+            line["rank_share_W%d_ms_per_step" % W] = rs["ms_per_step"]
+            line["rank_share_W%d_implied_efficiency_without_links" % W] = rs["implied_strong_scaling_efficiency_without_links"]
+        except Exception as e:      # noqa: BLE001 - an extra leg must not lose the line
+            line["rank_share_W%d" % args.rank_share] = {"error": repr(e)}
+    if isinstance(raw_leg, dict) and "queries_per_s" in raw_leg:
+        line["raw_in_ids_out_queries_per_s"] = raw_leg["queries_per_s"]      # (scalar: kept by the driver's parsed record)
     if shard_w1 and not do_shard:
         try:
             if not dist.is_initialized():
@@ -1485,8 +1568,19 @@ def main():
         wd.cancel()
         if world == 1:
             ls["ratio_to_unsharded_value"] = ls["queries_per_s"] / line["value"]
-            ls["rehearsal"] = ("ONE rank: every exchange goes through RCCL (uint8 MIN all-reduce, all-to-all, "
-                               "all-gather at world 1); what N ranks add is the links, not the code path")
+            ls["rehearsal"] = ("ONE rank: every exchange goes through RCCL (all-to-all, all-gather, and for the "
+                               "filtered exchange a uint8 MIN all-reduce, at world 1); what N ranks add is the links, "
+                               "not the code path")
+            # scalars at the top level: the driver's parsed record keeps those
+            line["list_sharded_ratio_to_unsharded_value"] = ls["ratio_to_unsharded_value"]
+            for key, rs in ls.items():
+                if key.startswith("rank_share_W") and isinstance(rs, dict) and "ms_per_step" in rs:
+                    W = rs["world"]
+                    rs["unsharded_ms_per_step_over_W"] = line["ms_per_step"] / W
+                    rs["target_ms_per_step_at_0.7_efficiency"] = line["ms_per_step"] / (0.7 * W)
+                    rs["implied_strong_scaling_efficiency_without_links"] = line["ms_per_step"] / W / rs["ms_per_step"]
+                    line[key + "_ms_per_step"] = rs["ms_per_step"]
+                    line[key + "_implied_efficiency_without_links"] = rs["implied_strong_scaling_efficiency_without_links"]
         if world > 1:
             # N > 1: the north_star split is the measured one; the replica rate stays beside it
             line["replica"] = {"queries_per_s": line["value"], "ms_per_step": line["ms_per_step"],

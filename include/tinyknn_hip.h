@@ -480,7 +480,10 @@ int tk_index_knn_brute(tk_index *ix, const float *q, int64_t nq, int k, int64_t 
  *   all-to-all(send -> recv)   equal splits of capacity*16 bytes (RCCL, by the caller);
  *   tk_index_shard_finish_dev  received segments -> distance rows of the home queries,
  *                              heap replay, rescoring; out_ids_home_dev: int64
- *                              (ceil(nq/world), k), rows past nq and missing ids = -1;
+ *                              (ceil(nq/world), k), rows past nq and missing ids = -1; flag_dev:
+ *                              the batch's flag word (may be NULL behind tk_index_shard_scan_dev /
+ *                              the two-phase scan; required behind tk_index_shard_scan_plain_dev,
+ *                              which may raise bit 4 in it, see there);
  *   all-gather of the id rows  (by the caller).
  * All calls enqueue on `stream` and use workspace `slot` (< pipeline depth), so that
  * several batches can be in flight on different streams.  nq <= 131072 per batch. */
@@ -499,7 +502,29 @@ int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_dev, const vo
                             int *flag_dev, void *stream);
 int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq, int k,
                               int n_probes, int pass_1, int64_t capacity, const void *recv_dev,
-                              int64_t *out_ids_home_dev, void *stream);
+                              int64_t *out_ids_home_dev, int *flag_dev, void *stream);
+/* tk_index_shard_scan_dev in the form the unsharded pipeline scans (ivf.py:137-150 through
+ * _fast_pq_256.pyx:73-156): of every owned segment only the rows a query scans first — the head of
+ * its first probed list, two heap sizes — go through the exact kernel, everything else is scored as
+ * plain sums on the int8 matrix cores, and the REPLAY at the query's home rank checks the condition
+ * under which those are the reference's values (its bound at the first plain block <= the limit C of
+ * the query's table; tk_index_set_plain_scan).  One kernel chain, no extra collective.  A home query
+ * that fails the check raises bit 4 of *flag_dev in tk_index_shard_finish_dev (the codes to scan it
+ * again exactly are on other ranks): the flag word travels with the ids, every rank sees it, and
+ * the batch is repeated through tk_index_shard_scan_dev.  Same arguments as tk_index_shard_scan_dev;
+ * falls back to it by itself where the form does not apply (tk_index_shard_plain says 0, labels
+ * repeat, heaps beyond the lane replay, world * capacity shorter than the longest list). */
+int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
+                                  int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                                  const int64_t *probes_all_dev, int64_t capacity, void *send_dev,
+                                  int *flag_dev, void *stream);
+/* Another rank's shard of a complete UNSHARDED index on the same device: a new handle that borrows
+ * the source's replicated arrays (PQ, centres, list tables, ids, vectors — the source must outlive
+ * it and must not be re-populated meanwhile) and owns only the codes of the lists with
+ * owner[l] == rank, compacted on the device.  The source stays usable and unsharded.  This is how
+ * several ranks of a list partition are played on ONE GPU (tests, bench.py's one-rank share of a
+ * W = 8 partition): a 100M x 128 index holds its 51 GB of vectors once, not once per rank. */
+tk_index *tk_index_clone_shard(tk_index *src, const int32_t *owner, int rank, int world);
 
 /* Longest (source -> home) stream of the slot's last tk_index_shard_scan_dev in uint4, fitted or
  * not: max-reduce it over the ranks and size `capacity` by it (the regions of the dense exchange

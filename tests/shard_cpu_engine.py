@@ -95,7 +95,21 @@ class OracleShardEngine:
         assert (self.first_bound[owned_elsewhere] == 255).all()
         self.rest_calls = getattr(self, "rest_calls", 0) + 1
 
-    def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home):
+    # ---- the scan in ONE phase (tk_index_shard_scan_plain_dev).  This engine has no second kernel: it
+    # scores every segment exactly (bytes that trivially satisfy the lemma); `fail_plain` makes the
+    # home replay of the next `fail_plain` such batches report a query that failed the check, which
+    # is how the tests drive the bit-4 protocol (flag travels with the ids, the batch is repeated
+    # in the two-phase form).
+    fail_plain = 0
+
+    def scan_plain(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None):
+        self.scan(slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=probes_all)
+        self.plain_calls = getattr(self, "plain_calls", 0) + 1
+
+    def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home, flag=None):
+        if flag is not None and self.fail_plain > 0:
+            self.fail_plain -= 1
+            flag.numpy()[0] |= 4
         qn = qn.numpy()
         probes, tables = self._front(qn, k, n_probes, pass_1)
         src, pos = shard_positions(probes, self.chunks, self.owner, self.world, capacity)

@@ -84,7 +84,9 @@ def _shard_worker(rank, world, port, tag, nq, k, n_probes, tiny, coarse, ret, ex
             idx.record_region[(nq, n_probes)] = 2    # the record regions overflow, the streams fit
         out = idx.query_batch(g["qn"][:nq], k, n_probes)
         if exchange == "filtered" and counts == "device":
-            out2 = idx.query_batch(g["qn"][:nq], k, n_probes)      # second look: regions trimmed
+            out2 = idx.query_batch(g["qn"][:nq], k, n_probes)
+            assert (out2 == out).all()
+            out2 = idx.query_batch(g["qn"][:nq], k, n_probes)      # third look: regions trimmed
             assert (out2 == out).all() and (nq, n_probes) in idx.record_region
         ret[rank] = (out, idx.capacity[(nq, n_probes)], getattr(eng, "coarse_calls", 0),
                      idx.bytes_sent, idx.bytes_dense)
@@ -266,6 +268,84 @@ def test_list_sharded_coalesced_submits_gloo():
         np.testing.assert_array_equal(tail_rows, exp)       # join() returns the batch it flushed
         np.testing.assert_array_equal(alone, exp)           # flushed when the arguments changed
         np.testing.assert_array_equal(other, exp2)
+
+
+def _one_phase_worker(rank, world, port, tag, nq, k, n_probes, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import golden
+        from test_oracle_golden import load_oracle_index
+        from shard_cpu_engine import OracleShardEngine
+        from oracle import oracle as O
+        from tinyknn_amd.multi_gpu import ListShardedIndex, shard_lists
+        g = golden(f"g6_ivf_{tag}.npz")
+        ox = load_oracle_index(O, g)
+
+        class HostSide:
+            def _prepare(self, qs):
+                return qs, ox.pq_query(qs)
+
+        owner = shard_lists(g["list_sizes"], world)
+        eng = OracleShardEngine(O, ox, owner, rank, world)
+        idx = ListShardedIndex(HostSide(), engine=eng, owner=owner, list_sizes=g["list_sizes"])
+        assert idx._one_phase
+        out = idx.query_batch(g["qn"][:nq], k, n_probes)
+        calls_ok = eng.plain_calls
+        # ONE rank's home replay reports a query the plain sums do not cover: the flag travels with the
+        # ids, EVERY rank repeats the batch in the two-phase form and keeps that form for these arguments
+        if rank == world - 1:
+            eng.fail_plain = 1
+        out2 = idx.query_batch(g["qn"][:nq], k, n_probes)
+        failed = (k, n_probes, None) in idx._plain_failed
+        rest = getattr(eng, "rest_calls", 0)
+        out3 = idx.query_batch(g["qn"][:nq], k, n_probes)
+        # ... and a submit()ted batch in flight: join() raises, the batch submitted again is answered
+        idx2 = ListShardedIndex(None, engine=eng, owner=owner, list_sizes=g["list_sizes"])
+        qn = torch.from_numpy(np.ascontiguousarray(g["qn"][:nq]))
+        qp = torch.from_numpy(np.ascontiguousarray(ox.pq_query(g["qn"][:nq])))
+        if rank == 0:
+            eng.fail_plain = 1
+        idx2.submit(qn, qp, k, n_probes)
+        raised = ""
+        try:
+            idx2.join()
+        except RuntimeError as e:
+            raised = str(e)
+        again = idx2.submit(qn, qp, k, n_probes)
+        idx2.join()
+        qh = -(-nq // world)
+        ret[rank] = (out, out2, out3, calls_ok, failed, rest, eng.plain_calls, raised,
+                     again[:, :-1].reshape(world * qh, k)[:nq].numpy().copy(), bool(again[:, -1].any()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_list_sharded_one_phase_scan_and_its_flag_gloo(world):
+    """Dense exchange, scan in one phase (tk_index_shard_scan_plain_dev's protocol): no bound
+    all-reduce; a home query that fails the replay's check raises bit 4 of the batch's flag word on
+    ONE rank, the all-gathered word switches every rank to the two-phase form and the batch is
+    answered again — synchronously (query_batch) and for batches in flight (submit / join)."""
+    import torch.multiprocessing as mp
+    from conftest import golden
+    tag, k, n_probes, nq = "an100", 10, 5, 19
+    port = 37500 + (os.getpid() * 3 + world) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_one_phase_worker, args=(world, port, tag, nq, k, n_probes, ret), nprocs=world, join=True)
+    exp = golden(f"g6_ivf_{tag}.npz")[f"ids_p{n_probes}"][:nq]
+    for r in range(world):
+        out, out2, out3, calls_ok, failed, rest, plain_calls, raised, again, again_flag = ret[r]
+        for o in (out, out2, out3, again):
+            np.testing.assert_array_equal(o, exp)
+        assert calls_ok == 1 and failed and rest >= 1       # one-phase, then the repeat went two-phase
+        assert plain_calls == 3                             # (+1 failed attempt, +1 idx2's first submit; none after)
+        assert "submit the batches again" in raised and not again_flag
 
 
 def _mismatch_worker(rank, world, port, ret):

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, owner=None,
-                   coarse="home", engines=None, sizes=None, exchange="dense", stats=None, plain=True):
+                   coarse="home", engines=None, sizes=None, exchange="dense", stats=None, plain=True,
+                   one_phase=False):
     """-> (ids (nq, k), overflow flags (world,), capacity).  coarse="home": every simulated rank
     runs the coarse stage of its home queries only and the probe lists are gathered by hand;
     "replicated": every rank derives all probe lists itself."""
@@ -50,7 +51,13 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
     # cores where the bound allows) wherever the engine says it applies, else in one
     two_phase = plain and engines[0].plain_ok(k, n_probes, pass_1)
     b_red = None
-    if two_phase:
+    if one_phase:
+        # tk_index_shard_scan_plain_dev: heads exactly, the rest on the matrix cores, no bound exchange;
+        # the home replays check the lemma (flag bit 4)
+        assert exchange == "dense"
+        for r, e in enumerate(engines):
+            e.scan_plain(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], probes_all=p_all)
+    elif two_phase:
         firsts = [torch.zeros(nq, dtype=torch.uint8, device="cuda") for _ in range(world)]
         for r, e in enumerate(engines):
             e.scan_first(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], firsts[r],
@@ -113,7 +120,7 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
         for h, e in enumerate(engines):
             recv = torch.stack([sends[s][h] for s in range(world)]).contiguous()   # all-to-all
             out = torch.zeros(qh * k, dtype=torch.int64, device="cuda")
-            e.finish(0, qn_t, k, n_probes, pass_1, capacity, recv, out)
+            e.finish(0, qn_t, k, n_probes, pass_1, capacity, recv, out, flag=flags[h] if one_phase else None)
             homes.append(out.view(qh, k))
     torch.cuda.synchronize()
     if stats is not None:
@@ -476,3 +483,75 @@ def test_resident_index_sharded_in_place(oracle):
             e.dev.shard_resident(owner, r, world)
             e.dev.set_pipeline(1)
             e.device = "cuda"
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("tag", G6_TAGS)
+def test_one_phase_scan_golden(tag, world):
+    """tk_index_shard_scan_plain_dev on the golden indexes: heads of the first lists exactly, everything
+    else as plain sums, the home replay checks — ids of the fixtures, no flag raised (where the form
+    does not apply — repeating labels, n_probes 1 — the call is the exact kernel's).  With the table
+    limits forced down (TK_OPT_PLAIN_LIMIT) a home rank must raise bit 4 instead of returning rows it
+    cannot vouch for."""
+    from tinyknn_amd import _lib
+    from tinyknn_amd.multi_gpu import _HipShardEngine, shard_lists
+    from test_hip_parity import ivf_from_fixture
+    g = golden(f"g6_ivf_{tag}.npz")
+    ivf = ivf_from_fixture(None, g)
+    for n_probes in g["probes_list"]:
+        n_probes = int(n_probes)
+        ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, one_phase=True)
+        assert not flags.any()
+        np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+    # forced failure: no bound is at or below a limit of -128
+    n_probes = int(max(g["probes_list"]))
+    L = ivf.active_centers.shape[0]
+    sizes = np.array([0 if isinstance(t, np.ndarray) else t.size for t in ivf.pq_transformed_points[:L]], dtype=np.int64)
+    owner = shard_lists(sizes, world)
+    engines = [_HipShardEngine(ivf, owner, r, world, 1) for r in range(world)]
+    for e in engines:
+        e.dev.set_option(_lib.OPT_PLAIN_LIMIT, -128)
+    ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, one_phase=True, engines=engines)
+    if not (flags & 4).any():
+        np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])      # the form did not apply: exact kernel
+    assert not (flags & 3).any()
+
+
+def test_simulated_peers_one_rank_of_a_partition(oracle):
+    """ListShardedIndex(simulate=SimulatedPeers(...)): ONE rank of a W-rank partition with the other
+    ranks' contributions recorded from clone shards on the same device — its home rows are the
+    unsharded rows, for every rank, dense (one- and two-phase) and filtered exchange, with batches in
+    flight; the unsharded index stays usable beside the clones."""
+    import torch
+    from tinyknn_amd import IVF, FastPQ
+    from tinyknn_amd.multi_gpu import ListShardedIndex, SimulatedPeers
+    np.random.seed(21)
+    n, nq, d = 50000, 1203, 100
+    cent = np.random.randn(120, d)
+    X = (cent[np.random.randint(120, size=n)] + 0.6 * np.random.randn(n, d)).astype(np.float32)
+    qs = (cent[np.random.randint(120, size=nq)] + 0.6 * np.random.randn(nq, d)).astype(np.float32)
+    ivf = IVF("angular", 150, FastPQ(2))
+    ivf.fit(X[:15000]).build(X, n_probes=1)
+    qn, qp = ivf._prepare(qs.copy())
+    dev = ivf.device_index()
+    want = dev.query_batch(qn, qp, 10, 6)
+    qn_t, qp_t = torch.from_numpy(qn).cuda(), torch.from_numpy(np.ascontiguousarray(qp)).cuda()
+    for world, rank in ((4, 0), (4, 3), (8, 5)):
+        peers = SimulatedPeers(ivf, world=world, rank=rank)
+        lo, hi = peers.home_range(nq)
+        for kw in (dict(exchange="dense"), dict(exchange="dense", plain="two-phase"), dict(exchange="filtered"),
+                   dict(exchange="dense", plain=False)):
+            idx = ListShardedIndex(ivf, simulate=peers, depth=2, **kw)
+            got = idx.query_prepared(qn_t, qp_t, 10, 6)
+            np.testing.assert_array_equal(got[lo:hi], want[lo:hi])
+            assert (got[:lo] == -1).all() and (got[hi:] == -1).all()        # the other ranks' rows are theirs
+            outs = [idx.submit(qn_t, qp_t, 10, 6) for _ in range(5)]
+            idx.join()
+            torch.cuda.synchronize()
+            qh = -(-nq // world)
+            for o in outs:
+                rows = o[:, :-1].reshape(world * qh, 10)[:nq].cpu().numpy()
+                np.testing.assert_array_equal(rows[lo:hi], want[lo:hi])
+                assert not o[:, -1].any()
+        peers.close()
+    np.testing.assert_array_equal(dev.query_batch(qn, qp, 10, 6), want)          # the lender is intact

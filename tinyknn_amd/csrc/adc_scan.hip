@@ -899,10 +899,17 @@ __global__ __launch_bounds__(1024) void pairs_scan3_kernel(PairSets ps, const in
     }
 }
 
+// pos / owner / me / ovf_pos (list-sharded index, api_shard.hip): only the pairs of the lists `me` owns get
+// records (make_slots counted only those), and a record's row offset is the segment's position in the send
+// buffer, pos[i].  pos[i] < 0 = the segment did not fit its region (the batch is flagged and repeated): a
+// padding record for the exact kernel; the plain kernel has none and scores the pair to ovf_pos, the
+// tail of the buffer, where the longest list fits.
 __global__ void pairs_fill3_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
                                    int64_t n_lists, const int *__restrict__ slot_prefix,
                                    const int *__restrict__ slot_exact, PairSets ps,
-                                   const int64_t *__restrict__ list_chunk_off)
+                                   const int64_t *__restrict__ list_chunk_off,
+                                   const int *__restrict__ pos, const int *__restrict__ owner, int me,
+                                   int ovf_pos)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     {   // the plain kernel's unit descriptors (unit_prefix is complete: pairs_scan3_kernel ran before)
@@ -915,12 +922,14 @@ __global__ void pairs_fill3_kernel(const int64_t *__restrict__ probes, int S, in
     const int s = (int)(i - qi * S);
     int64_t cl = probes[i];
     if (cl < 0) cl += n_lists;
-    const int f0 = slot_prefix[qi * (S + 1) + s];
+    if (owner && owner[cl] != me) return;
+    const int f0 = pos ? pos[i] : slot_prefix[qi * (S + 1) + s];
+    const bool ovf = pos && f0 < 0;
     const int e = slot_exact[qi];
     auto put = [&](int set) {
-        const int pos = atomicAdd(&ps.cursor[set][cl], 1);
-        ps.pair_q[set][ps.pair_off[set][cl] + pos] = (int)qi;
-        ps.pair_f0[set][ps.pair_off[set][cl] + pos] = f0;
+        const int at = ps.pair_off[set][cl] + atomicAdd(&ps.cursor[set][cl], 1);
+        ps.pair_q[set][at] = (ovf && set != 1) ? -1 : (int)qi;
+        ps.pair_f0[set][at] = ovf ? (set == 1 ? ovf_pos : 0) : f0;
     };
     if (e == 0 && s == 0) {        // head mode: first chunks exact, the whole list plain (overwritten)
         put(2);
@@ -954,7 +963,8 @@ void tk_launch_pairs_scan3(const TkPairSet &ex, const TkPairSet &pl, const TkPai
 void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
                            const int64_t *list_chunk_off, const int *slot_prefix,
                            const int *slot_exact, const TkPairSet &ex, const TkPairSet &pl,
-                           const TkPairSet &hd, int head_chunks, hipStream_t s)
+                           const TkPairSet &hd, int head_chunks, hipStream_t s, const int *pos,
+                           const int *owner, int me, int ovf_pos)
 {
     if (nq == 0 || S == 0) return;
     const int64_t np = nq * S;
@@ -962,7 +972,7 @@ void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_l
     hipLaunchKernelGGL(pairs_scan3_kernel, dim3(1), dim3(1024), 0, s, ps, list_chunk_off, (int)n_lists,
                        head_chunks);
     hipLaunchKernelGGL(pairs_fill3_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, probes, S,
-                       nq, n_lists, slot_prefix, slot_exact, ps, list_chunk_off);
+                       nq, n_lists, slot_prefix, slot_exact, ps, list_chunk_off, pos, owner, me, ovf_pos);
 }
 
 void tk_launch_pairs_scan(int *count, const int64_t *list_chunk_off, int64_t n_lists, int *pair_off,

@@ -300,6 +300,74 @@ extern "C" int tk_index_shard_resident(tk_index *ix, const int32_t *owner, int r
     return TK_OK;
 }
 
+// Another rank's shard of a complete unsharded index on the same device (tinyknn_hip.h): the clone borrows
+// the replicated arrays and owns the compacted codes of its lists.
+extern "C" tk_index *tk_index_clone_shard(tk_index *src, const int32_t *owner, int rank, int world)
+{
+    if (!src || !owner || world < 1 || rank < 0 || rank >= world || !src->have_lists || !src->have_data ||
+        src->sharded) {
+        (void)fail(TK_ERR_ARG, "bad argument: tk_index_clone_shard wants a complete unsharded index, an owner map and rank < world");
+        return nullptr;
+    }
+    IXLOCK(src);
+    if (flush_pending(src) != TK_OK || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    tk_index *ix = tk_index_create();
+    if (!ix) return nullptr;
+    ix->pq_centers.borrow(src->pq_centers);
+    ix->dq = src->dq; ix->dpb = src->dpb; ix->M = src->M; ix->f_order = src->f_order; ix->order = src->order;
+    ix->sqrt_nb = src->sqrt_nb;
+    ix->active_centers.borrow(src->active_centers);
+    ix->center_codes.borrow(src->center_codes);
+    ix->n_lists = src->n_lists; ix->center_chunks = src->center_chunks; ix->d = src->d;
+    ix->list_chunk_off.borrow(src->list_chunk_off);
+    ix->list_n.borrow(src->list_n);
+    ix->ids_off.borrow(src->ids_off);
+    ix->ids.borrow(src->ids);
+    ix->ids32.borrow(src->ids32);
+    ix->have_ids32 = src->have_ids32;
+    ix->total_chunks = src->total_chunks; ix->total_ids = src->total_ids;
+    ix->max_list_chunks = src->max_list_chunks;
+    ix->ids_unique = src->ids_unique;
+    ix->cslots_i.borrow(src->cslots_i);
+    ix->cslots_l.borrow(src->cslots_l);
+    ix->c_chunk_off.borrow(src->c_chunk_off);
+    ix->rot_t.borrow(src->rot_t);
+    ix->rot_d_pad = src->rot_d_pad;
+    ix->data.borrow(src->data);
+    ix->N = src->N; ix->data_is_f64 = src->data_is_f64;
+    ix->have_pq = ix->have_centers = ix->have_lists = ix->have_data = true;
+    ix->plain_mode = src->plain_mode;
+    // this rank's codes
+    const int64_t L = ix->n_lists;
+    std::vector<int64_t> sizes((size_t)L), loff((size_t)L + 1, 0);
+    bool ok = hipMemcpy(sizes.data(), src->list_n.p, (size_t)L * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    for (int64_t i = 0; ok && i < L; i++) {
+        ok = owner[i] >= 0 && owner[i] < world;
+        loff[(size_t)i + 1] = loff[(size_t)i] + (owner[i] == rank ? (sizes[(size_t)i] + 15) / 16 : 0);
+    }
+    const int P = ix->M / 2;
+    const size_t bytes = (size_t)tk_tiled_uint4s(loff[(size_t)L], P) * 16;
+    ok = ok && ix->owner.ensure((size_t)L * 4) == TK_OK && ix->local_chunk_off.ensure((size_t)(L + 1) * 8) == TK_OK &&
+         ix->codes.ensure(bytes > 0 ? bytes : 16) == TK_OK;
+    ok = ok && hipMemcpy(ix->owner.p, owner, (size_t)L * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(ix->local_chunk_off.p, loff.data(), (size_t)(L + 1) * 8, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(ix->codes.p, 0, bytes > 0 ? bytes : 16) == hipSuccess;
+    if (ok) {
+        tk_launch_compact_tiled(src->codes.as<uint4>(), ix->codes.as<uint4>(), P, ix->list_chunk_off.as<int64_t>(),
+                                ix->local_chunk_off.as<int64_t>(), (int)L, loff[(size_t)L], 0);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    }
+    if (!ok) {
+        (void)fail(TK_ERR_HIP, "tk_index_clone_shard: owner out of range, or a HIP call failed");
+        tk_index_destroy(ix);
+        return nullptr;
+    }
+    ix->sharded = true;
+    ix->rank = rank;
+    ix->world = world;
+    return ix;
+}
+
 // what a built index holds, back on the host in the reference's formats: list_sizes
 // (n_lists,), codes (total chunks, M) uint64 Quick-ADC layout, ids (sum sizes,) — any NULL
 extern "C" int tk_index_export_lists(tk_index *ix, int64_t *list_sizes, uint64_t *codes, int64_t *ids)

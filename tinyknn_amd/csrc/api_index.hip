@@ -575,6 +575,7 @@ static int head_rows(const tk_index *ix, const Plan &p)
 }
 // head pairs: the first ceil(head_rows / 16) chunks of the first probed list of a query in head mode
 static int head_chunks(const tk_index *ix, const Plan &p) { return (head_rows(ix, p) + 15) >> 4; }
+int head_chunks_of(const tk_index *ix, const Plan &p) { return head_chunks(ix, p); }
 
 static TkScanJob head_job(const tk_index *ix, const Work &w, const Plan &p)
 {
@@ -772,7 +773,7 @@ static void rescan_flagged(tk_index *ix, Work &w, int64_t q0, int64_t nq, const 
 
 int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq, int k,
                       const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf, bool plain,
-                      TkSecond q2, TkSecond out2)
+                      TkSecond q2, TkSecond out2, int *plain_flag)
 {
     const int *slot_exact = plain ? w.plain0.as<int>() + q0 : nullptr;     // (first plain chunk per query)
     const int *qlim = plain ? w.qlim.as<int>() + q0 : nullptr;
@@ -798,7 +799,9 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
                                              p.R, 1, 0, repeat_flag, w.mins.as<uint8_t>(),
                                              p.cap_min, nullptr, st, slot_exact, qlim))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
-        if (plain) {
+        if (plain && plain_flag) {
+            tk_launch_shard_flag_plain(repeat_flag, nq, plain_flag, st);
+        } else if (plain) {
             // flag 2 = the lane replay's "bound above the limit at the first plain block": exact
             // re-scan, then the packed kernel from a fresh heap (labels are distinct: no duplicate test)
             rescan_flagged(ix, w, q0, nq, p, st);

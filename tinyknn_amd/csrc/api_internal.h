@@ -40,9 +40,18 @@ static inline int require_gpu() { return tk_require_gpu(); }
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;      // memory of another index (tk_index_clone_shard): never freed or grown here
+    void borrow(const DevBuf &o)
+    {
+        release();
+        p = o.p;
+        cap = o.cap;
+        borrowed = p != nullptr;
+    }
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return TK_OK;
+        if (borrowed) return fail(TK_ERR_ARG, "bad argument: a borrowed array of a cloned shard cannot grow");
         if (p) HIPCHECK(hipFree(p));
         p = nullptr;
         cap = 0;
@@ -53,9 +62,10 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        borrowed = false;
     }
     template <typename T>
     T *as() const { return (T *)p; }
@@ -101,6 +111,7 @@ struct Work {
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
     bool shard_first = false;       // tk_index_shard_scan_first_dev ran: _rest_dev is owed
+    bool shard_plain = false;       // tk_index_shard_scan_plain_dev filled the send buffer: the home replay checks the lemma
     // pipelined mode (depth > 1): hand-offs between the caller's stream and a latency stream
     hipEvent_t tables_done = nullptr, coarse_scanned = nullptr, front_done = nullptr,
                scanned = nullptr, done = nullptr;
@@ -286,6 +297,9 @@ void coarse_slots(tk_index *ix, Work &w, const int64_t *probes, int64_t nq, cons
 int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,
                       int *pair_count, const int *owner, int me, hipStream_t st, Prof &pf,
                       bool plain = false, TkSecond q2 = TkSecond());
+// plain_flag (list-sharded home rank): queries the plain path's lemma does not cover raise bit 4 of
+// *plain_flag instead of being scanned again (the codes are on other ranks: the batch is repeated)
 int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq, int k,
                const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf, bool plain = false,
-               TkSecond q2 = TkSecond(), TkSecond out2 = TkSecond());
+               TkSecond q2 = TkSecond(), TkSecond out2 = TkSecond(), int *plain_flag = nullptr);
+int head_chunks_of(const tk_index *ix, const Plan &p);    // chunks of a first probed list the exact kernel keeps (head mode)

@@ -60,6 +60,39 @@ static int shard_args(tk_index *ix, int slot, int64_t nq, int64_t capacity, cons
     return TK_OK;
 }
 
+static bool shard_plain_possible(const tk_index *ix, const Plan &p)
+{
+    if (ix->plain_mode == 1 || !plain_env_on() || !ix->sharded || p.S < 2 || !tk_plain_fits(ix->M)) return false;
+    return ix->ids_unique || ix->plain_mode == 2;
+}
+
+static int reserve_shard_plain(tk_index *ix, Work &w, int64_t nq, const Plan &p)
+{
+    const size_t L = (size_t)ix->n_lists;
+    TRY(w.qlim.ensure((size_t)nq * 4));
+    TRY(w.plain_q.ensure((size_t)nq + 16));
+    DevBuf *zeroed[] = {&w.p_count, &w.h_count};
+    for (DevBuf *b : zeroed) {
+        const void *before = b->p;
+        TRY(b->ensure(L * 4));
+        if (b->p != before) HIPCHECK(hipMemset(b->p, 0, b->cap));
+    }
+    TRY(w.p_cursor.ensure(L * 4));
+    TRY(w.p_pair_off.ensure((L + 1) * 4));
+    TRY(w.p_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
+    TRY(w.p_pair_q.ensure(((size_t)nq * p.S + 4) * 4));
+    TRY(w.p_pair_f0.ensure(((size_t)nq * p.S + 4) * 4));
+    TRY(w.p_unit_desc.ensure(plain_desc_bytes(ix, nq, p)));
+    TRY(w.h_cursor.ensure(L * 4));
+    TRY(w.h_pair_off.ensure((L + 1) * 4));
+    TRY(w.h_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
+    TRY(w.h_pair_q.ensure(((size_t)nq + 4 * L + 4) * 4));       // (one-phase form: a head pair per query)
+    TRY(w.h_pair_f0.ensure(((size_t)nq + 4 * L + 4) * 4));
+    TRY(w.slot_exact.ensure((size_t)nq * 4));
+    TRY(w.plain0.ensure((size_t)nq * 4));
+    return TK_OK;
+}
+
 // Coarse stage sharded by HOME rank: tables for all nq queries (every rank scores segments of
 // every query), coarse scan + replay + rescoring only for this rank's ceil(nq/world) home
 // queries; the caller all-gathers the probe lists and hands them to tk_index_shard_scan_dev.
@@ -78,7 +111,10 @@ extern "C" int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_
     hipStream_t st = (hipStream_t)stream;
     TRY(reserve_shard(ix, w, nq, qh, p));
     Prof pf;
-    TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
+    // (the limits C of all nq tables ride in the table launch's shadow where a plain form may follow)
+    const bool limits = shard_plain_possible(ix, p);
+    if (limits) TRY(reserve_shard_plain(ix, w, nq, p));
+    TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, limits));
     const int64_t q0 = (int64_t)ix->rank * qh;
     int64_t nqh = nq - q0;
     nqh = nqh < 0 ? 0 : (nqh > qh ? qh : nqh);
@@ -158,6 +194,123 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     w.shard_probes = probes;
     w.shard_nq = nq;
     w.shard_capacity = capacity;
+    w.shard_plain = false;
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+// ---- the scan in ONE phase with the matrix-core kernel, as the unsharded pipeline runs it ----
+// tk_index_shard_scan_dev scores every owned segment exactly; the two-phase form below first learns the
+// bound B1 after every query's first list (a replay by value on its owner + a MIN all-reduce: one more
+// kernel chain and one more collective on the batch's critical path).  The unsharded index does neither:
+// it keeps only the first rows a query scans (the head of its first list: 2 heap sizes) on the exact
+// kernel, runs everything else as plain sums on the matrix cores, and lets the REPLAY check the lemma's
+// condition per query (bound at the first plain block <= the table's limit C; plain_scan.hip).  The
+// same here: every rank scores its segments of every query that way straight into the send buffer —
+// head chunks exact, the rest plain — and the home rank's replay (tk_index_shard_finish_dev) does the
+// check.  A query that fails it cannot be scanned again at home (the codes are elsewhere): bit 4 of the
+// batch's flag word is raised, it travels with the ids, and the caller repeats the batch through
+// tk_index_shard_scan_dev.  On the bench batches no query fails.  Same ids as every other form.
+// Applies where tk_index_shard_plain says yes AND the labels are distinct AND world * capacity holds the
+// longest list (the plain kernel scores an overflowed segment to the buffer's tail); otherwise this
+// call is tk_index_shard_scan_dev.
+extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float *q_dev,
+                                             const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
+                                             int n_probes, int pass_1, const int64_t *probes_all_dev,
+                                             int64_t capacity, void *send_dev, int *flag_dev, void *stream)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, capacity, p, qh));
+    ARGCHECK(send_dev && flag_dev, "send/flag buffers");
+    const int64_t tail = (int64_t)ix->world * capacity - ix->max_list_chunks;
+    if (!shard_plain_possible(ix, p) || !ix->ids_unique || tail < 0 || p.R > TK_LANES_MAX_R ||
+        ix->heap_mode != 0 || p.cap * 16 > 0xffffff)
+        return tk_index_shard_scan_dev(ix, slot, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1,
+                                       probes_all_dev, capacity, send_dev, flag_dev, stream);
+    Work &w = ix->works[(size_t)slot];
+    hipStream_t st = (hipStream_t)stream;
+    TRY(reserve_shard(ix, w, nq, qh, p));
+    TRY(reserve_shard_plain(ix, w, nq, p));
+    TRY(w.smins.ensure((size_t)ix->world * capacity + 16));
+    TRY(w.usage.ensure((size_t)ix->world * 2 * 8));
+    Prof pf;
+    const int *owner = ix->owner.as<int>();
+    const int64_t *probes = probes_all_dev;
+    if (probes) {
+        // tables and their limits: tk_index_shard_coarse_dev; the probe lists arrive gathered
+        coarse_slots(ix, w, probes, nq, p, w.u_count.as<int>(), owner, ix->rank, st, true);
+    } else {
+        TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, true));
+        launch_coarse_scan(ix, w, nq, p, st);
+        TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf, true));
+        probes = w.probes.as<int64_t>();
+    }
+    {
+        const int64_t n1 = nq * p.S + (int64_t)ix->world * qh * p.S + 1;
+        ARGCHECK(n1 < (1ll << 31), "too many (query, list) entries for one sharded batch");
+        TRY(w.pos_lens.ensure((size_t)n1 * 8));
+        TRY(w.pos_off.ensure((size_t)n1 * 8));
+        size_t tmp_bytes = 0;
+        ARGCHECK(tk_scan_exclusive64(nullptr, &tmp_bytes, w.pos_lens.as<long long>(),
+                                     w.pos_off.as<long long>(), n1, st) == 0,
+                 "hipcub scan (size query) failed");
+        TRY(w.scan_tmp.ensure(tmp_bytes + 16));
+        if (tk_launch_shard_positions(probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists, owner,
+                                      ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
+                                      w.rpos.as<int>(), flag_dev, w.usage.as<long long>(),
+                                      w.pos_lens.as<long long>(), w.pos_off.as<long long>(),
+                                      w.scan_tmp.p, tmp_bytes, st))
+            return fail(TK_ERR_HIP, "hipcub scan failed");
+    }
+    // three pair sets over the lists this rank owns (whole lists exact / plain tiles / heads), the
+    // records' row offsets = positions in the send buffer
+    const int64_t *lco = ix->local_chunk_off.as<int64_t>();
+    TkPairSet ex{w.u_count.as<int>(), w.u_cursor.as<int>(), w.u_pair_off.as<int>(),
+                 w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>()};
+    TkPairSet pl{w.p_count.as<int>(), w.p_cursor.as<int>(), w.p_pair_off.as<int>(),
+                 w.p_unit_prefix.as<int>(), w.p_pair_q.as<int>(), w.p_pair_f0.as<int>(),
+                 w.p_unit_desc.as<int>(), plain_k(ix, nq, p)};
+    TkPairSet hd{w.h_count.as<int>(), w.h_cursor.as<int>(), w.h_pair_off.as<int>(),
+                 w.h_unit_prefix.as<int>(), w.h_pair_q.as<int>(), w.h_pair_f0.as<int>()};
+    const int hc = head_chunks_of(ix, p);
+    tk_launch_unit_pairs2(nq, probes, p.S, ix->n_lists, lco, w.slot_prefix.as<int>(), w.slot_exact.as<int>(),
+                          ex, pl, hd, hc, st, w.spos.as<int>(), owner, ix->rank, (int)tail);
+    TkScanJob lj;
+    lj.codes = ix->codes.as<uint4>();
+    lj.tables = w.tables.as<uint4>();
+    lj.list_chunk_off = lco;
+    lj.n_lists = (int)ix->n_lists;
+    lj.unit_prefix = w.u_unit_prefix.as<int>();
+    lj.pair_off = w.u_pair_off.as<int>();
+    lj.pair_q = w.u_pair_q.as<int>();
+    lj.pair_f0 = w.u_pair_f0.as<int>();
+    lj.dist = (uint4 *)send_dev;
+    lj.cap = 0;
+    lj.mins = w.smins.as<uint8_t>();
+    lj.min_stride = 0;
+    TkScanJob pj = lj, hj = lj, none;
+    memset(&none, 0, sizeof none);
+    pj.unit_prefix = w.p_unit_prefix.as<int>();
+    pj.pair_off = w.p_pair_off.as<int>();
+    pj.pair_q = w.p_pair_q.as<int>();
+    pj.pair_f0 = w.p_pair_f0.as<int>();
+    pj.unit_desc4 = w.p_unit_desc.as<int>();
+    hj.unit_prefix = w.h_unit_prefix.as<int>();
+    hj.pair_off = w.h_pair_off.as<int>();
+    hj.pair_q = w.h_pair_q.as<int>();
+    hj.pair_f0 = w.h_pair_f0.as<int>();
+    hj.max_chunks = hc;
+    // (plain first: the exact kernel then overwrites the head chunks of the lists in head mode)
+    if (tk_launch_scan_plain(pj, ix->M, ix->order, plain_blocks(), st))
+        return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
+    tk_launch_scan_units2(lj, none, ix->M, ix->order, 768, st, &hj, ix->opt_scan_form);
+    w.shard_probes = probes;
+    w.shard_nq = nq;
+    w.shard_capacity = capacity;
+    w.shard_plain = true;
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
@@ -180,43 +333,12 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
 // tk_index_shard_plain: does this apply to (k, n_probes, pass_1)?  Replicated state only (every
 // rank answers alike): M <= 52, n_probes >= 2, distinct labels (or tk_index_set_plain_scan(ix, 2)),
 // not switched off.  Otherwise callers use tk_index_shard_scan_dev.
-static bool shard_plain_possible(const tk_index *ix, const Plan &p)
-{
-    if (ix->plain_mode == 1 || !plain_env_on() || !ix->sharded || p.S < 2 || !tk_plain_fits(ix->M)) return false;
-    return ix->ids_unique || ix->plain_mode == 2;
-}
-
 extern "C" int tk_index_shard_plain(tk_index *ix, int k, int n_probes, int pass_1)
 {
     IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     return shard_plain_possible(ix, p) ? 1 : 0;
-}
-
-static int reserve_shard_plain(tk_index *ix, Work &w, int64_t nq, const Plan &p)
-{
-    const size_t L = (size_t)ix->n_lists;
-    TRY(w.qlim.ensure((size_t)nq * 4));
-    TRY(w.plain_q.ensure((size_t)nq + 16));
-    DevBuf *zeroed[] = {&w.p_count, &w.h_count};
-    for (DevBuf *b : zeroed) {
-        const void *before = b->p;
-        TRY(b->ensure(L * 4));
-        if (b->p != before) HIPCHECK(hipMemset(b->p, 0, b->cap));
-    }
-    TRY(w.p_cursor.ensure(L * 4));
-    TRY(w.p_pair_off.ensure((L + 1) * 4));
-    TRY(w.p_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
-    TRY(w.p_pair_q.ensure(((size_t)nq * p.S + 4) * 4));
-    TRY(w.p_pair_f0.ensure(((size_t)nq * p.S + 4) * 4));
-    TRY(w.p_unit_desc.ensure(plain_desc_bytes(ix, nq, p)));
-    TRY(w.h_cursor.ensure(L * 4));
-    TRY(w.h_pair_off.ensure((L + 1) * 4));
-    TRY(w.h_unit_prefix.ensure(tk_unit_prefix_ints((int64_t)L) * 4));
-    TRY(w.h_pair_q.ensure((4 * L + 4) * 4));
-    TRY(w.h_pair_f0.ensure((4 * L + 4) * 4));
-    return TK_OK;
 }
 
 extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float *q_dev,
@@ -249,8 +371,9 @@ extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, nullptr, owner, ix->rank, st, pf));
         probes = w.probes.as<int64_t>();
     }
-    // the limits C of all nq tables (built by _shard_coarse_dev or just above)
-    tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st, ix->opt_plain_limit);
+    // the limits C of all nq tables (tk_index_shard_coarse_dev computed them beside its tables)
+    if (!probes_all_dev)
+        tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st, ix->opt_plain_limit);
     {
         const int64_t n1 = nq * p.S + (int64_t)ix->world * qh * p.S + 1;
         ARGCHECK(n1 < (1ll << 31), "too many (query, list) entries for one sharded batch");
@@ -283,6 +406,7 @@ extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float
     w.shard_probes = probes;
     w.shard_nq = nq;
     w.shard_capacity = capacity;
+    w.shard_plain = false;
     w.shard_first = true;
     // B1 of the queries whose first list lies here (ivf.py:137-152 over that list alone, by value)
     tk_launch_shard_first_bound(probes, w.slot_prefix.as<int>(), w.slot_n.as<int>(), p.S, nq,
@@ -571,7 +695,7 @@ extern "C" int tk_index_shard_finish_regions_dev(tk_index *ix, int slot, const f
 extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq,
                                          int k, int n_probes, int pass_1, int64_t capacity,
                                          const void *recv_dev, int64_t *out_ids_home_dev,
-                                         void *stream)
+                                         int *flag_dev, void *stream)
 {
     IXLOCK(ix);
     Plan p;
@@ -580,6 +704,7 @@ extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_
     TRY(shard_args(ix, slot, nq, capacity, p, qh));
     ARGCHECK(recv_dev && out_ids_home_dev, "recv/out buffers");
     Work &w = ix->works[(size_t)slot];
+    ARGCHECK(!w.shard_plain || flag_dev, "the one-phase plain scan needs the batch's flag word at the finish");
     hipStream_t st = (hipStream_t)stream;
     const int64_t q0 = (int64_t)ix->rank * qh;
     int64_t nqh = nq - q0;
@@ -590,7 +715,9 @@ extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_
                                w.slot_prefix.as<int>() + q0 * (p.S + 1), p.S, nqh,
                                w.dist.as<uint4>(), p.cap, w.mins.as<uint8_t>(), p.cap_min, 1, st);
         Prof pf;
-        TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf));
+        // (one-phase plain scan: the replay checks the lemma per home query and flags the batch)
+        TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf, w.shard_plain,
+                       TkSecond(), TkSecond(), w.shard_plain ? flag_dev : nullptr));
     }
     HIPCHECK(hipGetLastError());
     return TK_OK;

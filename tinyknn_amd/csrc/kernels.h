@@ -117,7 +117,10 @@ static inline int64_t tk_plain_units_bound(int64_t pairs, int64_t n_lists, int64
 void tk_launch_unit_pairs2(int64_t nq, const int64_t *probes, int S, int64_t n_lists,
                            const int64_t *list_chunk_off, const int *slot_prefix,
                            const int *slot_exact, const TkPairSet &ex, const TkPairSet &pl,
-                           const TkPairSet &hd, int head_chunks, hipStream_t s);
+                           const TkPairSet &hd, int head_chunks, hipStream_t s, const int *pos = nullptr,
+                           const int *owner = nullptr, int me = 0, int ovf_pos = 0);
+// pos / owner / me / ovf_pos: list-sharded index — records only for the lists `me` owns, row offsets =
+// positions in the send buffer (see pairs_fill3_kernel)
 
 // two jobs in ONE launch sharing one pool of 64-unit blocks (pipelined mode: the list scan
 // of one batch and the coarse scan of the next); signed tables
@@ -286,6 +289,8 @@ void tk_launch_shard_count_rest(const int64_t *probes, int S, int64_t nq, int64_
 void tk_launch_pairs_scan3(const TkPairSet &ex, const TkPairSet &pl, const TkPairSet &hd,
                            const int64_t *list_chunk_off, int64_t n_lists, int head_chunks,
                            hipStream_t s);
+// flags[q] == 2 for any q < nq: *flag |= 4 (a home query the plain path's lemma does not cover)
+void tk_launch_shard_flag_plain(const unsigned char *flags, int64_t nq, int *flag, hipStream_t s);
 // slot_prefix: rows of the home queries; dist/mins: (nq_home, cap) / (nq_home, min_stride)
 void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_prefix, int S,
                             int64_t nq_home, uint4 *dist, int64_t cap, uint8_t *mins,

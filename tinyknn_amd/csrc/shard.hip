@@ -283,6 +283,24 @@ void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_
                            slot_prefix, S, n_pairs, dist, cap, mins, min_stride);
 }
 
+// One-phase sharded scan on the matrix cores (tk_index_shard_scan_plain_dev): the home rank's lane replay
+// marks a query (flags[q] == 2) whose bound at its first plain block was above the limit of its table —
+// the lemma of plain_scan.hip does not cover it.  The unsharded index scans such a query again exactly;
+// a home rank does not hold the codes, so the BATCH is flagged (bit 4 of its overflow word, which
+// travels with the ids) and the caller repeats it on the exact kernel.
+__global__ void shard_flag_plain_kernel(const unsigned char *__restrict__ flags, int64_t nq, int *__restrict__ flag)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bad = q < nq && flags[q] == 2;
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 4);
+}
+
+void tk_launch_shard_flag_plain(const unsigned char *flags, int64_t nq, int *flag, hipStream_t s)
+{
+    if (nq == 0) return;
+    hipLaunchKernelGGL(shard_flag_plain_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, flags, nq, flag);
+}
+
 // ---------------------------------------------------------------------------
 // Filtered exchange.  Every insert of a block is below the bound
 // captured at the block's start (_fast_pq_256.pyx:73,111-123), so the bound never increases

@@ -432,11 +432,41 @@ class DeviceIndex:
             int(pass_1 or 0), probes_all_ptr, int(capacity), send_ptr, flag_ptr, stream))
 
     def shard_finish_dev(self, slot, qn_ptr, nq, k, n_probes, pass_1, capacity, recv_ptr, out_ptr,
-                         stream=0):
-        """Second half, after the all-to-all (tk_index_shard_finish_dev)."""
+                         stream=0, flag_ptr=None):
+        """Second half, after the all-to-all (tk_index_shard_finish_dev).  flag_ptr: the batch's flag
+        word — required behind shard_scan_plain_dev (bit 4: a home query failed the plain path's check)."""
         _lib.check(_lib.lib().tk_index_shard_finish_dev(
             self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0),
-            int(capacity), recv_ptr, out_ptr, stream))
+            int(capacity), recv_ptr, out_ptr, flag_ptr, stream))
+
+    def shard_scan_plain_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1, capacity,
+                             send_ptr, flag_ptr, stream=0, probes_all_ptr=None):
+        """The owned segments in ONE phase as the unsharded pipeline scores them: heads exactly, the rest
+        as plain sums on the matrix cores, checked by the home rank's replay
+        (tk_index_shard_scan_plain_dev; falls back to shard_scan_dev's kernel where that does not apply)."""
+        _lib.check(_lib.lib().tk_index_shard_scan_plain_dev(
+            self._h, int(slot), qn_ptr, qpq_ptr, int(bool(qpq_is_f64)), nq, int(k), int(n_probes),
+            int(pass_1 or 0), probes_all_ptr, int(capacity), send_ptr, flag_ptr, stream))
+
+    def clone_shard(self, owner, rank, world):
+        """Rank `rank`'s shard of this complete unsharded index as a NEW handle on the same device
+        (tk_index_clone_shard): it borrows the replicated arrays — this index must outlive it — and owns
+        the codes of its lists.  How several ranks of a list partition are played on one GPU."""
+        own = np.ascontiguousarray(owner, dtype=np.int32)
+        assert own.shape == (self.n_lists,)
+        h = _lib.lib().tk_index_clone_shard(self._h, _lib.ptr(own, _lib._i32p), int(rank), int(world))
+        if not h:
+            raise _lib.TinyKnnHipError(_lib.lib().tk_last_error().decode() or "tk_index_clone_shard failed")
+        c = DeviceIndex.__new__(DeviceIndex)
+        c._h = h
+        c._source = self            # keeps the lender alive
+        for a in ("dq", "dpb", "n_lists", "d", "list_sizes", "angular", "_R", "code_bytes"):
+            setattr(c, a, getattr(self, a, None))
+        c.N = getattr(self, "N", None)
+        c.rank, c.world = int(rank), int(world)
+        c._streams = {}
+        c._live_streams = weakref.WeakSet()
+        return c
 
     def shard_usage(self, slot):
         """Longest stream (uint4) of the slot's last shard_scan_dev (tk_index_shard_usage; syncs)."""

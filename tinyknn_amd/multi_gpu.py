@@ -130,9 +130,11 @@ def shard_positions(probes, chunks, owner, world, capacity):
 class _HipShardEngine:
     """scan / finish on the MI355X (torch tensors carry the device buffers)."""
 
-    def __init__(self, ivf, owner, rank, world, depth, resident=False):
+    def __init__(self, ivf, owner, rank, world, depth, resident=False, dev=None):
         from .ivf import DeviceIndex
-        if resident:
+        if dev is not None:
+            self.dev = dev              # e.g. DeviceIndex.clone_shard: another rank's shard on this device
+        elif resident:
             # the index was built in HBM (IVF.build_resident): shard it where it lies
             self.dev = ivf.device_index()
             self.dev.shard_resident(owner, rank, world)
@@ -173,11 +175,22 @@ class _HipShardEngine:
         self.dev.shard_scan_rest_dev(slot, qn.shape[0], k, n_probes, pass_1, capacity, send.data_ptr(),
                                      bound.data_ptr(), stream=st)
 
-    def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home):
+    # ... in ONE phase, heads exactly and the rest on the matrix cores, checked by the home replay
+    # (tk_index_shard_scan_plain_dev)
+    def scan_plain(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_scan_plain_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
+                                      qn.shape[0], k, n_probes, pass_1, capacity, send.data_ptr(),
+                                      flag.data_ptr(), stream=st,
+                                      probes_all_ptr=None if probes_all is None else probes_all.data_ptr())
+
+    def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home, flag=None):
         import torch
         st = torch.cuda.current_stream().cuda_stream
         self.dev.shard_finish_dev(slot, qn.data_ptr(), qn.shape[0], k, n_probes, pass_1, capacity,
-                                  recv.data_ptr(), out_home.data_ptr(), stream=st)
+                                  recv.data_ptr(), out_home.data_ptr(), stream=st,
+                                  flag_ptr=None if flag is None else flag.data_ptr())
 
     def usage(self, slot):
         return self.dev.shard_usage(slot)
@@ -261,16 +274,23 @@ class ListShardedIndex:
 
     def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None,
                  coarse="home", coalesce=1, exchange="dense", calibrate=True, force_collectives=None,
-                 counts="device", plain=True):
+                 counts="device", plain=True, simulate=None):
         import os
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.ivf, self.group = ivf, group
-        on = dist.is_available() and dist.is_initialized()
+        # simulate: a SimulatedPeers — this object is then ONE rank of peers.world whose collectives
+        # are answered locally with what the other ranks would have contributed (no process group)
+        self._sim = simulate
+        on = dist.is_available() and dist.is_initialized() and simulate is None
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         self.backend = dist.get_backend(group) if on else None
+        if simulate is not None:
+            self.world, self.rank = simulate.world, simulate.rank
+            owner = simulate.owner
+            engine = simulate.live_engine(depth)
         # force_collectives (or TINYKNN_FORCE_COLLECTIVES=1): with ONE rank the exchanges are
         # device copies; forced, they go through torch.distributed all the same — on a one-GPU box
         # that is how the RCCL code path (uint8 MIN all-reduce, equal- and variable-split
@@ -313,6 +333,11 @@ class ListShardedIndex:
             counts = "host"
         self.counts = counts
         self.plain = bool(plain) and all(hasattr(self.engine, a) for a in ("plain_ok", "scan_first", "scan_rest"))
+        # dense exchange: the scan in ONE phase (heads exactly, the rest on the matrix cores, the home
+        # replay checks the lemma per query and flags the batch: bit 4) where the engine has it;
+        # plain="two-phase" keeps the form with the bound after the first list for the dense exchange too
+        self._one_phase = self.plain and plain != "two-phase" and hasattr(self.engine, "scan_plain")
+        self._plain_failed = set()  # (k, n_probes, pass_1) whose one-phase batch raised bit 4: two-phase from then on
         self.record_region = {}     # (nq, n_probes) -> records per home-rank region (counts="device")
         self._rec_seen = {}         # ... largest per-home count of the batches looked at so far
         self._acc = None            # device: [largest per-home record count, records, dense blocks] since reset
@@ -353,8 +378,9 @@ class ListShardedIndex:
         self._pending = []
         self._deferred = None
         self._need = {}             # (nq, n_probes) -> longest streams seen by query_prepared
-        self._ovf = None            # device counter: overflow / bad-record flags of submit()ted batches
-        self._ovf_keys = set()      # capacities to grow if that counter is non-zero at join()
+        self._ovf = None            # device counters: [overflow / bad-record flags, plain-check flags] of submit()ted batches
+        self._ovf_keys = set()      # capacities to grow if the first counter is non-zero at join()
+        self._ovf_args = set()      # (k, n_probes, pass_1) of those batches
         self.last_flushed = None    # gathered tensor of the batch join() flushed (coalesce > 1)
 
     @property
@@ -381,7 +407,7 @@ class ListShardedIndex:
         """Every rank must hold the SAME index (same centres, same lists): positions in the
         exchange are computed, not transmitted.  An index fitted per rank from an unseeded RNG
         differs silently — compare a checksum once, at construction."""
-        if self.world == 1 and not self.force:
+        if (self.world == 1 and not self.force) or self._sim is not None:
             return
         import zlib
         crc = zlib.crc32(np.ascontiguousarray(self.list_sizes).tobytes())
@@ -399,8 +425,10 @@ class ListShardedIndex:
                                "differ) — build every rank's index from the same data and the same seed")
 
     # -- collectives (RCCL on device tensors; any other backend is staged through the host)
-    def _all_to_all(self, recv, send):
-        if self.world == 1 and not self.force:
+    def _all_to_all(self, recv, send, what="segments"):
+        if self._sim is not None:
+            self._sim.all_to_all(what, self._sim_ctx, recv, send)
+        elif self.world == 1 and not self.force:
             recv.copy_(send)
         elif self.backend == "nccl" or self.device == "cpu":
             self.dist.all_to_all_single(recv, send, group=self._cg)
@@ -409,8 +437,10 @@ class ListShardedIndex:
             self.dist.all_to_all_single(r, s_, group=self._cg)
             recv.copy_(r)
 
-    def _all_gather(self, out, inp):
-        if self.world == 1 and not self.force:
+    def _all_gather(self, out, inp, what="ids"):
+        if self._sim is not None:
+            self._sim.all_gather(what, self._sim_ctx, out, inp)
+        elif self.world == 1 and not self.force:
             out.copy_(inp)
         elif self.backend == "nccl" or self.device == "cpu":
             self.dist.all_gather_into_tensor(out, inp, group=self._cg)
@@ -420,6 +450,8 @@ class ListShardedIndex:
             out.copy_(o)
 
     def _all_reduce_min(self, t_):
+        if self._sim is not None:
+            return self._sim.all_reduce_min(self._sim_ctx, t_)
         if self.world == 1 and not self.force:
             return
         if self.backend == "nccl" or self.device == "cpu":
@@ -475,8 +507,8 @@ class ListShardedIndex:
         if W == 1 and not self.force:       # one rank: nothing travels, the regions are read where they lie
             rrec, rcounts = f["rec"], f["counts"]
         else:
-            self._all_to_all(f["rcounts"], f["counts"][:W])
-            self._all_to_all(f["rrec"], f["rec"])
+            self._all_to_all(f["rcounts"], f["counts"][:W], "counts")
+            self._all_to_all(f["rrec"], f["rec"], "records")
             rrec, rcounts = f["rrec"], f["rcounts"]
         self.engine.finish_regions(slot, qn, k, n_probes, pass_1, rrec, rcounts, region,
                                    out_home, b["flag"])
@@ -490,10 +522,12 @@ class ListShardedIndex:
         for key in keys:
             seen = self._rec_seen.setdefault(key, [])
             seen.append(int(need))
-            if self.calibrate and len(seen) >= 2:
-                self.record_region[key] = int(1.35 * max(seen)) + 64
+            if self.calibrate and len(seen) >= 3:
+                self.record_region[key] = int(1.5 * max(seen)) + 64
 
     def _max_over_ranks(self, v):
+        if self._sim is not None:
+            return int(v)
         if self.world > 1 or self.force:
             t_ = self.torch.tensor([int(v)], dtype=self.torch.int64,
                                    device=self.device if self.backend == "nccl" else "cpu")
@@ -507,6 +541,11 @@ class ListShardedIndex:
         Synchronises; every rank calls it at the same point."""
         if self._acc is None or not self._acc_keys:
             return None, ()
+        if self.device == "cuda":
+            # the filters of the batches in flight add to the tally from THEIR streams: a read (and the
+            # reset behind it) ordered only on the current stream lost counts on a fresh box — regions
+            # were then trimmed below what the next batch needed (the round-4 driver run's overflow)
+            self.torch.cuda.synchronize()
         v = int(self._acc[0].item())
         self._acc[0] = 0
         keys, self._acc_keys = self._acc_keys, set()
@@ -520,9 +559,10 @@ class ListShardedIndex:
             self.engine.bound(slot, qn, k, n_probes, pass_1, capacity, b["send"], f["bound"])
             self._all_reduce_min(f["bound"])
             bound = f["bound"]
+        assert self._sim is None, "simulated peers: counts=\"device\" only"
         self.engine.filter(slot, qn, k, n_probes, pass_1, capacity, b["send"], bound,
                            f["counts"], f["rec"])
-        self._all_to_all(f["rcounts"], f["counts"][:W])
+        self._all_to_all(f["rcounts"], f["counts"][:W], "counts")
         return f
 
     def _filtered_back(self, qn, f):
@@ -562,12 +602,30 @@ class ListShardedIndex:
             self._plain_ok[key] = bool(self.engine.plain_ok(k, n_probes, pass_1))
         return self._plain_ok[key]
 
+    def _one_phase_now(self, k, n_probes, pass_1):
+        """One-phase plain scan for this batch?  Replicated state only (the flag words that switch it off
+        are all-gathered), so every rank answers alike."""
+        return (self._one_phase and (k, n_probes, pass_1) not in self._plain_failed and
+                self._exchange_kind(k, n_probes, pass_1) == "dense" and self._use_plain(k, n_probes, pass_1))
+
+    def _finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, b, qh):
+        if b.get("one_phase"):
+            self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, recv, b["home"][:qh * k], flag=b["flag"])
+        else:
+            self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, recv, b["home"][:qh * k])
+
     def _scan(self, slot, qn, qp, k, n_probes, pass_1, capacity, b, probes_all=None):
         """The scan of the owned segments into b["send"]; returns the min-reduced bound after the
         first probed lists (two-phase form) or None."""
+        b["one_phase"] = False
         if not self._use_plain(k, n_probes, pass_1):
             self.engine.scan(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"],
                              probes_all=probes_all)
+            return None
+        if self._one_phase_now(k, n_probes, pass_1):
+            self.engine.scan_plain(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"],
+                                   probes_all=probes_all)
+            b["one_phase"] = True
             return None
         nq = qn.shape[0]
         if b.get("bound") is None or b["bound"].shape[0] != nq:
@@ -603,10 +661,17 @@ class ListShardedIndex:
         b = self._buffers(slot, nq, k, capacity)
         qh = -(-nq // self.world)
         b["flag"].zero_()
+        if self._sim is not None:
+            kind = self._exchange_kind(k, n_probes, pass_1)
+            self._sim_ctx = self._sim.context(
+                qn, qp, k, n_probes, pass_1, capacity, coarse=self.coarse, kind=kind,
+                region=self._region(nq, n_probes, capacity) if kind == "filtered" else 0,
+                form=("one" if self._one_phase_now(k, n_probes, pass_1) else
+                      "two" if self._use_plain(k, n_probes, pass_1) else "exact"))
         if self.coarse == "home":
             p_home, p_all = self._probe_buffers(slot, nq, n_probes)
             self.engine.coarse(slot, qn, qp, k, n_probes, pass_1, p_home)
-            self._all_gather(p_all, p_home)
+            self._all_gather(p_all, p_home, "probes")
             bound = self._scan(slot, qn, qp, k, n_probes, pass_1, capacity, b, probes_all=p_all)
         else:
             bound = self._scan(slot, qn, qp, k, n_probes, pass_1, capacity, b)
@@ -622,7 +687,7 @@ class ListShardedIndex:
             if self.world > 1 or self.force:
                 self._all_to_all(b["recv"], b["send"])
                 recv = b["recv"]
-            self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, recv, b["home"][:qh * k])
+            self._finish(slot, qn, k, n_probes, pass_1, capacity, recv, b, qh)
             self._gather_ids(b, qh, k)
         return st
 
@@ -665,6 +730,8 @@ class ListShardedIndex:
         if not hasattr(self.engine, "usage"):
             return None
         u = int(self.engine.usage(slot))
+        if self._sim is not None:
+            return max(u, self._sim.usage(self._sim_ctx))
         if self.world > 1 or self.force:
             t_ = self.torch.tensor([u], dtype=self.torch.int64,
                                    device=self.device if self.backend == "nccl" else "cpu")
@@ -687,6 +754,13 @@ class ListShardedIndex:
             g = g.cpu().numpy()
             if (g[:, -1] & 2).any():
                 raise RuntimeError("filtered exchange: a record outside the home rank's rows")
+            if (g[:, -1] & 4).any():
+                # a home query failed the one-phase plain scan's check (every rank sees the gathered flag):
+                # these arguments take the two-phase form from now on; the batch again
+                self._plain_failed.add((k, n_probes, pass_1))
+                if not (g[:, -1] & 1).any():
+                    self._take_rec_need()
+                    continue
             need = self._usage(slot)
             # (the device-side maximum is shared by every batch since the last look: batches still in
             #  flight from submit(), possibly with another (nq, n_probes), are credited with it too —
@@ -700,7 +774,7 @@ class ListShardedIndex:
                 if need is not None and self.calibrate:
                     seen = self._need.setdefault(key, [])
                     seen.append(need)
-                    if len(seen) >= 2 and int(1.35 * max(seen)) + 64 < 0.8 * cap:
+                    if len(seen) >= 3 and int(1.35 * max(seen)) + 64 < 0.8 * cap:
                         self.capacity[key] = int(1.35 * max(seen)) + 64
                 if rec_need is not None:
                     self._note_region(set(rec_keys) | {key}, rec_need)
@@ -759,11 +833,12 @@ class ListShardedIndex:
         t = self.torch
         cap = self._capacity(qn.shape[0], n_probes)
         self._ovf_keys.add((qn.shape[0], n_probes))
+        self._ovf_args.add((k, n_probes, pass_1))
         if self._streams is None:
             out = self._enqueue(qn, qp, k, n_probes, pass_1, cap)
             self._note_flags(out)
             return out
-        if self._roles is not None and self._exchange_kind(k, n_probes, pass_1) == "dense":
+        if self._roles is not None and self._exchange_kind(k, n_probes, pass_1) == "dense" and self._sim is None:
             return self._submit_roles(qn, qp, k, n_probes, pass_1, cap)
         st = self._streams[self._calls % self.depth]
         st.wait_stream(t.cuda.current_stream())
@@ -802,7 +877,7 @@ class ListShardedIndex:
                 b["flag"].zero_()
                 p_home, p_all = self._probe_buffers(slot, nq, n_probes)
                 self.engine.coarse(slot, qn, qp, k, n_probes, pass_1, p_home)
-                self._all_gather(p_all, p_home)
+                self._all_gather(p_all, p_home, "probes")
             R["scan"].wait_stream(R["front"])
         with t.cuda.stream(R["scan"]):
             if self.coarse != "home":
@@ -817,7 +892,7 @@ class ListShardedIndex:
             if self.world > 1 or self.force:
                 self._all_to_all(b["recv"], b["send"])
                 recv = b["recv"]
-            self.engine.finish(slot, qn, k, n_probes, pass_1, cap, recv, b["home"][:qh * k])
+            self._finish(slot, qn, k, n_probes, pass_1, cap, recv, b, qh)
             self._gather_ids(b, qh, k)
             out = b["all"].view(self.world, qh * k + 1)
             self._note_flags(out)
@@ -837,10 +912,11 @@ class ListShardedIndex:
         """The flag column of a submit()ted batch (every rank's overflow / bad-record flag) is
         added to a device counter, on the batch's stream: join() reads it once."""
         if self._ovf is None:
-            self._ovf = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
-            self._ovf_ix = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+            self._ovf = self.torch.zeros(2, dtype=self.torch.int64, device=self.device)
+            self._ovf_ix = self.torch.arange(2, dtype=self.torch.int64, device=self.device)
         # (an atomic add: batches on different streams may get here at the same time)
-        self._ovf.index_add_(0, self._ovf_ix, out[:, -1].sum().view(1))
+        fl = out[:, -1]
+        self._ovf.index_add_(0, self._ovf_ix, self.torch.stack([(fl & 3).sum(), (fl & 4).sum()]))
 
     def join(self):
         """Flushes a partly filled coalesced batch (its gathered tensor: the return value and
@@ -857,9 +933,17 @@ class ListShardedIndex:
                 for st in [self._roles["front"], self._roles["scan"]] + self._roles["replay"]:
                     cur.wait_stream(st)
         if self._ovf is not None and self._ovf_keys:
-            bad = int(self._ovf.item())         # (synchronises with the batches in flight)
+            bad, plain_bad = (int(x) for x in self._ovf.cpu().tolist())     # (synchronises with the batches in flight)
             keys, self._ovf_keys = self._ovf_keys, set()
+            args, self._ovf_args = self._ovf_args, set()
             rec_need, rec_keys = self._take_rec_need()
+            if plain_bad:
+                self._ovf.zero_()
+                self._plain_failed |= args
+                if not bad:
+                    raise RuntimeError("ListShardedIndex: a home query of a batch in flight failed the one-phase plain "
+                                       "scan's check (its rows are invalid); these arguments take the two-phase scan "
+                                       "from now on — submit the batches again")
             if bad:
                 self._ovf.zero_()
                 for key in keys:
@@ -877,3 +961,158 @@ class ListShardedIndex:
             if rec_need is not None:
                 self._note_region(rec_keys, rec_need)
         return flushed
+
+
+# ---------------------------------------------------------------------------
+# One rank of a W-rank list partition on a 1-GPU box
+
+class SimulatedPeers:
+    """The OTHER ranks of a W-rank list partition, played by this device, so that ONE rank's share of a
+    sharded batch — its 1/W of the lists for all queries, the replay and rescoring of its home queries,
+    every exchange buffer filled as the collectives would have filled it — can be run, checked and timed
+    where W RCCL ranks cannot exist (`ListShardedIndex(ivf, simulate=peers)`; bench.py's
+    `list_sharded.rank_share_W8`).
+
+    Every rank is a clone shard of the unsharded index (DeviceIndex.clone_shard: the replicated arrays
+    are borrowed, only the owned codes are per rank — a 100M x 128 index keeps its 51 GB of vectors
+    once).  For a batch the peers are run ONCE through the real entry points, on the same inputs, and
+    what they would have put on the links is recorded: the gathered probe lists, the min-reduced bound,
+    the (source -> this rank) regions of the all-to-all, the record regions and counts of the filtered
+    exchange.  A "collective" of the live rank is then a device copy of the recorded contribution of
+    the others (the bytes a real all-to-all would land in this rank's HBM) plus its own live part.
+    The unsharded index stays usable beside it."""
+
+    def __init__(self, ivf, world, rank, owner=None):
+        import torch
+        self.torch = torch
+        self.ivf, self.world, self.rank = ivf, int(world), int(rank)
+        self.base = ivf.device_index()
+        sizes = getattr(ivf, "list_sizes", None)
+        if sizes is None or getattr(ivf, "pq_transformed_points", 0) is not None:
+            sizes = [0 if isinstance(t, np.ndarray) else t.size
+                     for t in ivf.pq_transformed_points[:ivf.active_centers.shape[0]]]
+        self.list_sizes = np.array(sizes, dtype=np.int64)
+        self.owner = shard_lists(self.list_sizes, self.world) if owner is None else np.asarray(owner, dtype=np.int32)
+        self._engines = {}
+        self._live = None
+        self._rec = {}
+
+    def home_range(self, nq):
+        qh = -(-nq // self.world)
+        return self.rank * qh, min(nq, (self.rank + 1) * qh)
+
+    def _engine(self, r):
+        if r not in self._engines:
+            self._engines[r] = _HipShardEngine(self.ivf, self.owner, r, self.world, 1,
+                                               dev=self.base.clone_shard(self.owner, r, self.world))
+        return self._engines[r]
+
+    def live_engine(self, depth):
+        """The timed rank's own engine (`depth` workspace slots); the recording pass uses another clone."""
+        if self._live is None:
+            self._live = _HipShardEngine(self.ivf, self.owner, self.rank, self.world, depth,
+                                         dev=self.base.clone_shard(self.owner, self.rank, self.world))
+        return self._live
+
+    def close(self):
+        for e in list(self._engines.values()) + ([self._live] if self._live is not None else []):
+            e.dev.close()
+        self._engines, self._live, self._rec = {}, None, {}
+
+    # -- what the ranks contribute to one batch
+    def context(self, qn, qp, k, n_probes, pass_1, capacity, coarse="home", kind="dense", region=0, form="exact"):
+        key = (qn.data_ptr(), qn.shape[0], qp.data_ptr(), k, n_probes, pass_1, int(capacity), coarse, kind,
+               int(region), form)
+        if key not in self._rec:
+            if len(self._rec) >= 4:             # (a few batch shapes at a time: the regions are large)
+                self._rec.pop(next(iter(self._rec)))
+            self._rec[key] = self._record(qn, qp, k, n_probes, pass_1, int(capacity), coarse, kind, int(region), form)
+        return self._rec[key]
+
+    def _record(self, qn, qp, k, n_probes, pass_1, capacity, coarse, kind, region, form):
+        t, W, me = self.torch, self.world, self.rank
+        t.cuda.synchronize()
+        nq = qn.shape[0]
+        qh = -(-nq // W)
+        kc = min(n_probes, len(self.list_sizes))
+        rec = dict(usage=0)
+        with t.cuda.stream(t.cuda.Stream()):
+            p_all = None
+            if coarse == "home":
+                homes = [t.zeros(qh * kc, dtype=t.int64, device="cuda") for _ in range(W)]
+                for r in range(W):
+                    self._engine(r).coarse(0, qn, qp, k, n_probes, pass_1, homes[r])
+                p_all = t.cat(homes).contiguous()
+            rec["p_all"] = p_all
+            flag = t.zeros(1, dtype=t.int32, device="cuda")
+            bound = None
+            mine = t.empty((W, capacity * 16), dtype=t.uint8, device="cuda")        # (source s -> this rank)
+            sends = {}
+            if form == "two" or kind == "filtered":
+                firsts = []
+                for r in range(W):
+                    sends[r] = t.empty((W, capacity * 16), dtype=t.uint8, device="cuda")
+                    b_ = t.zeros(nq, dtype=t.uint8, device="cuda")
+                    if form == "two":
+                        self._engine(r).scan_first(0, qn, qp, k, n_probes, pass_1, capacity, sends[r], flag, b_,
+                                                   probes_all=p_all)
+                    else:
+                        self._engine(r).scan(0, qn, qp, k, n_probes, pass_1, capacity, sends[r], flag, probes_all=p_all)
+                        self._engine(r).bound(0, qn, k, n_probes, pass_1, capacity, sends[r].view(-1), b_)
+                    firsts.append(b_)
+                bound = t.stack(firsts).min(dim=0).values.contiguous()
+                if form == "two":
+                    for r in range(W):
+                        self._engine(r).scan_rest(0, qn, k, n_probes, pass_1, capacity, sends[r], bound)
+                for r in range(W):
+                    mine[r].copy_(sends[r][me])
+                    rec["usage"] = max(rec["usage"], 0)
+            else:
+                buf = t.empty((W, capacity * 16), dtype=t.uint8, device="cuda")
+                for r in range(W):
+                    eng = self._engine(r)
+                    (eng.scan_plain if form == "one" else eng.scan)(0, qn, qp, k, n_probes, pass_1, capacity, buf, flag,
+                                                                     probes_all=p_all)
+                    mine[r].copy_(buf[me])
+            rec["bound"] = bound
+            rec["recv"] = mine
+            if kind == "filtered":
+                assert region > 0, "simulated peers: the filtered exchange with counts=\"device\""
+                rrec = t.empty((W * region, 5), dtype=t.int32, device="cuda")
+                rcnt = t.zeros(W, dtype=t.int32, device="cuda")
+                for r in range(W):
+                    c = t.zeros(3 * W, dtype=t.int32, device="cuda")
+                    rr = t.empty((W * region, 5), dtype=t.int32, device="cuda")
+                    self._engine(r).filter_regions(0, qn, k, n_probes, pass_1, capacity, sends[r].view(-1), bound, c, rr,
+                                                   region, flag)
+                    rrec[r * region:(r + 1) * region].copy_(rr[me * region:(me + 1) * region])
+                    rcnt[r] = c[me]
+                rec["rrec"], rec["rcounts"] = rrec, rcnt
+            t.cuda.current_stream().synchronize()
+            rec["usage"] = max(int(self._engine(r).usage(0)) for r in range(W))
+            rec["flag"] = int(flag.item())
+        t.cuda.synchronize()
+        return rec
+
+    # -- the live rank's "collectives"
+    def all_gather(self, what, ctx, out, inp):
+        n = inp.numel()
+        if what == "probes":
+            out.copy_(ctx["p_all"])
+        else:                                   # ids: the other ranks' rows are theirs (-1 here), flags 0
+            out.fill_(-1)
+            out.view(self.world, n)[:, -1] = 0
+        out.view(self.world, n)[self.rank].copy_(inp)
+
+    def all_to_all(self, what, ctx, recv, send):
+        W, me = self.world, self.rank
+        src = ctx["recv"] if what == "segments" else ctx["rcounts"] if what == "counts" else ctx["rrec"]
+        recv.view(-1).copy_(src.view(-1))
+        n = recv.numel() // W
+        recv.view(W, n)[me].copy_(send.view(W, n)[me])
+
+    def all_reduce_min(self, ctx, t_):
+        self.torch.minimum(t_, ctx["bound"], out=t_)
+
+    def usage(self, ctx):
+        return ctx["usage"]
