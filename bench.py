@@ -338,8 +338,15 @@ def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8):
         kind = idx._exchange_kind(args.k, args.n_probes, None)
         idx.exchange = kind
         r = _list_sharded_run(args, idx, device, 1, 0, qn_t, qp_t, want, co, kind, sim=peers)
-        out = {k_: r[k_] for k_ in ("ms_per_step", "identical_rows_vs_replica", "rows", "windows_ms", "exchange", "scan",
+        out = {k_: r[k_] for k_ in ("ms_per_step", "host_enqueue_ms_per_step", "identical_rows_vs_replica", "rows", "windows_ms",
+                                    "window_drift_last_third_over_first_third", "windows_repeated_after_overflow", "exchange", "scan",
                                     "code_chunks_per_rank", "batches_in_flight", "steps_coalesced_per_exchange")}
+        if idx.stage_events:        # TINYKNN_SHARD_STAGE_EVENTS=1 with role streams: the last batches' stages, us
+            torch.cuda.synchronize()
+            evs = idx.stage_events[-10:]
+            z = evs[0][0]
+            out["stage_timeline_us"] = [[round(z.elapsed_time(e) * 1e3) for e in ev] for ev in evs]
+            out["stage_timeline_is"] = "per batch: front start, front end, scan start, scan end, back end (us from the first)"
         out.update(world=W, rank=0,
                    what="ONE rank's share of a W-rank partition on this GPU, the peers' contributions recorded and "
                         "copied in (no links): per step of --nq shared queries")
@@ -371,13 +378,18 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
     # every workspace slot must have seen a batch of the timed size before the clock starts: a slot
     # that grows inside the timed region pays hipMalloc/hipFree of gigabytes there (seen as a 4x
     # slower leg whenever the untimed calls above had left slot 0 at the single-batch size)
+    host_s = [0.0, 0]
+
     def run(n):
         """n submits + join; join() raises if a batch in flight overflowed its exchange regions
         (it has grown them): the run is then repeated — never timed with invalid rows."""
         for attempt in range(4):
             try:
+                th = time.perf_counter()
                 for _ in range(n):
                     idx.submit(qn_t, qp_t, args.k, args.n_probes)
+                host_s[0] += time.perf_counter() - th
+                host_s[1] += n
                 idx.join()
                 torch.cuda.synchronize()
                 return attempt
@@ -390,24 +402,55 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
     run(-(-max(args.warmup, args.shard_depth * co) // co) * co)
     if world > 1:
         dist.barrier()
-    # windows of --steps steps (each drained: the exchange is a collective, every rank joins);
-    # ms_per_step = the median window, as in the replica region
-    n_win = args.windows if args.windows > 0 else max(3, min(9, -(-300 // args.steps)))
-    wins, repeats = [], 0
+    # Timed region: ONE continuous run of `n_win` windows, as the replica region — a window is the smallest
+    # multiple of `co` steps >= --steps (whole sharded batches), closed by an event on a side stream that
+    # waits for every batch submitted so far (batches in flight finish out of order); nothing is
+    # drained and no submission waits (the collectives keep the ranks in step); ms_per_step = the
+    # median window behind the first (which pays the pipeline's fill).  A
+    # region in which a batch had to be repeated (overflow, failed plain check: join() raises) is run again.
+    steps_w = -(-max(args.steps, 6 * co if sim is not None else args.steps) // co) * co    # (a simulated rank of W: >= 6 batches per window)
+    n_win = args.windows if args.windows > 0 else max(4, min(10, -(-300 // steps_w) + 1))
     idx.bytes_sent = idx.bytes_dense = 0
-    for w in range(n_win):
+    repeats = 0
+    timing_stream = torch.cuda.Stream()
+    for attempt in range(4):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        t0 = time.perf_counter()
-        repeats += run(args.steps)
-        if world > 1:
-            dist.barrier()
-        wins.append(time.perf_counter() - t0)
-    t = torch.tensor(wins, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        host_s[0], host_s[1] = 0.0, 0
+        th = time.perf_counter()
+        evs[0].record()
+        for w in range(n_win):
+            for _ in range(steps_w):
+                idx.submit(qn_t, qp_t, args.k, args.n_probes)
+            idx.flush_host_decisions()
+            for bs in idx.batch_streams() or [torch.cuda.current_stream()]:
+                timing_stream.wait_stream(bs)
+            evs[w + 1].record(timing_stream)
+        host_s[0], host_s[1] = time.perf_counter() - th, n_win * steps_w
+        try:
+            idx.join()
+            torch.cuda.synchronize()
+            break
+        except RuntimeError as e:
+            if "submit the batches again" not in str(e) or attempt == 3:
+                raise
+            log(f"[bench] rank {rank}: {e}")
+            repeats += 1
+            torch.cuda.synchronize()
+    wins_all = [evs[w].elapsed_time(evs[w + 1]) * 1e-3 for w in range(n_win)]
+    t = torch.tensor(wins_all, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wins = sorted(t.tolist())
-    el = wins[len(wins) // 2]
+    wins_all = t.tolist()           # in time order; the first one pays the fill
+    wins = wins_all[1:]
+    # the MEAN window behind the first: with several batches in flight on their own streams the device
+    # does not finish batches in submission order, so single windows swing (a median would pick a
+    # lucky or an unlucky one); their sum is simply the time the steps behind the fill took
+    el = sum(wins) / len(wins)
+    third = max(1, len(wins) // 3)
+    drift = (sum(wins[-third:]) / third) / (sum(wins[:third]) / third)
     cap = idx.capacity[(args.nq * co, args.n_probes)] if (args.nq * co, args.n_probes) in idx.capacity \
         else idx.capacity[(args.nq, args.n_probes)]
     W_ix = idx.world            # (a simulated rank: the partition's world, not the process group's)
@@ -418,8 +461,8 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
         # counts, against the blocks of whole segments (16 B each, what the dense form needs at least)
         dense_b = idx.bytes_dense
         filt = {"kind": "filtered (bound after the first probed list; blocks below it as 20-byte records)",
-                "record_bytes_per_rank_per_step": int(idx.bytes_sent // (args.steps * n_win)),
-                "whole_segment_bytes_per_rank_per_step": int(dense_b // (args.steps * n_win)),
+                "record_bytes_per_rank_per_step": int(idx.bytes_sent // (steps_w * n_win)),
+                "whole_segment_bytes_per_rank_per_step": int(dense_b // (steps_w * n_win)),
                 "bytes_ratio": round(idx.bytes_sent / max(1, dense_b), 4),
                 "host_syncs_per_exchange": 0 if idx.counts == "device" else 1,
                 "counts": idx.counts + (" (fixed record regions, equal-split all-to-all, counts read on the device)"
@@ -427,11 +470,16 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
         if idx.counts == "device":
             key = (args.nq * co, args.n_probes)
             filt["record_region"] = int(idx._region(key[0], key[1], idx._capacity(*key)))
-            filt["records_held_bytes_per_rank_per_step"] = int(20 * idx.records_sent // (args.steps * n_win))
-    return {"queries_per_s": args.nq * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+            filt["records_held_bytes_per_rank_per_step"] = int(20 * idx.records_sent // (steps_w * n_win))
+    return {"queries_per_s": args.nq * steps_w / el, "ms_per_step": el / steps_w * 1e3,
+            "steps_per_window": steps_w,
+            "timing": "one continuous run; a window = %d steps (whole sharded batches), closed by an event behind every "
+                      "batch submitted so far; MEAN of the windows behind the first (= elapsed / steps behind the fill)" % steps_w,
             "scaling": "strong (one shared batch of %d queries per step)" % args.nq,
             "identical_rows_vs_replica": same, "rows": rows_checked,
-            "windows_ms": [w_ * 1e3 for w_ in wins], "windows_repeated_after_overflow": repeats,
+            "host_enqueue_ms_per_step": host_s[0] / max(host_s[1], 1) * 1e3,
+            "windows_ms": [w_ * 1e3 for w_ in wins_all], "windows_in_time_order": True,
+            "window_drift_last_third_over_first_third": drift, "windows_repeated_after_overflow": repeats,
             "exchange": {**filt, "all_to_all_bytes_per_rank_per_step": int(W_ix * cap * 16 // co),
                          "region_capacity_uint4": int(cap),
                          "probe_all_gather_bytes_per_rank_per_step":
@@ -966,7 +1014,7 @@ def main():
                          "implies --n 100000000 --d 128 --n-clusters 10000 --metric euclidean unless given")
     ap.add_argument("--shard", choices=["auto", "none", "lists"], default="auto",
                     help="list-sharded leg after the replica measurement (auto: when N > 1)")
-    ap.add_argument("--shard-depth", type=int, default=4,
+    ap.add_argument("--shard-depth", type=int, default=8,
                     help="list-sharded leg: batches in flight (each on its own stream)")
     ap.add_argument("--shard-coalesce", type=int, default=0,
                     help="list-sharded leg: consecutive steps answered as ONE sharded batch (<= 131072 queries); "
@@ -1028,6 +1076,12 @@ def main():
         args.py_cpu_sample = min(args.py_cpu_sample, 50)     # (N > 1: every rank generates and builds the
         #  same index from the seed, then keeps the codes of the lists it owns: tk_index_shard_resident)
 
+    # HIP maps every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that
+    # share one run in order.  The pipelined index needs four (caller, front, two replay streams: r04: more
+    # gain nothing for it); a list-sharded rank keeps --shard-depth batches in flight, each a chain of ~50
+    # short dependent kernels on its own stream — eight queues: 0.131 -> 0.114 ms per step of one rank's
+    # share of W = 8 (profiles/r05/rank_share_depth_queues.txt).  Read once, when HIP initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     ang = args.metric == "angular"

@@ -518,6 +518,12 @@ int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float *q_dev, co
                                   int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                                   const int64_t *probes_all_dev, int64_t capacity, void *send_dev,
                                   int *flag_dev, void *stream);
+/* The library's process-wide internal streams (one set per device): role 0 = the front stream (high
+ * priority: table builds, coarse stages), role 1 = replay stream i (0 <= i < 8).  For hosts that run a
+ * stage pipeline of their own over the list-sharded entry points — which only enqueue on the stream
+ * they are given — without creating streams that would share HIP's four hardware queues with these.
+ * NULL on error.  Never destroy them. */
+void *tk_shared_stream(int role, int i);
 /* Another rank's shard of a complete UNSHARDED index on the same device: a new handle that borrows
  * the source's replicated arrays (PQ, centres, list tables, ids, vectors — the source must outlive
  * it and must not be re-populated meanwhile) and owns only the codes of the lists with

@@ -1,0 +1,25 @@
+R=$PWD; O=$R/gpurun_out/r05; mkdir -p $O
+timeout -k 10 600 python bench.py --steps 20 --warmup 5 --sweep none --traffic none --no-hbm-leg --cpu-sample 500 --py-cpu-sample 20 > $O/run7_bench.json 2> $O/run7_bench.err
+echo "bench rc=$?"; grep "bench\]" $O/run7_bench.err
+python3 - <<'PY'
+import json
+j = json.loads([l for l in open("gpurun_out/r05/run7_bench.json") if l.startswith("{")][-1])
+ls = j.get("list_sharded", {})
+print("value", round(j["value"]), "ms", round(j["ms_per_step"], 4), "sharded", round(ls.get("queries_per_s", 0)), "ratio", round(ls.get("ratio_to_unsharded_value", 0), 3),
+      "rows", ls.get("identical_rows_vs_replica"), "windows", [round(x, 2) for x in ls.get("windows_ms", [])], "drift", ls.get("window_drift_last_third_over_first_third"), "rep", ls.get("windows_repeated_after_overflow"), "host", ls.get("host_enqueue_ms_per_step"))
+print("   scan", ls.get("scan", {}).get("form", "")[:40])
+print("   filtered", {k: (round(v) if isinstance(v, float) else v) for k, v in ls.get("filtered_exchange", {}).items() if k != "exchange"})
+print("   fixedq", ls.get("fixed_q_per_exchange"))
+for k, v in ls.items():
+    if k.startswith("rank_share"):
+        print("  ", k, {a: b for a, b in v.items() if a not in ("exchange", "scan", "what", "code_chunks_per_rank")})
+PY
+for d in 4 6; do
+timeout -k 10 600 python3 scripts/r05_rank_share.py --steps 20 --depth $d > $O/run7_rank_share_d$d.json 2> $O/run7_rank_share_d$d.err
+python3 - $d <<'PY'
+import json, sys
+d = sys.argv[1]
+j = json.loads([l for l in open(f"gpurun_out/r05/run7_rank_share_d{d}.json") if l.startswith("{")][-1])
+print("depth", d, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in j.items() if k in ("ms_per_step", "host_enqueue_ms_per_step", "unsharded_ms_per_step", "implied_strong_scaling_efficiency_without_links", "identical_rows_vs_replica")}, [round(x, 2) for x in j["windows_ms"]])
+PY
+done

@@ -120,6 +120,7 @@ def test_one_rank_of_eight_on_the_same_index(c5):
         lo, hi = peers.home_range(nq)
         np.testing.assert_array_equal(got[lo:hi], want[lo:hi])
         idx.exchange = "filtered"
+        peers.reset()
         got = idx.query_prepared(qn_t, qp_t, 10, 10)
         np.testing.assert_array_equal(got[lo:hi], want[lo:hi])
     finally:

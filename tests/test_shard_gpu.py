@@ -348,8 +348,9 @@ def test_sharded_world1_public_class():
     assert cap > 2
     np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=10), g["ids_p10"])
     assert idx.capacity[(len(g["qs"]), 10)] == cap                         # settled
-    idx.capacity[(len(g["qs"]), 5)] = 10 ** 6      # far too roomy -> trimmed to 1.25 x the longest stream
-    np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=5), g["ids_p5"])
+    idx.capacity[(len(g["qs"]), 5)] = 10 ** 6      # far too roomy -> trimmed to 1.35 x the longest stream seen,
+    for _ in range(2):                              # on the evidence of three batches (one ran above)
+        np.testing.assert_array_equal(idx.query_batch(g["qs"], 10, n_probes=5), g["ids_p5"])
     assert idx.capacity[(len(g["qs"]), 5)] < 10 ** 6 // 2
 
 
@@ -498,11 +499,20 @@ def test_one_phase_scan_golden(tag, world):
     from test_hip_parity import ivf_from_fixture
     g = golden(f"g6_ivf_{tag}.npz")
     ivf = ivf_from_fixture(None, g)
+    nq = len(g["qn"])
+    qh = -(-nq // world)
     for n_probes in g["probes_list"]:
         n_probes = int(n_probes)
         ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, one_phase=True)
-        assert not flags.any()
-        np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
+        assert not (flags & 3).any()
+        # bit 4 on a home rank = one of ITS queries met its first plain block with a bound above the
+        # table's limit (short lists: the exact head is two lists and the heap is still filling; the
+        # unsharded index scans such a query again, tests/test_plain_scan_gpu.py): that rank's rows are
+        # not vouched for, every other rank's are the fixture's
+        want = g[f"ids_p{n_probes}"]
+        for h in range(world):
+            if not flags[h] & 4:
+                np.testing.assert_array_equal(ids[h * qh:(h + 1) * qh], want[h * qh:(h + 1) * qh])
     # forced failure: no bound is at or below a limit of -128
     n_probes = int(max(g["probes_list"]))
     L = ivf.active_centers.shape[0]
@@ -542,6 +552,7 @@ def test_simulated_peers_one_rank_of_a_partition(oracle):
         for kw in (dict(exchange="dense"), dict(exchange="dense", plain="two-phase"), dict(exchange="filtered"),
                    dict(exchange="dense", plain=False)):
             idx = ListShardedIndex(ivf, simulate=peers, depth=2, **kw)
+            peers.reset()
             got = idx.query_prepared(qn_t, qp_t, 10, 6)
             np.testing.assert_array_equal(got[lo:hi], want[lo:hi])
             assert (got[:lo] == -1).all() and (got[hi:] == -1).all()        # the other ranks' rows are theirs

@@ -80,6 +80,7 @@ SIGNATURES = {
                                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_clone_shard": (C.c_void_p, [C.c_void_p, _i32p, C.c_int, C.c_int]),
+    "tk_shared_stream": (C.c_void_p, [C.c_int, C.c_int]),
     "tk_index_shard_usage": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "tk_index_shard_bound_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1146,6 +1146,22 @@ static hipError_t shared_replay_stream(int i, hipStream_t *st)
     return hipSuccess;
 }
 
+// The process-wide internal streams, for a host that runs its own stage pipeline over them (multi_gpu.py: the
+// list-sharded batches' coarse stages / exchanges + replays; role 0 = the high-priority front stream, role 1 =
+// replay stream i < 8).  The same streams tk_index_query_batch_dev uses in pipelined mode: HIP maps streams onto
+// four hardware queues in creation order, and a host that created four more of its own would share them.
+extern "C" void *tk_shared_stream(int role, int i)
+{
+    if (require_gpu() != TK_OK) return nullptr;
+    hipStream_t st = nullptr;
+    const hipError_t e = role == 0 ? shared_front_stream(&st) : (i >= 0 && i < 8 ? shared_replay_stream(i, &st) : hipErrorInvalidValue);
+    if (e != hipSuccess) {
+        (void)fail(TK_ERR_HIP, "tk_shared_stream: stream creation failed (or a replay stream index beyond 7)");
+        return nullptr;
+    }
+    return (void *)st;
+}
+
 // Pipelined mode, first half of enqueuing a batch: internal streams and events exist, the batch has
 // its workspace and streams, and `stt` — the stream its table build will run on — waits for the
 // caller's work so far and for the workspace's previous batch.
@@ -1471,6 +1487,11 @@ extern "C" int tk_index_quiesce(tk_index *ix)
         w.busy = false;
         w.plain_pending = false;
     }
+    // the workspaces and replay streams are taken in the order of the calls since the last
+    // tk_index_set_pipeline / tk_index_quiesce: a capture that follows repeats the warm-up's calls ON THE
+    // WORKSPACES the warm-up sized (a call that met a fresh workspace would hipMalloc inside the capture
+    // and invalidate it: 5 captured calls at depth 2 behind 5 warm-up calls used to land on workspaces 5, 6, 0, 1, 2)
+    ix->calls = 0;
     return TK_OK;
 }
 
