@@ -278,11 +278,14 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     import torch.distributed as dist
     from tinyknn_amd.multi_gpu import ListShardedIndex
     qn_t, qp_t, want = shard_inputs(args, ivf, cent, dev, device)
-    co = args.shard_coalesce if args.shard_coalesce > 0 else max(3, world)    # auto: a rank's home share = one batch
+    # auto: six steps per exchange (a rank's home share is then at least most of a batch: the latency-bound
+    # stages — two heap replays, the collectives — cost the same for 10 000 as for 60 000 home queries;
+    # same box, W = 1: 3 steps 18.5 M queries/s, 4: 19.4 M, 6: 21.1 M, profiles/r05/shard_w1_coalesce_depth.txt)
+    co = args.shard_coalesce if args.shard_coalesce > 0 else max(6, world)
     co = max(1, min(co, 131072 // args.nq))
     idx = ListShardedIndex(ivf, depth=args.shard_depth, coarse=args.shard_coarse, coalesce=co,
                            force_collectives=args.force_collectives, counts=args.shard_counts,
-                           plain={0: False, 1: True, 2: "two-phase"}[args.shard_plain])
+                           plain={0: False, 1: True, 2: "two-phase", 3: "head"}[args.shard_plain])
     if args.shard_exchange == "auto":
         idx.exchange = "auto"          # ListShardedIndex._exchange_kind: filtered where lists are long
         kinds = [idx._exchange_kind(args.k, args.n_probes, None)]
@@ -320,7 +323,7 @@ def list_sharded_leg(args, ivf, cent, dev, device, world, rank):
     return res
 
 
-def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8):
+def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8, co=0):
     """What ONE GPU can prove about W ranks: the time of ONE rank's share of a W-rank list partition —
     its 1/W of the lists for all queries of the shared batches, the coarse stage, replay and rescoring
     of its home queries, every exchange buffer filled locally with what the other W - 1 ranks
@@ -331,11 +334,13 @@ def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8):
     from tinyknn_amd.multi_gpu import ListShardedIndex, SimulatedPeers
     peers = SimulatedPeers(ivf, world=W, rank=0)
     try:
-        co = max(1, min(W, 131072 // args.nq))
+        co = max(1, min(co or max(W, args.shard_coalesce), 131072 // args.nq))
         idx = ListShardedIndex(ivf, simulate=peers, depth=args.shard_depth, coarse="home", coalesce=co,
-                               counts="device", plain={0: False, 1: True, 2: "two-phase"}[args.shard_plain],
+                               counts="device", plain={0: False, 1: True, 2: "two-phase", 3: "head"}[args.shard_plain],
                                exchange="auto")
         kind = idx._exchange_kind(args.k, args.n_probes, None)
+        if getattr(args, "rank_share_exchange", "auto") != "auto":
+            kind = args.rank_share_exchange
         idx.exchange = kind
         r = _list_sharded_run(args, idx, device, 1, 0, qn_t, qp_t, want, co, kind, sim=peers)
         out = {k_: r[k_] for k_ in ("ms_per_step", "host_enqueue_ms_per_step", "identical_rows_vs_replica", "rows", "windows_ms",
@@ -494,6 +499,11 @@ def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind
                               "(tk_index_shard_scan_plain_dev); no bound exchange",
                       "arguments_switched_to_two_phase": [list(map(str, a)) for a in sorted(idx._plain_failed, key=str)]}
                      if idx._one_phase_now(args.k, args.n_probes, None) else
+                     {"form": "one phase behind ONE byte per query: heads of the first lists exactly + the bound after them "
+                              "(its owner replays, MIN all-reduce), then heads exactly / everything else on the int8 matrix "
+                              "cores for the queries whose bound is at most their table's limit, exactly for the others "
+                              "(tk_index_shard_scan_head_dev / _scan_plain_dev(bound)): the check at home cannot fail"}
+                     if idx._head_phase_now(args.k, args.n_probes, None) else
                      {"form": "two-phase: first probed lists exactly, bound min-reduced over the ranks, the lists behind "
                               "them on the int8 matrix cores where the bound allows (tk_index_shard_scan_first_dev / _rest_dev)",
                       "last_batch_this_rank": idx.engine.dev.shard_plain_stats((idx._calls - 1) % idx.depth)}
@@ -1018,7 +1028,7 @@ def main():
                     help="list-sharded leg: batches in flight (each on its own stream)")
     ap.add_argument("--shard-coalesce", type=int, default=0,
                     help="list-sharded leg: consecutive steps answered as ONE sharded batch (<= 131072 queries); "
-                         "0 = max(3, N): a rank's home share is then a whole batch")
+                         "0 = max(6, N)")
     ap.add_argument("--shard-exchange", choices=["auto", "dense", "filtered", "both"], default="auto",
                     help="list-sharded leg: whole distance segments at fixed positions (no host "
                          "synchronisation), or SURVEY 8e's filtered records; both: dense is reported, the "
@@ -1040,9 +1050,10 @@ def main():
     ap.add_argument("--shard-counts", default="device", choices=["device", "host"],
                     help="filtered exchange: record counts read on the device (fixed regions, no host "
                          "synchronisation) or on the host (variable splits)")
-    ap.add_argument("--shard-plain", type=int, default=1, choices=[0, 1, 2],
+    ap.add_argument("--shard-plain", type=int, default=1, choices=[0, 1, 2, 3],
                     help="list-sharded leg: 1 = the matrix-core kernel, one phase for the dense exchange / two phases for "
-                         "the filtered one (default); 2 = two phases for both (A/B); 0 = exact kernel only")
+                         "the filtered one (default; the dense form falls back to 3 by itself where its check at home "
+                         "fails); 2 = two phases for both (A/B); 3 = one phase behind the head bounds; 0 = exact kernel only")
     ap.add_argument("--rank-share", type=int, default=8,
                     help="N = 1: after the list-sharded leg, time ONE rank's share of a partition over this many ranks "
                          "(peers simulated on this GPU); 0 = skip")

@@ -294,6 +294,12 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
 #define TK_OPT_SCAN_FORM 1
 #define TK_OPT_RESCORE_FORM 2
 #define TK_OPT_PLAIN_LIMIT 3
+/*   TK_OPT_REPLAY_LAZY   the lane replay of the probed lists: 1 = nothing is staged, a lane reads its row's block
+ *                        minima and fetches a block only where its minimum passes the bound (as FlatTop's
+ *                        replay); 0 = every block staged through LDS; -1 = by the index (DEFAULT: lazy where a
+ *                        query's probed lists hold more than 8 heap sizes of blocks — 100M x 128: 6 250 blocks
+ *                        against a heap of 111).  Identical results. */
+#define TK_OPT_REPLAY_LAZY 4
 int tk_index_set_option(tk_index *ix, int option, int value);
 
 /* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
@@ -511,13 +517,31 @@ int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_
  * the query's table; tk_index_set_plain_scan).  One kernel chain, no extra collective.  A home query
  * that fails the check raises bit 4 of *flag_dev in tk_index_shard_finish_dev (the codes to scan it
  * again exactly are on other ranks): the flag word travels with the ids, every rank sees it, and
- * the batch is repeated through tk_index_shard_scan_dev.  Same arguments as tk_index_shard_scan_dev;
- * falls back to it by itself where the form does not apply (tk_index_shard_plain says 0, labels
- * repeat, heaps beyond the lane replay, world * capacity shorter than the longest list). */
+ * the batch is repeated behind tk_index_shard_scan_head_dev (below).  Arguments as
+ * tk_index_shard_scan_dev + bound_dev (NULL here); falls back to tk_index_shard_scan_dev by itself
+ * where the form does not apply (tk_index_shard_plain says 0, labels repeat, heaps beyond the lane
+ * replay, world * capacity shorter than the longest list).
+ *
+ * The same with ONE byte per query exchanged first — for data on which the optimistic form fails (one
+ * query in 20 000 of the 100M x 128 index; a sharded batch holds 120 000):
+ *   tk_index_shard_scan_head_dev   tables / probe lists / segment positions as tk_index_shard_scan_dev;
+ *                                  the HEAD (two heap sizes of rows) of every first probed list this
+ *                                  rank owns scored exactly into send_dev; bound_dev[nq] = the bound
+ *                                  after it (order key, as tk_index_shard_bound_dev; 255 elsewhere);
+ *   all-reduce(MIN, uint8)         by the caller;
+ *   tk_index_shard_scan_plain_dev(bound_dev)
+ *                                  the one-phase scan, with every query whose bound is above its table's
+ *                                  limit kept on the exact kernel: the check at home cannot fail.
+ * Against tk_index_shard_scan_first_dev / _rest_dev, phase 1 scores ~14 chunks per query instead of a
+ * whole list, and replays as many. */
 int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
                                   int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                                   const int64_t *probes_all_dev, int64_t capacity, void *send_dev,
-                                  int *flag_dev, void *stream);
+                                  int *flag_dev, const uint8_t *bound_dev, void *stream);
+int tk_index_shard_scan_head_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
+                                 int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                                 const int64_t *probes_all_dev, int64_t capacity, void *send_dev,
+                                 int *flag_dev, uint8_t *bound_dev, void *stream);
 /* The library's process-wide internal streams (one set per device): role 0 = the front stream (high
  * priority: table builds, coarse stages), role 1 = replay stream i (0 <= i < 8).  For hosts that run a
  * stage pipeline of their own over the list-sharded entry points — which only enqueue on the stream

@@ -16,6 +16,8 @@ ap.add_argument("--depth", type=int, default=4)
 ap.add_argument("--plain", type=int, default=1)
 ap.add_argument("--windows", type=int, default=0)
 ap.add_argument("--nq", type=int, default=10000)
+ap.add_argument("--co", type=int, default=0)
+ap.add_argument("--exchange", default="auto")
 ap.add_argument("--clusters", type=int, default=0)
 a = ap.parse_args()
 glove = a.workload == "glove"
@@ -24,7 +26,7 @@ args = argparse.Namespace(n=a.n or (1183514 if glove else 25_000_000), d=100 if 
                           metric="angular" if glove else "euclidean", data="glove-like", cache_dir="/tmp", fit_sample=100000,
                           data_file=None, nq=a.nq, k=10, n_probes=10, workload=a.workload, shard_depth=a.depth,
                           shard_plain=a.plain, warmup=5, steps=a.steps, windows=a.windows, backend="nccl", shard_coarse="home",
-                          shard_counts="device", rank_share=a.world)
+                          shard_counts="device", rank_share=a.world, shard_coalesce=0, rank_share_exchange=a.exchange)
 device = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 from tinyknn_amd import _lib
@@ -43,7 +45,7 @@ pairs = 2 * args.nq <= dev.max_sub_batch(args.k, args.n_probes)
 un = B.timed_rate(dev, batches, f64, args.nq, args.k, args.n_probes, torch.cuda.current_stream().cuda_stream, 2, 2 if pairs else 1)
 dev.set_pipeline(1)
 qn_t, qp_t, want = B.shard_inputs(args, ivf, cent, dev, device)
-rs = B.rank_share_leg(args, ivf, device, qn_t, qp_t, want, a.world)
+rs = B.rank_share_leg(args, ivf, device, qn_t, qp_t, want, a.world, a.co)
 W = rs["world"]
 rs["unsharded_ms_per_step"] = un["ms_per_step"]
 rs["target_ms_per_step_at_0.7_efficiency"] = un["ms_per_step"] / (0.7 * W)

@@ -102,9 +102,39 @@ class OracleShardEngine:
     # in the two-phase form).
     fail_plain = 0
 
-    def scan_plain(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None):
+    def scan_plain(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None, bound=None):
+        if bound is not None:       # behind scan_head: the bytes are the min-reduced head bounds every rank must hold
+            b = bound.numpy()
+            mine = self.head_bound != 255
+            np.testing.assert_array_equal(b[mine], self.head_bound[mine])
+            self.head_calls = getattr(self, "head_calls", 0) + 1
+            return
         self.scan(slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=probes_all)
         self.plain_calls = getattr(self, "plain_calls", 0) + 1
+
+    def scan_head(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, bound, probes_all=None):
+        """tk_index_shard_scan_head_dev: (this engine scores everything at once) + the bound after the HEAD
+        of the first probed list — its first ceil(2 R / 16) chunks — for the queries whose first list is mine."""
+        self.scan(slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=probes_all)
+        qn_ = qn.numpy()
+        probes, tables = self._front(qn_, k, n_probes, pass_1)
+        R = self._heap_size(k, n_probes, pass_1)
+        E = (2 * R + 15) // 16
+        out = bound.numpy()
+        out[:] = 255
+        off = self.ox.list_chunk_off
+        for i in range(len(qn_)):
+            l = probes[i, 0]
+            if self.owner[l] != self.rank:
+                continue
+            idx = np.zeros(R, dtype=np.int64)
+            val = np.zeros(R, dtype=np.int32)
+            self.O.init_heap(idx, val, True)
+            codes = np.ascontiguousarray(self.ox.codes[off[l]:off[l + 1]][:E])
+            if len(codes):
+                self.O.query_pq(codes, min(int(self.ox.list_n[l]), 16 * len(codes)), tables[i], idx, val, True)
+            out[i] = (int(val[0]) & 0xff) ^ 0x80
+        self.head_bound = out.copy()
 
     def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home, flag=None):
         if flag is not None and self.fail_plain > 0:

@@ -334,6 +334,15 @@ def test_ivf_query_golden(tk, tag):
         finally:
             dev.set_option(_lib.OPT_RESCORE_FORM, 2)
         dev.set_scan_mode(0)
+        # the lazy lane replay (blocks fetched only where their minimum passes: the form long lists get by
+        # themselves) and the staged one are the same replay: the reference's heap arrays, layout included
+        for lazy in (1, 0):
+            dev.set_option(_lib.OPT_REPLAY_LAZY, lazy)
+            out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
+            np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])
+            np.testing.assert_array_equal(dbg["heap_val"], g[f"heap_val_p{n_probes}"])
+            np.testing.assert_array_equal(out, g[f"ids_p{n_probes}"])
+        dev.set_option(_lib.OPT_REPLAY_LAZY, -1)
         out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
         np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
         np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])

@@ -302,7 +302,7 @@ def _one_phase_worker(rank, world, port, tag, nq, k, n_probes, ret):
             eng.fail_plain = 1
         out2 = idx.query_batch(g["qn"][:nq], k, n_probes)
         failed = (k, n_probes, None) in idx._plain_failed
-        rest = getattr(eng, "rest_calls", 0)
+        rest = getattr(eng, "head_calls", 0)
         out3 = idx.query_batch(g["qn"][:nq], k, n_probes)
         # ... and a submit()ted batch in flight: join() raises, the batch submitted again is answered
         idx2 = ListShardedIndex(None, engine=eng, owner=owner, list_sizes=g["list_sizes"])
@@ -329,7 +329,7 @@ def _one_phase_worker(rank, world, port, tag, nq, k, n_probes, ret):
 def test_list_sharded_one_phase_scan_and_its_flag_gloo(world):
     """Dense exchange, scan in one phase (tk_index_shard_scan_plain_dev's protocol): no bound
     all-reduce; a home query that fails the replay's check raises bit 4 of the batch's flag word on
-    ONE rank, the all-gathered word switches every rank to the two-phase form and the batch is
+    ONE rank, the all-gathered word switches every rank to the scan behind the head bounds and the batch is
     answered again — synchronously (query_batch) and for batches in flight (submit / join)."""
     import torch.multiprocessing as mp
     from conftest import golden
@@ -343,7 +343,7 @@ def test_list_sharded_one_phase_scan_and_its_flag_gloo(world):
         out, out2, out3, calls_ok, failed, rest, plain_calls, raised, again, again_flag = ret[r]
         for o in (out, out2, out3, again):
             np.testing.assert_array_equal(o, exp)
-        assert calls_ok == 1 and failed and rest >= 1       # one-phase, then the repeat went two-phase
+        assert calls_ok == 1 and failed and rest >= 1       # one-phase, then the repeat went behind the head bounds
         assert plain_calls == 3                             # (+1 failed attempt, +1 idx2's first submit; none after)
         assert "submit the batches again" in raised and not again_flag
 

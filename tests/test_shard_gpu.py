@@ -51,7 +51,18 @@ def simulate_world(ivf, world, qn, qp, k, n_probes, capacity=None, pass_1=None, 
     # cores where the bound allows) wherever the engine says it applies, else in one
     two_phase = plain and engines[0].plain_ok(k, n_probes, pass_1)
     b_red = None
-    if one_phase:
+    if one_phase == "head":
+        # tk_index_shard_scan_head_dev -> all-reduce(MIN) -> tk_index_shard_scan_plain_dev(bound): the check
+        # at home cannot fail
+        assert exchange == "dense"
+        heads = [torch.zeros(nq, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        for r, e in enumerate(engines):
+            e.scan_head(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], heads[r], probes_all=p_all)
+        b_head = torch.stack(heads).min(dim=0).values.contiguous()
+        for r, e in enumerate(engines):
+            e.scan_plain(0, qn_t, qp_t, k, n_probes, pass_1, capacity, sends[r], flags[r], probes_all=p_all,
+                         bound=b_head)
+    elif one_phase:
         # tk_index_shard_scan_plain_dev: heads exactly, the rest on the matrix cores, no bound exchange;
         # the home replays check the lemma (flag bit 4)
         assert exchange == "dense"
@@ -525,6 +536,17 @@ def test_one_phase_scan_golden(tag, world):
     if not (flags & 4).any():
         np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])      # the form did not apply: exact kernel
     assert not (flags & 3).any()
+    # behind the head bounds nothing can fail: the fixture's ids, clean flag words — with the tables' own
+    # limits, and with limits no bound can meet (every query then stays on the exact kernel)
+    for forced in (False, True):
+        for n_probes in g["probes_list"]:
+            n_probes = int(n_probes)
+            engines = [_HipShardEngine(ivf, owner, r, world, 1) for r in range(world)]
+            for e in engines:
+                e.dev.set_option(_lib.OPT_PLAIN_LIMIT, -128 if forced else 0x7fffffff)
+            ids, flags, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, one_phase="head", engines=engines)
+            assert not flags.any(), (forced, n_probes, flags)
+            np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
 
 
 def test_simulated_peers_one_rank_of_a_partition(oracle):
@@ -550,7 +572,7 @@ def test_simulated_peers_one_rank_of_a_partition(oracle):
         peers = SimulatedPeers(ivf, world=world, rank=rank)
         lo, hi = peers.home_range(nq)
         for kw in (dict(exchange="dense"), dict(exchange="dense", plain="two-phase"), dict(exchange="filtered"),
-                   dict(exchange="dense", plain=False)):
+                   dict(exchange="dense", plain=False), dict(exchange="dense", plain="head")):
             idx = ListShardedIndex(ivf, simulate=peers, depth=2, **kw)
             peers.reset()
             got = idx.query_prepared(qn_t, qp_t, 10, 6)

@@ -31,7 +31,7 @@ _f64p = C.POINTER(C.c_double)
 
 # name -> (restype, argtypes); mirrors include/tinyknn_hip.h one to one
 # tk_index_set_option
-OPT_SCAN_FORM, OPT_RESCORE_FORM, OPT_PLAIN_LIMIT = 1, 2, 3
+OPT_SCAN_FORM, OPT_RESCORE_FORM, OPT_PLAIN_LIMIT, OPT_REPLAY_LAZY = 1, 2, 3, 4
 
 SIGNATURES = {
     "tk_last_error": (C.c_char_p, []),
@@ -78,7 +78,10 @@ SIGNATURES = {
                                             C.c_void_p, C.c_void_p]),
     "tk_index_shard_scan_plain_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_shard_scan_head_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_clone_shard": (C.c_void_p, [C.c_void_p, _i32p, C.c_int, C.c_int]),
     "tk_shared_stream": (C.c_void_p, [C.c_int, C.c_int]),
     "tk_index_shard_usage": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),

@@ -786,6 +786,13 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
     // (a list may then be scanned twice) re-run with the duplicate test.  Repeating labels
     // (build n_probes >= 2): the packed wave kernel with the duplicate test for everybody.
     const bool packed_ok = ix->heap_mode != 1 && p.cap * 16 <= 0xffffff;
+    // Lists far longer than the heap (100M x 128: a query's ten lists hold 6 250 blocks, its heap 111 entries):
+    // staging every block through LDS is what the replay then costs (16 row-per-lane loads + 16 LDS writes per
+    // segment and lane), while only the few blocks whose minimum passes the bound are ever looked at — the
+    // LAZY form fetches just those (heap.hip; what made FlatTop's replay 4 x faster in round 4).  Short
+    // lists keep the staged form: there most blocks of the first lists pass, and a dependent fetch each loses.
+    const int lazy = ix->opt_replay_lazy >= 0 ? ix->opt_replay_lazy
+                                              : ((double)p.S * (double)ix->total_chunks / (double)ix->n_lists >= 8.0 * p.R);
     if (packed_ok && ix->ids_unique) {
         const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
         if (!lanes)
@@ -797,7 +804,7 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
                                              slot_loff, p.S, ix->ids.as<int64_t>(),
                                              w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
                                              p.R, 1, 0, repeat_flag, w.mins.as<uint8_t>(),
-                                             p.cap_min, nullptr, st, slot_exact, qlim))
+                                             p.cap_min, nullptr, st, slot_exact, qlim, lazy))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
         if (plain && plain_flag) {
             tk_launch_shard_flag_plain(repeat_flag, nq, plain_flag, st);
@@ -1559,6 +1566,10 @@ extern "C" int tk_index_set_option(tk_index *ix, int option, int value)
         return TK_OK;
     case TK_OPT_PLAIN_LIMIT:
         ix->opt_plain_limit = value;
+        return TK_OK;
+    case TK_OPT_REPLAY_LAZY:
+        ARGCHECK(value >= -1 && value <= 1, "TK_OPT_REPLAY_LAZY: -1, 0 or 1");
+        ix->opt_replay_lazy = value;
         return TK_OK;
     default:
         return fail(TK_ERR_ARG, "bad argument: unknown option");

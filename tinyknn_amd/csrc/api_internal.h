@@ -112,6 +112,7 @@ struct Work {
     int64_t shard_nq = 0, shard_capacity = 0;
     bool shard_first = false;       // tk_index_shard_scan_first_dev ran: _rest_dev is owed
     bool shard_plain = false;       // tk_index_shard_scan_plain_dev filled the send buffer: the home replay checks the lemma
+    bool shard_head = false;        // tk_index_shard_scan_head_dev ran: _scan_plain_dev(bound_dev) is owed
     // pipelined mode (depth > 1): hand-offs between the caller's stream and a latency stream
     hipEvent_t tables_done = nullptr, coarse_scanned = nullptr, front_done = nullptr,
                scanned = nullptr, done = nullptr;
@@ -201,6 +202,7 @@ struct tk_index {
     int opt_scan_form = 0;             // exact list-major kernel: 0 per-lane table-row loads, 1 / 2 rows staged in LDS
     int opt_rescore_form = 2;          // rescoring: 2 / 1 rows staged through LDS in tiles of 32 / 64, 0 lane per row
     int opt_plain_limit = 0x7fffffff;  // a cap on every query's table limit (tests: provokes the re-scan path)
+    int opt_replay_lazy = -1;          // lane replay of the lists: 1 lazy (blocks fetched where their minimum passes), 0 staged, -1 auto
     bool flat_plain_ok = true;         // tk_index_top_centers: the plain path has not failed on this index
     int plain_state = 0;       // PLAIN_PROBE .. PLAIN_OFF (see plain_poll)
     int plain_skip = 0;        // OFF: batches left before the next probe

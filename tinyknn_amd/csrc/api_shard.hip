@@ -199,6 +199,122 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
     return TK_OK;
 }
 
+static bool shard_one_phase_possible(const tk_index *ix, const Plan &p, int64_t capacity)
+{
+    const int64_t tail = (int64_t)ix->world * capacity - ix->max_list_chunks;
+    return shard_plain_possible(ix, p) && ix->ids_unique && tail >= 0 && p.R <= TK_LANES_MAX_R &&
+           ix->heap_mode == 0 && p.cap * 16 <= 0xffffff;
+}
+
+// ---- ... and with ONE byte per query exchanged first, for data on which the check at home would fail ----
+// The one-phase scan is optimistic: one home query in 20 000 of the 100M x 128 index meets its first plain
+// block with a bound above its table's limit, and a sharded batch of 120 000 queries then fails as a whole.
+// tk_index_shard_scan_head_dev + all-reduce(MIN, uint8) + tk_index_shard_scan_plain_dev(bound_dev) decide per
+// query BEFORE the scan, at the price of the rows the exact kernel scores anyway: the HEAD of every first
+// probed list this rank owns (two heap sizes of rows) goes exactly into send_dev, the bound after it is
+// replayed by value on the spot (bound_dev[nq]: order key, 255 where the first list lies elsewhere), the
+// ranks min-reduce the byte, and the scan proper keeps every query whose bound is above its limit on the
+// exact kernel.  Against the two-phase form (tk_index_shard_scan_first_dev: WHOLE first lists exactly, the
+// bound after them) phase 1 touches 14 chunks per query instead of a whole list (313 at 25M x 128 / 5 000
+// lists).  Where the one-phase form does not apply this call is tk_index_shard_scan_dev (bound_dev = 255)
+// and the plain call behind it does nothing.
+extern "C" int tk_index_shard_scan_head_dev(tk_index *ix, int slot, const float *q_dev,
+                                            const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
+                                            int n_probes, int pass_1, const int64_t *probes_all_dev,
+                                            int64_t capacity, void *send_dev, int *flag_dev,
+                                            uint8_t *bound_dev, void *stream)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, capacity, p, qh));
+    ARGCHECK(send_dev && flag_dev && bound_dev, "send/flag/bound buffers");
+    Work &w = ix->works[(size_t)slot];
+    hipStream_t st = (hipStream_t)stream;
+    if (!shard_one_phase_possible(ix, p, capacity)) {
+        HIPCHECK(hipMemsetAsync(bound_dev, 0xff, (size_t)nq, st));
+        TRY(tk_index_shard_scan_dev(ix, slot, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1,
+                                    probes_all_dev, capacity, send_dev, flag_dev, stream));
+        w.shard_head = true;
+        return TK_OK;
+    }
+    TRY(reserve_shard(ix, w, nq, qh, p));
+    TRY(reserve_shard_plain(ix, w, nq, p));
+    TRY(w.smins.ensure((size_t)ix->world * capacity + 16));
+    TRY(w.usage.ensure((size_t)ix->world * 2 * 8));
+    Prof pf;
+    const int *owner = ix->owner.as<int>();
+    const int64_t *probes = probes_all_dev;
+    if (probes) {
+        coarse_slots(ix, w, probes, nq, p, nullptr, owner, ix->rank, st);
+    } else {
+        TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, true));
+        launch_coarse_scan(ix, w, nq, p, st);
+        TRY(stage_coarse_rest(ix, w, q_dev, nq, p, nullptr, owner, ix->rank, st, pf));
+        probes = w.probes.as<int64_t>();
+    }
+    {
+        const int64_t n1 = nq * p.S + (int64_t)ix->world * qh * p.S + 1;
+        ARGCHECK(n1 < (1ll << 31), "too many (query, list) entries for one sharded batch");
+        TRY(w.pos_lens.ensure((size_t)n1 * 8));
+        TRY(w.pos_off.ensure((size_t)n1 * 8));
+        size_t tmp_bytes = 0;
+        ARGCHECK(tk_scan_exclusive64(nullptr, &tmp_bytes, w.pos_lens.as<long long>(),
+                                     w.pos_off.as<long long>(), n1, st) == 0,
+                 "hipcub scan (size query) failed");
+        TRY(w.scan_tmp.ensure(tmp_bytes + 16));
+        if (tk_launch_shard_positions(probes, w.slot_prefix.as<int>(), p.S, nq, ix->n_lists, owner,
+                                      ix->rank, ix->world, qh, capacity, w.spos.as<int>(),
+                                      w.rpos.as<int>(), flag_dev, w.usage.as<long long>(),
+                                      w.pos_lens.as<long long>(), w.pos_off.as<long long>(),
+                                      w.scan_tmp.p, tmp_bytes, st))
+            return fail(TK_ERR_HIP, "hipcub scan failed");
+    }
+    // heads of the first slots this rank owns: exact, straight into the send buffer
+    const int64_t *lco = ix->local_chunk_off.as<int64_t>();
+    const int hc = head_chunks_of(ix, p);
+    TkPairSet ex{w.u_count.as<int>(), w.u_cursor.as<int>(), w.u_pair_off.as<int>(),
+                 w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>()};
+    TkPairSet pl{w.p_count.as<int>(), w.p_cursor.as<int>(), w.p_pair_off.as<int>(),
+                 w.p_unit_prefix.as<int>(), w.p_pair_q.as<int>(), w.p_pair_f0.as<int>(),
+                 w.p_unit_desc.as<int>(), plain_k(ix, nq, p)};
+    TkPairSet hd{w.h_count.as<int>(), w.h_cursor.as<int>(), w.h_pair_off.as<int>(),
+                 w.h_unit_prefix.as<int>(), w.h_pair_q.as<int>(), w.h_pair_f0.as<int>()};
+    tk_launch_shard_count_first(probes, p.S, nq, ix->n_lists, owner, ix->rank, w.h_count.as<int>(), st);
+    tk_launch_pairs_scan3(ex, pl, hd, lco, ix->n_lists, hc, st);      // (sets 0 and 1 are empty here)
+    tk_launch_shard_pairs_fill(probes, p.S, nq, ix->n_lists, owner, ix->rank, w.spos.as<int>(),
+                               w.h_pair_off.as<int>(), w.h_cursor.as<int>(), w.h_pair_q.as<int>(),
+                               w.h_pair_f0.as<int>(), st, 0, 1);
+    TkScanJob hj, none;
+    memset(&none, 0, sizeof none);
+    hj.codes = ix->codes.as<uint4>();
+    hj.tables = w.tables.as<uint4>();
+    hj.list_chunk_off = lco;
+    hj.n_lists = (int)ix->n_lists;
+    hj.unit_prefix = w.h_unit_prefix.as<int>();
+    hj.pair_off = w.h_pair_off.as<int>();
+    hj.pair_q = w.h_pair_q.as<int>();
+    hj.pair_f0 = w.h_pair_f0.as<int>();
+    hj.dist = (uint4 *)send_dev;
+    hj.cap = 0;
+    hj.mins = w.smins.as<uint8_t>();
+    hj.min_stride = 0;
+    hj.max_chunks = hc;
+    tk_launch_scan_units2(none, none, ix->M, ix->order, 512, st, &hj, 0);
+    // the bound after those heads, by value (ivf.py:137-152 over the list's first rows)
+    tk_launch_shard_first_bound(probes, w.slot_prefix.as<int>(), w.slot_n.as<int>(), p.S, nq, ix->n_lists,
+                                owner, ix->rank, w.spos.as<int>(), (const uint4 *)send_dev,
+                                w.smins.as<uint8_t>(), p.R, bound_dev, st, hc);
+    w.shard_probes = probes;
+    w.shard_nq = nq;
+    w.shard_capacity = capacity;
+    w.shard_plain = false;
+    w.shard_head = true;
+    HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
 // ---- the scan in ONE phase with the matrix-core kernel, as the unsharded pipeline runs it ----
 // tk_index_shard_scan_dev scores every owned segment exactly; the two-phase form below first learns the
 // bound B1 after every query's first list (a replay by value on its owner + a MIN all-reduce: one more
@@ -217,7 +333,8 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
 extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float *q_dev,
                                              const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
                                              int n_probes, int pass_1, const int64_t *probes_all_dev,
-                                             int64_t capacity, void *send_dev, int *flag_dev, void *stream)
+                                             int64_t capacity, void *send_dev, int *flag_dev,
+                                             const uint8_t *bound_dev, void *stream)
 {
     IXLOCK(ix);
     Plan p;
@@ -225,13 +342,22 @@ extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float
     int64_t qh = 0;
     TRY(shard_args(ix, slot, nq, capacity, p, qh));
     ARGCHECK(send_dev && flag_dev, "send/flag buffers");
-    const int64_t tail = (int64_t)ix->world * capacity - ix->max_list_chunks;
-    if (!shard_plain_possible(ix, p) || !ix->ids_unique || tail < 0 || p.R > TK_LANES_MAX_R ||
-        ix->heap_mode != 0 || p.cap * 16 > 0xffffff)
+    const int64_t tail = (int64_t)ix->world * capacity - ix->max_list_chunks;      // (>= 0 where the form applies)
+    Work &w = ix->works[(size_t)slot];
+    if (!shard_one_phase_possible(ix, p, capacity)) {
+        // (behind tk_index_shard_scan_head_dev, which then was tk_index_shard_scan_dev itself: nothing is owed)
+        if (bound_dev && w.shard_head) {
+            w.shard_head = false;
+            return TK_OK;
+        }
         return tk_index_shard_scan_dev(ix, slot, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1,
                                        probes_all_dev, capacity, send_dev, flag_dev, stream);
-    Work &w = ix->works[(size_t)slot];
+    }
     hipStream_t st = (hipStream_t)stream;
+    const bool behind_head = bound_dev != nullptr;
+    ARGCHECK(!behind_head || (w.shard_head && w.shard_probes && w.shard_nq == nq && w.shard_capacity == capacity),
+             "bound_dev: tk_index_shard_scan_head_dev of this slot (same nq and capacity) comes first");
+    w.shard_head = false;
     TRY(reserve_shard(ix, w, nq, qh, p));
     TRY(reserve_shard_plain(ix, w, nq, p));
     TRY(w.smins.ensure((size_t)ix->world * capacity + 16));
@@ -239,7 +365,14 @@ extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float
     Prof pf;
     const int *owner = ix->owner.as<int>();
     const int64_t *probes = probes_all_dev;
-    if (probes) {
+    if (behind_head) {
+        // the head call left tables, limits, probe lists and positions; queries whose bound after the head
+        // is above their table's limit leave the plain path (all their lists exact) — the rest is the
+        // one-phase scan, which now cannot fail its check at home
+        probes = w.shard_probes;
+        tk_launch_shard_mask_limits(bound_dev, nq, w.qlim.as<int>(), st);
+        coarse_slots(ix, w, probes, nq, p, w.u_count.as<int>(), owner, ix->rank, st, true);
+    } else if (probes) {
         // tables and their limits: tk_index_shard_coarse_dev; the probe lists arrive gathered
         coarse_slots(ix, w, probes, nq, p, w.u_count.as<int>(), owner, ix->rank, st, true);
     } else {
@@ -248,7 +381,7 @@ extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf, true));
         probes = w.probes.as<int64_t>();
     }
-    {
+    if (!behind_head) {
         const int64_t n1 = nq * p.S + (int64_t)ix->world * qh * p.S + 1;
         ARGCHECK(n1 < (1ll << 31), "too many (query, list) entries for one sharded batch");
         TRY(w.pos_lens.ensure((size_t)n1 * 8));

@@ -301,7 +301,9 @@ void tk_launch_shard_unpack(const uint4 *recv, const int *rpos, const int *slot_
 void tk_launch_shard_first_bound(const int64_t *probes, const int *slot_prefix, const int *slot_n,
                                  int S, int64_t nq, int64_t n_lists, const int *owner, int me,
                                  const int *spos, const uint4 *scan, const uint8_t *smins, int R,
-                                 uint8_t *bound, hipStream_t s);
+                                 uint8_t *bound, hipStream_t s, int max_chunks = 0);
+// qlim[q] = TK_PLAIN_NEVER where the (order-key) bound is above it
+void tk_launch_shard_mask_limits(const uint8_t *bound, int64_t nq, int *qlim, hipStream_t s);
 // pair_cnt / pair_off: nq * S + 1 ints (pair_cnt's last entry zeroed by the caller); tmp: room
 // for tk_scan_exclusive over that many; tally: 256 * W ints, zeroed by the caller
 int tk_scan_exclusive(void *tmp, size_t *tmp_bytes, const int *in, int *out, int64_t n, hipStream_t s);

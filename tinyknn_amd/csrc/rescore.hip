@@ -447,6 +447,18 @@ __global__ void make_slots_kernel(const int64_t *__restrict__ probes, int S, int
     if (repeat_flag) repeat_flag[qi] = wrapped;
 }
 
+// The same with one WAVE per query, lane s = slot s (S <= 64): the thread-per-query form walks its S slots one
+// dependent load after the other — 76 us for the 80 000 queries x 10 slots of a list-sharded batch at W = 8,
+// every rank doing all of it; here the slots of a query are loaded at once and scanned by shuffles.
+__global__ __launch_bounds__(256) void make_slots_wave_kernel(const int64_t *__restrict__ probes, int S, int64_t nq,
+                                                              const TkSlotsOut so)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;       // (whole waves leave: the ballots below see full waves only)
+    slots_epilogue(so, qi, S, lane, lane < S ? probes[qi * S + lane] : -1);
+}
+
 void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc, int64_t nq,
                           int64_t n_lists, const int64_t *list_chunk_off, const int64_t *list_n,
                           const int64_t *ids_off, int *slot_prefix, int64_t *slot_chunk0,
@@ -458,6 +470,15 @@ void tk_launch_make_slots(const int64_t *probes, const int *probe_count, int kc,
     (void)probe_count;
     if (nq == 0) return;
     if (!qlim || !pair_count2 || !plain0 || !pair_count3) slot_exact = nullptr;
+    if (kc <= 64 && nq >= 4096) {
+        TkSlotsOut so;
+        so.n_lists = n_lists; so.list_chunk_off = list_chunk_off; so.list_n = list_n; so.ids_off = ids_off;
+        so.slot_prefix = slot_prefix; so.slot_chunk0 = slot_chunk0; so.slot_n = slot_n; so.slot_label_off = slot_label_off;
+        so.repeat_flag = repeat_flag; so.pair_count = pair_count; so.owner = owner; so.me = me; so.qlim = qlim; so.R = R;
+        so.slot_exact = slot_exact; so.pair_count2 = pair_count2; so.plain0 = plain0; so.pair_count3 = pair_count3;
+        hipLaunchKernelGGL(make_slots_wave_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, probes, kc, nq, so);
+        return;
+    }
     hipLaunchKernelGGL(make_slots_kernel, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, s,
                        probes, kc, nq, n_lists, list_chunk_off, list_n, ids_off, slot_prefix,
                        slot_chunk0, slot_n, slot_label_off, repeat_flag, pair_count, owner, me,

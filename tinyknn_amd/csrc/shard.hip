@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void shard_first_bound_kernel(
     const int *__restrict__ slot_n, int S, int64_t nq, int64_t n_lists,
     const int *__restrict__ owner, int me, const int *__restrict__ spos,
     const uint4 *__restrict__ scan, const uint8_t *__restrict__ smins, int R,
-    uint8_t *__restrict__ bound)
+    uint8_t *__restrict__ bound, int max_chunks)
 {
     __shared__ uint32_t s_hist[4][256];
     __shared__ uint4 s_blk[4][64];
@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void shard_first_bound_kernel(
     }
     uint32_t *hist = s_hist[wv];
     for (int b = lane; b < 256; b += 64) hist[b] = b == 255 ? (uint32_t)R : 0u;   // init_heap: R x 127
-    const int nch = slot_prefix[q * (S + 1) + 1] - slot_prefix[q * (S + 1)];
+    int nch = slot_prefix[q * (S + 1) + 1] - slot_prefix[q * (S + 1)];
+    if (max_chunks > 0 && max_chunks < nch) nch = max_chunks;      // (the bound after the list's HEAD only)
     int n = slot_n[q * S];
     n = n < 0 ? 0 : n;
     int mx = 255;                                      // wave-uniform: the bound so far ...
@@ -401,12 +402,29 @@ __global__ __launch_bounds__(256) void shard_first_bound_kernel(
 void tk_launch_shard_first_bound(const int64_t *probes, const int *slot_prefix, const int *slot_n,
                                  int S, int64_t nq, int64_t n_lists, const int *owner, int me,
                                  const int *spos, const uint4 *scan, const uint8_t *smins, int R,
-                                 uint8_t *bound, hipStream_t s)
+                                 uint8_t *bound, hipStream_t s, int max_chunks)
 {
     if (nq == 0 || S == 0) return;
     hipLaunchKernelGGL(shard_first_bound_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s,
                        probes, slot_prefix, slot_n, S, nq, n_lists, owner, me, spos, scan, smins, R,
-                       bound);
+                       bound, max_chunks);
+}
+
+// tk_index_shard_scan_plain_dev behind tk_index_shard_scan_head_dev: a query whose bound after the head of
+// its first list (min-reduced over the ranks: order key, byte ^ 0x80) is above the limit of its table is
+// taken off the plain path — its limit becomes TK_PLAIN_NEVER, make_slots then keeps all its lists exact.
+__global__ void shard_mask_limits_kernel(const uint8_t *__restrict__ bound, int64_t nq, int *__restrict__ qlim)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int b = (int)(int8_t)(bound[q] ^ 0x80u);
+    if (b > qlim[q]) qlim[q] = TK_PLAIN_NEVER;
+}
+
+void tk_launch_shard_mask_limits(const uint8_t *bound, int64_t nq, int *qlim, hipStream_t s)
+{
+    if (nq == 0) return;
+    hipLaunchKernelGGL(shard_mask_limits_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, bound, nq, qlim);
 }
 
 // One wave per (query, slot) this rank owns.  PACK = false: blocks that pass -> pair_cnt

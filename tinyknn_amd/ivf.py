@@ -440,13 +440,23 @@ class DeviceIndex:
             int(capacity), recv_ptr, out_ptr, flag_ptr, stream))
 
     def shard_scan_plain_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1, capacity,
-                             send_ptr, flag_ptr, stream=0, probes_all_ptr=None):
+                             send_ptr, flag_ptr, stream=0, probes_all_ptr=None, bound_ptr=None):
         """The owned segments in ONE phase as the unsharded pipeline scores them: heads exactly, the rest
         as plain sums on the matrix cores, checked by the home rank's replay
-        (tk_index_shard_scan_plain_dev; falls back to shard_scan_dev's kernel where that does not apply)."""
+        (tk_index_shard_scan_plain_dev; falls back to shard_scan_dev's kernel where that does not apply).
+        bound_ptr: the min-reduced bounds of shard_scan_head_dev — queries above their table's limit
+        stay exact, the check at home cannot fail."""
         _lib.check(_lib.lib().tk_index_shard_scan_plain_dev(
             self._h, int(slot), qn_ptr, qpq_ptr, int(bool(qpq_is_f64)), nq, int(k), int(n_probes),
-            int(pass_1 or 0), probes_all_ptr, int(capacity), send_ptr, flag_ptr, stream))
+            int(pass_1 or 0), probes_all_ptr, int(capacity), send_ptr, flag_ptr, bound_ptr, stream))
+
+    def shard_scan_head_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1, capacity,
+                            send_ptr, flag_ptr, bound_ptr, stream=0, probes_all_ptr=None):
+        """Heads of the first probed lists this rank owns, exactly, + the bound after them
+        (tk_index_shard_scan_head_dev); the caller min-reduces the bytes, then shard_scan_plain_dev(bound_ptr)."""
+        _lib.check(_lib.lib().tk_index_shard_scan_head_dev(
+            self._h, int(slot), qn_ptr, qpq_ptr, int(bool(qpq_is_f64)), nq, int(k), int(n_probes),
+            int(pass_1 or 0), probes_all_ptr, int(capacity), send_ptr, flag_ptr, bound_ptr, stream))
 
     def clone_shard(self, owner, rank, world):
         """Rank `rank`'s shard of this complete unsharded index as a NEW handle on the same device

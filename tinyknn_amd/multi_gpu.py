@@ -20,6 +20,22 @@ logic under gloo without a GPU.
 import numpy as np
 
 
+class _Everything:
+    """A set that holds everything (ListShardedIndex(plain="head"): every argument tuple has "failed")."""
+
+    def __contains__(self, x):
+        return True
+
+    def add(self, x):
+        pass
+
+    def __ior__(self, other):
+        return self
+
+    def __iter__(self):
+        return iter(())
+
+
 def shard_bounds(nq, world, rank):
     """Balanced contiguous slice [lo, hi) of nq queries for `rank`."""
     base, extra = divmod(nq, world)
@@ -177,13 +193,23 @@ class _HipShardEngine:
 
     # ... in ONE phase, heads exactly and the rest on the matrix cores, checked by the home replay
     # (tk_index_shard_scan_plain_dev)
-    def scan_plain(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None):
+    def scan_plain(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, probes_all=None, bound=None):
         import torch
         st = torch.cuda.current_stream().cuda_stream
         self.dev.shard_scan_plain_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
                                       qn.shape[0], k, n_probes, pass_1, capacity, send.data_ptr(),
                                       flag.data_ptr(), stream=st,
-                                      probes_all_ptr=None if probes_all is None else probes_all.data_ptr())
+                                      probes_all_ptr=None if probes_all is None else probes_all.data_ptr(),
+                                      bound_ptr=None if bound is None else bound.data_ptr())
+
+    # ... behind one byte per query: heads of the first lists + the bound after them (tk_index_shard_scan_head_dev)
+    def scan_head(self, slot, qn, qp, k, n_probes, pass_1, capacity, send, flag, bound, probes_all=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.dev.shard_scan_head_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
+                                     qn.shape[0], k, n_probes, pass_1, capacity, send.data_ptr(),
+                                     flag.data_ptr(), bound.data_ptr(), stream=st,
+                                     probes_all_ptr=None if probes_all is None else probes_all.data_ptr())
 
     def finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, out_home, flag=None):
         import torch
@@ -337,7 +363,13 @@ class ListShardedIndex:
         # replay checks the lemma per query and flags the batch: bit 4) where the engine has it;
         # plain="two-phase" keeps the form with the bound after the first list for the dense exchange too
         self._one_phase = self.plain and plain != "two-phase" and hasattr(self.engine, "scan_plain")
-        self._plain_failed = set()  # (k, n_probes, pass_1) whose one-phase batch raised bit 4: two-phase from then on
+        # ... and where that check fails (bit 4: one query in 20 000 of the 100M x 128 index), or on request
+        # (plain="head"): the same scan behind ONE byte per query — the bound after the HEAD of the first
+        # list, replayed by its owner and min-reduced — which keeps such queries on the exact kernel
+        self._head_phase = self._one_phase and hasattr(self.engine, "scan_head")
+        self._plain_failed = set()  # (k, n_probes, pass_1) whose one-phase batch raised bit 4
+        if plain == "head":
+            self._plain_failed = _Everything()
         self.record_region = {}     # (nq, n_probes) -> records per home-rank region (counts="device")
         self._rec_seen = {}         # ... largest per-home count of the batches looked at so far
         self._acc = None            # device: [largest per-home record count, records, dense blocks] since reset
@@ -628,6 +660,17 @@ class ListShardedIndex:
         return (self._one_phase and (k, n_probes, pass_1) not in self._plain_failed and
                 self._exchange_kind(k, n_probes, pass_1) == "dense" and self._use_plain(k, n_probes, pass_1))
 
+    def _head_phase_now(self, k, n_probes, pass_1):
+        """The one-phase scan behind the head bounds: the dense exchange's form once the optimistic one
+        has failed for these arguments (or plain="head")."""
+        return (self._head_phase and (k, n_probes, pass_1) in self._plain_failed and
+                self._exchange_kind(k, n_probes, pass_1) == "dense" and self._use_plain(k, n_probes, pass_1))
+
+    def _scan_form(self, k, n_probes, pass_1):
+        return ("one" if self._one_phase_now(k, n_probes, pass_1) else
+                "head" if self._head_phase_now(k, n_probes, pass_1) else
+                "two" if self._use_plain(k, n_probes, pass_1) else "exact")
+
     def _finish(self, slot, qn, k, n_probes, pass_1, capacity, recv, b, qh):
         if b.get("one_phase"):
             self.engine.finish(slot, qn, k, n_probes, pass_1, capacity, recv, b["home"][:qh * k], flag=b["flag"])
@@ -648,6 +691,16 @@ class ListShardedIndex:
             b["one_phase"] = True
             return None
         nq = qn.shape[0]
+        if self._head_phase_now(k, n_probes, pass_1):
+            if b.get("bound") is None or b["bound"].shape[0] != nq:
+                b["bound"] = self.torch.empty(nq, dtype=self.torch.uint8, device=self.device)
+            self.engine.scan_head(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"], b["bound"],
+                                  probes_all=probes_all)
+            self._all_reduce_min(b["bound"])
+            self.engine.scan_plain(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"],
+                                   probes_all=probes_all, bound=b["bound"])
+            b["one_phase"] = True       # (the finish takes the flag word; by construction it stays clean)
+            return None
         if b.get("bound") is None or b["bound"].shape[0] != nq:
             b["bound"] = self.torch.empty(nq, dtype=self.torch.uint8, device=self.device)
         self.engine.scan_first(slot, qn, qp, k, n_probes, pass_1, capacity, b["send"], b["flag"],
@@ -712,8 +765,7 @@ class ListShardedIndex:
         self._sim_ctx = self._sim.context(
             qn, qp, k, n_probes, pass_1, capacity, coarse=self.coarse, kind=kind,
             region=self._region(qn.shape[0], n_probes, capacity) if kind == "filtered" else 0,
-            form=("one" if self._one_phase_now(k, n_probes, pass_1) else
-                  "two" if self._use_plain(k, n_probes, pass_1) else "exact"))
+            form=self._scan_form(k, n_probes, pass_1))
 
     def _exchange_kind(self, k, n_probes, pass_1):
         """"auto": the filter drops what is not below the bound after the first list — worth its
@@ -1156,6 +1208,19 @@ class SimulatedPeers:
                 for r in range(W):
                     mine[r].copy_(sends[r][me])
                     rec["usage"] = max(rec["usage"], 0)
+            elif form == "head":
+                firsts = []
+                for r in range(W):
+                    sends[r] = t.empty((W, capacity * 16), dtype=t.uint8, device="cuda")
+                    b_ = t.zeros(nq, dtype=t.uint8, device="cuda")
+                    self._engine(r).scan_head(0, qn, qp, k, n_probes, pass_1, capacity, sends[r], flag, b_, probes_all=p_all)
+                    firsts.append(b_)
+                bound = t.stack(firsts).min(dim=0).values.contiguous()
+                for r in range(W):
+                    self._engine(r).scan_plain(0, qn, qp, k, n_probes, pass_1, capacity, sends[r], flag, probes_all=p_all,
+                                               bound=bound)
+                    mine[r].copy_(sends[r][me])
+                sends = {}
             else:
                 buf = t.empty((W, capacity * 16), dtype=t.uint8, device="cuda")
                 for r in range(W):
