@@ -634,6 +634,19 @@ def hbm_scale_leg(device):
     return res
 
 
+class ctypes_double:
+    """a C double and its byref (tk_measure_* out-parameters)"""
+
+    def __init__(self):
+        import ctypes
+        self._v = ctypes.c_double(0.0)
+        self.ref = ctypes.byref(self._v)
+
+    @property
+    def value(self):
+        return self._v.value
+
+
 def launch_batches(args):
     """Steps whose queries ONE scan launch of the timed region covers (tk_index_set_coalesce): two,
     where a pair's distance rows fit one workspace (main() sets args.pairs_fit)."""
@@ -1011,6 +1024,8 @@ def main():
     ap.add_argument("--scan-form", type=int, default=0,
                     help="tk_index_set_option TK_OPT_SCAN_FORM (A/B): 0 table rows by per-lane global loads (default, fastest); "
                          "1 rows through LDS, 4 waves/SIMD; 2 LDS, 3 waves/SIMD")
+    ap.add_argument("--replay-lazy", type=int, default=-1, choices=[-1, 0, 1],
+                    help="TK_OPT_REPLAY_LAZY (A/B): -1 = by the index (lazy for long lists), 0 = staged, 1 = lazy")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="replay streams (tk_index_set_pipeline): caller + coarse stream + these = 4 HW queues")
     ap.add_argument("--coalesce", type=int, default=2, choices=[1, 2],
@@ -1175,6 +1190,7 @@ def main():
     dev.set_scan_mode(args.scan_mode)
     dev.set_option(_lib.OPT_SCAN_FORM, args.scan_form)
     dev.set_option(_lib.OPT_RESCORE_FORM, args.rescore_form)
+    dev.set_option(_lib.OPT_REPLAY_LAZY, args.replay_lazy)
     n_step = [0]
 
     def step(done_event=None):
@@ -1246,6 +1262,16 @@ def main():
     iso_stages, iso_bytes, _ = dev.last_profile()
     dev.set_profiling(False)
     plain_stats = dev.plain_stats()      # of the last batch: tiles, pairs by kernel, queries re-scanned
+    # the list replay's insert rounds of ONE batch (roofline.replay): a device counter, one extra step
+    replay_rounds = None
+    try:
+        dev.set_option(_lib.OPT_REPLAY_COUNT, 1)
+        step()
+        torch.cuda.synchronize()
+        replay_rounds = dev.replay_stats()
+        dev.set_option(_lib.OPT_REPLAY_COUNT, 0)
+    except Exception as e:      # noqa: BLE001 - measurement plumbing
+        log(f"[bench] replay rounds not counted: {e!r}")
     if args.profile_only:
         if rank == 0:
             print(json.dumps({"profile_only": True, "ms_per_step": elapsed / args.steps * 1e3,
@@ -1503,6 +1529,56 @@ def main():
         cpu["note"] = ("value = C batch loop of the port (no per-query Python overhead: the STRONGER "
                        "baseline); python_loop = the reference's own measurement protocol")
 
+    # -- the two biggest consumers of GPU time beside the scan, each against the resource that binds it
+    side_roofs = {}
+    try:
+        R_heap = (args.n_probes + 1) * args.k + 1
+        if replay_rounds and replay_rounds["waves"]:
+            mx, waves = replay_rounds["max_rounds_of_a_wave"], replay_rounds["waves"]
+            iso_ms, timed_ms = iso_stages["heap"], stages["heap"]
+            # a round = one insert step of a wave: every lane with a pending candidate sifts it down its own heap
+            # (log2(R) levels: 3 in registers, the rest one dependent LDS round trip each) + the block bookkeeping
+            # around it; profiles/r02_replay_phases.md counted ~240 dependent VALU (4-5 cycles each, one wave on its
+            # SIMD) + 4 LDS round trips (~128 cycles each) per round at R = 111: ~1 500 cycles = the floor used here
+            floor_cyc = 1500.0
+            clock_ghz = 2.1
+            floor_ms = mx * floor_cyc / (clock_ghz * 1e6)
+            side_roofs["replay"] = {
+                "kernel": "heap_replay_lanes_kernel (the probed lists through one heap per query, lane per query)",
+                "bound": "latency (a dependent chain per wave; %d waves on 1024 SIMDs: no pipe is busy)" % waves,
+                "insert_rounds_of_the_slowest_wave": mx, "insert_rounds_mean_per_wave": replay_rounds["rounds"] / waves,
+                "waves": waves, "segments_walked_per_wave": replay_rounds["segments"] / waves,
+                "kernel_ms_isolated": iso_ms, "stage_ms_timed_region": timed_ms,
+                "ns_per_round_isolated": iso_ms * 1e6 / max(mx, 1),
+                "floor_ms": floor_ms, "floor_is": "rounds of the slowest wave x ~1 500 cycles per round at 2.1 GHz (the chain "
+                                                  "of one insert step: ~240 dependent VALU + 4 LDS round trips, "
+                                                  "profiles/r02_replay_phases.md); the stage also holds pad_fix and, for "
+                                                  "flagged / wrapped queries, the wave-per-query replays",
+                "frac": floor_ms / iso_ms if iso_ms > 0 else None,
+                "frac_timed_region": floor_ms / timed_ms if timed_ms > 0 else None,
+                "covers": "ONE batch of %d queries, one batch in flight (a pair of calls runs as one launch of twice the "
+                          "waves in about the same time)" % args.nq}
+        row_bytes = args.d * 4
+        if row_bytes % 16 == 0 and row_bytes <= 1024 and ivf.data.dtype == np.float32:
+            gb = ctypes_double()
+            _lib.check(_lib.lib().tk_measure_gather_bandwidth(int(min(args.n, 4_000_000)) * row_bytes, row_bytes,
+                                                              int(args.nq) * R_heap, 20, gb.ref))
+            gathered = float(args.nq) * R_heap * row_bytes
+            iso_ms, timed_ms = iso_stages["rescore"], stages["rescore"]
+            side_roofs["rescore"] = {
+                "kernel": "rescore_staged_kernel<32> (exact distances of the heap's candidates, top-k)",
+                "bound": "hbm (random rows of %d bytes: %d per query)" % (row_bytes, R_heap),
+                "gathered_bytes_per_step": gathered, "kernel_ms_isolated": iso_ms, "stage_ms_timed_region": timed_ms,
+                "achieved": gathered / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else None, "unit": "GB/s",
+                "peak": gb.value, "peak_is": "a kernel that only gathers as many random %d-byte rows out of a table of the same "
+                                             "row size with the same access pattern (tk_measure_gather_bandwidth), this box; "
+                                             "MI355X_MICROARCH.md: 5.5-5.6 TB/s for 1 152-byte rows, 8 TB/s streaming" % row_bytes,
+                "frac": (gathered / (iso_ms * 1e-3) / 1e9) / gb.value if iso_ms > 0 and gb.value > 0 else None,
+                "frac_timed_region": (gathered / (timed_ms * 1e-3) / 1e9) / gb.value if timed_ms > 0 and gb.value > 0 else None,
+                "frac_of_hbm_peak": gathered / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if iso_ms > 0 else None}
+    except Exception as e:      # noqa: BLE001 - extra entries must not lose the line
+        side_roofs["error"] = repr(e)
+
     sweep = None
     if args.sweep == "auto" and default_wl and world == 1 and not args.data_file:
         try:
@@ -1579,6 +1655,15 @@ def main():
         "parity_vs_oracle": parity,
         "sweep": sweep,
     }
+    # the other two chains of a batch, next to the scan kernel's entry (and their fractions as top-level scalars)
+    if isinstance(line.get("roofline"), dict):
+        line["roofline"]["replay"] = side_roofs.get("replay")
+        line["roofline"]["rescore"] = side_roofs.get("rescore")
+        if side_roofs.get("error"):
+            line["roofline"]["replay_rescore_error"] = side_roofs["error"]
+        for key in ("replay", "rescore"):
+            if side_roofs.get(key) and side_roofs[key].get("frac") is not None:
+                line["roofline_%s_frac" % key] = side_roofs[key]["frac"]
     if args.workload == "c5" and world == 1 and args.rank_share > 1 and not do_shard:
         # configs[4] is the workload north_star shards: one rank's share of a W-rank partition of THIS index
         # (the resident index stays unsharded: the simulated ranks are clone shards that borrow its arrays)

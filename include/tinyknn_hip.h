@@ -300,6 +300,9 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
  *                        query's probed lists hold more than 8 heap sizes of blocks — 100M x 128: 6 250 blocks
  *                        against a heap of 111).  Identical results. */
 #define TK_OPT_REPLAY_LAZY 4
+/*   TK_OPT_REPLAY_COUNT  1: the lane replays of the probed lists count their insert rounds (measurement plumbing
+ *                        for bench.py's roofline.replay; read and zeroed by tk_index_replay_stats); 0 (DEFAULT): off */
+#define TK_OPT_REPLAY_COUNT 5
 int tk_index_set_option(tk_index *ix, int option, int value);
 
 /* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
@@ -316,7 +319,14 @@ int tk_index_last_profile(tk_index *ix, float *ms8, double *scan_bytes, int *bat
 
 /* measurement plumbing (bench.py): GB/s of a kernel that only reads `bytes` of HBM, every byte
  * once with the flat scan's access pattern — the streaming-read ceiling of the box */
+/* out4 = insert rounds summed over the replay waves, the most rounds one wave ran, waves, 16-block segments walked,
+ * since TK_OPT_REPLAY_COUNT was set / the last call (synchronises, zeroes) */
+int tk_index_replay_stats(tk_index *ix, int64_t *out4);
 int tk_measure_read_bandwidth(int64_t bytes, int reps, double *gbps);
+/* ... and of a kernel that gathers n_gather random rows of row_bytes (16 .. 1024, a multiple of 16) out of
+ * table_bytes of HBM with the rescoring kernel's access pattern (knn_brute1's `data[indices]`, utils.py:89-92):
+ * the ceiling bench.py's roofline.rescore is quoted against. */
+int tk_measure_gather_bandwidth(int64_t table_bytes, int row_bytes, int64_t n_gather, int reps, double *gbps);
 
 /* ---- device-resident build ----------------------------------------
  * IVF.build(X, n_probes = 1 or 2) (ivf.py:77-102) for float32 vectors that are produced IN HBM

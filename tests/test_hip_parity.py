@@ -339,6 +339,7 @@ def test_ivf_query_golden(tk, tag):
         for lazy in (1, 0):
             dev.set_option(_lib.OPT_REPLAY_LAZY, lazy)
             out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
+            np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
             np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])
             np.testing.assert_array_equal(dbg["heap_val"], g[f"heap_val_p{n_probes}"])
             np.testing.assert_array_equal(out, g[f"ids_p{n_probes}"])

@@ -30,7 +30,7 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->ids32, &ix->data, &ix->cslots_i,
                       &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage, &ix->owner,
                       &ix->local_chunk_off, &ix->rot_t, &ix->br_ynorm, &ix->br_vals, &ix->br_tau,
-                      &ix->br_cand, &ix->br_count, &ix->br_out, &ix->br_q, &ix->br_sample};
+                      &ix->br_cand, &ix->br_count, &ix->br_out, &ix->br_q, &ix->br_sample, &ix->replay_counters};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
     // (the internal streams belong to the process: shared_streams below)
@@ -804,7 +804,8 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
                                              slot_loff, p.S, ix->ids.as<int64_t>(),
                                              w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
                                              p.R, 1, 0, repeat_flag, w.mins.as<uint8_t>(),
-                                             p.cap_min, nullptr, st, slot_exact, qlim, lazy))
+                                             p.cap_min, nullptr, st, slot_exact, qlim, lazy,
+                                             ix->opt_replay_count ? ix->replay_counters.as<unsigned long long>() : nullptr))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
         if (plain && plain_flag) {
             tk_launch_shard_flag_plain(repeat_flag, nq, plain_flag, st);
@@ -1567,6 +1568,13 @@ extern "C" int tk_index_set_option(tk_index *ix, int option, int value)
     case TK_OPT_PLAIN_LIMIT:
         ix->opt_plain_limit = value;
         return TK_OK;
+    case TK_OPT_REPLAY_COUNT:
+        ix->opt_replay_count = value != 0;
+        if (value) {
+            TRY(ix->replay_counters.ensure(64));
+            HIPCHECK(hipMemset(ix->replay_counters.p, 0, 64));
+        }
+        return TK_OK;
     case TK_OPT_REPLAY_LAZY:
         ARGCHECK(value >= -1 && value <= 1, "TK_OPT_REPLAY_LAZY: -1, 0 or 1");
         ix->opt_replay_lazy = value;
@@ -1638,6 +1646,24 @@ extern "C" int tk_index_plain_stats(tk_index *ix, int64_t *out8)
         out8[0] = tiles;
         out8[5] = cps;
     }
+    return TK_OK;
+}
+
+// TK_OPT_REPLAY_COUNT: what the lane replays of the probed lists did since the option was set / the last call
+// (synchronises; zeroes the counters): out4 = insert rounds summed over the waves, the most rounds any wave ran
+// (the kernel's critical path: a round is one dependent insert step of a wave), waves, 16-block segments walked.
+extern "C" int tk_index_replay_stats(tk_index *ix, int64_t *out4)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix && out4, "null index / buffer");
+    for (int i = 0; i < 4; i++) out4[i] = 0;
+    if (!ix->replay_counters.p) return TK_OK;
+    TRY(flush_pending(ix));
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long v[4];
+    HIPCHECK(hipMemcpy(v, ix->replay_counters.p, sizeof v, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemset(ix->replay_counters.p, 0, 64));
+    for (int i = 0; i < 4; i++) out4[i] = (int64_t)v[i];
     return TK_OK;
 }
 

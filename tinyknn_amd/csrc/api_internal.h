@@ -202,6 +202,8 @@ struct tk_index {
     int opt_scan_form = 0;             // exact list-major kernel: 0 per-lane table-row loads, 1 / 2 rows staged in LDS
     int opt_rescore_form = 2;          // rescoring: 2 / 1 rows staged through LDS in tiles of 32 / 64, 0 lane per row
     int opt_plain_limit = 0x7fffffff;  // a cap on every query's table limit (tests: provokes the re-scan path)
+    DevBuf replay_counters;            // TK_OPT_REPLAY_COUNT: 4 x uint64 the list replays add to (tk_index_replay_stats)
+    bool opt_replay_count = false;
     int opt_replay_lazy = -1;          // lane replay of the lists: 1 lazy (blocks fetched where their minimum passes), 0 staged, -1 auto
     bool flat_plain_ok = true;         // tk_index_top_centers: the plain path has not failed on this index
     int plain_state = 0;       // PLAIN_PROBE .. PLAIN_OFF (see plain_poll)

@@ -888,3 +888,40 @@ extern "C" int tk_measure_read_bandwidth(int64_t bytes, int reps, double *gbps)
     out.release();
     return rc;
 }
+
+// GB/s of a kernel that gathers random rows of `row_bytes` out of `table_bytes` of HBM the way the rescoring
+// kernel does (measurement plumbing for bench.py's roofline.rescore)
+extern "C" int tk_measure_gather_bandwidth(int64_t table_bytes, int row_bytes, int64_t n_gather, int reps, double *gbps)
+{
+    TRY(require_gpu());
+    ARGCHECK(row_bytes >= 16 && row_bytes <= 1024 && row_bytes % 16 == 0 && table_bytes >= (1 << 20) && n_gather >= 1 &&
+             reps >= 1 && gbps, "16 <= row_bytes <= 1024 (a multiple of 16), table_bytes >= 1 MiB, n_gather, reps >= 1");
+    DevBuf buf, out;
+    const int64_t n_rows = table_bytes / row_bytes;
+    int rc = buf.ensure((size_t)n_rows * row_bytes);
+    if (rc == TK_OK) rc = out.ensure(16);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (rc == TK_OK) {
+        hipError_t e = hipMemset(buf.p, 1, (size_t)n_rows * row_bytes);
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) {
+            tk_launch_gather_rows(buf.p, n_rows, row_bytes, n_gather, out.as<uint32_t>(), nullptr);
+            e = hipDeviceSynchronize();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+        for (int r = 0; r < reps && e == hipSuccess; r++)
+            tk_launch_gather_rows(buf.p, n_rows, row_bytes, n_gather, out.as<uint32_t>(), nullptr);
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && ms > 0) *gbps = (double)n_gather * row_bytes * reps / (ms * 1e-3) / 1e9;
+        else rc = fail(TK_ERR_HIP, e == hipSuccess ? "zero elapsed time" : hipGetErrorString(e));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    buf.release();
+    out.release();
+    return rc;
+}

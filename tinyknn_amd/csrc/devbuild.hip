@@ -262,3 +262,41 @@ void tk_launch_read_only(const void *src, int64_t n_uint4, uint32_t *out, hipStr
 {
     hipLaunchKernelGGL(read_only_kernel, dim3(65536), dim3(256), 0, s, (const uint4 *)src, n_uint4, out);
 }
+
+// ... and one that reads `n_gather` ROWS of `row16` 16-byte pieces each, chosen at random among n_rows (a hash
+// of the gather index), the way the rescoring kernel reads its candidates: consecutive lanes = consecutive
+// pieces of a row, a wave's load instruction covers 64 / lanes_per_row whole rows, 16 loads in flight per lane.
+// The ceiling of `roofline.rescore` (MI355X_MICROARCH.md quotes 5.5-5.6 TB/s for 1 152-byte rows; GloVe's are 400).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4 *__restrict__ src, int64_t n_rows, int row16,
+                                                          int lpr_log, int64_t n_gather, uint32_t *__restrict__ out)
+{
+    const int lpr = 1 << lpr_log;
+    const int64_t lane_rows = ((int64_t)gridDim.x * blockDim.x) >> lpr_log;       // rows in flight per load round
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lpr_log;
+    const int pc = threadIdx.x & (lpr - 1);
+    uint32_t acc = 0;
+    for (int64_t g = g0; g < n_gather; g += 16 * lane_rows) {
+        uint4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const uint64_t gi = (uint64_t)(g + u * lane_rows);
+            uint64_t h = gi * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 32;
+            const int64_t row = (int64_t)(h % (uint64_t)n_rows);
+            v[u] = (pc < row16 && gi < (uint64_t)n_gather) ? src[row * row16 + pc] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+void tk_launch_gather_rows(const void *src, int64_t n_rows, int row_bytes, int64_t n_gather, uint32_t *out, hipStream_t s)
+{
+    const int row16 = row_bytes / 16;
+    const int lpr_log = row16 <= 16 ? 4 : (row16 <= 32 ? 5 : 6);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(8192), dim3(256), 0, s, (const uint4 *)src, n_rows, row16, lpr_log,
+                       n_gather, out);
+}

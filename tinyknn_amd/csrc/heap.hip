@@ -789,6 +789,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
         mins_nx = TK_MINS_ROW(0);
         if (!LAZY) TK_FETCH_BLOCKS(0)
     }
+    int rounds = 0;               // wave-uniform: iterations of the insert loop (each a dependent chain: roofline.replay)
     for (int g = 0; g < max_nseg; g++) {
         if (!LAZY) {
 #pragma unroll
@@ -829,6 +830,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                 }
             }
             if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
+            rounds++;
             if (bits) {   // one insert per lane with a pending candidate
                 const int r = __builtin_ctz(bits);
                 bits &= bits - 1;
@@ -955,6 +957,12 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     }
 #undef TK_FETCH_BLOCKS
 #undef TK_MINS_ROW
+    if (dbg && lane == 0) {       // TK_OPT_REPLAY_COUNT: [0] += rounds, [1] = max rounds of a wave, [2] += waves, [3] += segments
+        atomicAdd(&dbg[0], (unsigned long long)rounds);
+        atomicMax(&dbg[1], (unsigned long long)rounds);
+        atomicAdd(&dbg[2], 1ull);
+        atomicAdd(&dbg[3], (unsigned long long)max_nseg);
+    }
     // registers back to their heap rows
     if (R > 0) H[0 * LW + lane] = h0;
     if (R > 1) H[1 * LW + lane] = h1;
@@ -1189,7 +1197,8 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R,
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
-                                hipStream_t s, const int *plain0, const int *qlim, int lazy)
+                                hipStream_t s, const int *plain0, const int *qlim, int lazy,
+                                unsigned long long *counters)
 {
     if (nq == 0 || R == 0) return 0;
     if (!plain0 || !qlim || !skip || !signd) plain0 = qlim = nullptr;
@@ -1238,14 +1247,14 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
 #define TK_LAUNCH3(S_, D_, L_)                                                                    \
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, L_>), grid, dim3(64), lds, s, dist, cap, nq,  \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
-                       slots_uniform, skip, 1, mins, cap_min, labels32, nullptr, prio, wave_lds,  \
+                       slots_uniform, skip, 1, mins, cap_min, labels32, counters, prio, wave_lds,  \
                        plain0, qlim)
     if (dedupe) { if (signd) TK_LAUNCH3(true, true, 32); else TK_LAUNCH3(false, true, 32); }
     else if (lazy) {
 #define TK_LAUNCH_LAZY(S_)                                                                        \
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, false, 64, true>), grid, dim3(64), lds, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
-                       slots_uniform, skip, 1, mins, cap_min, labels32, nullptr, prio, wave_lds,  \
+                       slots_uniform, skip, 1, mins, cap_min, labels32, counters, prio, wave_lds,  \
                        plain0, qlim)
         if (signd) TK_LAUNCH_LAZY(true); else TK_LAUNCH_LAZY(false);
 #undef TK_LAUNCH_LAZY

@@ -174,7 +174,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
                                 hipStream_t s, const int *plain0 = nullptr, const int *qlim = nullptr,
-                                int lazy = 0);
+                                int lazy = 0, unsigned long long *counters = nullptr);
 // lazy: blocks are fetched only where their minimum passes (rows far longer than the heap; distinct labels)
 
 // Wave-per-query replay on packed 32-bit entries from FRESH heaps (R*4 B of LDS, or
@@ -352,6 +352,8 @@ void tk_launch_pack_lists(const uint8_t *labels, int M, const int *rows_sorted, 
                           const uint8_t *zero_code, uint4 *tiled, int64_t total_chunks, hipStream_t s);
 void tk_launch_gather_rows(const float *X, int d, const int64_t *rows, int64_t n, float *out, hipStream_t s);
 void tk_launch_read_only(const void *src, int64_t n_uint4, uint32_t *out, hipStream_t s);
+// n_gather random rows of row_bytes (a multiple of 16, <= 1024) out of n_rows, read as the rescoring kernel reads
+void tk_launch_gather_rows(const void *src, int64_t n_rows, int row_bytes, int64_t n_gather, uint32_t *out, hipStream_t s);
 void tk_launch_compact_tiled(const uint4 *src, uint4 *dst, int P, const int64_t *global_off,
                              const int64_t *local_off, int n_lists, int64_t local_chunks, hipStream_t s);
 

@@ -550,6 +550,14 @@ class DeviceIndex:
             self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0), records_ptr,
             counts_recv_ptr, int(region), out_ptr, flag_ptr, stream))
 
+    def replay_stats(self):
+        """What the lane replays of the probed lists did since set_option(OPT_REPLAY_COUNT, 1) / the last call
+        (tk_index_replay_stats; synchronises): insert rounds over all waves, the most one wave ran, waves,
+        16-block segments walked."""
+        o = np.zeros(4, dtype=np.int64)
+        _lib.check(_lib.lib().tk_index_replay_stats(self._h, _lib.ptr(o, _lib._i64p)))
+        return dict(rounds=int(o[0]), max_rounds_of_a_wave=int(o[1]), waves=int(o[2]), segments=int(o[3]))
+
     def reserve(self, nq, k, n_probes, pass_1=None):
         _lib.check(_lib.lib().tk_index_reserve(self._h, nq, int(k), int(n_probes), int(pass_1 or 0)))
 
