@@ -396,7 +396,6 @@ __device__ __forceinline__ void finish_chunk(uint32_t (&a0)[8], uint4 &o, uint32
     o.w = __builtin_amdgcn_perm(a0[7], a0[6], 0x07030501u);
 }
 
-#define TK_UNIT_Q 4
 #include "tickets.h"
 
 // One scan job of the list-major kernel: everything tk_launch_scan_units takes.

@@ -501,16 +501,27 @@ int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_
 {
     TRY(pf.mark(st));
     // 1. distance tables                                   fast_pq.py:186-222
+    // (+ on the side, by the wave that holds a query's table: its limit for the plain kernel, and the
+    //  descriptors of the list-major coarse scan — every query scans the one list of coded centres: no idle
+    //  lanes; two short kernels less at the head of the front stream's chain)
+    TkTablesExtra ex;
+    if (plain) {        // per query: below which value clamp(plain sum) is the saturated value
+        ex.qlim = w.qlim.as<int>();
+        ex.lim_avx = ix->order == TK_ORDER_AVX;
+        ex.lim_m_used = ex.lim_avx ? (ix->M & ~3) : ix->M;       // the AVX kernels read block pairs two at a time
+        ex.lim_force = ix->opt_plain_limit;
+    }
+    if (coarse_units(ix, nq)) {
+        ex.c_pair_off = w.c_pair_off.as<int>();
+        ex.c_unit_prefix = w.c_unit_prefix.as<int>();
+        ex.c_pair_q = w.c_pair_q.as<int>();
+        ex.c_pair_f0 = w.c_pair_f0.as<int>();
+        ex.c_chunks = (int)ix->center_chunks;
+        ex.c_nq = nq;
+    }
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
                            qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>(), w.shift.p,
-                           w.scale.as<double>(), st, qpq2);
-    if (plain)      // per query: below which value clamp(plain sum) is the saturated value
-        tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st, ix->opt_plain_limit);
-    if (coarse_units(ix, nq))
-        // every query scans the one list of coded centres: list-major, no idle lanes
-        tk_launch_identity_pairs(nq, (int)ix->center_chunks, w.c_pair_off.as<int>(),
-                                 w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
-                                 w.c_pair_f0.as<int>(), st);
+                           w.scale.as<double>(), st, qpq2, &ex);
     TRY(pf.mark(st));
     return TK_OK;
 }

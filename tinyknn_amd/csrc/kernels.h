@@ -201,9 +201,23 @@ struct TkSecond {
     int64_t n_a = 0;
 };
 
+// what the table build can do on the side for the batch pipeline (every wave has its query's table at hand): the
+// limit C of plain_scan.hip's lemma per query (tk_launch_table_limits' result: qlim, avx order?, blocks the
+// reference's kernel reads, cap), and the descriptors of "every query scans the one list of coded centres"
+// (tk_launch_identity_pairs' result for c_nq <= nq queries over c_chunks chunks) — two kernels less at the head
+// of the front stream's chain
+#define TK_UNIT_Q 4          // queries a lane of the list-major exact kernel scores per pass (records padded to it)
+struct TkTablesExtra {
+    int *qlim = nullptr;
+    int lim_avx = 0, lim_m_used = 0, lim_force = 0x7fffffff;
+    int *c_pair_off = nullptr, *c_unit_prefix = nullptr, *c_pair_q = nullptr, *c_pair_f0 = nullptr;
+    int c_chunks = 0;
+    int64_t c_nq = 0;
+};
 void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, const void *q,
                             int q_is_f64, int64_t nq, double aux0, double aux1, int signd,
-                            uint8_t *tables, void *shift, double *scale, hipStream_t s, TkSecond q2 = TkSecond());
+                            uint8_t *tables, void *shift, double *scale, hipStream_t s, TkSecond q2 = TkSecond(),
+                            const TkTablesExtra *extra = nullptr);
 
 // Exact rescoring + ascending top-k.
 // cand: (nq, R) int64 candidate ids (heap order).  strip: drop -1 entries first

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include "kernels.h"
 #include "np_order.h"
+#include "tickets.h"
 
 // numpy's pairwise recursion over n elements (n > 128 splits at n2 = n/2 - (n/2)%8
 // into [0,n2) and [n2,n)) depends only on n, so the host lays it out once per
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
     const float *__restrict__ centers, int dq, int dpb, int f_order, const T *__restrict__ qs,
     double aux0, double aux1, uint8_t *__restrict__ tables, T *__restrict__ shift_out,
     double *__restrict__ scale_out, int64_t nq, int wave_lds, const PwProgram pw,
-    const T *__restrict__ qs_b, int64_t n_a)
+    const T *__restrict__ qs_b, int64_t n_a, const TkTablesExtra ex)
 {
     // a wave = one query's chain of dependent LDS round trips; in the pipelined mode it shares its SIMD
     // with the scans of earlier batches and heads the stream the launches wait for: its instructions
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
     // in OUTPUT order (entry o = m * 16 + i), four bytes per lane: one coalesced dword store
     // instead of four byte stores 16 bytes apart
     uint32_t *out4 = reinterpret_cast<uint32_t *>(tables + qi * (int64_t)cnt);
+    int n0 = 0, n1 = 0;         // ex.qlim: negative mass of the two saturating chains (plain_scan.hip's lemma)
     for (int o4 = lane; o4 < cnt / 4; o4 += 64) {
         uint32_t pack = 0;
 #pragma unroll
@@ -248,6 +250,53 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
             pack |= (uint32_t)(uint8_t)(int32_t)v << (8 * b);  // :217-221
         }
         out4[o4] = pack;
+        if (SIGNED && ex.qlim) {
+            // the four lanes 4j .. 4j + 3 hold the four dwords of block m = o4 >> 2 (4 M dwords: whole groups
+            // are active or idle together): its smallest entry, as the reference's signed table reads it
+            int mn = min(min((int)(int8_t)pack, (int)(int8_t)(pack >> 8)), min((int)(int8_t)(pack >> 16), (int)(int8_t)(pack >> 24)));
+            mn = min(mn, __shfl_xor(mn, 1, 64));
+            mn = min(mn, __shfl_xor(mn, 2, 64));
+            const int m = o4 >> 2;
+            if ((o4 & 3) == 0 && m < ex.lim_m_used) {
+                const int neg = mn < 0 ? -mn : 0;
+                if (ex.lim_avx && ((m >> 1) & 1)) n1 += neg; else n0 += neg;
+            }
+        }
+    }
+    if (SIGNED && ex.qlim) {    // C of the lemma per query, or TK_PLAIN_NEVER (what table_limits_kernel computes)
+        for (int o = 32; o > 0; o >>= 1) {
+            n0 += __shfl_xor(n0, o, 64);
+            n1 += __shfl_xor(n1, o, 64);
+        }
+        if (lane == 0) {
+            int c = (n0 <= 128 && n1 <= 128) ? 127 - n0 - n1 : TK_PLAIN_NEVER;
+            if (ex.lim_force != 0x7fffffff && c > ex.lim_force) c = ex.lim_force;
+            ex.qlim[qi] = c;
+        }
+    }
+    if (ex.c_pair_q) {
+        // "every query scans the one list of coded centres" (pairs_identity_kernel): pair qi = query qi, the
+        // records padded to groups of four, the header and the scan's work counters by the first wave
+        const int64_t nrec = (ex.c_nq + TK_UNIT_Q - 1) / TK_UNIT_Q * TK_UNIT_Q;
+        if (qi < ex.c_nq) {
+            if (lane == 0) {
+                ex.c_pair_q[qi] = (int)qi;
+                ex.c_pair_f0[qi] = 0;
+            }
+            if (qi == ex.c_nq - 1 && lane >= 1 && ex.c_nq + lane - 1 < nrec) {
+                ex.c_pair_q[ex.c_nq + lane - 1] = -1;
+                ex.c_pair_f0[ex.c_nq + lane - 1] = 0;
+            }
+        }
+        if (qi == 0) {
+            if (lane == 0) {
+                ex.c_pair_off[0] = 0;
+                ex.c_pair_off[1] = (int)nrec;
+                ex.c_unit_prefix[0] = 0;
+                ex.c_unit_prefix[1] = (int)(nrec / TK_UNIT_Q) * ex.c_chunks;
+            }
+            if (lane < TK_TICKETS) ex.c_unit_prefix[TK_TICKET_OFF(1) + lane * 32] = 0;
+        }
     }
     if (lane == 0) {
         shift_out[qi] = shift;
@@ -257,9 +306,12 @@ __global__ __launch_bounds__(256) void build_tables_kernel(
 
 void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, const void *q,
                             int q_is_f64, int64_t nq, double aux0, double aux1, int signd,
-                            uint8_t *tables, void *shift, double *scale, hipStream_t s, TkSecond q2)
+                            uint8_t *tables, void *shift, double *scale, hipStream_t s, TkSecond q2,
+                            const TkTablesExtra *extra)
 {
     if (nq == 0) return;
+    TkTablesExtra ex;
+    if (extra) ex = *extra;
     const int M = dq / dpb;
     const size_t esz = q_is_f64 ? 8 : 4;
     // per-wave LDS: dists + 64x8 accumulators + 128 tree nodes
@@ -276,21 +328,21 @@ void tk_launch_build_tables(const float *centers, int dq, int dpb, int f_order, 
             hipLaunchKernelGGL((build_tables_kernel<double, true>), grid, block, lds, s, centers, dq,
                                pdpb, f_order, (const double *)q, aux0, aux1, tables,
                                (double *)shift, scale, nq, wave_lds, pw,
-                               (const double *)q2.b, q2.n_a);
+                               (const double *)q2.b, q2.n_a, ex);
         else
             hipLaunchKernelGGL((build_tables_kernel<double, false>), grid, block, lds, s, centers,
                                dq, pdpb, f_order, (const double *)q, aux0, aux1, tables,
                                (double *)shift, scale, nq, wave_lds, pw,
-                               (const double *)q2.b, q2.n_a);
+                               (const double *)q2.b, q2.n_a, ex);
     } else {
         if (signd)
             hipLaunchKernelGGL((build_tables_kernel<float, true>), grid, block, lds, s, centers, dq,
                                pdpb, f_order, (const float *)q, aux0, aux1, tables, (float *)shift, scale, nq, wave_lds, pw,
-                               (const float *)q2.b, q2.n_a);
+                               (const float *)q2.b, q2.n_a, ex);
         else
             hipLaunchKernelGGL((build_tables_kernel<float, false>), grid, block, lds, s, centers,
                                dq, pdpb, f_order, (const float *)q, aux0, aux1, tables,
                                (float *)shift, scale, nq, wave_lds, pw,
-                               (const float *)q2.b, q2.n_a);
+                               (const float *)q2.b, q2.n_a, ex);
     }
 }
