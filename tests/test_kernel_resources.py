@@ -38,7 +38,7 @@ PINNED = {
     ("tables.hip", "build_tables_kernelIfLb1EE"): (128, 4),
     ("tables.hip", "build_tables_kernelIdLb1EE"): (128, 4),
     # the lazy lane replay of long rows (FlatTop, configs[2]) and the wave-per-query replays
-    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb1EE"): (64, 8),
+    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb1EE"): (72, 7),
     ("heap.hip", "heap_replay_packed_kernelILb1ELb0EE"): (64, 8),
     ("heap.hip", "heap_replay_packed_kernelILb1ELb1EE"): (64, 8),
 }

@@ -785,8 +785,15 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) nx[k] = make_uint4(0, 0, 0, 0);
+    // LAZY: the minima run TWO segments ahead, so that at the start of segment g those of g + 1 are in registers
+    // and the FIRST block of g + 1 whose minimum passes the bound of now — a superset of what will pass then —
+    // can be requested while segment g is replayed: on long lists ~1.3 blocks of a segment with any hit pass
+    // (500 of 6 250 per query at 100M x 128), each was a dependent trip to memory of its own.
+    uint4 mins_n2 = make_uint4(0, 0, 0, 0), pre = make_uint4(0, 0, 0, 0), pre_n = make_uint4(0, 0, 0, 0);
+    int pre_blk = -1, pre_n_blk = -1;
     if (max_nseg > 0) {
         mins_nx = TK_MINS_ROW(0);
+        if (LAZY && max_nseg > 1) mins_n2 = TK_MINS_ROW(1);
         if (!LAZY) TK_FETCH_BLOCKS(0)
     }
     int rounds = 0;               // wave-uniform: iterations of the insert loop (each a dependent chain: roofline.replay)
@@ -796,9 +803,25 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
             for (int k = 0; k < 16; k++) ST[k * LW + lane] = nx[k];
         }
         const uint4 mins_cur = mins_nx;
-        if (g + 1 < max_nseg) {
+        if (LAZY) {
+            mins_nx = mins_n2;                              // segment g + 1: requested an iteration ago
+            if (g + 2 < max_nseg) mins_n2 = TK_MINS_ROW(g + 2);
+            pre = pre_n;
+            pre_blk = pre_n_blk;
+            pre_n_blk = -1;
+            if (g + 1 < max_nseg) {
+                int kn = total - 16 * (g + 1);
+                kn = kn < 0 ? 0 : (kn > 16 ? 16 : kn);
+                uint32_t hn = mask_lt16_swar<SIGNED>(mins_nx, bb);
+                hn &= kn >= 16 ? 0xffffu : ((1u << kn) - 1u);
+                if (hn) {
+                    pre_n_blk = 16 * (g + 1) + __builtin_ctz(hn);
+                    pre_n = drow[pre_n_blk < last_blk ? pre_n_blk : last_blk];
+                }
+            }
+        } else if (g + 1 < max_nseg) {
             mins_nx = TK_MINS_ROW(g + 1);
-            if (!LAZY) TK_FETCH_BLOCKS(g + 1)
+            TK_FETCH_BLOCKS(g + 1)
         }
         const int buf = 0;
         int kmax = total - 16 * g;
@@ -818,7 +841,12 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                 const int k = __builtin_ctz(hit);
                 hit &= hit - 1;
                 cur = 16 * g + k;
-                dd = LAZY ? drow[cur < last_blk ? cur : last_blk] : ST[(buf * 16 + k) * LW + lane];
+                if (LAZY) {
+                    if (cur == pre_blk) dd = pre;           // (requested while the previous segment was replayed)
+                    else dd = drow[cur < last_blk ? cur : last_blk];
+                } else {
+                    dd = ST[(buf * 16 + k) * LW + lane];
+                }
                 // `pos < n` (:111): the rows that pad a list's last chunk were set to the largest
                 // value by pad_fix_kernel and can never be below a bound — no row count, and
                 // with distinct labels no slot cursor at all, is needed here
