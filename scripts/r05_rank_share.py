@@ -18,6 +18,7 @@ ap.add_argument("--windows", type=int, default=0)
 ap.add_argument("--nq", type=int, default=10000)
 ap.add_argument("--co", type=int, default=0)
 ap.add_argument("--exchange", default="auto")
+ap.add_argument("--replay-lazy", type=int, default=-1, help="TK_OPT_REPLAY_LAZY of every engine (A/B)")
 ap.add_argument("--clusters", type=int, default=0)
 a = ap.parse_args()
 glove = a.workload == "glove"
@@ -31,6 +32,15 @@ device = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 from tinyknn_amd import _lib
 _lib.check(_lib.lib().tk_set_device(0))
+if a.replay_lazy >= 0:       # A/B: the lane replay's form on every shard handle of this process
+    from tinyknn_amd import multi_gpu as MG
+    _init = MG._HipShardEngine.__init__
+
+    def _patched(self, *x, **kw):
+        _init(self, *x, **kw)
+        self.dev.set_option(_lib.OPT_REPLAY_LAZY, a.replay_lazy)
+
+    MG._HipShardEngine.__init__ = _patched
 ivf, cent = B.build_index(args, device) if glove else B.build_index_c5(args, device)
 dev = ivf.device_index()
 # the unsharded rate beside it (pipelined, pairs of calls), as bench.py's sweep measures it
