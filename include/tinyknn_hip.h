@@ -303,7 +303,19 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
 /*   TK_OPT_REPLAY_COUNT  1: the lane replays of the probed lists count their insert rounds (measurement plumbing
  *                        for bench.py's roofline.replay; read and zeroed by tk_index_replay_stats); 0 (DEFAULT): off */
 #define TK_OPT_REPLAY_COUNT 5
+/*   TK_OPT_REPLAY_TWIN   labels that repeat (IVF.build(n_probes >= 2), ivf.py:53): 1 (DEFAULT) = the lane replay
+ *                        decides `insert`'s duplicate test (_fast_pq.pyx:284-287) from the positions of a row's
+ *                        other copies (twins.hip's table, heap.hip TWIN form: 64 queries per wave, position
+ *                        entries, no set of labels); 0 = the hash set of the labels in the heap (32 queries per
+ *                        wave).  Identical results. */
+#define TK_OPT_REPLAY_TWIN 6
 int tk_index_set_option(tk_index *ix, int option, int value);
+/* The table behind TK_OPT_REPLAY_TWIN (diagnostics, tests): *rows = stored rows (the length of the concatenated
+ * ids), *w = other copies listed per row (0: no table — labels distinct, not int32, or one label stored more
+ * than 17 times); list_out / off_out (rows x w int32 each, or NULL): list and offset inside that list of a
+ * row's u-th other copy, -1 where a label has fewer copies.  What the reference finds by scanning the heap's
+ * labels in `insert` (_fast_pq.pyx:284-287) follows from these positions (heap.hip, TWIN form). */
+int tk_index_twin_table(tk_index *ix, int64_t *rows, int *w, int32_t *list_out, int32_t *off_out);
 
 /* Stage timing.  on = n > 0: every n-th (sub-)batch records HIP events on its streams
  * around the stages (no synchronisation in the query call; 1 = every batch).

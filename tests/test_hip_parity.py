@@ -336,14 +336,18 @@ def test_ivf_query_golden(tk, tag):
         dev.set_scan_mode(0)
         # the lazy lane replay (blocks fetched only where their minimum passes: the form long lists get by
         # themselves) and the staged one are the same replay: the reference's heap arrays, layout included
-        for lazy in (1, 0):
+        # ... and so are, for labels that repeat (an100b2), the two forms of `insert`'s duplicate test: decided from
+        # the positions of a row's other copies (TWIN, the default) and by the hash set of the labels in the heap
+        for lazy, twin in ((1, 1), (0, 1), (0, 0)):
             dev.set_option(_lib.OPT_REPLAY_LAZY, lazy)
+            dev.set_option(_lib.OPT_REPLAY_TWIN, twin)
             out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
             np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
             np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])
             np.testing.assert_array_equal(dbg["heap_val"], g[f"heap_val_p{n_probes}"])
             np.testing.assert_array_equal(out, g[f"ids_p{n_probes}"])
         dev.set_option(_lib.OPT_REPLAY_LAZY, -1)
+        dev.set_option(_lib.OPT_REPLAY_TWIN, 1)
         out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
         np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
         np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])
@@ -399,11 +403,12 @@ def _oracle_index(oracle, ivf):
                               [ivf.ids[i] for i in range(L)], ivf.data)
 
 
-@pytest.mark.parametrize("build_probes", [1, 2])
+@pytest.mark.parametrize("build_probes", [1, 2, 3])
 def test_ivf_saturating_and_duplicates(tk, oracle, build_probes):
     """Far-apart clusters: int8 sums hit both rails, coarse heaps keep -1 sentinels
     (which wrap to the last list, fast_pq.py:311 / ivf.py:141), and with
-    build_probes=2 every point sits in two lists (dedupe across lists)."""
+    build_probes=2 / 3 every point sits in two / three lists (dedupe across lists: the lane
+    replay's TWIN form by default, the queries whose probe list wraps by the packed kernel)."""
     from tinyknn_amd import IVF, FastPQ
     np.random.seed(3)
     n, d, nq = 6000, 20, 200

@@ -1,0 +1,120 @@
+"""IVF.build(n_probes = 2 / 3) (the reference's default is 2, ivf.py:53): every row in two / three lists, and
+`insert`'s duplicate test (_fast_pq.pyx:284-287) decides what a label's later copies do.  The lane replay's TWIN
+form (heap.hip; lemma: tests/test_twin_dedupe_lemma.py) against the oracle: heap arrays with their layout and
+final ids, with the exact kernel alone and with the plain sums on the matrix cores behind the heads, lazy and
+staged, one batch in flight and pipelined in pairs; and against the hash-set form it replaces."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[2, 3])
+def setup(request, oracle):
+    import torch
+    from tinyknn_amd import IVF, FastPQ, _lib
+    assert _lib.device_count() >= 1, "no GPU visible"
+    b = request.param
+    np.random.seed(20 + b)
+    n, nq, d = 120000, 3000, 100
+    cent = np.random.randn(400, d)
+    X = (cent[np.random.randint(400, size=n)] + 0.7 * np.random.randn(n, d)).astype(np.float32)
+    qs = (cent[np.random.randint(400, size=nq)] + 0.7 * np.random.randn(nq, d)).astype(np.float32)
+    ivf = IVF("angular", 150, FastPQ(2))
+    ivf.fit(X[:30000]).build(X, n_probes=b)
+    L = len(ivf.active_centers)
+    ox = oracle.OracleIndex(ivf.pq.centers, 2, ivf.pq.R, ivf.pq.sqrt_n_blocks, ivf.active_centers,
+                            ivf.pq_transformed_centers.packed,
+                            [ivf.pq_transformed_points[i].packed for i in range(L)],
+                            [ivf.pq_transformed_points[i].size for i in range(L)],
+                            [ivf.ids[i] for i in range(L)], ivf.data)
+    qn, qp = ivf._prepare(qs.copy())
+    return torch, _lib, b, ivf, ox, qn, np.ascontiguousarray(qp)
+
+
+def test_twin_table_lists_every_other_copy(setup):
+    torch, _lib, b, ivf, ox, qn, qp = setup
+    dev = ivf.device_index()
+    tl, to = dev.twin_table()
+    assert tl.shape == (sum(len(x) for x in ivf.ids), b - 1)
+    ids = np.concatenate(ivf.ids)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in ivf.ids])])
+    assert (tl >= 0).all()
+    flat = off[tl] + to                           # flat rows of the other copies
+    assert (ids[flat] == ids[:, None]).all()      # they carry the row's label
+    assert (flat != np.arange(len(ids))[:, None]).all()
+    if b == 3:
+        assert (flat[:, 0] != flat[:, 1]).all()
+
+
+@pytest.mark.parametrize("plain", [False, "always"])
+def test_heaps_and_ids_against_the_oracle(setup, plain):
+    torch, _lib, b, ivf, ox, qn, qp = setup
+    dev = ivf.device_index()
+    dev.set_plain_scan(plain)                    # exact kernel only / plain sums behind the heads
+    try:
+        for n_probes in (2, 10, 25):
+            want = ox.query_batch(qn, 10, n_probes)
+            ref = None
+            for lazy, twin in ((0, 1), (1, 1), (0, 0)):
+                dev.set_option(_lib.OPT_REPLAY_LAZY, lazy)
+                dev.set_option(_lib.OPT_REPLAY_TWIN, twin)
+                out, dbg = dev.query_batch(qn, qp, 10, n_probes, debug=True)
+                np.testing.assert_array_equal(out, want)
+                if ref is None:
+                    ref = dbg
+                    for qi in range(0, len(qn), 97):
+                        _, odbg = ox.query(qn[qi], 10, n_probes=n_probes, debug=True)
+                        np.testing.assert_array_equal(dbg["heap_idx"][qi], odbg["heap_idx"], err_msg=f"q{qi} p{n_probes}")
+                        np.testing.assert_array_equal(dbg["heap_val"][qi], odbg["heap_val"], err_msg=f"q{qi} p{n_probes}")
+                else:
+                    np.testing.assert_array_equal(dbg["heap_idx"], ref["heap_idx"])
+                    np.testing.assert_array_equal(dbg["heap_val"], ref["heap_val"])
+    finally:
+        dev.set_option(_lib.OPT_REPLAY_LAZY, -1)
+        dev.set_option(_lib.OPT_REPLAY_TWIN, 1)
+        dev.set_plain_scan(True)
+
+
+def test_forced_rescan_of_every_query(setup):
+    """table limits forced down: every query of a plain batch fails the lemma's check, is scanned again exactly and
+    replayed by the packed kernel with the reference's scan of the labels"""
+    torch, _lib, b, ivf, ox, qn, qp = setup
+    dev = ivf.device_index()
+    dev.set_plain_scan("always")
+    dev.set_option(_lib.OPT_PLAIN_LIMIT, -128)
+    try:
+        want = ox.query_batch(qn[:400], 10, 8)
+        np.testing.assert_array_equal(dev.query_batch(qn[:400], qp[:400], 10, 8), want)
+    finally:
+        dev.set_option(_lib.OPT_PLAIN_LIMIT, 0x7fffffff)
+        dev.set_plain_scan(True)
+
+
+def test_pipelined_pairs(setup):
+    torch, _lib, b, ivf, ox, qn, qp = setup
+    f64 = qp.dtype != np.float32
+    dev = ivf.device_index()
+    dev.set_pipeline(2)
+    dev.set_coalesce(2)
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        want = ox.query_batch(qn, 10, 10)
+        q_dev, qp_dev = torch.from_numpy(qn).cuda(), torch.from_numpy(qp).cuda()
+        esz = 8 if f64 else 4
+        dq = qp.shape[1]
+        calls = [(0, 700), (700, 1500), (1500, 1501), (1501, 2400), (2400, 3000), (0, 3000), (100, 2100)]
+        outs = []
+        for rep in range(2):                      # (the second round runs with the plain path's verdict in)
+            for a, e in calls:
+                o = torch.full((e - a, 10), -1, dtype=torch.int64, device="cuda")
+                outs.append((a, e, o))
+                dev.query_batch_dev(q_dev.data_ptr() + a * qn.shape[1] * 4, qp_dev.data_ptr() + a * dq * esz, f64,
+                                    e - a, 10, 10, o.data_ptr(), stream=st)
+        dev.join(st)
+        torch.cuda.synchronize()
+        for a, e, o in outs:
+            np.testing.assert_array_equal(o.cpu().numpy(), want[a:e])
+    finally:
+        dev.set_coalesce(1)
+        dev.set_pipeline(1)

@@ -31,7 +31,7 @@ _f64p = C.POINTER(C.c_double)
 
 # name -> (restype, argtypes); mirrors include/tinyknn_hip.h one to one
 # tk_index_set_option
-OPT_SCAN_FORM, OPT_RESCORE_FORM, OPT_PLAIN_LIMIT, OPT_REPLAY_LAZY, OPT_REPLAY_COUNT = 1, 2, 3, 4, 5
+OPT_SCAN_FORM, OPT_RESCORE_FORM, OPT_PLAIN_LIMIT, OPT_REPLAY_LAZY, OPT_REPLAY_COUNT, OPT_REPLAY_TWIN = 1, 2, 3, 4, 5, 6
 
 SIGNATURES = {
     "tk_last_error": (C.c_char_p, []),
@@ -109,6 +109,7 @@ SIGNATURES = {
     "tk_measure_read_bandwidth": (C.c_int, [C.c_int64, C.c_int, _f64p]),
     "tk_measure_gather_bandwidth": (C.c_int, [C.c_int64, C.c_int, C.c_int64, C.c_int, _f64p]),
     "tk_index_replay_stats": (C.c_int, [C.c_void_p, _i64p]),
+    "tk_index_twin_table": (C.c_int, [C.c_void_p, _i64p, _i32p, _i32p, _i32p]),
     "tk_index_alloc_data": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int]),
     "tk_index_synth_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int,
                                       C.c_float]),

@@ -256,6 +256,7 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
     ix->total_ids = T;
     ix->max_list_chunks = (int)maxc;
     ix->have_centers = ix->have_lists = ix->have_data = true;
+    TRY(build_twins(ix, N));
     if (n_active_out) *n_active_out = L;
     return TK_OK;
 }
@@ -325,6 +326,10 @@ extern "C" tk_index *tk_index_clone_shard(tk_index *src, const int32_t *owner, i
     ix->ids.borrow(src->ids);
     ix->ids32.borrow(src->ids32);
     ix->have_ids32 = src->have_ids32;
+    ix->twin_list.borrow(src->twin_list);
+    ix->twin_off.borrow(src->twin_off);
+    ix->twin_w = src->twin_w;
+    ix->opt_replay_twin = src->opt_replay_twin;
     ix->total_chunks = src->total_chunks; ix->total_ids = src->total_ids;
     ix->max_list_chunks = src->max_list_chunks;
     ix->ids_unique = src->ids_unique;

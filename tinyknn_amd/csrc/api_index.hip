@@ -30,7 +30,8 @@ extern "C" void tk_index_destroy(tk_index *ix)
                       &ix->list_n, &ix->ids_off, &ix->ids, &ix->codes, &ix->ids32, &ix->data, &ix->cslots_i,
                       &ix->cslots_l, &ix->c_chunk_off, &ix->q, &ix->qpq, &ix->stage, &ix->owner,
                       &ix->local_chunk_off, &ix->rot_t, &ix->br_ynorm, &ix->br_vals, &ix->br_tau,
-                      &ix->br_cand, &ix->br_count, &ix->br_out, &ix->br_q, &ix->br_sample, &ix->replay_counters};
+                      &ix->br_cand, &ix->br_count, &ix->br_out, &ix->br_q, &ix->br_sample, &ix->replay_counters,
+                      &ix->twin_list, &ix->twin_off};
     for (DevBuf *b : bufs) b->release();
     for (Work &w : ix->works) w.release();
     // (the internal streams belong to the process: shared_streams below)
@@ -93,6 +94,56 @@ extern "C" int tk_index_set_centers(tk_index *ix, const float *active_centers, i
     HIPCHECK(hipMemcpy(ix->cslots_i.p, ci, sizeof ci, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ix->cslots_l.p, cl, sizeof cl, hipMemcpyHostToDevice));
     ix->have_centers = true;
+    return TK_OK;
+}
+
+// twins.hip's table for an index whose lists, ids_off and int32 labels are in place
+int build_twins(tk_index *ix, int64_t label_bound)
+{
+    ix->twin_w = 0;
+    ix->twin_list.release();
+    ix->twin_off.release();
+    const int64_t T = ix->total_ids;
+    if (!ix->have_ids32 || ix->ids_unique || T <= 0 || T >= (1ll << 31) || label_bound <= 0 ||
+        label_bound > 8 * T + 1024 || ix->n_lists >= (1ll << 31))
+        return TK_OK;
+    DevBuf cnt, where;
+    TRY(cnt.ensure((size_t)(label_bound + 1) * 4));
+    HIPCHECK(hipMemsetAsync(cnt.p, 0, (size_t)(label_bound + 1) * 4, 0));
+    int *cnt_max = cnt.as<int>() + label_bound;
+    tk_launch_twin_count(ix->ids32.as<int32_t>(), T, cnt.as<int>(), cnt_max, 0);
+    int b = 0;
+    HIPCHECK(hipMemcpy(&b, cnt_max, 4, hipMemcpyDeviceToHost));
+    int rc = TK_OK;
+    if (b >= 2 && b <= 17) {
+        const int w = b - 1;
+        rc = where.ensure((size_t)label_bound * b * 4);
+        if (rc == TK_OK) rc = ix->twin_list.ensure((size_t)T * w * 4);
+        if (rc == TK_OK) rc = ix->twin_off.ensure((size_t)T * w * 4);
+        if (rc == TK_OK) {
+            HIPCHECK(hipMemsetAsync(cnt.p, 0, (size_t)label_bound * 4, 0));
+            tk_launch_twin_fill(ix->ids32.as<int32_t>(), T, cnt.as<int>(), where.as<int>(), b,
+                                ix->ids_off.as<int64_t>(), (int)ix->n_lists, ix->twin_list.as<int32_t>(),
+                                ix->twin_off.as<int32_t>(), 0);
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipDeviceSynchronize());
+            ix->twin_w = w;
+        }
+    }
+    cnt.release();
+    where.release();
+    return rc;
+}
+
+extern "C" int tk_index_twin_table(tk_index *ix, int64_t *rows, int *w, int32_t *list_out, int32_t *off_out)
+{
+    IXLOCK(ix);
+    ARGCHECK(ix && ix->have_lists, "an index with its lists");
+    if (rows) *rows = ix->total_ids;
+    if (w) *w = ix->twin_w;
+    const size_t bytes = (size_t)ix->total_ids * (size_t)ix->twin_w * 4;
+    if (list_out && bytes) HIPCHECK(hipMemcpy(list_out, ix->twin_list.p, bytes, hipMemcpyDeviceToHost));
+    if (off_out && bytes) HIPCHECK(hipMemcpy(off_out, ix->twin_off.p, bytes, hipMemcpyDeviceToHost));
     return TK_OK;
 }
 
@@ -175,6 +226,11 @@ static int set_lists_impl(tk_index *ix, const int64_t *list_sizes, const uint64_
     ix->total_ids = ioff[L];
     ix->max_list_chunks = (int)maxc;
     ix->have_lists = true;
+    {   // labels that repeat: where every row's other copies are (the lane replay's duplicate test)
+        int64_t mx = -1;
+        for (int64_t i = 0; i < ioff[L]; i++) mx = ids[i] > mx ? ids[i] : mx;
+        TRY(build_twins(ix, mx + 1));
+    }
     return TK_OK;
 }
 
@@ -246,6 +302,14 @@ bool plain_env_on()
     }
     return on != 0;
 }
+// the TWIN form of the lane replay applies (heap.hip): repeating labels with a twin table, fresh heaps on packed
+// position entries, an unsharded index (the probe lists of the batch are the workspace's)
+bool twin_replay(const tk_index *ix, const Plan &p)
+{
+    return !ix->ids_unique && ix->twin_w > 0 && ix->opt_replay_twin && !ix->sharded && ix->heap_mode == 0 &&
+           ix->total_ids < (1ll << 31) && p.cap * 16 <= 0xffffff && tk_lanes_twin_fits(p.R, p.S);
+}
+
 static bool plain_possible(const tk_index *ix, const Plan &p)
 {
     if (ix->plain_mode == 1 || !plain_env_on() || ix->sharded || p.S < 2 || !tk_plain_fits(ix->M)) return false;
@@ -828,6 +892,28 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
                                          p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                          w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 2, 0, st);
         }
+        tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                     p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                     w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
+    } else if (packed_ok && twin_replay(ix, p)) {
+        // repeating labels, every copy of a label with ONE value (IVF.build(n_probes >= 2)): one query per lane,
+        // position entries, `insert`'s duplicate test decided from the twin table (heap.hip, TWIN form).  The
+        // queries that probe a list twice (repeat_flag, and with `plain` those the lemma's check flags) go to
+        // the packed kernel with the reference's scan of the labels
+        TkTwins tw;
+        tw.list = ix->twin_list.as<int32_t>();
+        tw.off = ix->twin_off.as<int32_t>();
+        tw.w = ix->twin_w;
+        tw.probes = w.probes.as<int64_t>() + q0 * p.S;
+        if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
+                                        slot_loff, p.S, ix->ids.as<int64_t>(),
+                                        w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), p.R, 1,
+                                        0, repeat_flag, w.mins.as<uint8_t>(), p.cap_min, nullptr, st,
+                                        slot_exact, qlim, lazy,
+                                        ix->opt_replay_count ? ix->replay_counters.as<unsigned long long>() : nullptr,
+                                        &tw))
+            return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
+        if (plain) rescan_flagged(ix, w, q0, nq, p, st);
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                      p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                      w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
@@ -1589,6 +1675,10 @@ extern "C" int tk_index_set_option(tk_index *ix, int option, int value)
     case TK_OPT_REPLAY_LAZY:
         ARGCHECK(value >= -1 && value <= 1, "TK_OPT_REPLAY_LAZY: -1, 0 or 1");
         ix->opt_replay_lazy = value;
+        return TK_OK;
+    case TK_OPT_REPLAY_TWIN:
+        ARGCHECK(value == 0 || value == 1, "TK_OPT_REPLAY_TWIN: 0 or 1");
+        ix->opt_replay_twin = value;
         return TK_OK;
     default:
         return fail(TK_ERR_ARG, "bad argument: unknown option");

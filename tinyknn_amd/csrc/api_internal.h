@@ -177,6 +177,10 @@ struct tk_index {
     // lists
     DevBuf list_chunk_off, list_n, ids_off, ids, codes, ids32;
     bool have_ids32 = false;   // every label fits int32: the lane kernel can run the duplicate test
+    // repeating labels: where the other copies of every stored row are (twins.hip); twin_w = copies - 1, 0 = no table
+    DevBuf twin_list, twin_off;
+    int twin_w = 0;
+    int opt_replay_twin = 1;   // TK_OPT_REPLAY_TWIN: 1 = the lane replay decides `insert`'s duplicate test from the twin table
     int64_t total_chunks = 0, total_ids = 0;
     int max_list_chunks = 0;
     bool ids_unique = false;   // no label occurs twice => the lane-per-query replay is exact
@@ -281,6 +285,10 @@ struct Prof {
 
 // ---- api_index.hip, used by the other files
 int flush_pending(tk_index *ix);
+// the twin table of an index whose int32 labels (all in [0, label_bound)) are in place; no table (twin_w = 0) where
+// the labels are distinct, too sparse, or one label has more than 16 copies
+int build_twins(tk_index *ix, int64_t label_bound);
+bool twin_replay(const tk_index *ix, const struct Plan &p);
 int make_plan(const tk_index *ix, int k, int n_probes, int pass_1, Plan &p);
 bool plain_env_on();
 int plain_k(const tk_index *ix, int64_t nq, const Plan &p);

@@ -664,7 +664,24 @@ __global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq
 // segment ahead, and fetches a block from global memory only when its minimum passes the bound.
 // A handful of blocks in 4 000 segments pass once the heap is warm; staging every block cost 16
 // row-per-lane loads and 16 LDS writes per segment and lane (55 of the 90 ms per 10 000 queries).
-template <bool SIGNED, bool DEDUPE, int LW, bool LAZY = false>
+// TWIN (labels may repeat AND every copy of a label carries ONE value: the lists of IVF.build(n_probes >= 2),
+// ivf.py:53,77-102 — same code, same table): the duplicate test without a set of labels.  Entries stay
+// POSITIONS as with distinct labels; the lane keeps f = the smallest value of any root it has evicted.  Every
+// entry but the root is <= f (a root is the maximum when it leaves; a later insert above f stays at the root
+// and is the next to leave).  A row that passes its block's bound (captured at block start, never rising from
+// block to block) and has an EARLIER copy in the lists replayed so far: that copy passed too (same value, a
+// bound no lower) and went in, or found a still earlier one in the heap.  So a copy is in the heap now
+//     always                                         where v <  f  (nothing of value v has ever left),
+//     iff the root is one of the earlier copies      where v >  f,
+//     iff some entry is one of the earlier copies    where v == f  (the one case that scans the heap);
+// and a row without an earlier copy never finds its label.  Checked at every passing row of random and
+// adversarial streams against the reference's loop: tests/test_twin_dedupe_lemma.py.  Where the earlier
+// copies are comes from twins.hip's table (list + offset of a stored row's other copies) and the query's
+// probe list: one 4-byte load per candidate, fetched a candidate ahead; a 64-bit mask of the lists replayed
+// so far answers "not probed" for most rows at once, the probe list in LDS answers exactly.  The hash set
+// of the DEDUPE form (64 KB per 64 queries, its removal and insertion inside every round) is gone: 64
+// queries per wave, three workgroups per CU, the LAZY form and pairs of calls apply as with distinct labels.
+template <bool SIGNED, bool DEDUPE, int LW, bool LAZY = false, bool TWIN = false>
 __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
@@ -672,8 +689,9 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
     unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
     int64_t cap_min, const int32_t *__restrict__ labels32, unsigned long long *__restrict__ dbg,
-    int prio, int wave_lds, const int *__restrict__ plain0_arr, const int *__restrict__ qlim)
+    int prio, int wave_lds, const int *__restrict__ plain0_arr, const int *__restrict__ qlim, const TkTwins tw)
 {
+    static_assert(!(TWIN && DEDUPE), "one form of the duplicate test");
     // the replay is a chain of dependent LDS round trips on 157 waves; when it shares SIMDs
     // with other batches' VALU-bound scan waves, let the arbiter issue its instructions first
     if ((prio & 0xff) >= 3) __builtin_amdgcn_s_setprio(3);
@@ -698,6 +716,9 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     // chunk c in slot s = labels32[SB[s] + 16 c + r])
     int *SE = (int *)(ST + 16 * LW);
     int *SB = SE + (size_t)S * LW;
+    // TWIN: the probed lists of the lane's query, four to a uint4: PL[t / 4][lane]
+    uint4 *PL = (uint4 *)(SB + (size_t)S * LW);
+    const int S4 = (S + 3) >> 2;
 #define TK_LAB(slot) LAB[(((slot) >> 2) * LW + lane) * 4 + ((slot) & 3)]
     // a workgroup = blockDim.x / 64 independent query-waves, each with its own LDS region
     const int lane = threadIdx.x & 63;
@@ -750,13 +771,27 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     }
     max_nseg = __builtin_amdgcn_readfirstlane(max_nseg);
 
-    // DEDUPE: slot cursor (monotonic) over the LDS slot table
+    // DEDUPE / TWIN: slot cursor (monotonic) over the LDS slot table
     int s = 0;
-    if (DEDUPE) {
+    if (DEDUPE || TWIN) {
         for (int t = 0; t < S; t++) {
             const int e0 = prefix[t], e1 = prefix[t + 1];
             SE[t * LW + lane] = valid ? e1 : 0x7fffffff;
             SB[t * LW + lane] = (int)(slot_label_off[qs * S + t] - 16 * (int64_t)e0);
+        }
+    }
+    // TWIN: f (see the head of the kernel), pm = bit (list & 63) of every list replayed before slot s
+    int f = 0x7fffffff;
+    uint64_t pm = 0;
+    if (TWIN) {
+        const int64_t *pq = tw.probes + qc * S;
+        for (int g = 0; g < S4; g++) {
+            uint4 pl;
+            pl.x = (uint32_t)(int)pq[4 * g];                                    // (a probe of -1 flags its query: `skip`)
+            pl.y = 4 * g + 1 < S ? (uint32_t)(int)pq[4 * g + 1] : 0x7fffffffu;
+            pl.z = 4 * g + 2 < S ? (uint32_t)(int)pq[4 * g + 2] : 0x7fffffffu;
+            pl.w = 4 * g + 3 < S ? (uint32_t)(int)pq[4 * g + 3] : 0x7fffffffu;
+            PL[g * LW + lane] = pl;
         }
     }
 
@@ -835,6 +870,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
         int cur = 0;
         uint32_t lab_next = 0;        // DEDUPE: label of the lowest pending row, fetched ahead
         int lab_base = 0;             //         labels32 index of row 0 of the current block
+        int tw_next = -1;             // TWIN: list of the lowest pending row's first other copy, fetched ahead
         for (;;) {
             // next block of this segment with a byte below the live bound
             while (bits == 0 && hit) {
@@ -855,6 +891,14 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                     while (cur >= SE[s * LW + lane]) s++;   // next probed list (empty ones stepped over)
                     lab_base = SB[s * LW + lane] + 16 * cur;
                     lab_next = (uint32_t)labels32[(int64_t)lab_base + __builtin_ctz(bits)];
+                }
+                if (TWIN && bits) {
+                    while (cur >= SE[s * LW + lane]) {      // next probed list: the one left joins the mask
+                        pm |= 1ull << (((const int *)PL)[(((s >> 2) * LW + lane) << 2) + (s & 3)] & 63);
+                        s++;
+                    }
+                    lab_base = SB[s * LW + lane] + 16 * cur;
+                    tw_next = tw.list[((int64_t)lab_base + __builtin_ctz(bits)) * tw.w];
                 }
             }
             if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
@@ -928,6 +972,40 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                 }
                 const uint32_t entry = (by << 24) | low;
                 const int v = entry_val<SIGNED>(entry);
+                if (TWIN) {
+                    const int64_t row = (int64_t)lab_base + r;      // the candidate's row in the twin table
+                    int c = tw_next;
+                    if (bits) tw_next = tw.list[((int64_t)lab_base + __builtin_ctz(bits)) * tw.w];
+                    for (int u = 0; u < tw.w && !dup; u++) {
+                        if (u > 0) c = tw.list[row * tw.w + u];
+                        if (c < 0) break;                           // no further copies
+                        if (!((pm >> (c & 63)) & 1ull)) continue;   // not among the lists replayed so far
+                        int t = -1;                                 // its slot, if it was probed before this list
+#pragma unroll 4
+                        for (int g = 0; g < S4; g++) {
+                            const uint4 pl = PL[g * LW + lane];
+                            t = ((int)pl.x == c && 4 * g < s) ? 4 * g : t;
+                            t = ((int)pl.y == c && 4 * g + 1 < s) ? 4 * g + 1 : t;
+                            t = ((int)pl.z == c && 4 * g + 2 < s) ? 4 * g + 2 : t;
+                            t = ((int)pl.w == c && 4 * g + 3 < s) ? 4 * g + 3 : t;
+                        }
+                        if (t < 0) continue;
+                        if (v < f) { dup = true; break; }           // nothing of this value has ever left
+                        // the earlier copy as an entry: same value, its position in this query's rows
+                        const uint32_t E = (by << 24) | (uint32_t)(16 * prefix[t] + tw.off[row * tw.w + u]);
+                        if (v > f) {
+                            dup = h0 == E;                          // only the root can be above f
+                        } else {
+                            bool found = (h0 == E) | (h1 == E) | (h2 == E) | (h3 == E) | (h4 == E) | (h5 == E) | (h6 == E);
+                            for (int j = 7; j < R; j++) found |= H[j * LW + lane] == E;
+                            dup = found;
+                        }
+                    }
+                    if (!dup) {
+                        const int root = entry_val<SIGNED>(h0);
+                        f = root < f ? root : f;
+                    }
+                }
                 if (!dup)
                 // insert, _fast_pq.pyx:291-307.  Levels 0-2 in registers, the rest in
                 // LDS, branch-free per level: rows R and R+1 hold a value no entry
@@ -1001,7 +1079,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     if (R > 6) H[6 * LW + lane] = h6;
     if (!valid) return;
     // re-scan + replay again: flag 2 with distinct labels (no duplicate test needed then), 1 otherwise
-    if (plain0_arr && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) skip[q] = DEDUPE ? 1 : 2;
+    if (plain0_arr && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) skip[q] = (DEDUPE || TWIN) ? 1 : 2;
     // ---- resolve flat positions (or slots) to labels
     const int64_t *loffs = slot_label_off + qs * S;
     for (int j = 0; j < R; j++) {
@@ -1214,6 +1292,15 @@ static size_t tk_lanes_fixed_lds(int R, int S, int dedupe)
 {
     return (size_t)(R + 2) * 256 + (dedupe ? (size_t)((R + 3) / 4) * 1024 + 65536 + (size_t)S * 512 : 0);
 }
+// ... of the TWIN form: heap columns, slot table, probe list
+static size_t tk_lanes_twin_lds(int R, int S)
+{
+    return (size_t)(R + 2) * 256 + (size_t)S * 512 + (size_t)((S + 3) / 4) * 1024;
+}
+int tk_lanes_twin_fits(int R, int S)
+{
+    return R <= TK_LANES_MAX_R && tk_lanes_twin_lds(R, S) + 16384 <= 160 * 1024;
+}
 
 int tk_lanes_dedupe_fits(int R, int S)
 {
@@ -1226,11 +1313,13 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
                                 hipStream_t s, const int *plain0, const int *qlim, int lazy,
-                                unsigned long long *counters)
+                                unsigned long long *counters, const TkTwins *twins)
 {
     if (nq == 0 || R == 0) return 0;
     if (!plain0 || !qlim || !skip || !signd) plain0 = qlim = nullptr;
     const int dedupe = labels32 != nullptr;
+    const bool twin = !dedupe && twins && twins->w > 0 && twins->list && twins->off && twins->probes && !slots_uniform;
+    const TkTwins tw = twin ? *twins : TkTwins();
     // Queries per wave: 64, or 32 with the duplicate test — a 64-query wave then needs 140+ KB of
     // LDS at R = 111: one workgroup per CU, and the two replay kernels of the pipelined mode (2 x 157
     // workgroups on 256 CUs) waited for each other's CUs (1.6 ms alone became 2.9 ms in the
@@ -1241,7 +1330,8 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     const int LWr = dedupe ? 32 : 64;
     // heap columns (+ label slots) + one staged segment (16 blocks x LW lanes x 16 B; the next one
     // waits in registers), scaled to the columns in use
-    const size_t lds = tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64 + (size_t)16384 * LWr / 64;
+    const size_t lds = twin ? tk_lanes_twin_lds(R, S) + 16384
+                            : tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64 + (size_t)16384 * LWr / 64;
     static bool attr_set = false;
     if (!attr_set) {
         const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false, 64>,
@@ -1249,7 +1339,11 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                              (const void *)heap_replay_lanes_kernel<true, true, 32>,
                              (const void *)heap_replay_lanes_kernel<false, true, 32>,
                              (const void *)heap_replay_lanes_kernel<true, false, 64, true>,
-                             (const void *)heap_replay_lanes_kernel<false, false, 64, true>};
+                             (const void *)heap_replay_lanes_kernel<false, false, 64, true>,
+                             (const void *)heap_replay_lanes_kernel<true, false, 64, false, true>,
+                             (const void *)heap_replay_lanes_kernel<false, false, 64, false, true>,
+                             (const void *)heap_replay_lanes_kernel<true, false, 64, true, true>,
+                             (const void *)heap_replay_lanes_kernel<false, false, 64, true, true>};
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                 hipSuccess)
@@ -1276,14 +1370,23 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, L_>), grid, dim3(64), lds, s, dist, cap, nq,  \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, 1, mins, cap_min, labels32, counters, prio, wave_lds,  \
-                       plain0, qlim)
+                       plain0, qlim, tw)
     if (dedupe) { if (signd) TK_LAUNCH3(true, true, 32); else TK_LAUNCH3(false, true, 32); }
-    else if (lazy) {
+    else if (twin) {
+#define TK_LAUNCH_TWIN(S_, Z_)                                                                    \
+    hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, false, 64, Z_, true>), grid, dim3(64), lds, s, dist, cap, nq, \
+                       slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
+                       slots_uniform, skip, 1, mins, cap_min, labels32, counters, prio, wave_lds,  \
+                       plain0, qlim, tw)
+        if (signd) { if (lazy) TK_LAUNCH_TWIN(true, true); else TK_LAUNCH_TWIN(true, false); }
+        else { if (lazy) TK_LAUNCH_TWIN(false, true); else TK_LAUNCH_TWIN(false, false); }
+#undef TK_LAUNCH_TWIN
+    } else if (lazy) {
 #define TK_LAUNCH_LAZY(S_)                                                                        \
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, false, 64, true>), grid, dim3(64), lds, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, 1, mins, cap_min, labels32, counters, prio, wave_lds,  \
-                       plain0, qlim)
+                       plain0, qlim, tw)
         if (signd) TK_LAUNCH_LAZY(true); else TK_LAUNCH_LAZY(false);
 #undef TK_LAUNCH_LAZY
     } else { if (signd) TK_LAUNCH3(true, false, 64); else TK_LAUNCH3(false, false, 64); }

@@ -153,6 +153,14 @@ void tk_launch_heap_replay(const uint4 *dist, int64_t cap, int64_t nq, const int
 void tk_launch_flat_top_one(const uint4 *dist, const uint8_t *mins, int chunks, int h, int64_t n, int R, int signd,
                             uint4 *cdist, int *cblock, int64_t *out_idx, int32_t *out_val, hipStream_t s);
 
+// twins.hip's table + the probe lists of the batch, for the TWIN form of the lane replay
+struct TkTwins {
+    const int32_t *list = nullptr;    // (total rows, w): list of the u-th other copy of a stored row, -1 = none
+    const int32_t *off = nullptr;     // ... its offset inside that list
+    int w = 0;
+    const int64_t *probes = nullptr;  // (nq, S) the probed lists of every query (ivf.py:131)
+};
+
 // Lane-per-query form of the same replay: 64 queries per wave.  Preconditions
 // (checked by the caller): heaps start fresh (-1 / 127|255), no label can repeat
 // among a query's lists (so `insert`'s duplicate test cannot fire), R*256 B of LDS
@@ -165,6 +173,7 @@ void tk_launch_flat_top_one(const uint4 *dist, const uint8_t *mins, int chunks, 
 // slot table
 #define TK_LANES_MAX_R_DEDUPE 149
 int tk_lanes_dedupe_fits(int R, int S);     // ... and the slot table of S probed lists fits too
+int tk_lanes_twin_fits(int R, int S);       // the TWIN form: heap columns + slot table + probe list
 // plain0 / qlim (both nq ints, or NULL): the blocks from flat chunk plain0[q] on carry clamp(plain
 // sums) (plain_scan.hip); a query whose bound at its first such block is above qlim[q] gets
 // skip[q] = 1 written (skip must then be writable) and is to be re-scanned exactly and replayed again.
@@ -174,8 +183,11 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
                                 hipStream_t s, const int *plain0 = nullptr, const int *qlim = nullptr,
-                                int lazy = 0, unsigned long long *counters = nullptr);
+                                int lazy = 0, unsigned long long *counters = nullptr,
+                                const TkTwins *twins = nullptr);
 // lazy: blocks are fetched only where their minimum passes (rows far longer than the heap; distinct labels)
+// twins (labels32 == NULL): labels may repeat, every label's copies carry ONE value, and the duplicate test is
+// decided from the twin table (heap.hip, TWIN form); `skip` must flag the queries that probe a list twice
 
 // Wave-per-query replay on packed 32-bit entries from FRESH heaps (R*4 B of LDS, or
 // R*12 with `dedupe`: int64 labels per slot + the reference's duplicate-label test,
@@ -189,6 +201,11 @@ void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, co
 
 void tk_launch_heap_fill(int64_t *heap_idx, int32_t *heap_val, int64_t count, int32_t v,
                          hipStream_t s);
+
+// twins.hip: the other copies of every stored row (labels that repeat: IVF.build(n_probes >= 2))
+void tk_launch_twin_count(const int32_t *ids32, int64_t T, int *cnt, int *cnt_max, hipStream_t s);
+void tk_launch_twin_fill(const int32_t *ids32, int64_t T, int *cursor, int *where, int b, const int64_t *ids_off,
+                         int n_lists, int32_t *twin_list, int32_t *twin_off, hipStream_t s);
 // single insert on a device heap (insertion-sort variant when `is`)
 void tk_launch_heap_insert(int64_t *heap_idx, int32_t *heap_val, int R, int64_t i, int32_t v,
                            int is, hipStream_t s);

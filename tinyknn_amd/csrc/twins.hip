@@ -1,0 +1,76 @@
+// twins.hip — for every stored row, where the OTHER copies of its label are stored.
+//
+// IVF.build(n_probes = b >= 2) (ivf.py:53, :77-102: knn_brute(data, all_centers, k=n_probes) ->
+// group_data_by_indices) puts every row into b lists.  The reference's `insert` finds a label's second
+// arrival by scanning the heap's labels (_fast_pq.pyx:284-287); the TWIN form of the lane replay
+// (heap.hip) decides the same test from the positions of a row's earlier copies, which it gets from
+// this table: twin_list[i * w + u] / twin_off[i * w + u] = list and offset inside that list of the u-th
+// other copy of flat row i (flat = the index into the concatenated ids), -1 where a label has fewer
+// copies.  w = (largest number of copies of any label) - 1.
+//
+// Built on the device from the int32 labels (host upload and device build alike): a count per label,
+// one slot per copy handed out by an atomic cursor, then every row lists the other slots of its label.
+#include "kernels.h"
+
+__global__ void twin_count_kernel(const int32_t *__restrict__ ids32, int64_t T, int *__restrict__ cnt,
+                                  int *__restrict__ cnt_max)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const int c = atomicAdd(&cnt[ids32[i]], 1) + 1;
+    // (the last arrival of a label sees its full count)
+    if (c > 1) atomicMax(cnt_max, c);
+}
+
+__global__ void twin_where_kernel(const int32_t *__restrict__ ids32, int64_t T, int *__restrict__ cursor,
+                                  int *__restrict__ where, int b)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const int64_t L = ids32[i];
+    const int t = atomicAdd(&cursor[L], 1);
+    where[L * b + t] = (int)i;
+}
+
+__global__ void twin_fill_kernel(const int32_t *__restrict__ ids32, int64_t T, const int *__restrict__ cnt,
+                                 const int *__restrict__ where, int b, const int64_t *__restrict__ ids_off,
+                                 int n_lists, int32_t *__restrict__ twin_list, int32_t *__restrict__ twin_off)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const int64_t L = ids32[i];
+    const int c = cnt[L];
+    const int w = b - 1;
+    int k = 0;
+    for (int t = 0; t < c; t++) {
+        const int j = where[L * b + t];
+        if (j == (int)i) continue;
+        int lo = 0, hi = n_lists;            // ids_off[lo] <= j < ids_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (ids_off[mid] <= (int64_t)j) lo = mid; else hi = mid;
+        }
+        twin_list[i * w + k] = lo;
+        twin_off[i * w + k] = (int32_t)((int64_t)j - ids_off[lo]);
+        k++;
+    }
+    for (; k < w; k++) twin_list[i * w + k] = twin_off[i * w + k] = -1;
+}
+
+// cnt: label_bound ints, zeroed; returns the largest count through *cnt_max (device int, zeroed)
+void tk_launch_twin_count(const int32_t *ids32, int64_t T, int *cnt, int *cnt_max, hipStream_t s)
+{
+    if (T == 0) return;
+    hipLaunchKernelGGL(twin_count_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, ids32, T, cnt, cnt_max);
+}
+
+// cursor: label_bound ints, zeroed (it holds the counts again afterwards); where: label_bound * b ints
+void tk_launch_twin_fill(const int32_t *ids32, int64_t T, int *cursor, int *where, int b, const int64_t *ids_off,
+                         int n_lists, int32_t *twin_list, int32_t *twin_off, hipStream_t s)
+{
+    if (T == 0) return;
+    const dim3 grid((unsigned)((T + 255) / 256)), block(256);
+    hipLaunchKernelGGL(twin_where_kernel, grid, block, 0, s, ids32, T, cursor, where, b);
+    hipLaunchKernelGGL(twin_fill_kernel, grid, block, 0, s, ids32, T, cursor, where, b, ids_off, n_lists, twin_list,
+                       twin_off);
+}

@@ -558,6 +558,18 @@ class DeviceIndex:
         _lib.check(_lib.lib().tk_index_replay_stats(self._h, _lib.ptr(o, _lib._i64p)))
         return dict(rounds=int(o[0]), max_rounds_of_a_wave=int(o[1]), waves=int(o[2]), segments=int(o[3]))
 
+    def twin_table(self):
+        """(list, offset) of every stored row's other copies, two (rows, w) int32 arrays (tk_index_twin_table):
+        what the lane replay decides `insert`'s duplicate test from where labels repeat (build n_probes >= 2).
+        w = 0: no table."""
+        rows, w = np.zeros(1, np.int64), np.zeros(1, np.int32)
+        _lib.check(_lib.lib().tk_index_twin_table(self._h, _lib.ptr(rows, _lib._i64p), _lib.ptr(w, _lib._i32p), None, None))
+        tl = np.zeros((int(rows[0]), int(w[0])), np.int32)
+        to = np.zeros_like(tl)
+        if tl.size:
+            _lib.check(_lib.lib().tk_index_twin_table(self._h, None, None, _lib.ptr(tl, _lib._i32p), _lib.ptr(to, _lib._i32p)))
+        return tl, to
+
     def reserve(self, nq, k, n_probes, pass_1=None):
         _lib.check(_lib.lib().tk_index_reserve(self._h, nq, int(k), int(n_probes), int(pass_1 or 0)))
 
@@ -567,7 +579,8 @@ class DeviceIndex:
 
     def set_option(self, option, value):
         """Per-index A/B and test options (tk_index_set_option): _lib.OPT_SCAN_FORM,
-        _lib.OPT_RESCORE_FORM, _lib.OPT_PLAIN_LIMIT."""
+        _lib.OPT_RESCORE_FORM, _lib.OPT_PLAIN_LIMIT, _lib.OPT_REPLAY_LAZY, _lib.OPT_REPLAY_COUNT,
+        _lib.OPT_REPLAY_TWIN."""
         _lib.check(_lib.lib().tk_index_set_option(self._h, int(option), int(value)))
 
     def set_coalesce(self, n):
