@@ -315,7 +315,9 @@ static bool plain_possible(const tk_index *ix, const Plan &p)
     if (ix->plain_mode == 1 || !plain_env_on() || ix->sharded || p.S < 2 || !tk_plain_fits(ix->M)) return false;
     if (ix->heap_mode != 0 || ix->scan_mode == 1 || p.cap * 16 > 0xffffff) return false;
     if (ix->ids_unique) return p.R <= TK_LANES_MAX_R;
-    // repeating labels (build n_probes >= 2): such a batch is bound by the replay with the duplicate
+    // repeating labels with the TWIN form of the lane replay: as with distinct labels
+    if (twin_replay(ix, p)) return true;
+    // repeating labels with the hash set (build n_probes >= 2): such a batch is bound by the replay with the duplicate
     // test (1.56 ms alone for 10 000 queries, two in flight), not by the scan, and the plain kernel
     // beside it only stretches that replay — same box, glove-like build_probes = 2: 1.33 ms per batch
     // on the exact kernel, 1.55 ms with the plain path (profiles/r03/ab_build_probes2.txt).  Only on
@@ -1432,10 +1434,11 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
     const int64_t ms = sub_batch(p);
     ARGCHECK(!(out_ids_pinned || done_ev) || (nq >= 1 && nq <= ms),
              "a completion event / host copy belongs to ONE sub-batch (tk_index_max_sub_batch)");
-    // (repeating labels — IVF.build(n_probes >= 2) — run the duplicate-test replay: 32 queries and 70 KB
-    //  of LDS per wave, two waves per CU; a doubled batch would not fit the chip in one round of waves:
-    //  5.1 M queries/s paired against 7.7 M alone, profiles/r04/bench_full_first.json)
-    if (ix->depth > 1 && ix->coalesce == 2 && ix->ids_unique && nq >= 1 && nq <= ms)
+    // (repeating labels — IVF.build(n_probes >= 2) — pair up where the TWIN form of the lane replay applies; the
+    //  hash-set form runs 32 queries and 70 KB of LDS per wave, two waves per CU, and a doubled batch would not
+    //  fit the chip in one round of waves: 5.1 M queries/s paired against 7.7 M alone,
+    //  profiles/r04/bench_full_first.json)
+    if (ix->depth > 1 && ix->coalesce == 2 && (ix->ids_unique || twin_replay(ix, p)) && nq >= 1 && nq <= ms)
         return coalesce_call(ix, p, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, out_ids_dev,
                              out_ids_pinned, done_ev, caller);
     if (ix->held) TRY(launch_held(ix));
