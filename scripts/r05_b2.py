@@ -27,14 +27,18 @@ for b in range(2):
 st = torch.cuda.current_stream().cuda_stream
 ox = bench.oracle_index(ivf)
 want = ox.query_batch(bs[0]["qn"][:500], a.k, 10)
-for twin, co, plain in (((1, 2, True),) if only else ((0, 1, True), (1, 1, False), (1, 1, True), (1, 2, False), (1, 2, True), (1, 2, "always"))):
+lazy_arg = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+for twin, co, plain, lazy in (((1, 2, True, lazy_arg),) if only else
+                              ((0, 1, True, -1), (1, 1, False, -1), (1, 1, True, -1), (1, 2, False, -1), (1, 2, True, -1),
+                               (1, 2, True, 0), (1, 2, True, 1), (1, 2, "always", -1))):
     dev.set_option(_lib.OPT_REPLAY_TWIN, twin)
+    dev.set_option(_lib.OPT_REPLAY_LAZY, lazy)
     dev.set_plain_scan(plain)
     r = bench.timed_rate(dev, bs, False, a.nq, a.k, 10, st, 2, co)
     torch.cuda.synchronize()
     got = bs[0]["out"].cpu().numpy()[:500]
     pst = dev.plain_stats() or {}
-    print(json.dumps({"twin": twin, "coalesce": co, "plain": str(plain), "M_qps": round(r["queries_per_s"] / 1e6, 2),
+    print(json.dumps({"twin": twin, "coalesce": co, "plain": str(plain), "lazy": lazy, "M_qps": round(r["queries_per_s"] / 1e6, 2),
                       "ms": round(r["ms_per_step"], 4), "identical_rows": int((want == got).all(axis=1).sum()),
                       "plain_state": pst.get("state"), "flagged": pst.get("flagged_queries")}), flush=True)
 if only:
@@ -42,14 +46,15 @@ if only:
 # stage times alone and the replay's rounds (one batch in flight)
 dev.set_pipeline(1)
 dev.set_plain_scan(True)
-for twin in (1, 0):
+for twin, lazy in ((1, 0), (1, 1), (0, 0)):
     dev.set_option(_lib.OPT_REPLAY_TWIN, twin)
+    dev.set_option(_lib.OPT_REPLAY_LAZY, lazy)
     dev.set_option(_lib.OPT_REPLAY_COUNT, 1)
     dev.set_profiling(1)
     for _ in range(6):
         dev.query_batch_dev(bs[0]["q_dev"].data_ptr(), bs[0]["qp_dev"].data_ptr(), False, a.nq, a.k, 10, bs[0]["out"].data_ptr(), stream=st)
     torch.cuda.synchronize()
     prof = dev.last_profile()
-    print(json.dumps({"twin": twin, "alone_ms": {k_: round(v_, 4) for k_, v_ in prof[0].items()}, "replay": dev.replay_stats()}), flush=True)
+    print(json.dumps({"twin": twin, "lazy": lazy, "alone_ms": {k_: round(v_, 4) for k_, v_ in prof[0].items()}, "replay": dev.replay_stats()}), flush=True)
     dev.set_profiling(0)
     dev.set_option(_lib.OPT_REPLAY_COUNT, 0)

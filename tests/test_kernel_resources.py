@@ -28,7 +28,7 @@ PINNED = {
     ("plain_scan.hip", "scan_plain_wave_kernelILi26ELb1E"): (256, 2),
     ("plain_scan.hip", "scan_plain_wave_kernelILi16ELb1E"): (256, 2),
     # lane-per-query replay, distinct labels, 64 queries per wave
-    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb0EE"): (128, 4),
+    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb0ELb0EE"): (128, 4),
     # one query over a long array: one workgroup of 16 waves, heap in registers
     ("heap.hip", "flat_top_one_kernelILb1EE"): (128, 4),
     ("rescore.hip", "rescore_staged_kernelILi32EE"): (128, 4),
@@ -38,7 +38,11 @@ PINNED = {
     ("tables.hip", "build_tables_kernelIfLb1EE"): (128, 4),
     ("tables.hip", "build_tables_kernelIdLb1EE"): (128, 4),
     # the lazy lane replay of long rows (FlatTop, configs[2]) and the wave-per-query replays
-    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb1EE"): (72, 7),
+    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb1ELb0EE"): (80, 4),
+    # labels that repeat (IVF.build(n_probes >= 2), the reference's default): the TWIN form, staged and lazy
+    # (one wave per SIMD is all a replay gets: 157 - 314 waves on 1024 SIMDs)
+    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb0ELb1EE"): (144, 3),
+    ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb1ELb1EE"): (96, 4),
     ("heap.hip", "heap_replay_packed_kernelILb1ELb0EE"): (64, 8),
     ("heap.hip", "heap_replay_packed_kernelILb1ELb1EE"): (64, 8),
 }
@@ -49,7 +53,11 @@ PINNED = {
 NO_SCRATCH_FILES = ("adc_scan.hip", "plain_scan.hip", "tables.hip", "rescore.hip", "heap.hip")
 # SGPR spills tolerated (to VGPR lanes, not memory): the duplicate-test lane replay of build_probes >= 2
 # ... and the SSE-order form of the plain kernel (the reference's non-AVX module order; no BASELINE config)
-SGPR_SPILLS_OK = {"heap_replay_lanes_kernelILb1ELb1ELi32ELb0EE": 40, "heap_replay_lanes_kernelILb0ELb1ELi32ELb0EE": 40,
+# ... and its TWIN form: kernel arguments that are only needed behind the replay loop, parked in VGPR lanes in the
+# prologue and fetched back in the epilogue (no v_readlane / v_writelane inside the loop: read off the ISA)
+SGPR_SPILLS_OK = {"heap_replay_lanes_kernelILb1ELb1ELi32ELb0ELb0EE": 40, "heap_replay_lanes_kernelILb0ELb1ELi32ELb0ELb0EE": 40,
+                  "heap_replay_lanes_kernelILb1ELb0ELi64ELb0ELb1EE": 16, "heap_replay_lanes_kernelILb0ELb0ELi64ELb0ELb1EE": 16,
+                  "heap_replay_lanes_kernelILb1ELb0ELi64ELb1ELb1EE": 24, "heap_replay_lanes_kernelILb0ELb0ELi64ELb1ELb1EE": 24,
                   "scan_plain_wave_kernelILi26ELb0EE": 16}
 
 
@@ -86,7 +94,8 @@ def test_no_scratch_and_occupancy(usage, key):
     assert hits, f"no kernel matching {sub} in {fname}: " + ", ".join(sorted(usage[fname]))[:2000]
     for name, u in hits.items():
         assert u.get("ScratchSize") == 0, (name, u)
-        assert u.get("VGPRs Spill", 0) == 0 and u.get("SGPRs Spill", 0) == 0, (name, u)
+        ok_sgpr = max([n for sub_, n in SGPR_SPILLS_OK.items() if sub_ in name] + [0])
+        assert u.get("VGPRs Spill", 0) == 0 and u.get("SGPRs Spill", 0) <= ok_sgpr, (name, u)
         assert u["VGPRs"] + u.get("AGPRs", 0) <= max_vgpr, (name, u)
         assert u["Occupancy"] >= min_waves, (name, u)
 

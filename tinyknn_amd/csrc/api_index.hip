@@ -115,7 +115,7 @@ int build_twins(tk_index *ix, int64_t label_bound)
     int b = 0;
     HIPCHECK(hipMemcpy(&b, cnt_max, 4, hipMemcpyDeviceToHost));
     int rc = TK_OK;
-    if (b >= 2 && b <= 17) {
+    if (b >= 2 && b <= 17 && T * (b - 1) < (1ll << 31)) {     // (the replay indexes the table with 32-bit arithmetic)
         const int w = b - 1;
         rc = where.ensure((size_t)label_bound * b * 4);
         if (rc == TK_OK) rc = ix->twin_list.ensure((size_t)T * w * 4);
@@ -306,8 +306,8 @@ bool plain_env_on()
 // position entries, an unsharded index (the probe lists of the batch are the workspace's)
 bool twin_replay(const tk_index *ix, const Plan &p)
 {
-    return !ix->ids_unique && ix->twin_w > 0 && ix->opt_replay_twin && !ix->sharded && ix->heap_mode == 0 &&
-           ix->total_ids < (1ll << 31) && p.cap * 16 <= 0xffffff && tk_lanes_twin_fits(p.R, p.S);
+    return !ix->ids_unique && ix->twin_w > 0 && ix->opt_replay_twin == 1 && !ix->sharded && ix->heap_mode == 0 &&
+           ix->total_ids < (1ll << 31) && p.cap * 16 <= 0xffffff && tk_lanes_twin_fits(p.R, p.S, ix->n_lists);
 }
 
 static bool plain_possible(const tk_index *ix, const Plan &p)
@@ -868,8 +868,12 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
     // segment and lane), while only the few blocks whose minimum passes the bound are ever looked at — the
     // LAZY form fetches just those (heap.hip; what made FlatTop's replay 4 x faster in round 4).  Short
     // lists keep the staged form: there most blocks of the first lists pass, and a dependent fetch each loses.
+    // (TWIN form, labels that repeat: staged up to 40 heap sizes — its look-ahead for a candidate's row of the twin
+    //  table needs the block in LDS; GloVe-shaped build(n_probes=2), 2 722 blocks against 111 entries: 15.0 M
+    //  queries/s staged, 12.6 M lazy, profiles/r05/b2_twin_replay.txt)
+    const double blocks_per_query = (double)p.S * (double)ix->total_chunks / (double)ix->n_lists;
     const int lazy = ix->opt_replay_lazy >= 0 ? ix->opt_replay_lazy
-                                              : ((double)p.S * (double)ix->total_chunks / (double)ix->n_lists >= 8.0 * p.R);
+                                              : (blocks_per_query >= (twin_replay(ix, p) ? 40.0 : 8.0) * p.R);
     if (packed_ok && ix->ids_unique) {
         const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
         if (!lanes)
@@ -907,6 +911,7 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
         tw.off = ix->twin_off.as<int32_t>();
         tw.w = ix->twin_w;
         tw.probes = w.probes.as<int64_t>() + q0 * p.S;
+        tw.bm_words = tk_lanes_twin_bm_words(ix->n_lists);
         if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
                                         slot_loff, p.S, ix->ids.as<int64_t>(),
                                         w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(), p.R, 1,

@@ -681,8 +681,10 @@ __global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq
 // so far answers "not probed" for most rows at once, the probe list in LDS answers exactly.  The hash set
 // of the DEDUPE form (64 KB per 64 queries, its removal and insertion inside every round) is gone: 64
 // queries per wave, three workgroups per CU, the LAZY form and pairs of calls apply as with distinct labels.
+// (amdgpu_waves_per_eu(1, 4): a replay never has more than one wave on a SIMD — 157 to 314 waves on 1024 — so the
+//  compiler is not to trade registers for an occupancy nothing uses: the LAZY form spilled 48 B per lane to reach 7)
 template <bool SIGNED, bool DEDUPE, int LW, bool LAZY = false, bool TWIN = false>
-__global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
@@ -719,6 +721,10 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     // TWIN: the probed lists of the lane's query, four to a uint4: PL[t / 4][lane]
     uint4 *PL = (uint4 *)(SB + (size_t)S * LW);
     const int S4 = (S + 3) >> 2;
+    // TWIN: one bit per list of the index, set for the lists replayed before slot s: BM[list / 32][lane] (where the
+    // index has few enough lists: tw.bm_words > 0; a 64-bit mask of list & 63 in front of a search of PL otherwise)
+    uint32_t *BM = (uint32_t *)(PL + (size_t)S4 * LW);
+    const int BMW = TWIN ? tw.bm_words : 0;
 #define TK_LAB(slot) LAB[(((slot) >> 2) * LW + lane) * 4 + ((slot) & 3)]
     // a workgroup = blockDim.x / 64 independent query-waves, each with its own LDS region
     const int lane = threadIdx.x & 63;
@@ -793,6 +799,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
             pl.w = 4 * g + 3 < S ? (uint32_t)(int)pq[4 * g + 3] : 0x7fffffffu;
             PL[g * LW + lane] = pl;
         }
+        for (int g = 0; g < BMW; g++) BM[g * LW + lane] = 0;
     }
 
     // Segment g + 1 (16 blocks per lane, each lane from its own row, + its 16 block minima) is
@@ -871,14 +878,19 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
         uint32_t lab_next = 0;        // DEDUPE: label of the lowest pending row, fetched ahead
         int lab_base = 0;             //         labels32 index of row 0 of the current block
         int tw_next = -1;             // TWIN: list of the lowest pending row's first other copy, fetched ahead
-        for (;;) {
-            // next block of this segment with a byte below the live bound
+        // LAZY: the next block of `hit` is requested when the last candidate of the current block is taken, ahead of
+        // that candidate's insert (la_blk, la_dd): a dependent trip to memory per passing block otherwise
+        uint32_t la_x = 0, la_y = 0, la_z = 0, la_w = 0;      // (four words: a uint4 the lambda below takes by reference went to scratch)
+        int la_blk = -1;
+        // next block of this segment with a byte below the live bound
+        auto advance = [&]() {
             while (bits == 0 && hit) {
                 const int k = __builtin_ctz(hit);
                 hit &= hit - 1;
                 cur = 16 * g + k;
                 if (LAZY) {
                     if (cur == pre_blk) dd = pre;           // (requested while the previous segment was replayed)
+                    else if (cur == la_blk) dd = make_uint4(la_x, la_y, la_z, la_w);   // (... while the previous block's last row went in)
                     else dd = drow[cur < last_blk ? cur : last_blk];
                 } else {
                     dd = ST[(buf * 16 + k) * LW + lane];
@@ -893,19 +905,39 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                     lab_next = (uint32_t)labels32[(int64_t)lab_base + __builtin_ctz(bits)];
                 }
                 if (TWIN && bits) {
-                    while (cur >= SE[s * LW + lane]) {      // next probed list: the one left joins the mask
-                        pm |= 1ull << (((const int *)PL)[(((s >> 2) * LW + lane) << 2) + (s & 3)] & 63);
+                    while (cur >= SE[s * LW + lane]) {      // next probed list: the one left joins the set
+                        const int cs = ((const int *)PL)[(((s >> 2) * LW + lane) << 2) + (s & 3)];
+                        if (BMW) BM[(cs >> 5) * LW + lane] |= 1u << (cs & 31);
+                        else pm |= 1ull << (cs & 63);
                         s++;
                     }
                     lab_base = SB[s * LW + lane] + 16 * cur;
-                    tw_next = tw.list[((int64_t)lab_base + __builtin_ctz(bits)) * tw.w];
+                    // (rows of the first probed list have no earlier copy: nothing to ask)
+                    if (s > 0) tw_next = tw.list[(lab_base + __builtin_ctz(bits)) * tw.w];
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
-            rounds++;
+        };
+        // One round: the lanes with a pending candidate take it through the duplicate test and the register levels of
+        // `insert`; every lane without one looks for its next block (`advance`, one call site); the sifts go on
+        // through the LDS levels.  TWIN with staged blocks looks BEFORE the LDS levels — the block is in LDS, and
+        // the request for the candidate's row of the twin table is then in flight while the sift runs (a trip to
+        // memory in every round otherwise: 1.7 against 1.0 us per round); the other forms look after them (LAZY:
+        // the next block was requested when the last candidate of the current one was taken).
+        for (;;) {
+            int j = 0;             // > 0: the sift goes on below node j (3..6), whose children are in LDS
+            uint32_t entry = 0;
+            int v = 0;
             if (bits) {   // one insert per lane with a pending candidate
                 const int r = __builtin_ctz(bits);
                 bits &= bits - 1;
+                if (LAZY && bits == 0 && hit) {
+                    const int kn = 16 * g + __builtin_ctz(hit);
+                    if (kn != pre_blk) {
+                        la_blk = kn;
+                        const uint4 t4 = drow[kn < last_blk ? kn : last_blk];
+                        la_x = t4.x; la_y = t4.y; la_z = t4.z; la_w = t4.w;
+                    }
+                }
                 const uint32_t w = r < 4 ? dd.x : r < 8 ? dd.y : r < 12 ? dd.z : dd.w;
                 const uint32_t by = (w >> (8 * (r & 3))) & 0xffu;
                 uint32_t low = (uint32_t)(16 * cur + r);
@@ -970,18 +1002,23 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                         TK_LAB(low) = label;
                     }
                 }
-                const uint32_t entry = (by << 24) | low;
-                const int v = entry_val<SIGNED>(entry);
-                if (TWIN) {
-                    const int64_t row = (int64_t)lab_base + r;      // the candidate's row in the twin table
+                entry = (by << 24) | low;
+                v = entry_val<SIGNED>(entry);
+                if (TWIN && s > 0) {
+                    const int row = lab_base + r;                   // the candidate's row in the twin table
                     int c = tw_next;
-                    if (bits) tw_next = tw.list[((int64_t)lab_base + __builtin_ctz(bits)) * tw.w];
+                    if (bits) tw_next = tw.list[(lab_base + __builtin_ctz(bits)) * tw.w];
+#pragma nounroll
                     for (int u = 0; u < tw.w && !dup; u++) {
                         if (u > 0) c = tw.list[row * tw.w + u];
                         if (c < 0) break;                           // no further copies
-                        if (!((pm >> (c & 63)) & 1ull)) continue;   // not among the lists replayed so far
-                        int t = -1;                                 // its slot, if it was probed before this list
-#pragma unroll 4
+                        // was list c replayed before this one?
+                        if (BMW) {
+                            if (!((BM[(c >> 5) * LW + lane] >> (c & 31)) & 1u)) continue;
+                        } else if (!((pm >> (c & 63)) & 1ull)) continue;
+                        if (BMW && v < f) { dup = true; break; }    // nothing of this value has ever left
+                        int t = -1;                                 // its slot (the mask: exactly; the bitmap: for the position)
+#pragma nounroll
                         for (int g = 0; g < S4; g++) {
                             const uint4 pl = PL[g * LW + lane];
                             t = ((int)pl.x == c && 4 * g < s) ? 4 * g : t;
@@ -997,19 +1034,20 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                             dup = h0 == E;                          // only the root can be above f
                         } else {
                             bool found = (h0 == E) | (h1 == E) | (h2 == E) | (h3 == E) | (h4 == E) | (h5 == E) | (h6 == E);
-                            for (int j = 7; j < R; j++) found |= H[j * LW + lane] == E;
+#pragma nounroll
+                            for (int jj = 7; jj < R; jj++) found |= H[jj * LW + lane] == E;
                             dup = found;
                         }
                     }
-                    if (!dup) {
-                        const int root = entry_val<SIGNED>(h0);
-                        f = root < f ? root : f;
-                    }
                 }
-                if (!dup)
+                if (TWIN && !dup) {
+                    const int root = entry_val<SIGNED>(h0);
+                    f = root < f ? root : f;
+                }
                 // insert, _fast_pq.pyx:291-307.  Levels 0-2 in registers, the rest in
                 // LDS, branch-free per level: rows R and R+1 hold a value no entry
                 // exceeds, so children beyond the heap (clamped to R) are never taken.
+                if (!dup)
                 {   // node 0, children 1 and 2
                     const int v1 = entry_val<SIGNED>(h1), v2 = entry_val<SIGNED>(h2);
                     const bool c1 = v1 > v;
@@ -1024,8 +1062,22 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                         const bool cb = vb > nv1;
                         const uint32_t ne1 = cb ? b : (ca ? a : entry);
                         if (c2) h2 = ne1; else h1 = ne1;
-                        if (ca | cb) {   // node 3..6, children in LDS
-                            int j = (c2 ? 5 : 3) + (cb ? 1 : 0);
+                        if (ca | cb) j = (c2 ? 5 : 3) + (cb ? 1 : 0);
+                    }
+                }
+                // the new root is known: the bound after the block (:123) does not wait for the levels below
+                if (bits == 0) {
+                    bound = h0 >> 24;
+                    bb = bound_bytes<SIGNED>(bound);
+                    b_plain = cur < plain0 ? bound : b_plain;
+                }
+            }
+            if (TWIN && !LAZY) advance();
+            {
+                if (j)
+                {
+                    {
+                        {
                             bool first = true, go = true;
                             do {
                                 const int l = 2 * j + 1;
@@ -1053,12 +1105,10 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
                         }
                     }
                 }
-                if (bits == 0) {
-                    bound = h0 >> 24;                     // refresh after the block, :123
-                    bb = bound_bytes<SIGNED>(bound);
-                    b_plain = cur < plain0 ? bound : b_plain;
-                }
             }
+            if (!(TWIN && !LAZY)) advance();
+            if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
+            rounds++;
         }
     }
 #undef TK_FETCH_BLOCKS
@@ -1293,13 +1343,15 @@ static size_t tk_lanes_fixed_lds(int R, int S, int dedupe)
     return (size_t)(R + 2) * 256 + (dedupe ? (size_t)((R + 3) / 4) * 1024 + 65536 + (size_t)S * 512 : 0);
 }
 // ... of the TWIN form: heap columns, slot table, probe list
-static size_t tk_lanes_twin_lds(int R, int S)
+static size_t tk_lanes_twin_lds(int R, int S, int bm_words)
 {
-    return (size_t)(R + 2) * 256 + (size_t)S * 512 + (size_t)((S + 3) / 4) * 1024;
+    return (size_t)(R + 2) * 256 + (size_t)S * 512 + (size_t)((S + 3) / 4) * 1024 + (size_t)bm_words * 256;
 }
-int tk_lanes_twin_fits(int R, int S)
+// one bit per list and query where that is at most 32 KB per wave of 64 queries (4096 lists)
+int tk_lanes_twin_bm_words(int64_t n_lists) { return n_lists <= 4096 ? (int)((n_lists + 31) / 32) : 0; }
+int tk_lanes_twin_fits(int R, int S, int64_t n_lists)
 {
-    return R <= TK_LANES_MAX_R && tk_lanes_twin_lds(R, S) + 16384 <= 160 * 1024;
+    return R <= TK_LANES_MAX_R && tk_lanes_twin_lds(R, S, tk_lanes_twin_bm_words(n_lists)) + 16384 <= 160 * 1024;
 }
 
 int tk_lanes_dedupe_fits(int R, int S)
@@ -1330,7 +1382,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     const int LWr = dedupe ? 32 : 64;
     // heap columns (+ label slots) + one staged segment (16 blocks x LW lanes x 16 B; the next one
     // waits in registers), scaled to the columns in use
-    const size_t lds = twin ? tk_lanes_twin_lds(R, S) + 16384
+    const size_t lds = twin ? tk_lanes_twin_lds(R, S, tw.bm_words) + 16384
                             : tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64 + (size_t)16384 * LWr / 64;
     static bool attr_set = false;
     if (!attr_set) {

@@ -159,6 +159,7 @@ struct TkTwins {
     const int32_t *off = nullptr;     // ... its offset inside that list
     int w = 0;
     const int64_t *probes = nullptr;  // (nq, S) the probed lists of every query (ivf.py:131)
+    int bm_words = 0;                 // tk_lanes_twin_bm_words(n_lists): dwords of the per-query list bitmap, 0 = none
 };
 
 // Lane-per-query form of the same replay: 64 queries per wave.  Preconditions
@@ -173,7 +174,8 @@ struct TkTwins {
 // slot table
 #define TK_LANES_MAX_R_DEDUPE 149
 int tk_lanes_dedupe_fits(int R, int S);     // ... and the slot table of S probed lists fits too
-int tk_lanes_twin_fits(int R, int S);       // the TWIN form: heap columns + slot table + probe list
+int tk_lanes_twin_bm_words(int64_t n_lists);
+int tk_lanes_twin_fits(int R, int S, int64_t n_lists);   // the TWIN form: heap columns + slot table + probe list + list bitmap
 // plain0 / qlim (both nq ints, or NULL): the blocks from flat chunk plain0[q] on carry clamp(plain
 // sums) (plain_scan.hip); a query whose bound at its first such block is above qlim[q] gets
 // skip[q] = 1 written (skip must then be writable) and is to be re-scanned exactly and replayed again.
