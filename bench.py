@@ -1184,7 +1184,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     dev.set_pipeline(args.pipeline)
     dev.set_coalesce(args.coalesce if args.pipeline > 1 else 1)
-    args.pairs_fit = 2 * args.nq <= dev.max_sub_batch(args.k, args.n_probes) and args.build_probes == 1
+    # (labels that repeat — build_probes >= 2 — pair up where the index has its twin table: heap.hip, TWIN form)
+    args.pairs_fit = (2 * args.nq <= dev.max_sub_batch(args.k, args.n_probes)
+                      and (args.build_probes == 1 or dev.twin_table_width() > 0))
     dev.reserve(args.nq * launch_batches(args), args.k, args.n_probes)
     dev.set_heap_mode(args.heap_mode)
     dev.set_scan_mode(args.scan_mode)

@@ -878,10 +878,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         uint32_t lab_next = 0;        // DEDUPE: label of the lowest pending row, fetched ahead
         int lab_base = 0;             //         labels32 index of row 0 of the current block
         int tw_next = -1;             // TWIN: list of the lowest pending row's first other copy, fetched ahead
-        // LAZY: the next block of `hit` is requested when the last candidate of the current block is taken, ahead of
-        // that candidate's insert (la_blk, la_dd): a dependent trip to memory per passing block otherwise
-        uint32_t la_x = 0, la_y = 0, la_z = 0, la_w = 0;      // (four words: a uint4 the lambda below takes by reference went to scratch)
-        int la_blk = -1;
         // next block of this segment with a byte below the live bound
         auto advance = [&]() {
             while (bits == 0 && hit) {
@@ -890,7 +886,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 cur = 16 * g + k;
                 if (LAZY) {
                     if (cur == pre_blk) dd = pre;           // (requested while the previous segment was replayed)
-                    else if (cur == la_blk) dd = make_uint4(la_x, la_y, la_z, la_w);   // (... while the previous block's last row went in)
                     else dd = drow[cur < last_blk ? cur : last_blk];
                 } else {
                     dd = ST[(buf * 16 + k) * LW + lane];
@@ -917,27 +912,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 }
             }
         };
-        // One round: the lanes with a pending candidate take it through the duplicate test and the register levels of
-        // `insert`; every lane without one looks for its next block (`advance`, one call site); the sifts go on
-        // through the LDS levels.  TWIN with staged blocks looks BEFORE the LDS levels — the block is in LDS, and
-        // the request for the candidate's row of the twin table is then in flight while the sift runs (a trip to
-        // memory in every round otherwise: 1.7 against 1.0 us per round); the other forms look after them (LAZY:
-        // the next block was requested when the last candidate of the current one was taken).
+        // One round: every lane without a pending candidate looks for its next block (`advance`, one call site); the
+        // lanes with one take it through the duplicate test and `insert` — register levels, then LDS levels.  TWIN
+        // with staged blocks (EARLY) looks between the two: the new root — the bound behind the block — is known
+        // after the register levels, the block is in LDS, and the request for the next candidate's row of the twin
+        // table is then in flight while the sift goes through the LDS levels (a trip to memory in every round
+        // otherwise: 1.7 us per round against 1.0 of the form without the test; 1.35 this way).  Requesting a LAZY
+        // form's next passing block ahead of the insert in the same manner was measured and is not kept (100M x 128:
+        // 6.27 M queries/s with, 6.27 without, same box).
+        constexpr bool EARLY = TWIN && !LAZY;
         for (;;) {
+            if (!EARLY) {
+                advance();
+                if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
+                rounds++;
+            }
             int j = 0;             // > 0: the sift goes on below node j (3..6), whose children are in LDS
             uint32_t entry = 0;
             int v = 0;
             if (bits) {   // one insert per lane with a pending candidate
                 const int r = __builtin_ctz(bits);
                 bits &= bits - 1;
-                if (LAZY && bits == 0 && hit) {
-                    const int kn = 16 * g + __builtin_ctz(hit);
-                    if (kn != pre_blk) {
-                        la_blk = kn;
-                        const uint4 t4 = drow[kn < last_blk ? kn : last_blk];
-                        la_x = t4.x; la_y = t4.y; la_z = t4.z; la_w = t4.w;
-                    }
-                }
                 const uint32_t w = r < 4 ? dd.x : r < 8 ? dd.y : r < 12 ? dd.z : dd.w;
                 const uint32_t by = (w >> (8 * (r & 3))) & 0xffu;
                 uint32_t low = (uint32_t)(16 * cur + r);
@@ -1072,7 +1067,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                     b_plain = cur < plain0 ? bound : b_plain;
                 }
             }
-            if (TWIN && !LAZY) advance();
+            if (EARLY) advance();
             {
                 if (j)
                 {
@@ -1106,9 +1101,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                     }
                 }
             }
-            if (!(TWIN && !LAZY)) advance();
-            if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
-            rounds++;
+            if (EARLY) {
+                if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
+                rounds++;
+            }
         }
     }
 #undef TK_FETCH_BLOCKS

@@ -558,6 +558,12 @@ class DeviceIndex:
         _lib.check(_lib.lib().tk_index_replay_stats(self._h, _lib.ptr(o, _lib._i64p)))
         return dict(rounds=int(o[0]), max_rounds_of_a_wave=int(o[1]), waves=int(o[2]), segments=int(o[3]))
 
+    def twin_table_width(self):
+        """Other copies listed per stored row (tk_index_twin_table): 0 = no table (distinct labels, ...)."""
+        w = np.zeros(1, np.int32)
+        _lib.check(_lib.lib().tk_index_twin_table(self._h, None, _lib.ptr(w, _lib._i32p), None, None))
+        return int(w[0])
+
     def twin_table(self):
         """(list, offset) of every stored row's other copies, two (rows, w) int32 arrays (tk_index_twin_table):
         what the lane replay decides `insert`'s duplicate test from where labels repeat (build n_probes >= 2).
