@@ -161,3 +161,23 @@ def test_index_persistence_roundtrips(tmp_path):
             assert a.size == b.size
             np.testing.assert_array_equal(a.packed, b.packed)
             np.testing.assert_array_equal(ia, ib)
+
+
+def test_a_forked_child_does_not_release_the_parents_device_handles():
+    """A process forked from the one that loaded the library (multiprocessing.Manager, fork start method)
+    holds copies of the Python wrappers; their close() / __del__ must not call into the library — the HIP
+    context does not survive a fork, and a garbage collection in such a child once aborted a GPU test run."""
+    import os
+    from tinyknn_amd import _lib
+    _lib.lib()
+    assert _lib.owns_handles()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        os.close(r)
+        os.write(w, b"1" if _lib.owns_handles() else b"0")
+        os._exit(0)
+    os.close(w)
+    assert os.read(r, 1) == b"0"
+    os.waitpid(pid, 0)
+    os.close(r)

@@ -190,7 +190,8 @@ def test_sharded_filtered_golden(tag, world, coarse):
 def test_two_phase_scan_on_the_matrix_cores(world):
     """tk_index_shard_scan_first_dev / _rest_dev: first lists exactly, their bound min-reduced, the
     lists behind them on the plain kernel for the queries whose bound allows — golden ids for both
-    exchanges; with repeating labels only on request (tk_index_set_plain_scan(ix, 2)), same ids."""
+    exchanges; with repeating labels beside the TWIN replay (beside the hash-set replay only on request:
+    tk_index_set_plain_scan(ix, 2)), same ids."""
     from test_hip_parity import ivf_from_fixture
     from tinyknn_amd.multi_gpu import _HipShardEngine, shard_lists
     for tag in ("an100", "eu128", "an100b2"):
@@ -203,9 +204,15 @@ def test_two_phase_scan_on_the_matrix_cores(world):
             for exchange in ("dense", "filtered-regions"):
                 engines = [_HipShardEngine(ivf, owner, r, world, 1) for r in range(world)]
                 if tag.endswith("b2"):
-                    assert not engines[0].plain_ok(10, n_probes, None)      # repeating labels: on request only
-                    for e in engines:
-                        e.dev.set_plain_scan("always")
+                    # repeating labels: the plain path goes with the TWIN form of the lane replay (the default);
+                    # beside the hash-set replay only on request
+                    from tinyknn_amd import _lib
+                    engines[0].dev.set_option(_lib.OPT_REPLAY_TWIN, 0)
+                    assert not engines[0].plain_ok(10, n_probes, None)
+                    engines[0].dev.set_plain_scan("always")
+                    assert engines[0].plain_ok(10, n_probes, None)
+                    engines[0].dev.set_plain_scan(True)
+                    engines[0].dev.set_option(_lib.OPT_REPLAY_TWIN, 1)
                 assert engines[0].plain_ok(10, n_probes, None)
                 assert not engines[0].plain_ok(10, 1, None)                 # one list: nothing behind it
                 st = {}
@@ -226,8 +233,7 @@ def test_two_phase_scan_on_the_matrix_cores(world):
                         assert pass_1 != 3 or st["plain"][0]["plain_queries"] >= nq_ // 2, st["plain"]
                     b, _, _ = simulate_world(ivf, world, g["qn"], g["qpq"], 10, n_probes, pass_1=pass_1,
                                              owner=owner, exchange=exchange, plain=False)
-                    if not tag.endswith("b2"):
-                        np.testing.assert_array_equal(a, b)
+                    np.testing.assert_array_equal(a, b)
 
 
 def test_sharded_overflow_is_flagged_and_harmless():

@@ -35,7 +35,7 @@ _codes_cache = {}      # id(array) -> (weakref, handle, (data pointer, shape))
 
 def _drop(key):
     ent = _codes_cache.pop(key, None)
-    if ent is not None:
+    if ent is not None and _lib.owns_handles():
         _lib.lib().tk_codes_free(ent[1])
 
 

@@ -21,6 +21,7 @@ def lib_path():
 
 
 _lib = None
+_lib_pid = None     # the process that loaded the library (and owns every device handle made through it)
 
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
@@ -169,9 +170,16 @@ SIGNATURES = {
 }
 
 
+def owns_handles():
+    """False in a process forked from the one that loaded the library: its copies of the Python objects
+    must not free device memory of the parent (a HIP context does not survive fork; a garbage collection
+    inside e.g. a multiprocessing.Manager child used to abort with a memory fault)."""
+    return _lib is not None and _lib_pid == os.getpid()
+
+
 def lib():
     """The loaded library.  Raises TinyKnnHipError when it is not built."""
-    global _lib
+    global _lib, _lib_pid
     if _lib is None:
         path = lib_path()
         if not os.path.exists(path):
@@ -188,6 +196,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        _lib_pid = os.getpid()
     return _lib
 
 

@@ -303,10 +303,10 @@ bool plain_env_on()
     return on != 0;
 }
 // the TWIN form of the lane replay applies (heap.hip): repeating labels with a twin table, fresh heaps on packed
-// position entries, an unsharded index (the probe lists of the batch are the workspace's)
+// position entries
 bool twin_replay(const tk_index *ix, const Plan &p)
 {
-    return !ix->ids_unique && ix->twin_w > 0 && ix->opt_replay_twin == 1 && !ix->sharded && ix->heap_mode == 0 &&
+    return !ix->ids_unique && ix->twin_w > 0 && ix->opt_replay_twin == 1 && ix->heap_mode == 0 &&
            ix->total_ids < (1ll << 31) && p.cap * 16 <= 0xffffff && tk_lanes_twin_fits(p.R, p.S, ix->n_lists);
 }
 
@@ -904,13 +904,14 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
     } else if (packed_ok && twin_replay(ix, p)) {
         // repeating labels, every copy of a label with ONE value (IVF.build(n_probes >= 2)): one query per lane,
         // position entries, `insert`'s duplicate test decided from the twin table (heap.hip, TWIN form).  The
-        // queries that probe a list twice (repeat_flag, and with `plain` those the lemma's check flags) go to
-        // the packed kernel with the reference's scan of the labels
+        // queries that probe a list twice (repeat_flag 1) and, with `plain`, those the lemma's check flags (2)
+        // go to the packed kernel with the reference's scan of the labels
         TkTwins tw;
         tw.list = ix->twin_list.as<int32_t>();
         tw.off = ix->twin_off.as<int32_t>();
         tw.w = ix->twin_w;
-        tw.probes = w.probes.as<int64_t>() + q0 * p.S;
+        // (a list-sharded index replays its home queries: the batch's probe lists are the scan stage's)
+        tw.probes = (ix->sharded && w.shard_probes ? w.shard_probes : w.probes.as<int64_t>()) + q0 * p.S;
         tw.bm_words = tk_lanes_twin_bm_words(ix->n_lists);
         if (tk_launch_heap_replay_lanes(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
                                         slot_loff, p.S, ix->ids.as<int64_t>(),
@@ -920,7 +921,14 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
                                         ix->opt_replay_count ? ix->replay_counters.as<unsigned long long>() : nullptr,
                                         &tw))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
-        if (plain) rescan_flagged(ix, w, q0, nq, p, st);
+        if (plain && plain_flag) {
+            tk_launch_shard_flag_plain(repeat_flag, nq, plain_flag, st);
+        } else if (plain) {
+            rescan_flagged(ix, w, q0, nq, p, st);
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 2, 1, st);
+        }
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                      p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                      w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);

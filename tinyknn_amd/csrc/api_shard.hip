@@ -63,7 +63,7 @@ static int shard_args(tk_index *ix, int slot, int64_t nq, int64_t capacity, cons
 static bool shard_plain_possible(const tk_index *ix, const Plan &p)
 {
     if (ix->plain_mode == 1 || !plain_env_on() || !ix->sharded || p.S < 2 || !tk_plain_fits(ix->M)) return false;
-    return ix->ids_unique || ix->plain_mode == 2;
+    return ix->ids_unique || twin_replay(ix, p) || ix->plain_mode == 2;
 }
 
 static int reserve_shard_plain(tk_index *ix, Work &w, int64_t nq, const Plan &p)
@@ -202,7 +202,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
 static bool shard_one_phase_possible(const tk_index *ix, const Plan &p, int64_t capacity)
 {
     const int64_t tail = (int64_t)ix->world * capacity - ix->max_list_chunks;
-    return shard_plain_possible(ix, p) && ix->ids_unique && tail >= 0 && p.R <= TK_LANES_MAX_R &&
+    return shard_plain_possible(ix, p) && (ix->ids_unique || twin_replay(ix, p)) && tail >= 0 && p.R <= TK_LANES_MAX_R &&
            ix->heap_mode == 0 && p.cap * 16 <= 0xffffff;
 }
 

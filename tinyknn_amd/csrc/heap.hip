@@ -1124,8 +1124,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     if (R > 5) H[5 * LW + lane] = h5;
     if (R > 6) H[6 * LW + lane] = h6;
     if (!valid) return;
-    // re-scan + replay again: flag 2 with distinct labels (no duplicate test needed then), 1 otherwise
-    if (plain0_arr && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) skip[q] = (DEDUPE || TWIN) ? 1 : 2;
+    // re-scan + replay again: flag 2 with distinct labels (no duplicate test needed then) and from the TWIN form, 1 otherwise
+    if (plain0_arr && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) skip[q] = DEDUPE ? 1 : 2;
     // ---- resolve flat positions (or slots) to labels
     const int64_t *loffs = slot_label_off + qs * S;
     for (int j = 0; j < R; j++) {

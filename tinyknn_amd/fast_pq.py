@@ -273,7 +273,8 @@ class FlatTop:
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().tk_index_destroy(self._h)
+            if _lib.owns_handles():
+                _lib.lib().tk_index_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -83,7 +83,8 @@ class QueryStream:
 
     def close(self):
         if getattr(self, "_s", None):
-            _lib.lib().tk_stream_destroy(self._s)
+            if _lib.owns_handles():
+                _lib.lib().tk_stream_destroy(self._s)
             self._s = None
 
     def __del__(self):
@@ -289,7 +290,8 @@ class DeviceIndex:
             st.close()
         self._streams = {}
         if getattr(self, "_h", None):
-            _lib.lib().tk_index_destroy(self._h)
+            if _lib.owns_handles():
+                _lib.lib().tk_index_destroy(self._h)
             self._h = None
 
     # ---- streaming (exact) ---------------------------------------------------
