@@ -524,6 +524,19 @@ int tk_index_shard_resident(tk_index *ix, const int32_t *owner, int rank, int wo
 int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
                               int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                               int64_t *probes_home_dev, void *stream);
+/* The same with the distance tables built for the HOME queries only (fast_pq.py:186-222 once per query in the
+ * whole job instead of once per query and rank): tables_home_dev (ceil(nq/world) x M x 16 bytes) and
+ * limits_home_dev (ceil(nq/world) int32: the tables' limits for the plain-sum scan) are filled for the caller to
+ * all-gather beside the probe lists; tk_index_shard_set_tables_dev then hands the gathered rows — query order,
+ * world x ceil(nq/world) of them — to the scans of the slot, which read the tables where they lie (the buffer
+ * belongs to the batch until it is done).  832 bytes per query on the links (M = 52) against a table build per
+ * query on every rank. */
+int tk_index_shard_coarse_home_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
+                                   int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
+                                   int64_t *probes_home_dev, void *tables_home_dev, int32_t *limits_home_dev,
+                                   void *stream);
+int tk_index_shard_set_tables_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
+                                  const void *tables_all_dev, const int32_t *limits_all_dev, void *stream);
 int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
                             int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                             const int64_t *probes_all_dev, int64_t capacity, void *send_dev,

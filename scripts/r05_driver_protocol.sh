@@ -1,11 +1,11 @@
-# round 5: the driver's own command, timed, its line kept under gpurun_out/r05/ (copied to profiles/r05/bench_default.json)
-R=$PWD; O=$R/gpurun_out/r05; mkdir -p $O
+# round 5: the driver's own command, timed, its line kept under gpurun_out/r05b/ (copied to profiles/r05/bench_default.json)
+R=$PWD; O=$R/gpurun_out/r05b; mkdir -p $O
 t0=$(date +%s)
 timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 echo "rc=$? seconds=$(( $(date +%s) - t0 ))"; grep "bench\]" $O/bench_default.err | tail -5
 python3 - <<'PY'
 import json
-j = json.loads([l for l in open("gpurun_out/r05/bench_default.json") if l.startswith("{")][-1])
+j = json.loads([l for l in open("gpurun_out/r05b/bench_default.json") if l.startswith("{")][-1])
 ls = j.get("list_sharded", {})
 print("value", round(j["value"]), "ms", round(j["ms_per_step"], 4), "recall", j["config"]["recall10@10"], "parity", j["parity_vs_oracle"], "cpu", round(j["cpu_baseline"]["value"]))
 r = j["roofline"]

@@ -558,8 +558,9 @@ def test_one_phase_scan_golden(tag, world):
 def test_simulated_peers_one_rank_of_a_partition(oracle):
     """ListShardedIndex(simulate=SimulatedPeers(...)): ONE rank of a W-rank partition with the other
     ranks' contributions recorded from clone shards on the same device — its home rows are the
-    unsharded rows, for every rank, dense (one- and two-phase) and filtered exchange, with batches in
-    flight; the unsharded index stays usable beside the clones."""
+    unsharded rows, for every rank, dense (one- and two-phase) and filtered exchange, tables built on every rank (the default)
+    or at home and gathered, with batches in flight; the unsharded index stays usable beside
+    the clones."""
     import torch
     from tinyknn_amd import IVF, FastPQ
     from tinyknn_amd.multi_gpu import ListShardedIndex, SimulatedPeers
@@ -578,7 +579,10 @@ def test_simulated_peers_one_rank_of_a_partition(oracle):
         peers = SimulatedPeers(ivf, world=world, rank=rank)
         lo, hi = peers.home_range(nq)
         for kw in (dict(exchange="dense"), dict(exchange="dense", plain="two-phase"), dict(exchange="filtered"),
-                   dict(exchange="dense", plain=False), dict(exchange="dense", plain="head")):
+                   dict(exchange="dense", plain=False), dict(exchange="dense", plain="head"),
+                   # (tables="home": a query's table is built on its home rank and gathered; default: on every rank)
+                   dict(exchange="dense", tables="home"), dict(exchange="filtered", tables="home"),
+                   dict(exchange="dense", plain="head", tables="home")):
             idx = ListShardedIndex(ivf, simulate=peers, depth=2, **kw)
             peers.reset()
             got = idx.query_prepared(qn_t, qp_t, 10, 6)

@@ -71,6 +71,11 @@ SIGNATURES = {
     "tk_index_shard_coarse_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p]),
+    "tk_index_shard_coarse_home_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tk_index_shard_set_tables_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_shard_scan_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

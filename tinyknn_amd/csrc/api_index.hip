@@ -563,7 +563,7 @@ bool coarse_units(const tk_index *ix, int64_t nq)
 }
 
 int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_t nq,
-                        hipStream_t st, Prof &pf, bool plain, TkSecond qpq2)
+                        hipStream_t st, Prof &pf, bool plain, TkSecond qpq2, int64_t row0)
 {
     TRY(pf.mark(st));
     // 1. distance tables                                   fast_pq.py:186-222
@@ -572,7 +572,7 @@ int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_
     //  lanes; two short kernels less at the head of the front stream's chain)
     TkTablesExtra ex;
     if (plain) {        // per query: below which value clamp(plain sum) is the saturated value
-        ex.qlim = w.qlim.as<int>();
+        ex.qlim = w.qlim.as<int>() + row0;
         ex.lim_avx = ix->order == TK_ORDER_AVX;
         ex.lim_m_used = ex.lim_avx ? (ix->M & ~3) : ix->M;       // the AVX kernels read block pairs two at a time
         ex.lim_force = ix->opt_plain_limit;
@@ -586,7 +586,7 @@ int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_
         ex.c_nq = nq;
     }
     tk_launch_build_tables(ix->pq_centers.as<float>(), ix->dq, ix->dpb, ix->f_order, qpq_dev,
-                           qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>(), w.shift.p,
+                           qpq_f64, nq, ix->sqrt_nb, 0.0, 1, w.tables.as<uint8_t>() + (size_t)row0 * ix->M * 16, w.shift.p,
                            w.scale.as<double>(), st, qpq2, &ex);
     TRY(pf.mark(st));
     return TK_OK;
@@ -597,7 +597,7 @@ TkScanJob coarse_job(const tk_index *ix, const Work &w, const Plan &p)
 {
     TkScanJob j;
     j.codes = ix->center_codes.as<uint4>();
-    j.tables = w.tables.as<uint4>();
+    j.tables = tables_of(w);
     j.list_chunk_off = ix->c_chunk_off.as<int64_t>();
     j.n_lists = 1;
     j.unit_prefix = w.c_unit_prefix.as<int>();
@@ -615,7 +615,7 @@ static TkScanJob list_job(const tk_index *ix, const Work &w, const Plan &p)
 {
     TkScanJob j;
     j.codes = ix->codes.as<uint4>();
-    j.tables = w.tables.as<uint4>();
+    j.tables = tables_of(w);
     j.list_chunk_off = ix->list_chunk_off.as<int64_t>();
     j.n_lists = (int)ix->n_lists;
     j.unit_prefix = w.u_unit_prefix.as<int>();

@@ -110,6 +110,9 @@ struct Work {
     // list-sharded batch: what tk_index_shard_scan_dev left for the filtered exchange
     const int64_t *shard_probes = nullptr;
     int64_t shard_nq = 0, shard_capacity = 0;
+    // list-sharded batch whose tables were built by the queries' HOME ranks and all-gathered by the caller
+    // (tk_index_shard_coarse_home_dev / tk_index_shard_set_tables_dev): the gathered rows, in the caller's buffer
+    const uint4 *ext_tables = nullptr;
     bool shard_first = false;       // tk_index_shard_scan_first_dev ran: _rest_dev is owed
     bool shard_plain = false;       // tk_index_shard_scan_plain_dev filled the send buffer: the home replay checks the lemma
     bool shard_head = false;        // tk_index_shard_scan_head_dev ran: _scan_plain_dev(bound_dev) is owed
@@ -283,6 +286,9 @@ struct Prof {
     }
 };
 
+// the distance tables a batch's scans read: the workspace's, or the gathered rows of a list-sharded batch
+inline const uint4 *tables_of(const Work &w) { return w.ext_tables ? w.ext_tables : w.tables.as<uint4>(); }
+
 // ---- api_index.hip, used by the other files
 int flush_pending(tk_index *ix);
 // the twin table of an index whose int32 labels (all in [0, label_bound)) are in place; no table (twin_w = 0) where
@@ -295,8 +301,9 @@ int plain_k(const tk_index *ix, int64_t nq, const Plan &p);
 size_t plain_desc_bytes(const tk_index *ix, int64_t nq, const Plan &p);
 double workspace_bytes();
 bool coarse_units(const tk_index *ix, int64_t nq);
+// row0: the tables (and limits) of rows [row0, row0 + nq) of the workspace; qpq_dev points at row row0's query
 int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_t nq, hipStream_t st, Prof &pf,
-                 bool plain = false, TkSecond qpq2 = TkSecond());
+                 bool plain = false, TkSecond qpq2 = TkSecond(), int64_t row0 = 0);
 TkScanJob coarse_job(const tk_index *ix, const Work &w, const Plan &p);
 int plain_blocks();
 void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st,

@@ -96,32 +96,49 @@ static int reserve_shard_plain(tk_index *ix, Work &w, int64_t nq, const Plan &p)
 // Coarse stage sharded by HOME rank: tables for all nq queries (every rank scores segments of
 // every query), coarse scan + replay + rescoring only for this rank's ceil(nq/world) home
 // queries; the caller all-gathers the probe lists and hands them to tk_index_shard_scan_dev.
-extern "C" int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_dev,
-                                         const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
-                                         int n_probes, int pass_1, int64_t *probes_home_dev,
-                                         void *stream)
+// tables_home_dev == NULL: as above.  Otherwise (tk_index_shard_coarse_home_dev) the tables are built for the HOME
+// queries only and leave, with their limits, in the caller's buffers for an all-gather: a rank of W then builds
+// nq / W tables instead of nq (a W = 8 rank of the GloVe-shaped index: 0.14 ms of its 80 000-query batch).
+static int shard_coarse_impl(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev, int q_pq_is_f64,
+                             int64_t nq, int k, int n_probes, int pass_1, int64_t *probes_home_dev,
+                             void *tables_home_dev, int32_t *limits_home_dev, void *stream)
 {
-    IXLOCK(ix);
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     int64_t qh = 0;
     TRY(shard_args(ix, slot, nq, 1, p, qh));
     ARGCHECK(probes_home_dev, "probes buffer");
+    ARGCHECK(!tables_home_dev || limits_home_dev, "tables and limits leave together");
     Work &w = ix->works[(size_t)slot];
     hipStream_t st = (hipStream_t)stream;
     TRY(reserve_shard(ix, w, nq, qh, p));
+    w.ext_tables = nullptr;
     Prof pf;
     // (the limits C of all nq tables ride in the table launch's shadow where a plain form may follow)
     const bool limits = shard_plain_possible(ix, p);
-    if (limits) TRY(reserve_shard_plain(ix, w, nq, p));
-    TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, limits));
+    if (limits || tables_home_dev) TRY(reserve_shard_plain(ix, w, nq, p));
     const int64_t q0 = (int64_t)ix->rank * qh;
     int64_t nqh = nq - q0;
     nqh = nqh < 0 ? 0 : (nqh > qh ? qh : nqh);
+    const size_t esz = q_pq_is_f64 ? 8 : 4;
+    if (!tables_home_dev) {
+        TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, limits));
+    } else {
+        // rows past nq: zero tables with the limit of "never plain" (defined for the all-gather; no query reads them)
+        HIPCHECK(hipMemsetAsync(tables_home_dev, 0, (size_t)qh * ix->M * 16, st));
+        HIPCHECK(hipMemsetAsync(limits_home_dev, 0x80, (size_t)qh * 4, st));
+        if (nqh > 0) {
+            TRY(stage_tables(ix, w, (const char *)q_pq_dev + (size_t)q0 * ix->dq * esz, q_pq_is_f64, nqh, st, pf, true,
+                             TkSecond(), q0));
+            HIPCHECK(hipMemcpyAsync(tables_home_dev, w.tables.as<uint8_t>() + (size_t)q0 * ix->M * 16,
+                                    (size_t)nqh * ix->M * 16, hipMemcpyDeviceToDevice, st));
+            HIPCHECK(hipMemcpyAsync(limits_home_dev, w.qlim.as<int>() + q0, (size_t)nqh * 4, hipMemcpyDeviceToDevice, st));
+        }
+    }
     // rows past nq: list 0 (never read by a consumer; defined for the all-gather)
     HIPCHECK(hipMemsetAsync(probes_home_dev, 0, (size_t)qh * p.kc * 8, st));
     if (nqh > 0) {
-        if (coarse_units(ix, nqh))     // identity pairs of the home range (stage_tables: of all nq)
+        if (!tables_home_dev && coarse_units(ix, nqh))     // identity pairs of the home range (stage_tables wrote those of all nq)
             tk_launch_identity_pairs(nqh, (int)ix->center_chunks, w.c_pair_off.as<int>(),
                                      w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
                                      w.c_pair_f0.as<int>(), st);
@@ -129,6 +146,47 @@ extern "C" int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_
         TRY(coarse_replay_probes(ix, w, q_dev + q0 * ix->d, nqh, p, probes_home_dev, st, pf));
     }
     HIPCHECK(hipGetLastError());
+    return TK_OK;
+}
+
+extern "C" int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_dev,
+                                         const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
+                                         int n_probes, int pass_1, int64_t *probes_home_dev,
+                                         void *stream)
+{
+    IXLOCK(ix);
+    return shard_coarse_impl(ix, slot, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, probes_home_dev,
+                             nullptr, nullptr, stream);
+}
+
+extern "C" int tk_index_shard_coarse_home_dev(tk_index *ix, int slot, const float *q_dev,
+                                              const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
+                                              int n_probes, int pass_1, int64_t *probes_home_dev,
+                                              void *tables_home_dev, int32_t *limits_home_dev, void *stream)
+{
+    IXLOCK(ix);
+    ARGCHECK(tables_home_dev && limits_home_dev, "tables / limits buffers");
+    return shard_coarse_impl(ix, slot, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, probes_home_dev,
+                             tables_home_dev, limits_home_dev, stream);
+}
+
+// The gathered tables of a batch (world x ceil(nq / world) rows of M x 16 bytes, in query order) and their limits:
+// the scans of this slot read the tables where they lie (the caller keeps the buffer until the batch is done);
+// the limits — 4 bytes per query — are copied into the workspace.
+extern "C" int tk_index_shard_set_tables_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
+                                             const void *tables_all_dev, const int32_t *limits_all_dev, void *stream)
+{
+    IXLOCK(ix);
+    Plan p;
+    TRY(make_plan(ix, k, n_probes, pass_1, p));
+    int64_t qh = 0;
+    TRY(shard_args(ix, slot, nq, 1, p, qh));
+    ARGCHECK(tables_all_dev && limits_all_dev, "tables / limits buffers");
+    Work &w = ix->works[(size_t)slot];
+    TRY(reserve_shard(ix, w, nq, qh, p));
+    TRY(reserve_shard_plain(ix, w, nq, p));
+    w.ext_tables = (const uint4 *)tables_all_dev;
+    HIPCHECK(hipMemcpyAsync(w.qlim.p, limits_all_dev, (size_t)nq * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return TK_OK;
 }
 
@@ -157,6 +215,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
         coarse_slots(ix, w, probes, nq, p, w.u_count.as<int>(), owner, ix->rank, st);
     } else {
         // replicated coarse stage: every rank derives every probe list itself
+        w.ext_tables = nullptr;
         TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
         launch_coarse_scan(ix, w, nq, p, st);
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf));
@@ -187,7 +246,7 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
                                w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(), st);
     // the owned segments are scored straight into the send buffer (row stride 0, the
     // record's offset is the segment's position); the minima are rebuilt by the receiver
-    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
+    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, tables_of(w), nq, p.S, ix->n_lists,
                          ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                          w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
                          (uint4 *)send_dev, 0, w.smins.as<uint8_t>(), 0, 1, ix->order, 768, st);
@@ -249,6 +308,7 @@ extern "C" int tk_index_shard_scan_head_dev(tk_index *ix, int slot, const float 
     if (probes) {
         coarse_slots(ix, w, probes, nq, p, nullptr, owner, ix->rank, st);
     } else {
+        w.ext_tables = nullptr;
         TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, true));
         launch_coarse_scan(ix, w, nq, p, st);
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, nullptr, owner, ix->rank, st, pf));
@@ -289,7 +349,7 @@ extern "C" int tk_index_shard_scan_head_dev(tk_index *ix, int slot, const float 
     TkScanJob hj, none;
     memset(&none, 0, sizeof none);
     hj.codes = ix->codes.as<uint4>();
-    hj.tables = w.tables.as<uint4>();
+    hj.tables = tables_of(w);
     hj.list_chunk_off = lco;
     hj.n_lists = (int)ix->n_lists;
     hj.unit_prefix = w.h_unit_prefix.as<int>();
@@ -376,6 +436,7 @@ extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float
         // tables and their limits: tk_index_shard_coarse_dev; the probe lists arrive gathered
         coarse_slots(ix, w, probes, nq, p, w.u_count.as<int>(), owner, ix->rank, st, true);
     } else {
+        w.ext_tables = nullptr;
         TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, true));
         launch_coarse_scan(ix, w, nq, p, st);
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf, true));
@@ -413,7 +474,7 @@ extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float
                           ex, pl, hd, hc, st, w.spos.as<int>(), owner, ix->rank, (int)tail);
     TkScanJob lj;
     lj.codes = ix->codes.as<uint4>();
-    lj.tables = w.tables.as<uint4>();
+    lj.tables = tables_of(w);
     lj.list_chunk_off = lco;
     lj.n_lists = (int)ix->n_lists;
     lj.unit_prefix = w.u_unit_prefix.as<int>();
@@ -499,6 +560,7 @@ extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float
     if (probes) {
         coarse_slots(ix, w, probes, nq, p, nullptr, owner, ix->rank, st);
     } else {
+        w.ext_tables = nullptr;
         TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
         launch_coarse_scan(ix, w, nq, p, st);
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, nullptr, owner, ix->rank, st, pf));
@@ -506,7 +568,7 @@ extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float
     }
     // the limits C of all nq tables (tk_index_shard_coarse_dev computed them beside its tables)
     if (!probes_all_dev)
-        tk_launch_table_limits(w.tables.as<uint4>(), ix->M, ix->order, nq, w.qlim.as<int>(), st, ix->opt_plain_limit);
+        tk_launch_table_limits(tables_of(w), ix->M, ix->order, nq, w.qlim.as<int>(), st, ix->opt_plain_limit);
     {
         const int64_t n1 = nq * p.S + (int64_t)ix->world * qh * p.S + 1;
         ARGCHECK(n1 < (1ll << 31), "too many (query, list) entries for one sharded batch");
@@ -532,7 +594,7 @@ extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float
     tk_launch_shard_pairs_fill(probes, p.S, nq, ix->n_lists, owner, ix->rank, w.spos.as<int>(),
                                w.u_pair_off.as<int>(), w.u_cursor.as<int>(), w.u_pair_q.as<int>(),
                                w.u_pair_f0.as<int>(), st, 0, 1);
-    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
+    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, tables_of(w), nq, p.S, ix->n_lists,
                          ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                          w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
                          (uint4 *)send_dev, 0, w.smins.as<uint8_t>(), 0, 1, ix->order, 768, st);
@@ -591,7 +653,7 @@ extern "C" int tk_index_shard_scan_rest_dev(tk_index *ix, int slot, int64_t nq, 
                                (int)(tail > 0 ? tail : 0));
     TkScanJob pj;
     pj.codes = ix->codes.as<uint4>();
-    pj.tables = w.tables.as<uint4>();
+    pj.tables = tables_of(w);
     pj.list_chunk_off = ix->local_chunk_off.as<int64_t>();
     pj.n_lists = (int)ix->n_lists;
     pj.unit_prefix = w.p_unit_prefix.as<int>();
@@ -605,7 +667,7 @@ extern "C" int tk_index_shard_scan_rest_dev(tk_index *ix, int slot, int64_t nq, 
     pj.min_stride = 0;
     if (tk_launch_scan_plain(pj, ix->M, ix->order, plain_blocks(), st))
         return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
-    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>(), nq, p.S, ix->n_lists,
+    tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, tables_of(w), nq, p.S, ix->n_lists,
                          ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),
                          w.u_unit_prefix.as<int>(), w.u_pair_q.as<int>(), w.u_pair_f0.as<int>(),
                          (uint4 *)send_dev, 0, w.smins.as<uint8_t>(), 0, 1, ix->order, 768, st);

@@ -425,6 +425,25 @@ class DeviceIndex:
             self._h, int(slot), qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
             int(pass_1 or 0), probes_home_ptr, stream))
 
+    def shard_coarse_home_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1,
+                              probes_home_ptr, tables_home_ptr, limits_home_ptr, stream=0):
+        """Tables + limits + coarse stage of this rank's home queries only (tk_index_shard_coarse_home_dev);
+        the caller all-gathers probe lists, tables and limits and calls shard_set_tables_dev."""
+        _lib.check(_lib.lib().tk_index_shard_coarse_home_dev(
+            self._h, int(slot), qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
+            int(pass_1 or 0), probes_home_ptr, tables_home_ptr, limits_home_ptr, stream))
+
+    def shard_set_tables_dev(self, slot, nq, k, n_probes, pass_1, tables_all_ptr, limits_all_ptr, stream=0):
+        """The gathered tables / limits of a batch for the scans of the slot (tk_index_shard_set_tables_dev)."""
+        _lib.check(_lib.lib().tk_index_shard_set_tables_dev(
+            self._h, int(slot), nq, int(k), int(n_probes), int(pass_1 or 0), tables_all_ptr, limits_all_ptr,
+            stream))
+
+    @property
+    def M(self):
+        """PQ blocks per vector (a distance table is M x 16 bytes)"""
+        return self.dq // self.dpb
+
     def shard_scan_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1, capacity,
                        send_ptr, flag_ptr, stream=0, probes_all_ptr=None):
         """Scan of the owned segments into the send buffer (tk_index_shard_scan_dev);
