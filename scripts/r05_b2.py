@@ -28,17 +28,18 @@ st = torch.cuda.current_stream().cuda_stream
 ox = bench.oracle_index(ivf)
 want = ox.query_batch(bs[0]["qn"][:500], a.k, 10)
 lazy_arg = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+depth = int(sys.argv[4]) if len(sys.argv) > 4 else 2           # replay streams of the pipelined mode
 for twin, co, plain, lazy in (((1, 2, True, lazy_arg),) if only else
                               ((0, 1, True, -1), (1, 1, False, -1), (1, 1, True, -1), (1, 2, False, -1), (1, 2, True, -1),
                                (1, 2, True, 0), (1, 2, True, 1), (1, 2, "always", -1))):
     dev.set_option(_lib.OPT_REPLAY_TWIN, twin)
     dev.set_option(_lib.OPT_REPLAY_LAZY, lazy)
     dev.set_plain_scan(plain)
-    r = bench.timed_rate(dev, bs, False, a.nq, a.k, 10, st, 2, co)
+    r = bench.timed_rate(dev, bs, False, a.nq, a.k, 10, st, depth, co)
     torch.cuda.synchronize()
     got = bs[0]["out"].cpu().numpy()[:500]
     pst = dev.plain_stats() or {}
-    print(json.dumps({"twin": twin, "coalesce": co, "plain": str(plain), "lazy": lazy, "M_qps": round(r["queries_per_s"] / 1e6, 2),
+    print(json.dumps({"twin": twin, "coalesce": co, "plain": str(plain), "lazy": lazy, "depth": depth, "M_qps": round(r["queries_per_s"] / 1e6, 2),
                       "ms": round(r["ms_per_step"], 4), "identical_rows": int((want == got).all(axis=1).sum()),
                       "plain_state": pst.get("state"), "flagged": pst.get("flagged_queries")}), flush=True)
 if only:

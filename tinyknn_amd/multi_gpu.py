@@ -427,8 +427,13 @@ class ListShardedIndex:
         # overlap; every rank issues the same sequence on each group.
         self._slot_groups = None
         self._cg = group
+        # One communicator per batch in flight lets the collectives of different batches overlap — verified with ONE
+        # rank (the forced-collectives rehearsal).  RCCL has never run this at world > 1 (no multi-GPU node so far), and
+        # concurrent communicators can deadlock where their kernels cannot all be resident: until such a run has passed,
+        # world > 1 takes the process group's single communicator (torch serialises its collectives on one internal
+        # stream: correct for any issue order the ranks share) unless TINYKNN_SHARD_COMMS=1 asks for one per batch.
         if (on and depth > 1 and self.backend == "nccl" and (self.world > 1 or self.force) and
-                os.environ.get("TINYKNN_SHARD_COMMS", "1") != "0"):
+                os.environ.get("TINYKNN_SHARD_COMMS", "1" if self.world == 1 else "0") != "0"):
             ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
             self._slot_groups = [dist.new_group(ranks=ranks, backend="nccl") for _ in range(depth)]
         self._roles = None
