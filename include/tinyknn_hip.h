@@ -309,6 +309,13 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
  *                        entries, no set of labels); 0 = the hash set of the labels in the heap (32 queries per
  *                        wave).  Identical results. */
 #define TK_OPT_REPLAY_TWIN 6
+/*   TK_OPT_TWIN_VOUCH    the TWIN form rests on two facts about the lists: the copies of a label lie in different lists
+ *                        and carry the same code — true of IVF.build's lists (ivf.py:77-102: a list's codes are the codes
+ *                        of data[ids]).  tk_index_set_lists and tk_index_build_dev hold every list's codes and CHECK
+ *                        them on the device (an index that fails keeps the label-based test); a rank that was handed
+ *                        only its own lists' codes (tk_index_set_lists_shard) cannot, and uses the table only behind
+ *                        1 = "the caller has checked" (tinyknn_amd.DeviceIndex does, on the host).  0 (DEFAULT). */
+#define TK_OPT_TWIN_VOUCH 7
 int tk_index_set_option(tk_index *ix, int option, int value);
 /* The table behind TK_OPT_REPLAY_TWIN (diagnostics, tests): *rows = stored rows (the length of the concatenated
  * ids), *w = other copies listed per row (0: no table — labels distinct, not int32, or one label stored more

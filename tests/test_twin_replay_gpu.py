@@ -118,3 +118,70 @@ def test_pipelined_pairs(setup):
     finally:
         dev.set_coalesce(1)
         dev.set_pipeline(1)
+
+
+def _oracle_of(oracle, ivf):
+    L = len(ivf.active_centers)
+    return oracle.OracleIndex(ivf.pq.centers, 2, ivf.pq.R, ivf.pq.sqrt_n_blocks, ivf.active_centers,
+                              ivf.pq_transformed_centers.packed,
+                              [ivf.pq_transformed_points[i].packed for i in range(L)],
+                              [ivf.pq_transformed_points[i].size for i in range(L)],
+                              [ivf.ids[i] for i in range(L)], ivf.data)
+
+
+@pytest.mark.parametrize("damage", ["other_code", "same_list", "none"])
+def test_lists_that_do_not_meet_the_premises_keep_the_label_test(oracle, damage):
+    """The TWIN form rests on: copies of a label lie in different lists and carry the same code.  IVF.build's lists do;
+    an uploaded index may not (the reference's `insert` compares LABELS, whatever the codes).  The library checks both
+    on the device when the lists arrive and keeps the label-based duplicate test for an index that fails; either way
+    the heaps and ids are the oracle's for the lists as given."""
+    from conftest import golden
+    from test_hip_parity import ivf_from_fixture
+    from tinyknn_amd.fast_pq import TransformedData
+    g = golden("g6_ivf_an100b2.npz")
+    ivf = ivf_from_fixture(None, g)
+    big = int(np.argmax(g["list_sizes"]))
+    if damage == "other_code":          # every 5th row of the longest list gets another code: its copy elsewhere keeps the old one
+        td = ivf.pq_transformed_points[big]
+        pk = np.array(td.packed, copy=True)
+        b = pk.view(np.uint8).reshape(pk.shape[0], pk.shape[1] // 2, 16)
+        b[:, :, ::5] ^= 0x35
+        ivf.pq_transformed_points[big] = TransformedData(td.size, pk)
+    elif damage == "same_list":         # a label twice in one list
+        ids = np.array(ivf.ids[big], copy=True)
+        ids[1::7] = ids[0:-1:7][:len(ids[1::7])]
+        ivf.ids[big] = ids
+    dev = ivf.device_index()
+    assert (dev.twin_table_width() > 0) == (damage == "none")
+    ox = _oracle_of(oracle, ivf)
+    for n_probes in (5, 10):
+        out, dbg = dev.query_batch(g["qn"], g["qpq"], 10, n_probes, debug=True)
+        for qi in range(len(g["qn"])):
+            ids_, odbg = ox.query(g["qn"][qi], 10, n_probes=n_probes, debug=True)
+            np.testing.assert_array_equal(dbg["heap_idx"][qi], odbg["heap_idx"], err_msg=f"{damage} q{qi} p{n_probes}")
+            np.testing.assert_array_equal(dbg["heap_val"][qi], odbg["heap_val"], err_msg=f"{damage} q{qi} p{n_probes}")
+            np.testing.assert_array_equal(out[qi][:len(ids_)], ids_)
+
+
+def test_a_sharded_rank_vouches_only_for_lists_it_has_checked():
+    """tk_index_set_lists_shard hands a rank the codes of its own lists only: the library cannot check the premises, the
+    Python wrapper does on the host (all lists are there) and vouches — or does not."""
+    from conftest import golden
+    from test_hip_parity import ivf_from_fixture
+    from tinyknn_amd.fast_pq import TransformedData
+    from tinyknn_amd.ivf import DeviceIndex
+    from tinyknn_amd.multi_gpu import shard_lists
+    from tinyknn_amd import _lib
+    g = golden("g6_ivf_an100b2.npz")
+    ivf = ivf_from_fixture(None, g)
+    owner = shard_lists(np.asarray(g["list_sizes"], dtype=np.int64), 2)
+    good = DeviceIndex(ivf, owner, 0, 2)
+    assert good.twin_table_width() > 0 and good.shard_plain(10, 5, None)
+    good.close()
+    td = ivf.pq_transformed_points[0]
+    pk = np.array(td.packed, copy=True)
+    pk.view(np.uint8)[3] ^= 0x11
+    ivf.pq_transformed_points[0] = TransformedData(td.size, pk)
+    bad = DeviceIndex(ivf, owner, 0, 2)
+    assert not bad.shard_plain(10, 5, None)          # no TWIN replay: the plain path stays "on request only"
+    bad.close()

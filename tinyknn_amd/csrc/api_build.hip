@@ -329,6 +329,8 @@ extern "C" tk_index *tk_index_clone_shard(tk_index *src, const int32_t *owner, i
     ix->twin_list.borrow(src->twin_list);
     ix->twin_off.borrow(src->twin_off);
     ix->twin_w = src->twin_w;
+    ix->twin_unverified = src->twin_unverified;
+    ix->twin_vouched = src->twin_vouched;
     ix->opt_replay_twin = src->opt_replay_twin;
     ix->total_chunks = src->total_chunks; ix->total_ids = src->total_ids;
     ix->max_list_chunks = src->max_list_chunks;

@@ -101,6 +101,7 @@ extern "C" int tk_index_set_centers(tk_index *ix, const float *active_centers, i
 int build_twins(tk_index *ix, int64_t label_bound)
 {
     ix->twin_w = 0;
+    ix->twin_unverified = false;
     ix->twin_list.release();
     ix->twin_off.release();
     const int64_t T = ix->total_ids;
@@ -128,6 +129,20 @@ int build_twins(tk_index *ix, int64_t label_bound)
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipDeviceSynchronize());
             ix->twin_w = w;
+            ix->twin_unverified = ix->sharded;
+            if (!ix->sharded) {      // every list's codes are here: the table's two premises, checked (twins.hip)
+                HIPCHECK(hipMemsetAsync(cnt.p, 0, 4, 0));
+                tk_launch_twin_verify(ix->codes.as<uint4>(), ix->M / 2, ix->list_chunk_off.as<int64_t>(),
+                                      ix->ids_off.as<int64_t>(), (int)ix->n_lists, ix->twin_list.as<int32_t>(),
+                                      ix->twin_off.as<int32_t>(), w, T, cnt.as<int>(), 0);
+                int bad = 0;
+                HIPCHECK(hipMemcpy(&bad, cnt.p, 4, hipMemcpyDeviceToHost));
+                if (bad) {           // copies with different codes, or two in one list: the label-based test only
+                    ix->twin_w = 0;
+                    ix->twin_list.release();
+                    ix->twin_off.release();
+                }
+            }
         }
     }
     cnt.release();
@@ -307,6 +322,7 @@ bool plain_env_on()
 bool twin_replay(const tk_index *ix, const Plan &p)
 {
     return !ix->ids_unique && ix->twin_w > 0 && ix->opt_replay_twin == 1 && ix->heap_mode == 0 &&
+           (!ix->twin_unverified || ix->twin_vouched) &&
            ix->total_ids < (1ll << 31) && p.cap * 16 <= 0xffffff && tk_lanes_twin_fits(p.R, p.S, ix->n_lists);
 }
 
@@ -1695,6 +1711,10 @@ extern "C" int tk_index_set_option(tk_index *ix, int option, int value)
     case TK_OPT_REPLAY_TWIN:
         ARGCHECK(value == 0 || value == 1, "TK_OPT_REPLAY_TWIN: 0 or 1");
         ix->opt_replay_twin = value;
+        return TK_OK;
+    case TK_OPT_TWIN_VOUCH:
+        ARGCHECK(value == 0 || value == 1, "TK_OPT_TWIN_VOUCH: 0 or 1");
+        ix->twin_vouched = value != 0;
         return TK_OK;
     default:
         return fail(TK_ERR_ARG, "bad argument: unknown option");

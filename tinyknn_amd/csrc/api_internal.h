@@ -183,6 +183,10 @@ struct tk_index {
     // repeating labels: where the other copies of every stored row are (twins.hip); twin_w = copies - 1, 0 = no table
     DevBuf twin_list, twin_off;
     int twin_w = 0;
+    // the table rests on two facts the index build checks where it holds every list's codes (twins.hip: copies of a
+    // label lie in different lists and carry the same code); a rank that was handed only its own lists' codes
+    // (tk_index_set_lists_shard) cannot, and uses the table only if the caller vouches (TK_OPT_TWIN_VOUCH)
+    bool twin_unverified = false, twin_vouched = false;
     int opt_replay_twin = 1;   // TK_OPT_REPLAY_TWIN: 1 = the lane replay decides `insert`'s duplicate test from the twin table
     int64_t total_chunks = 0, total_ids = 0;
     int max_list_chunks = 0;

@@ -206,6 +206,9 @@ void tk_launch_heap_fill(int64_t *heap_idx, int32_t *heap_val, int64_t count, in
 
 // twins.hip: the other copies of every stored row (labels that repeat: IVF.build(n_probes >= 2))
 void tk_launch_twin_count(const int32_t *ids32, int64_t T, int *cnt, int *cnt_max, hipStream_t s);
+// *flag |= 1: two copies of a label with different codes; |= 2: two copies in one list (the TWIN form then does not apply)
+void tk_launch_twin_verify(const uint4 *codes, int P, const int64_t *list_chunk_off, const int64_t *ids_off, int n_lists,
+                           const int32_t *twin_list, const int32_t *twin_off, int w, int64_t T, int *flag, hipStream_t s);
 void tk_launch_twin_fill(const int32_t *ids32, int64_t T, int *cursor, int *where, int b, const int64_t *ids_off,
                          int n_lists, int32_t *twin_list, int32_t *twin_off, hipStream_t s);
 // single insert on a device heap (insertion-sort variant when `is`)

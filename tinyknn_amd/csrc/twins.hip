@@ -57,6 +57,50 @@ __global__ void twin_fill_kernel(const int32_t *__restrict__ ids32, int64_t T, c
     for (; k < w; k++) twin_list[i * w + k] = twin_off[i * w + k] = -1;
 }
 
+// What the TWIN form rests on, checked instead of assumed (an index may come from anywhere: tk_index_set_lists takes
+// any ids and codes): the copies of a label lie in DIFFERENT lists (flag bit 1 otherwise) and carry the SAME code
+// (bit 0 otherwise) — what IVF.build's lists have by construction (ivf.py:77-102: a list's codes are the codes of
+// data[ids]).  One thread per stored row: its own (list, offset) by a search of ids_off, then M/2 bytes of its
+// code against every other copy's.  codes: the tiled array of ALL lists (kernels.h), list_chunk_off its chunks.
+__global__ void twin_verify_kernel(const uint4 *__restrict__ codes, int P, const int64_t *__restrict__ list_chunk_off,
+                                   const int64_t *__restrict__ ids_off, int n_lists,
+                                   const int32_t *__restrict__ twin_list, const int32_t *__restrict__ twin_off, int w,
+                                   int64_t T, int *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    int lo = 0, hi = n_lists;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ids_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int64_t ga = list_chunk_off[lo] + ((i - ids_off[lo]) >> 4);     // the row's chunk in the whole array
+    const int ra = (int)((i - ids_off[lo]) & 15);
+    int bad = 0;
+    for (int u = 0; u < w; u++) {
+        const int l2 = twin_list[i * w + u];
+        if (l2 < 0) break;
+        if (l2 == lo) { bad |= 2; continue; }
+        const int64_t o2 = twin_off[i * w + u];
+        const int64_t gb = list_chunk_off[l2] + (o2 >> 4);
+        const int rb = (int)(o2 & 15);
+        for (int p = 0; p < P; p++) {
+            const uint8_t *a = (const uint8_t *)&codes[(ga >> 3) * (int64_t)(8 * P) + p * 8 + (ga & 7)];
+            const uint8_t *b = (const uint8_t *)&codes[(gb >> 3) * (int64_t)(8 * P) + p * 8 + (gb & 7)];
+            if (a[ra] != b[rb]) bad |= 1;
+        }
+    }
+    if (bad) atomicOr(flag, bad);
+}
+
+void tk_launch_twin_verify(const uint4 *codes, int P, const int64_t *list_chunk_off, const int64_t *ids_off, int n_lists,
+                           const int32_t *twin_list, const int32_t *twin_off, int w, int64_t T, int *flag, hipStream_t s)
+{
+    if (T == 0) return;
+    hipLaunchKernelGGL(twin_verify_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, codes, P, list_chunk_off,
+                       ids_off, n_lists, twin_list, twin_off, w, T, flag);
+}
+
 // cnt: label_bound ints, zeroed; returns the largest count through *cnt_max (device int, zeroed)
 void tk_launch_twin_count(const int32_t *ids32, int64_t T, int *cnt, int *cnt_max, hipStream_t s)
 {

@@ -111,6 +111,33 @@ class ResidentData:
         return self._dev.read_rows(rows).reshape(rows.shape + (self.shape[1],))
 
 
+def _copies_carry_one_code(ivf, n_lists):
+    """Rows with equal ids lie in different lists and carry equal codes — what IVF.build's lists have by construction
+    (ivf.py:77-102) and what the lane replay's TWIN form rests on (heap.hip).  The library checks it on the device
+    where it holds every list's codes; a rank of a list-sharded index uploads only its own lists, so this is the
+    same check on the host, over all lists, before the rank vouches (TK_OPT_TWIN_VOUCH)."""
+    labels, lists, sigs = [], [], []
+    for i in range(n_lists):
+        td = ivf.pq_transformed_points[i]
+        if isinstance(td, np.ndarray) or td.size == 0:
+            continue
+        pk = np.ascontiguousarray(td.packed, dtype=np.uint64)              # (chunks, M): per chunk M / 2 groups of 16 bytes
+        P = pk.shape[1] // 2
+        rows = pk.view(np.uint8).reshape(pk.shape[0], P, 16).transpose(0, 2, 1).reshape(-1, P)[:td.size]
+        labels.append(np.asarray(ivf.ids[i], dtype=np.int64)[:td.size])
+        lists.append(np.full(td.size, i, dtype=np.int64))
+        sigs.append(rows)
+    if not labels:
+        return True
+    labels, lists, sigs = np.concatenate(labels), np.concatenate(lists), np.concatenate(sigs)
+    order = np.lexsort((lists, labels))
+    la, li, sg = labels[order], lists[order], sigs[order]
+    same = la[1:] == la[:-1]
+    if (same & (li[1:] == li[:-1])).any():          # two copies in one list
+        return False
+    return bool((sg[1:][same] == sg[:-1][same]).all())
+
+
 class DeviceIndex:
     """HBM-resident copy of a built IVF (C ABI: tk_index_*)."""
 
@@ -180,6 +207,10 @@ class DeviceIndex:
             R = np.ascontiguousarray(pq.R, dtype=np.float64)
             _lib.check(L.tk_index_set_rotation(self._h, R.ctypes.data, R.shape[1]))
             self._R = R
+        # labels that repeat on a list-sharded rank: the library cannot check the twin table's premises against codes
+        # it was not given — the host can (all lists are here), and vouches
+        if owner is not None and self.twin_table_width() > 0 and _copies_carry_one_code(ivf, self.n_lists):
+            self.set_option(_lib.OPT_TWIN_VOUCH, 1)
 
     @classmethod
     def resident(cls, ivf, N, d):
