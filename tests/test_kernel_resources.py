@@ -56,7 +56,7 @@ NO_SCRATCH_FILES = ("adc_scan.hip", "plain_scan.hip", "tables.hip", "rescore.hip
 # ... and its TWIN form: kernel arguments that are only needed behind the replay loop, parked in VGPR lanes in the
 # prologue and fetched back in the epilogue (no v_readlane / v_writelane inside the loop: read off the ISA)
 SGPR_SPILLS_OK = {"heap_replay_lanes_kernelILb1ELb1ELi32ELb0ELb0EE": 40, "heap_replay_lanes_kernelILb0ELb1ELi32ELb0ELb0EE": 40,
-                  "heap_replay_lanes_kernelILb1ELb0ELi64ELb0ELb1EE": 16, "heap_replay_lanes_kernelILb0ELb0ELi64ELb0ELb1EE": 16,
+                  "heap_replay_lanes_kernelILb1ELb0ELi64ELb0ELb1EE": 24, "heap_replay_lanes_kernelILb0ELb0ELi64ELb0ELb1EE": 24,
                   "heap_replay_lanes_kernelILb1ELb0ELi64ELb1ELb1EE": 24, "heap_replay_lanes_kernelILb0ELb0ELi64ELb1ELb1EE": 24,
                   "scan_plain_wave_kernelILi26ELb0EE": 16}
 
@@ -109,3 +109,30 @@ def test_no_kernel_of_the_hot_files_uses_scratch(usage):
             if v.get("ScratchSize", 0) != 0 or v.get("VGPRs Spill", 0) != 0 or v.get("SGPRs Spill", 0) > ok_sgpr:
                 bad[k] = {x: v.get(x) for x in ("ScratchSize", "VGPRs Spill", "SGPRs Spill")}
     assert not bad, bad
+
+
+def test_twin_replay_parks_its_sgprs_outside_the_loops():
+    """The TWIN form of the lane replay reports SGPR spills: kernel arguments that are only needed behind the replay
+    loop.  They must stay there — no v_readlane / v_writelane in any basic block of a loop (read off the ISA)."""
+    if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "heap.s")
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                            "--cuda-device-only", "-S", "-o", out, "heap.hip"], cwd=CSRC, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = open(out).read()
+    seen = 0
+    for name in re.findall(r"^(_Z24heap_replay_lanes_kernelILb[01]ELb0ELi64ELb[01]ELb1EE\S*):", asm, flags=re.M):
+        body = asm[asm.index("\n" + name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        in_loop = False
+        for line in body.split("\n"):
+            m = re.match(r"^\.LBB\d+_\d+:\s*(;.*)?", line)
+            if m:
+                in_loop = "Loop" in (m.group(1) or "")
+            elif in_loop:
+                assert "v_readlane" not in line and "v_writelane" not in line, (name[:60], line.strip())
+        seen += 1
+    assert seen == 4

@@ -681,10 +681,8 @@ __global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq
 // so far answers "not probed" for most rows at once, the probe list in LDS answers exactly.  The hash set
 // of the DEDUPE form (64 KB per 64 queries, its removal and insertion inside every round) is gone: 64
 // queries per wave, three workgroups per CU, the LAZY form and pairs of calls apply as with distinct labels.
-// (amdgpu_waves_per_eu(1, 4): a replay never has more than one wave on a SIMD — 157 to 314 waves on 1024 — so the
-//  compiler is not to trade registers for an occupancy nothing uses: the LAZY form spilled 48 B per lane to reach 7)
 template <bool SIGNED, bool DEDUPE, int LW, bool LAZY = false, bool TWIN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void heap_replay_lanes_kernel(
+__global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const uint4 *__restrict__ dist, int64_t cap, int64_t nq, const int *__restrict__ slot_prefix,
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
@@ -789,6 +787,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     // TWIN: f (see the head of the kernel), pm = bit (list & 63) of every list replayed before slot s
     int f = 0x7fffffff;
     uint64_t pm = 0;
+    int se_cur = 0x7fffffff, sb_cur = 0;      // SE[s], SB[s] of the slot the cursor is in
+    if (TWIN && S > 0) {
+        se_cur = valid ? prefix[1] : 0x7fffffff;
+        sb_cur = (int)(slot_label_off[qs * S] - 16 * (int64_t)prefix[0]);
+    }
     if (TWIN) {
         const int64_t *pq = tw.probes + qc * S;
         for (int g = 0; g < S4; g++) {
@@ -878,40 +881,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         uint32_t lab_next = 0;        // DEDUPE: label of the lowest pending row, fetched ahead
         int lab_base = 0;             //         labels32 index of row 0 of the current block
         int tw_next = -1;             // TWIN: list of the lowest pending row's first other copy, fetched ahead
-        // next block of this segment with a byte below the live bound
-        auto advance = [&]() {
-            while (bits == 0 && hit) {
-                const int k = __builtin_ctz(hit);
-                hit &= hit - 1;
-                cur = 16 * g + k;
-                if (LAZY) {
-                    if (cur == pre_blk) dd = pre;           // (requested while the previous segment was replayed)
-                    else dd = drow[cur < last_blk ? cur : last_blk];
-                } else {
-                    dd = ST[(buf * 16 + k) * LW + lane];
-                }
-                // `pos < n` (:111): the rows that pad a list's last chunk were set to the largest
-                // value by pad_fix_kernel and can never be below a bound — no row count, and
-                // with distinct labels no slot cursor at all, is needed here
-                bits = mask_lt16_swar<SIGNED>(dd, bb);        // cmp_mask, _fast_pq_256.pyx:81-90
-                if (DEDUPE && bits) {
-                    while (cur >= SE[s * LW + lane]) s++;   // next probed list (empty ones stepped over)
-                    lab_base = SB[s * LW + lane] + 16 * cur;
-                    lab_next = (uint32_t)labels32[(int64_t)lab_base + __builtin_ctz(bits)];
-                }
-                if (TWIN && bits) {
-                    while (cur >= SE[s * LW + lane]) {      // next probed list: the one left joins the set
-                        const int cs = ((const int *)PL)[(((s >> 2) * LW + lane) << 2) + (s & 3)];
-                        if (BMW) BM[(cs >> 5) * LW + lane] |= 1u << (cs & 31);
-                        else pm |= 1ull << (cs & 63);
-                        s++;
-                    }
-                    lab_base = SB[s * LW + lane] + 16 * cur;
-                    // (rows of the first probed list have no earlier copy: nothing to ask)
-                    if (s > 0) tw_next = tw.list[(lab_base + __builtin_ctz(bits)) * tw.w];
-                }
+        // next block of this segment with a byte below the live bound (a macro, not a lambda: inline at the head of the
+        // round loop the compiler folds this loop into it; as a lambda it stayed a nested loop of its own and the form
+        // without a duplicate test lost 7 % alone).  `pos < n` (:111): the rows that pad a list's last chunk were set to the
+        // largest value by pad_fix_kernel and can never be below a bound — no row count, and with distinct labels no slot
+        // cursor at all, is needed; cmp_mask: _fast_pq_256.pyx:81-90; DEDUPE / TWIN: the slot cursor steps over empty lists,
+        // TWIN: the list left joins the set, rows of the first probed list have no earlier copy (nothing to ask)
+#define TK_ADVANCE() \
+            while (bits == 0 && hit) { \
+                const int k = __builtin_ctz(hit); \
+                hit &= hit - 1; \
+                cur = 16 * g + k; \
+                if (LAZY) { \
+                    if (cur == pre_blk) dd = pre; \
+                    else dd = drow[cur < last_blk ? cur : last_blk]; \
+                } else { \
+                    dd = ST[(buf * 16 + k) * LW + lane]; \
+                } \
+                bits = mask_lt16_swar<SIGNED>(dd, bb); \
+                if (DEDUPE && bits) { \
+                    while (cur >= SE[s * LW + lane]) s++; \
+                    lab_base = SB[s * LW + lane] + 16 * cur; \
+                    lab_next = (uint32_t)labels32[(int64_t)lab_base + __builtin_ctz(bits)]; \
+                } \
+                if (TWIN && bits) { \
+                    while (cur >= se_cur) { \
+                        const int cs = ((const int *)PL)[(((s >> 2) * LW + lane) << 2) + (s & 3)]; \
+                        if (BMW) BM[(cs >> 5) * LW + lane] |= 1u << (cs & 31); \
+                        else pm |= 1ull << (cs & 63); \
+                        s++; \
+                        se_cur = SE[s * LW + lane]; \
+                        sb_cur = SB[s * LW + lane]; \
+                    } \
+                    lab_base = sb_cur + 16 * cur; \
+                    if (s > 0) tw_next = tw.list[(lab_base + __builtin_ctz(bits)) * tw.w]; \
+                } \
             }
-        };
         // One round: every lane without a pending candidate looks for its next block (`advance`, one call site); the
         // lanes with one take it through the duplicate test and `insert` — register levels, then LDS levels.  TWIN
         // with staged blocks (EARLY) looks between the two: the new root — the bound behind the block — is known
@@ -921,9 +926,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         // form's next passing block ahead of the insert in the same manner was measured and is not kept (100M x 128:
         // 6.27 M queries/s with, 6.27 without, same box).
         constexpr bool EARLY = TWIN && !LAZY;
+        // `insert` below node j (3..6): children in LDS, branch-free per level — rows R and R+1 hold a value no entry
+        // exceeds, so children beyond the heap (clamped to R) are never taken
+        auto lds_levels = [&](int j, const uint32_t entry, const int v) {
+            bool first = true, go = true;
+            do {
+                const int l = 2 * j + 1;
+                const int lc = l < R ? l : R;
+                const uint32_t el = H[lc * LW + lane];
+                const uint32_t er = H[(lc + 1) * LW + lane];
+                const int vl = entry_val<SIGNED>(el), vr = entry_val<SIGNED>(er);
+                const bool cl = vl > v;                 // vals[l] > nxt_val
+                const int nvv = cl ? vl : v;
+                uint32_t ne = cl ? el : entry;
+                int nxt = cl ? l : j;
+                const bool cr = vr > nvv;               // vals[r] > nxt_val
+                ne = cr ? er : ne;
+                nxt = cr ? l + 1 : nxt;
+                if (first) {
+                    h3 = j == 3 ? ne : h3; h4 = j == 4 ? ne : h4;
+                    h5 = j == 5 ? ne : h5; h6 = j == 6 ? ne : h6;
+                    first = false;
+                } else {
+                    H[j * LW + lane] = ne;              // entry itself when nxt == j
+                }
+                go = nxt != j;
+                j = nxt;
+            } while (go);
+        };
         for (;;) {
             if (!EARLY) {
-                advance();
+                TK_ADVANCE()
                 if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
                 rounds++;
             }
@@ -1057,56 +1090,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                         const bool cb = vb > nv1;
                         const uint32_t ne1 = cb ? b : (ca ? a : entry);
                         if (c2) h2 = ne1; else h1 = ne1;
-                        if (ca | cb) j = (c2 ? 5 : 3) + (cb ? 1 : 0);
+                        if (ca | cb) {
+                            j = (c2 ? 5 : 3) + (cb ? 1 : 0);
+                            if (!EARLY) lds_levels(j, entry, v);        // (EARLY: behind the look-ahead below)
+                        }
                     }
                 }
-                // the new root is known: the bound after the block (:123) does not wait for the levels below
+                // refresh after the block, :123 (EARLY: the new root is known behind the register levels — the bound
+                // does not wait for the levels below)
                 if (bits == 0) {
                     bound = h0 >> 24;
                     bb = bound_bytes<SIGNED>(bound);
                     b_plain = cur < plain0 ? bound : b_plain;
                 }
             }
-            if (EARLY) advance();
-            {
-                if (j)
-                {
-                    {
-                        {
-                            bool first = true, go = true;
-                            do {
-                                const int l = 2 * j + 1;
-                                const int lc = l < R ? l : R;
-                                const uint32_t el = H[lc * LW + lane];
-                                const uint32_t er = H[(lc + 1) * LW + lane];
-                                const int vl = entry_val<SIGNED>(el), vr = entry_val<SIGNED>(er);
-                                const bool cl = vl > v;                 // vals[l] > nxt_val
-                                const int nvv = cl ? vl : v;
-                                uint32_t ne = cl ? el : entry;
-                                int nxt = cl ? l : j;
-                                const bool cr = vr > nvv;               // vals[r] > nxt_val
-                                ne = cr ? er : ne;
-                                nxt = cr ? l + 1 : nxt;
-                                if (first) {
-                                    h3 = j == 3 ? ne : h3; h4 = j == 4 ? ne : h4;
-                                    h5 = j == 5 ? ne : h5; h6 = j == 6 ? ne : h6;
-                                    first = false;
-                                } else {
-                                    H[j * LW + lane] = ne;              // entry itself when nxt == j
-                                }
-                                go = nxt != j;
-                                j = nxt;
-                            } while (go);
-                        }
-                    }
-                }
-            }
             if (EARLY) {
+                TK_ADVANCE()
+                if (j) lds_levels(j, entry, v);
                 if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) break;
                 rounds++;
             }
         }
     }
+#undef TK_ADVANCE
 #undef TK_FETCH_BLOCKS
 #undef TK_MINS_ROW
     if (dbg && lane == 0) {       // TK_OPT_REPLAY_COUNT: [0] += rounds, [1] = max rounds of a wave, [2] += waves, [3] += segments
