@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     // DEDUPE: slot table of the lane's query, SE[s][lane] = first flat chunk past slot s,
     // SB[s][lane] = label offset of slot s - 16 * its first flat chunk (label of row r of flat
     // chunk c in slot s = labels32[SB[s] + 16 c + r])
-    int *SE = (int *)(ST + 16 * LW);
+    int *SE = (int *)(ST + (LAZY && !DEDUPE ? 0 : 16 * LW));      // (the LAZY form stages nothing: no ST rows)
     int *SB = SE + (size_t)S * LW;
     // TWIN: the probed lists of the lane's query, four to a uint4: PL[t / 4][lane]
     uint4 *PL = (uint4 *)(SB + (size_t)S * LW);
@@ -1384,8 +1384,10 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     const int LWr = dedupe ? 32 : 64;
     // heap columns (+ label slots) + one staged segment (16 blocks x LW lanes x 16 B; the next one
     // waits in registers), scaled to the columns in use
-    const size_t lds = twin ? tk_lanes_twin_lds(R, S, tw.bm_words) + 16384
-                            : tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64 + (size_t)16384 * LWr / 64;
+    // (the LAZY form stages nothing: no ST rows)
+    const size_t st_rows = lazy && !dedupe ? 0 : (size_t)16384;
+    const size_t lds = twin ? tk_lanes_twin_lds(R, S, tw.bm_words) + st_rows
+                            : tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64 + st_rows * LWr / 64;
     static bool attr_set = false;
     if (!attr_set) {
         const void *fns[] = {(const void *)heap_replay_lanes_kernel<true, false, 64>,
