@@ -850,13 +850,24 @@ int stage_coarse_rest(tk_index *ix, Work &w, const float *q_dev, int64_t nq, con
 // rescoring.  q_dev: row 0 = query q0.
 // the queries the lane replay flagged (bound above the table's limit at the first plain block:
 // plain_scan.hip): every probed list again with the exact kernel, then the replay again
-static void rescan_flagged(tk_index *ix, Work &w, int64_t q0, int64_t nq, const Plan &p, hipStream_t st)
+// the flagged count is on its way to the page-locked word: the event the state machine polls behind
+static void plain_verdict_event(tk_index *ix, Work &w, int64_t nq, hipStream_t st)
 {
-    int *list = w.flag_list.as<int>();
-    tk_launch_flagged_list(w.repeat_flag.as<unsigned char>() + q0, nq, list, st, w.flag_host);
     if (w.plain_ev && !ix->capturing && hipEventRecord(w.plain_ev, st) == hipSuccess) {
         w.plain_pending = true;
         w.plain_nq = nq;
+    }
+}
+
+// list_built: the lane replay compiled the list of flagged queries itself (tk_launch_heap_replay_lanes' flag_list); the
+// count then reaches the host through the packed kernel behind the re-scan (plain_verdict_event there)
+static void rescan_flagged(tk_index *ix, Work &w, int64_t q0, int64_t nq, const Plan &p, hipStream_t st,
+                           bool list_built = false)
+{
+    int *list = w.flag_list.as<int>();
+    if (!list_built) {
+        tk_launch_flagged_list(w.repeat_flag.as<unsigned char>() + q0, nq, list, st, w.flag_host);
+        plain_verdict_event(ix, w, nq, st);
     }
     tk_launch_scan_probes(ix->codes.as<uint4>(), ix->M, w.tables.as<uint4>() + q0 * ix->M, nq,
                           w.slot_prefix.as<int>() + q0 * (p.S + 1), w.slot_chunk0.as<int64_t>() + q0 * p.S,
@@ -902,18 +913,28 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
                                              w.heap_idx.as<int64_t>(), w.heap_val.as<int32_t>(),
                                              p.R, 1, 0, repeat_flag, w.mins.as<uint8_t>(),
                                              p.cap_min, nullptr, st, slot_exact, qlim, lazy,
-                                             ix->opt_replay_count ? ix->replay_counters.as<unsigned long long>() : nullptr))
+                                             ix->opt_replay_count ? ix->replay_counters.as<unsigned long long>() : nullptr,
+                                             nullptr, lanes && plain && !plain_flag ? w.flag_list.as<int>() : nullptr))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
         if (plain && plain_flag) {
             tk_launch_shard_flag_plain(repeat_flag, nq, plain_flag, st);
+        } else if (plain && lanes) {
+            // flag 2 = the lane replay's "bound above the limit at the first plain block", flag 1 = a probe list that
+            // names a list twice: exact re-scan of both kinds (the lane replay listed them), then ONE launch of the
+            // packed kernel with the duplicate test from fresh heaps (where labels are distinct the test never fires)
+            rescan_flagged(ix, w, q0, nq, p, st, true);
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, -1, 1, st,
+                                         w.flag_list.as<int>(), w.flag_host);
+            plain_verdict_event(ix, w, nq, st);
         } else if (plain) {
-            // flag 2 = the lane replay's "bound above the limit at the first plain block": exact
-            // re-scan, then the packed kernel from a fresh heap (labels are distinct: no duplicate test)
             rescan_flagged(ix, w, q0, nq, p, st);
             tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                          p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                          w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 2, 0, st);
         }
+        if (!(plain && lanes && !plain_flag))
         tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                      p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                      w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
@@ -935,19 +956,25 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
                                         0, repeat_flag, w.mins.as<uint8_t>(), p.cap_min, nullptr, st,
                                         slot_exact, qlim, lazy,
                                         ix->opt_replay_count ? ix->replay_counters.as<unsigned long long>() : nullptr,
-                                        &tw))
+                                        &tw, plain && !plain_flag ? w.flag_list.as<int>() : nullptr))
             return fail(TK_ERR_HIP, "hipFuncSetAttribute(LDS size) failed");
         if (plain && plain_flag) {
             tk_launch_shard_flag_plain(repeat_flag, nq, plain_flag, st);
-        } else if (plain) {
-            rescan_flagged(ix, w, q0, nq, p, st);
             tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                          p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 2, 1, st);
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
+        } else if (plain) {         // (flags 1 and 2 alike: re-scan, one launch of the packed kernel)
+            rescan_flagged(ix, w, q0, nq, p, st, true);
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, -1, 1, st,
+                                         w.flag_list.as<int>(), w.flag_host);
+            plain_verdict_event(ix, w, nq, st);
+        } else {
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
         }
-        tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
-                                     p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                     w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
     } else if (packed_ok && ix->have_ids32 && ix->heap_mode == 0 && tk_lanes_dedupe_fits(p.R, p.S) &&
                ix->total_ids < (1ll << 31)) {
         // repeating labels that fit int32: one query per lane with the duplicate test

@@ -621,9 +621,11 @@ __device__ __forceinline__ uint32_t mask_lt16_swar(const uint4 v, uint32_t bb)
 template <bool SIGNED>
 __global__ void pad_fix_kernel(uint4 *__restrict__ dist, int64_t cap, int64_t nq,
                                const int *__restrict__ slot_prefix, const int *__restrict__ slot_n,
-                               int S, int slots_uniform, uint8_t *__restrict__ mins, int64_t cap_min)
+                               int S, int slots_uniform, uint8_t *__restrict__ mins, int64_t cap_min,
+                               int *__restrict__ flag_list)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && flag_list) flag_list[0] = 0;      // the lane replay behind this kernel appends the queries it flags
     if (i >= nq * S) return;
     const int64_t q = i / S;
     const int sl = (int)(i - q * S);
@@ -689,7 +691,8 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
     unsigned char *__restrict__ skip, int nbuf, const uint8_t *__restrict__ mins,
     int64_t cap_min, const int32_t *__restrict__ labels32, unsigned long long *__restrict__ dbg,
-    int prio, int wave_lds, const int *__restrict__ plain0_arr, const int *__restrict__ qlim, const TkTwins tw)
+    int prio, int wave_lds, const int *__restrict__ plain0_arr, const int *__restrict__ qlim, const TkTwins tw,
+    int *__restrict__ flag_list)
 {
     static_assert(!(TWIN && DEDUPE), "one form of the duplicate test");
     // the replay is a chain of dependent LDS round trips on 157 waves; when it shares SIMDs
@@ -1129,9 +1132,18 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     if (R > 4) H[4 * LW + lane] = h4;
     if (R > 5) H[5 * LW + lane] = h5;
     if (R > 6) H[6 * LW + lane] = h6;
-    if (!valid) return;
+    // flag_list: the queries left to the kernels behind this one — flagged before it (probe lists that name a list
+    // twice) or by the check below — [0] = their count (zeroed by pad_fix_kernel), then their numbers in any order:
+    // what a separate one-workgroup kernel over all nq flags used to compile (30 us of every batch's replay stream)
+    if (!valid) {
+        if (flag_list && q < nq) flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
+        return;
+    }
     // re-scan + replay again: flag 2 with distinct labels (no duplicate test needed then) and from the TWIN form, 1 otherwise
-    if (plain0_arr && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) skip[q] = DEDUPE ? 1 : 2;
+    if (plain0_arr && plain0 < total && (int)(int8_t)b_plain > qlim[qc]) {
+        skip[q] = DEDUPE ? 1 : 2;
+        if (flag_list) flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
+    }
     // ---- resolve flat positions (or slots) to labels
     const int64_t *loffs = slot_label_off + qs * S;
     for (int j = 0; j < R; j++) {
@@ -1176,8 +1188,11 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
     const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off, int S,
     const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx,
     int32_t *__restrict__ heap_val, int R, int slots_uniform,
-    const unsigned char *__restrict__ flags, int run_if, int64_t nq)
+    const unsigned char *__restrict__ flags, int run_if, int64_t nq, const int *__restrict__ flag_list,
+    volatile int *host_count)
 {
+    // (the count of the flagged queries to the page-locked word the host polls: plain_scan's state machine)
+    if (host_count && flag_list && blockIdx.x == 0 && threadIdx.x == 0) *host_count = flag_list[0];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6;
     const size_t wstride = DEDUPE ? (((size_t)R * 12 + 15) & ~(size_t)15) : (size_t)R * 4;
@@ -1186,7 +1201,7 @@ __global__ __launch_bounds__(64 * TK_HEAP_WAVES) void heap_replay_packed_kernel(
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (q >= nq) return;   // wave-uniform; no workgroup barrier below
-    if (flags && (int)flags[q] != run_if) return;
+    if (flags && (run_if < 0 ? flags[q] == 0 : (int)flags[q] != run_if)) return;      // run_if < 0: every flagged query
     const int64_t qs = slots_uniform ? 0 : q;
     const int *prefix = slot_prefix + qs * (S + 1);
     const uint4 *drow = dist + q * cap;
@@ -1319,7 +1334,7 @@ void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, co
                                   const int *slot_n, const int64_t *slot_label_off, int S,
                                   const int64_t *labels, int64_t *heap_idx, int32_t *heap_val,
                                   int R, int signd, int slots_uniform, const unsigned char *flags,
-                                  int run_if, int dedupe, hipStream_t s)
+                                  int run_if, int dedupe, hipStream_t s, const int *flag_list, int *host_count)
 {
     if (nq == 0 || R == 0) return;
     const size_t wstride = dedupe ? (((size_t)R * 12 + 15) & ~(size_t)15) : (size_t)R * 4;
@@ -1330,7 +1345,7 @@ void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, co
 #define TK_LAUNCH(S_, D_)                                                                        \
     hipLaunchKernelGGL((heap_replay_packed_kernel<S_, D_>), grid, block, lds, s, dist, cap,      \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,    \
-                       slots_uniform, flags, run_if, nq)
+                       slots_uniform, flags, run_if, nq, flag_list, host_count)
     if (signd) { if (dedupe) TK_LAUNCH(true, true); else TK_LAUNCH(true, false); }
     else { if (dedupe) TK_LAUNCH(false, true); else TK_LAUNCH(false, false); }
 #undef TK_LAUNCH
@@ -1367,7 +1382,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 int signd, int slots_uniform, unsigned char *skip,
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
                                 hipStream_t s, const int *plain0, const int *qlim, int lazy,
-                                unsigned long long *counters, const TkTwins *twins)
+                                unsigned long long *counters, const TkTwins *twins, int *flag_list)
 {
     if (nq == 0 || R == 0) return 0;
     if (!plain0 || !qlim || !skip || !signd) plain0 = qlim = nullptr;
@@ -1411,10 +1426,10 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
         const unsigned pg = (unsigned)((items + 255) / 256);
         if (items > 0 && signd)
             hipLaunchKernelGGL(pad_fix_kernel<true>, dim3(pg), dim3(256), 0, s, (uint4 *)dist, cap, nq,
-                               slot_prefix, slot_n, S, slots_uniform, (uint8_t *)mins, cap_min);
+                               slot_prefix, slot_n, S, slots_uniform, (uint8_t *)mins, cap_min, flag_list);
         else if (items > 0)
             hipLaunchKernelGGL(pad_fix_kernel<false>, dim3(pg), dim3(256), 0, s, (uint4 *)dist, cap, nq,
-                               slot_prefix, slot_n, S, slots_uniform, (uint8_t *)mins, cap_min);
+                               slot_prefix, slot_n, S, slots_uniform, (uint8_t *)mins, cap_min, flag_list);
     }
     // one query-wave per workgroup (multi-wave workgroups are placed only when a whole CU has room,
     // which next to the persistent scan kernels means at their launch boundaries)
@@ -1426,14 +1441,14 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, D_, L_>), grid, dim3(64), lds, s, dist, cap, nq,  \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, 1, mins, cap_min, labels32, counters, prio, wave_lds,  \
-                       plain0, qlim, tw)
+                       plain0, qlim, tw, flag_list)
     if (dedupe) { if (signd) TK_LAUNCH3(true, true, 32); else TK_LAUNCH3(false, true, 32); }
     else if (twin) {
 #define TK_LAUNCH_TWIN(S_, Z_)                                                                    \
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, false, 64, Z_, true>), grid, dim3(64), lds, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, 1, mins, cap_min, labels32, counters, prio, wave_lds,  \
-                       plain0, qlim, tw)
+                       plain0, qlim, tw, flag_list)
         if (signd) { if (lazy) TK_LAUNCH_TWIN(true, true); else TK_LAUNCH_TWIN(true, false); }
         else { if (lazy) TK_LAUNCH_TWIN(false, true); else TK_LAUNCH_TWIN(false, false); }
 #undef TK_LAUNCH_TWIN
@@ -1442,7 +1457,7 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     hipLaunchKernelGGL((heap_replay_lanes_kernel<S_, false, 64, true>), grid, dim3(64), lds, s, dist, cap, nq, \
                        slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R,     \
                        slots_uniform, skip, 1, mins, cap_min, labels32, counters, prio, wave_lds,  \
-                       plain0, qlim, tw)
+                       plain0, qlim, tw, flag_list)
         if (signd) TK_LAUNCH_LAZY(true); else TK_LAUNCH_LAZY(false);
 #undef TK_LAUNCH_LAZY
     } else { if (signd) TK_LAUNCH3(true, false, 64); else TK_LAUNCH3(false, false, 64); }

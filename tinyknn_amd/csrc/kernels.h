@@ -186,7 +186,9 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
                                 const uint8_t *mins, int64_t cap_min, const int32_t *labels32,
                                 hipStream_t s, const int *plain0 = nullptr, const int *qlim = nullptr,
                                 int lazy = 0, unsigned long long *counters = nullptr,
-                                const TkTwins *twins = nullptr);
+                                const TkTwins *twins = nullptr, int *flag_list = nullptr);
+// flag_list (nq + 1 ints, or NULL): [0] = how many queries this replay leaves to the kernels behind it (flagged in
+// `skip` before it, or by its own check), then their numbers in any order — tk_launch_scan_probes' `only`
 // lazy: blocks are fetched only where their minimum passes (rows far longer than the heap; distinct labels)
 // twins (labels32 == NULL): labels may repeat, every label's copies carry ONE value, and the duplicate test is
 // decided from the twin table (heap.hip, TWIN form); `skip` must flag the queries that probe a list twice
@@ -199,7 +201,9 @@ void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, co
                                   const int *slot_n, const int64_t *slot_label_off, int S,
                                   const int64_t *labels, int64_t *heap_idx, int32_t *heap_val,
                                   int R, int signd, int slots_uniform, const unsigned char *flags,
-                                  int run_if, int dedupe, hipStream_t s);
+                                  int run_if, int dedupe, hipStream_t s, const int *flag_list = nullptr,
+                                  int *host_count = nullptr);
+// run_if < 0: every query with a non-zero flag.  flag_list + host_count (page-locked): *host_count = flag_list[0]
 
 void tk_launch_heap_fill(int64_t *heap_idx, int32_t *heap_val, int64_t count, int32_t v,
                          hipStream_t s);
