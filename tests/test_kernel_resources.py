@@ -55,7 +55,7 @@ NO_SCRATCH_FILES = ("adc_scan.hip", "plain_scan.hip", "tables.hip", "rescore.hip
 # ... and the SSE-order form of the plain kernel (the reference's non-AVX module order; no BASELINE config)
 # ... and its TWIN form: kernel arguments that are only needed behind the replay loop, parked in VGPR lanes in the
 # prologue and fetched back in the epilogue (no v_readlane / v_writelane inside the loop: read off the ISA)
-SGPR_SPILLS_OK = {"heap_replay_lanes_kernelILb1ELb1ELi32ELb0ELb0EE": 40, "heap_replay_lanes_kernelILb0ELb1ELi32ELb0ELb0EE": 40,
+SGPR_SPILLS_OK = {"heap_replay_lanes_kernelILb1ELb1ELi32ELb0ELb0EE": 48, "heap_replay_lanes_kernelILb0ELb1ELi32ELb0ELb0EE": 48,
                   "heap_replay_lanes_kernelILb1ELb0ELi64ELb0ELb1EE": 24, "heap_replay_lanes_kernelILb0ELb0ELi64ELb0ELb1EE": 24,
                   "heap_replay_lanes_kernelILb1ELb0ELi64ELb1ELb1EE": 24, "heap_replay_lanes_kernelILb0ELb0ELi64ELb1ELb1EE": 24,
                   "scan_plain_wave_kernelILi26ELb0EE": 16}
