@@ -185,3 +185,42 @@ def test_a_sharded_rank_vouches_only_for_lists_it_has_checked():
     bad = DeviceIndex(ivf, owner, 0, 2)
     assert not bad.shard_plain(10, 5, None)          # no TWIN replay: the plain path stays "on request only"
     bad.close()
+
+
+def test_default_build_at_full_size(oracle):
+    """BASELINE configs[1]'s data set built the reference's DEFAULT way — IVF.build(n_probes=2), ivf.py:53: 2.37 M stored
+    rows in 1087 lists — as bench.py's sweep measures it: ids of 2048 queries at n_probes 1 / 10 / 20 against the
+    oracle, one batch at a time and pipelined + paired, both forms of the duplicate test; heap arrays of a sample."""
+    import argparse, os, sys
+    import torch
+    from tinyknn_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    args = argparse.Namespace(n=1183514, d=100, n_clusters=1087, seed=10, build_probes=2,
+                              metric="angular", data="glove-like", fit_sample=100000,
+                              cache_dir=os.environ.get("TMPDIR", "/tmp"), data_file=None)
+    ivf, cent = bench.build_index(args, torch.device("cuda", 0))
+    ox = bench.oracle_index(ivf)
+    qs = bench.synth_queries(cent, 2048, 777, kind="glove-like")
+    qn, qp = ivf._prepare(qs.copy())
+    dev = ivf.device_index()
+    assert dev.twin_table_width() == 1 and sum(len(x) for x in ivf.ids) == 2 * 1183514
+    try:
+        for n_probes in (1, 10, 20):
+            want = ox.query_batch(qn, 10, n_probes)
+            for twin, depth in ((1, 1), (1, 2), (0, 1)):
+                dev.set_option(_lib.OPT_REPLAY_TWIN, twin)
+                dev.set_pipeline(depth)
+                dev.set_coalesce(2 if depth > 1 else 1)
+                got = dev.query_batch(qn, qp, 10, n_probes)
+                bad = np.flatnonzero((got != want).any(axis=1))
+                assert bad.size == 0, (n_probes, twin, depth, bad[:5])
+            dev.set_pipeline(1); dev.set_coalesce(1); dev.set_option(_lib.OPT_REPLAY_TWIN, 1)
+            _, dbg = dev.query_batch(qn[:64], qp[:64], 10, n_probes, debug=True)
+            for qi in range(0, 64, 7):
+                _, odbg = ox.query(qn[qi], 10, n_probes=n_probes, debug=True)
+                np.testing.assert_array_equal(dbg["heap_idx"][qi], odbg["heap_idx"])
+                np.testing.assert_array_equal(dbg["heap_val"][qi], odbg["heap_val"])
+    finally:
+        dev.set_pipeline(1); dev.set_coalesce(1); dev.set_option(_lib.OPT_REPLAY_TWIN, 1)
