@@ -562,6 +562,9 @@ void tk_launch_flat_top_one(const uint4 *dist, const uint8_t *mins, int chunks, 
 //     tests 16 minima at once and touches only blocks that can contain a hit;
 //   * the top three heap levels (nodes 0..6) are kept in registers;
 //   * labels are resolved from the flat positions once, at the end.
+#ifndef TK_LANES_SEG
+#define TK_LANES_SEG 16     // blocks per staged segment of the lane replay's forms without a hash set: 16 or 8
+#endif
 template <bool SIGNED>
 __device__ __forceinline__ int entry_val(uint32_t e)
 {
@@ -717,7 +720,8 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     // DEDUPE: slot table of the lane's query, SE[s][lane] = first flat chunk past slot s,
     // SB[s][lane] = label offset of slot s - 16 * its first flat chunk (label of row r of flat
     // chunk c in slot s = labels32[SB[s] + 16 c + r])
-    int *SE = (int *)(ST + (LAZY && !DEDUPE ? 0 : 16 * LW));      // (the LAZY form stages nothing: no ST rows)
+    // (staging rows: 16 blocks with the hash set, TK_LANES_SEG otherwise, none when LAZY)
+    int *SE = (int *)(ST + (DEDUPE ? 16 : LAZY ? 0 : TK_LANES_SEG) * LW);
     int *SB = SE + (size_t)S * LW;
     // TWIN: the probed lists of the lane's query, four to a uint4: PL[t / 4][lane]
     uint4 *PL = (uint4 *)(SB + (size_t)S * LW);
@@ -770,7 +774,11 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     const int plain0 = (plain0_arr && valid) ? plain0_arr[qc] : 0x7fffffff;
     uint32_t b_plain = SIGNED ? 0x7fu : 0xffu;
     const uint4 *mrow = (const uint4 *)(mins + qc * cap_min);   // per-block minima, 16 per uint4
-    int nseg = (total + 15) >> 4;
+    // Blocks per staged segment.  The staging rows are LDS SPACE, which is what the pipelined batch runs out of
+    // (DESIGN §3.6): the forms without a hash set stage 8 blocks at a time (8 KB per wave instead of 16, 32 prefetch
+    // registers instead of 64); the minima still arrive 16 to a load, a pair of segments shares one.
+    constexpr int SEG = (LAZY || DEDUPE) ? 16 : TK_LANES_SEG;
+    int nseg = (total + SEG - 1) / SEG;
     int max_nseg = nseg;
     for (int o = LW / 2; o > 0; o >>= 1) {
         int other = __shfl_xor(max_nseg, o, 64);
@@ -820,19 +828,20 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     // Blocks past the lane's row are clamped to its last valid address and never looked at.
     const int last_blk = (int)(cap > 0 ? cap - 1 : 0);
     const int last_m = (int)(cap_min / 16) - 1;
-    uint4 nx[16];
+    uint4 nx[SEG];
     uint4 mins_nx = make_uint4(0, 0, 0, 0);
-#define TK_MINS_ROW(g_) mrow[(g_) < last_m ? (g_) : (last_m > 0 ? last_m : 0)]
+#define TK_MINS_ROW16(g_) mrow[(g_) < last_m ? (g_) : (last_m > 0 ? last_m : 0)]
+#define TK_MINS_ROW(g_) TK_MINS_ROW16(SEG == 16 ? (g_) : (g_) >> 1)
 #define TK_FETCH_BLOCKS(g_)                                                       \
     {                                                                             \
-        _Pragma("unroll") for (int k = 0; k < 16; k++) {                          \
-            int blk_ = 16 * (g_) + k;                                             \
+        _Pragma("unroll") for (int k = 0; k < SEG; k++) {                         \
+            int blk_ = SEG * (g_) + k;                                            \
             blk_ = blk_ < last_blk ? blk_ : last_blk;                             \
             nx[k] = drow[blk_];                                                   \
         }                                                                         \
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) nx[k] = make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < SEG; k++) nx[k] = make_uint4(0, 0, 0, 0);
     // LAZY: the minima run TWO segments ahead, so that at the start of segment g those of g + 1 are in registers
     // and the FIRST block of g + 1 whose minimum passes the bound of now — a superset of what will pass then —
     // can be requested while segment g is replayed: on long lists ~1.3 blocks of a segment with any hit pass
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     for (int g = 0; g < max_nseg; g++) {
         if (!LAZY) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) ST[k * LW + lane] = nx[k];
+            for (int k = 0; k < SEG; k++) ST[k * LW + lane] = nx[k];
         }
         const uint4 mins_cur = mins_nx;
         if (LAZY) {
@@ -872,12 +881,13 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
             TK_FETCH_BLOCKS(g + 1)
         }
         const int buf = 0;
-        int kmax = total - 16 * g;
-        kmax = kmax < 0 ? 0 : (kmax > 16 ? 16 : kmax);
+        int kmax = total - SEG * g;
+        kmax = kmax < 0 ? 0 : (kmax > SEG ? SEG : kmax);
         // blocks whose minimum is below the bound at segment start: a superset of the
         // blocks the reference enters (the bound only decreases)
         uint32_t hit = mask_lt16_swar<SIGNED>(mins_cur, bb);
-        hit &= kmax >= 16 ? 0xffffu : ((1u << kmax) - 1u);
+        if (SEG == 8) hit = (hit >> (8 * (g & 1))) & 0xffu;       // (this segment's half of the 16 minima)
+        hit &= kmax >= SEG ? ((1u << SEG) - 1u) : ((1u << kmax) - 1u);
         uint32_t bits = 0;
         uint4 dd = make_uint4(0, 0, 0, 0);
         int cur = 0;
@@ -894,7 +904,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
             while (bits == 0 && hit) { \
                 const int k = __builtin_ctz(hit); \
                 hit &= hit - 1; \
-                cur = 16 * g + k; \
+                cur = SEG * g + k; \
                 if (LAZY) { \
                     if (cur == pre_blk) dd = pre; \
                     else dd = drow[cur < last_blk ? cur : last_blk]; \
@@ -1118,6 +1128,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
 #undef TK_ADVANCE
 #undef TK_FETCH_BLOCKS
 #undef TK_MINS_ROW
+#undef TK_MINS_ROW16
     if (dbg && lane == 0) {       // TK_OPT_REPLAY_COUNT: [0] += rounds, [1] = max rounds of a wave, [2] += waves, [3] += segments
         atomicAdd(&dbg[0], (unsigned long long)rounds);
         atomicMax(&dbg[1], (unsigned long long)rounds);
@@ -1399,8 +1410,8 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     const int LWr = dedupe ? 32 : 64;
     // heap columns (+ label slots) + one staged segment (16 blocks x LW lanes x 16 B; the next one
     // waits in registers), scaled to the columns in use
-    // (the LAZY form stages nothing: no ST rows)
-    const size_t st_rows = lazy && !dedupe ? 0 : (size_t)16384;
+    // (staging rows: the hash-set form 16 blocks, the others TK_LANES_SEG, or none: LAZY)
+    const size_t st_rows = dedupe ? (size_t)16384 : lazy ? 0 : (size_t)1024 * TK_LANES_SEG;
     const size_t lds = twin ? tk_lanes_twin_lds(R, S, tw.bm_words) + st_rows
                             : tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64 + st_rows * LWr / 64;
     static bool attr_set = false;
