@@ -1115,6 +1115,13 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
 // waves: 512 -> 4.15 ms per batch, 576 -> 3.95, 640 -> 3.89, 704 -> 3.84, 768 -> 4.03
 // (profiles/r02_scan_grid.md), so the grid is 704 above ~6 M estimated units.
 static int scan_blocks_pipelined(double est_units) { return est_units > 6.0e6 ? 704 : 512; }
+// ... and of the plain kernel beside the other batches' kernels: what the pipelined batch runs out of is LDS SPACE
+//  — two paired lane replays, the coarse replay and 512 plain workgroups ask for more than the chip's
+// 41 MB, and whoever comes last waits.  The plain kernel is as fast on 320 workgroups as on 512 there (its waves wait
+// on latencies, not on each other), and with the lane replay's 8-block segments (heap.hip) everything fits: same
+// box, headline batch 25.4-25.8 M queries/s against 24.4-24.7 M (320 or 256; 192: 25.0; 512 with 8-block segments:
+// 24.0-25.4, bimodal).  Long launches keep 512: 100M x 128 loses 5 % on 320, build(n_probes=2) 4 %.
+static int plain_blocks_pipelined(double est_units) { return est_units > 6.0e6 ? 512 : 320; }
 
 // depth > 1: the launch on the caller's stream that carries the list scan of `prev` (may be
 // NULL) and the coarse scan of `cur` (may be NULL), and what follows each on its stream.
@@ -1151,7 +1158,9 @@ static int pipeline_step(tk_index *ix, Pending *prev, Pending *cur)
     // (plain first: the exact kernel then overwrites the head chunks of the lists in head mode)
     if (prev && prev->plain) {
         TRY(prev->pf.mark_plain(0, st));
-        if (tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order, plain_blocks(), st))
+        if (tk_launch_scan_plain(plain_job(ix, *prev->w, prev->p), M, ix->order,
+                                 plain_blocks_pipelined((double)prev->nq * prev->p.S / 4.0 *
+                                                        ((double)ix->total_chunks / (double)ix->n_lists)), st))
             return fail(TK_ERR_HIP, "scan_plain_wave_kernel: LDS attribute / unsupported M");
         TRY(prev->pf.mark_plain(1, st));
         if (prev->pf.evs && prev->pf.set >= 0) ix->ev_plain[(size_t)prev->pf.set] = 1;

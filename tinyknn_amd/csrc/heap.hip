@@ -563,7 +563,7 @@ void tk_launch_flat_top_one(const uint4 *dist, const uint8_t *mins, int chunks, 
 //   * the top three heap levels (nodes 0..6) are kept in registers;
 //   * labels are resolved from the flat positions once, at the end.
 #ifndef TK_LANES_SEG
-#define TK_LANES_SEG 16     // blocks per staged segment of the lane replay's forms without a hash set: 16 or 8
+#define TK_LANES_SEG 8      // blocks per staged segment of the lane replay's form without a duplicate test: 16 or 8
 #endif
 template <bool SIGNED>
 __device__ __forceinline__ int entry_val(uint32_t e)
@@ -720,8 +720,8 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     // DEDUPE: slot table of the lane's query, SE[s][lane] = first flat chunk past slot s,
     // SB[s][lane] = label offset of slot s - 16 * its first flat chunk (label of row r of flat
     // chunk c in slot s = labels32[SB[s] + 16 c + r])
-    // (staging rows: 16 blocks with the hash set, TK_LANES_SEG otherwise, none when LAZY)
-    int *SE = (int *)(ST + (DEDUPE ? 16 : LAZY ? 0 : TK_LANES_SEG) * LW);
+    // (staging rows: none when LAZY, TK_LANES_SEG blocks without a duplicate test, 16 otherwise)
+    int *SE = (int *)(ST + (DEDUPE ? 16 : LAZY ? 0 : TWIN ? 16 : TK_LANES_SEG) * LW);
     int *SB = SE + (size_t)S * LW;
     // TWIN: the probed lists of the lane's query, four to a uint4: PL[t / 4][lane]
     uint4 *PL = (uint4 *)(SB + (size_t)S * LW);
@@ -775,9 +775,13 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     uint32_t b_plain = SIGNED ? 0x7fu : 0xffu;
     const uint4 *mrow = (const uint4 *)(mins + qc * cap_min);   // per-block minima, 16 per uint4
     // Blocks per staged segment.  The staging rows are LDS SPACE, which is what the pipelined batch runs out of
-    // (DESIGN §3.6): the forms without a hash set stage 8 blocks at a time (8 KB per wave instead of 16, 32 prefetch
-    // registers instead of 64); the minima still arrive 16 to a load, a pair of segments shares one.
-    constexpr int SEG = (LAZY || DEDUPE) ? 16 : TK_LANES_SEG;
+    // (DESIGN §3.6): the form without a duplicate test — every index with distinct labels, and the coarse stage of
+    // all — stages 8 blocks at a time (8 KB per wave instead of 16, 32 prefetch registers instead of 64, 86 VGPRs
+    // instead of 118; the minima still arrive 16 to a load, a pair of segments shares one).  Alone that replay is 9 %
+    // slower (twice the segments, a prefetch eight blocks ahead); with the plain kernel on 320 instead of 512
+    // workgroups beside it the batch's kernels fit the chip's LDS and the headline batch gains 4-5 % (25.4-25.8
+    // against 24.4-24.7 M queries/s, same box).  The TWIN form keeps 16 (replay-bound: 15.5 against 14.9 M).
+    constexpr int SEG = (LAZY || DEDUPE || TWIN) ? 16 : TK_LANES_SEG;
     int nseg = (total + SEG - 1) / SEG;
     int max_nseg = nseg;
     for (int o = LW / 2; o > 0; o >>= 1) {
@@ -1410,8 +1414,8 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
     const int LWr = dedupe ? 32 : 64;
     // heap columns (+ label slots) + one staged segment (16 blocks x LW lanes x 16 B; the next one
     // waits in registers), scaled to the columns in use
-    // (staging rows: the hash-set form 16 blocks, the others TK_LANES_SEG, or none: LAZY)
-    const size_t st_rows = dedupe ? (size_t)16384 : lazy ? 0 : (size_t)1024 * TK_LANES_SEG;
+    // (staging rows: none when LAZY, TK_LANES_SEG blocks without a duplicate test, 16 otherwise)
+    const size_t st_rows = dedupe ? (size_t)16384 : lazy ? 0 : twin ? (size_t)16384 : (size_t)1024 * TK_LANES_SEG;
     const size_t lds = twin ? tk_lanes_twin_lds(R, S, tw.bm_words) + st_rows
                             : tk_lanes_fixed_lds(R, S, dedupe) * LWr / 64 + st_rows * LWr / 64;
     static bool attr_set = false;
