@@ -1191,6 +1191,7 @@ class SimulatedPeers:
         self._engines = {}
         self._live = None
         self._rec = {}
+        self.records = 0        # recording passes so far (each runs every peer once: a second or more)
 
     def home_range(self, nq):
         qh = -(-nq // self.world)
@@ -1232,6 +1233,7 @@ class SimulatedPeers:
 
     def _record(self, qn, qp, k, n_probes, pass_1, capacity, coarse, kind, region, form):
         t, W, me = self.torch, self.world, self.rank
+        self.records += 1
         t.cuda.synchronize()
         nq = qn.shape[0]
         qh = -(-nq // W)
