@@ -683,6 +683,9 @@ static TkScanJob head_job(const tk_index *ix, const Work &w, const Plan &p)
 
 // persistent workgroups of the plain kernel: two per CU (58 KB of LDS, 256 registers per lane)
 int plain_blocks() { return 512; }
+// ... of a list-sharded rank's scans (eight batches in flight, each with its own replays: LDS space again — one rank
+// through RCCL 20.4 -> 21.6 M queries/s on 320, same box)
+int shard_plain_blocks() { return 320; }
 
 // 2a. coarse scan = the scan of dtable.top(centers)          ivf.py:131, fast_pq.py:284-312
 void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st,
@@ -1117,11 +1120,13 @@ static int run_batch_inline(tk_index *ix, Pending &b, const void *qpq_dev, int q
 static int scan_blocks_pipelined(double est_units) { return est_units > 6.0e6 ? 704 : 512; }
 // ... and of the plain kernel beside the other batches' kernels: what the pipelined batch runs out of is LDS SPACE
 //  — two paired lane replays, the coarse replay and 512 plain workgroups ask for more than the chip's
-// 41 MB, and whoever comes last waits.  The plain kernel is as fast on 320 workgroups as on 512 there (its waves wait
+// 41 MB, and whoever comes last waits.  The plain kernel is as fast on 256 workgroups as on 512 there (its waves wait
 // on latencies, not on each other), and with the lane replay's 8-block segments (heap.hip) everything fits: same
 // box, headline batch 25.4-25.8 M queries/s against 24.4-24.7 M (320 or 256; 192: 25.0; 512 with 8-block segments:
 // 24.0-25.4, bimodal).  Long launches keep 512: 100M x 128 loses 5 % on 320, build(n_probes=2) 4 %.
-static int plain_blocks_pipelined(double est_units) { return est_units > 6.0e6 ? 512 : 320; }
+// (256 against 320, seven runs each in turn on one box: 25.5-25.75 M every time against 25.4-25.6 M with one run
+//  of 23.4 M — a whole process in a slow mode, one in six on another box too.)
+static int plain_blocks_pipelined(double est_units) { return est_units > 6.0e6 ? 512 : 256; }
 
 // depth > 1: the launch on the caller's stream that carries the list scan of `prev` (may be
 // NULL) and the coarse scan of `cur` (may be NULL), and what follows each on its stream.

@@ -310,6 +310,7 @@ int stage_tables(tk_index *ix, Work &w, const void *qpq_dev, int qpq_f64, int64_
                  bool plain = false, TkSecond qpq2 = TkSecond(), int64_t row0 = 0);
 TkScanJob coarse_job(const tk_index *ix, const Work &w, const Plan &p);
 int plain_blocks();
+int shard_plain_blocks();
 void launch_coarse_scan(tk_index *ix, Work &w, int64_t nq, const Plan &p, hipStream_t st,
                         const uint4 *tables = nullptr);
 int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64_t nq, const Plan &p,

@@ -498,7 +498,7 @@ extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float
     hj.pair_f0 = w.h_pair_f0.as<int>();
     hj.max_chunks = hc;
     // (plain first: the exact kernel then overwrites the head chunks of the lists in head mode)
-    if (tk_launch_scan_plain(pj, ix->M, ix->order, plain_blocks(), st))
+    if (tk_launch_scan_plain(pj, ix->M, ix->order, shard_plain_blocks(), st))
         return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
     tk_launch_scan_units2(lj, none, ix->M, ix->order, 768, st, &hj, ix->opt_scan_form);
     w.shard_probes = probes;
@@ -665,7 +665,7 @@ extern "C" int tk_index_shard_scan_rest_dev(tk_index *ix, int slot, int64_t nq, 
     pj.cap = 0;
     pj.mins = w.smins.as<uint8_t>();
     pj.min_stride = 0;
-    if (tk_launch_scan_plain(pj, ix->M, ix->order, plain_blocks(), st))
+    if (tk_launch_scan_plain(pj, ix->M, ix->order, shard_plain_blocks(), st))
         return fail(TK_ERR_HIP, "scan_plain_kernel: LDS attribute / unsupported M");
     tk_launch_scan_units(ix->codes.as<uint4>(), ix->M, tables_of(w), nq, p.S, ix->n_lists,
                          ix->local_chunk_off.as<int64_t>(), w.u_pair_off.as<int>(),

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void heap_replay_lanes_kernel(
     // (DESIGN §3.6): the form without a duplicate test — every index with distinct labels, and the coarse stage of
     // all — stages 8 blocks at a time (8 KB per wave instead of 16, 32 prefetch registers instead of 64, 86 VGPRs
     // instead of 118; the minima still arrive 16 to a load, a pair of segments shares one).  Alone that replay is 9 %
-    // slower (twice the segments, a prefetch eight blocks ahead); with the plain kernel on 320 instead of 512
+    // slower (twice the segments, a prefetch eight blocks ahead); with the plain kernel on 256 instead of 512
     // workgroups beside it the batch's kernels fit the chip's LDS and the headline batch gains 4-5 % (25.4-25.8
     // against 24.4-24.7 M queries/s, same box).  The TWIN form keeps 16 (replay-bound: 15.5 against 14.9 M).
     constexpr int SEG = (LAZY || DEDUPE || TWIN) ? 16 : TK_LANES_SEG;
