@@ -476,7 +476,9 @@ def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8, co=0):
     stands in for the bytes the links would land in this rank's HBM).  W consecutive steps are answered
     as one sharded batch (a rank's home share is then one batch of --nq queries), as the N > 1 leg does."""
     import torch
-    from tinyknn_amd.multi_gpu import ListShardedIndex, SimulatedPeers
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from simulated_peers import SimulatedPeers
     peers = SimulatedPeers(ivf, world=W, rank=0)
     try:
         co = max(1, min(co or max(W, args.shard_coalesce), 131072 // args.nq))

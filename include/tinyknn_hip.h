@@ -346,6 +346,10 @@ int tk_measure_read_bandwidth(int64_t bytes, int reps, double *gbps);
  * table_bytes of HBM with the rescoring kernel's access pattern (knn_brute1's `data[indices]`, utils.py:89-92):
  * the ceiling bench.py's roofline.rescore is quoted against. */
 int tk_measure_gather_bandwidth(int64_t table_bytes, int row_bytes, int64_t n_gather, int reps, double *gbps);
+/* The library's own exclusive prefix sum (one launch, decoupled look-back: devbuild.hip) on host arrays — the
+ * per-batch sums of a list-sharded rank go through it on the device; this entry exists so that a test can check it
+ * against numpy at any length.  is64: int64 elements, else int32.  in_host == out_host is allowed. */
+int tk_scan_exclusive_host(const void *in_host, void *out_host, int64_t n, int is64);
 
 /* ---- device-resident build ----------------------------------------
  * IVF.build(X, n_probes = 1 or 2) (ivf.py:77-102) for float32 vectors that are produced IN HBM
@@ -561,8 +565,12 @@ int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_dev, int64_
  * again exactly are on other ranks): the flag word travels with the ids, every rank sees it, and
  * the batch is repeated behind tk_index_shard_scan_head_dev (below).  Arguments as
  * tk_index_shard_scan_dev + bound_dev (NULL here); falls back to tk_index_shard_scan_dev by itself
- * where the form does not apply (tk_index_shard_plain says 0, labels repeat, heaps beyond the lane
- * replay, world * capacity shorter than the longest list).
+ * where the form does not apply (tk_index_shard_plain says 0, heaps beyond the lane replay, world *
+ * capacity shorter than the longest list, labels that repeat WITHOUT a twin table).  Labels that repeat
+ * (IVF.build(n_probes >= 2)) take this form through the lane replay's TWIN test where the index holds
+ * the twin table (tk_index_twin_table: width > 0) and its premises are verified — on a rank that was
+ * handed only its own lists' codes (tk_index_set_lists_shard) the device cannot check them: the host
+ * wrapper checks over all lists and vouches (tk_index_set_option TK_OPT_TWIN_VOUCH).
  *
  * The same with ONE byte per query exchanged first — for data on which the optimistic form fails (one
  * query in 20 000 of the 100M x 128 index; a sharded batch holds 120 000):
@@ -657,7 +665,8 @@ int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_de
  *                                  filtered exchange (with this bound: no tk_index_shard_bound_dev)
  *                                  follow as after tk_index_shard_scan_dev and return the same ids.
  * tk_index_shard_plain: 1 if the two-phase form applies to (k, n_probes, pass_1) — M <= 52,
- * n_probes >= 2, distinct labels (or tk_index_set_plain_scan(ix, 2)), not switched off; replicated
+ * n_probes >= 2, distinct labels or labels that repeat under a (verified or vouched) twin table, or
+ * tk_index_set_plain_scan(ix, 2); not switched off; replicated
  * state only, so every rank answers alike — else 0 (use tk_index_shard_scan_dev), < 0 on error. */
 int tk_index_shard_plain(tk_index *ix, int k, int n_probes, int pass_1);
 int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,

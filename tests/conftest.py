@@ -13,6 +13,8 @@ import torch  # noqa: F401,E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "scripts") not in sys.path:      # bench / test scaffolding (simulated_peers.py)
+    sys.path.append(os.path.join(ROOT, "scripts"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

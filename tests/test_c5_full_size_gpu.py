@@ -109,7 +109,8 @@ def test_one_rank_of_eight_on_the_same_index(c5):
     segments of the other seven ranks come from seven more passes of the same device with their
     owner maps (a 1-GPU box cannot host eight RCCL ranks).  Home rows = the unsharded rows."""
     torch, ivf, dev, ox, data, qn, qp, sizes = c5
-    from tinyknn_amd.multi_gpu import SimulatedPeers, ListShardedIndex
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+    from simulated_peers import SimulatedPeers
     nq = 4000
     want = dev.query_batch(qn[:nq], qp[:nq], 10, 10)
     qn_t, qp_t = torch.from_numpy(qn[:nq]).cuda(), torch.from_numpy(qp[:nq]).cuda()

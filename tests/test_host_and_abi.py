@@ -181,3 +181,45 @@ def test_a_forked_child_does_not_release_the_parents_device_handles():
     assert os.read(r, 1) == b"0"
     os.waitpid(pid, 0)
     os.close(r)
+
+
+def test_copies_carry_one_code_host_check():
+    """ivf._copies_carry_one_code (what a list-sharded rank vouches for before the TWIN replay): hashes per row
+    instead of the code bytes — same verdicts on lists that meet the premises, that carry another code on one copy,
+    and that hold a label twice."""
+    from types import SimpleNamespace
+    from tinyknn_amd.ivf import _copies_carry_one_code
+    from tinyknn_amd._transform import transform_data
+
+    rng = np.random.RandomState(3)
+    M, n_rows, L = 8, 1000, 6
+    codes = rng.randint(0, 16, size=(n_rows, M)).astype(np.uint8)
+
+    def make(assign, codes_of=lambda lst, rows: codes[rows]):
+        tds, ids = [], []
+        for lst in range(L):
+            rows = np.flatnonzero((assign == lst).any(axis=1))
+            pad = (-len(rows)) % 16
+            c = np.concatenate([codes_of(lst, rows), np.zeros((pad, M), np.uint8)])
+            tds.append(SimpleNamespace(packed=transform_data(c), size=len(rows)) if len(rows) else np.empty((0, M)))
+            ids.append(rows.astype(np.int64))
+        return SimpleNamespace(pq_transformed_points=tds, ids=ids)
+
+    first = rng.randint(0, L - 1, size=n_rows)
+    assign = np.stack([first, (first + 1 + rng.randint(0, L - 2, size=n_rows)) % (L - 1)], axis=1)   # two DIFFERENT lists, list L-1 empty
+    assert (assign[:, 0] != assign[:, 1]).all()
+    assert _copies_carry_one_code(make(assign), L)
+    # one copy of one row with another code
+    victim = int(np.flatnonzero(assign[:, 1] == 2)[0])
+
+    def damaged(lst, rows):
+        c = codes[rows].copy()
+        if lst == 2:
+            c[rows == victim, 3] ^= 1
+        return c
+    assert not _copies_carry_one_code(make(assign, damaged), L)
+    # a label twice in one list
+    ivf = make(assign)
+    ivf.ids[1] = ivf.ids[1].copy()
+    ivf.ids[1][1] = ivf.ids[1][0]
+    assert not _copies_carry_one_code(ivf, L)

@@ -563,7 +563,8 @@ def test_simulated_peers_one_rank_of_a_partition(oracle):
     the clones."""
     import torch
     from tinyknn_amd import IVF, FastPQ
-    from tinyknn_amd.multi_gpu import ListShardedIndex, SimulatedPeers
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+    from simulated_peers import SimulatedPeers
     np.random.seed(21)
     n, nq, d = 50000, 1203, 100
     cent = np.random.randn(120, d)

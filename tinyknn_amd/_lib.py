@@ -114,6 +114,7 @@ SIGNATURES = {
                                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_measure_read_bandwidth": (C.c_int, [C.c_int64, C.c_int, _f64p]),
     "tk_measure_gather_bandwidth": (C.c_int, [C.c_int64, C.c_int, C.c_int64, C.c_int, _f64p]),
+    "tk_scan_exclusive_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "tk_index_replay_stats": (C.c_int, [C.c_void_p, _i64p]),
     "tk_index_twin_table": (C.c_int, [C.c_void_p, _i64p, _i32p, _i32p, _i32p]),
     "tk_index_alloc_data": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int]),

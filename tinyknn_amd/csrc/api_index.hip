@@ -97,7 +97,54 @@ extern "C" int tk_index_set_centers(tk_index *ix, const float *active_centers, i
     return TK_OK;
 }
 
-// twins.hip's table for an index whose lists, ids_off and int32 labels are in place
+// twins.hip's table for an index whose lists, ids_off and int32 labels are in place.  The table is an
+// ACCELERATOR (the TWIN replay; without it the label-based duplicate test runs): an allocation or HIP failure
+// in here means "no table", never a failed upload — the temporaries go on every path, the error is cleared.
+struct TwinScratch {
+    DevBuf cnt, where;
+    ~TwinScratch() { cnt.release(); where.release(); }
+};
+
+static int build_twins_try(tk_index *ix, int64_t label_bound, TwinScratch &t)
+{
+    const int64_t T = ix->total_ids;
+    TRY(t.cnt.ensure((size_t)(label_bound + 1) * 4));
+    HIPCHECK(hipMemsetAsync(t.cnt.p, 0, (size_t)(label_bound + 1) * 4, 0));
+    int *cnt_max = t.cnt.as<int>() + label_bound;
+    tk_launch_twin_count(ix->ids32.as<int32_t>(), T, t.cnt.as<int>(), cnt_max, 0);
+    int b = 0;
+    HIPCHECK(hipMemcpy(&b, cnt_max, 4, hipMemcpyDeviceToHost));
+    if (!(b >= 2 && b <= 17 && T * (b - 1) < (1ll << 31)))     // (the replay indexes the table with 32-bit arithmetic)
+        return TK_OK;
+    const int w = b - 1;
+    // transient label_bound * b * 4 bytes + 2 * T * w * 4 persistent: only where the device has them to spare
+    size_t free_b = 0, total_b = 0;
+    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (size_t)label_bound * b * 4 + 2 * (size_t)T * w * 4;
+    if (need + need / 4 + (512u << 20) > free_b) return TK_OK;
+    TRY(t.where.ensure((size_t)label_bound * b * 4));
+    TRY(ix->twin_list.ensure((size_t)T * w * 4));
+    TRY(ix->twin_off.ensure((size_t)T * w * 4));
+    HIPCHECK(hipMemsetAsync(t.cnt.p, 0, (size_t)label_bound * 4, 0));
+    tk_launch_twin_fill(ix->ids32.as<int32_t>(), T, t.cnt.as<int>(), t.where.as<int>(), b,
+                        ix->ids_off.as<int64_t>(), (int)ix->n_lists, ix->twin_list.as<int32_t>(),
+                        ix->twin_off.as<int32_t>(), 0);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    if (!ix->sharded) {      // every list's codes are here: the table's two premises, checked (twins.hip)
+        HIPCHECK(hipMemsetAsync(t.cnt.p, 0, 4, 0));
+        tk_launch_twin_verify(ix->codes.as<uint4>(), ix->M / 2, ix->list_chunk_off.as<int64_t>(),
+                              ix->ids_off.as<int64_t>(), (int)ix->n_lists, ix->twin_list.as<int32_t>(),
+                              ix->twin_off.as<int32_t>(), w, T, t.cnt.as<int>(), 0);
+        int bad = 0;
+        HIPCHECK(hipMemcpy(&bad, t.cnt.p, 4, hipMemcpyDeviceToHost));
+        if (bad) return TK_OK;   // copies with different codes, or two in one list: the label-based test only
+    }
+    ix->twin_w = w;              // (set last: a failure above leaves "no table")
+    ix->twin_unverified = ix->sharded;
+    return TK_OK;
+}
+
 int build_twins(tk_index *ix, int64_t label_bound)
 {
     ix->twin_w = 0;
@@ -108,46 +155,16 @@ int build_twins(tk_index *ix, int64_t label_bound)
     if (!ix->have_ids32 || ix->ids_unique || T <= 0 || T >= (1ll << 31) || label_bound <= 0 ||
         label_bound > 8 * T + 1024 || ix->n_lists >= (1ll << 31))
         return TK_OK;
-    DevBuf cnt, where;
-    TRY(cnt.ensure((size_t)(label_bound + 1) * 4));
-    HIPCHECK(hipMemsetAsync(cnt.p, 0, (size_t)(label_bound + 1) * 4, 0));
-    int *cnt_max = cnt.as<int>() + label_bound;
-    tk_launch_twin_count(ix->ids32.as<int32_t>(), T, cnt.as<int>(), cnt_max, 0);
-    int b = 0;
-    HIPCHECK(hipMemcpy(&b, cnt_max, 4, hipMemcpyDeviceToHost));
-    int rc = TK_OK;
-    if (b >= 2 && b <= 17 && T * (b - 1) < (1ll << 31)) {     // (the replay indexes the table with 32-bit arithmetic)
-        const int w = b - 1;
-        rc = where.ensure((size_t)label_bound * b * 4);
-        if (rc == TK_OK) rc = ix->twin_list.ensure((size_t)T * w * 4);
-        if (rc == TK_OK) rc = ix->twin_off.ensure((size_t)T * w * 4);
-        if (rc == TK_OK) {
-            HIPCHECK(hipMemsetAsync(cnt.p, 0, (size_t)label_bound * 4, 0));
-            tk_launch_twin_fill(ix->ids32.as<int32_t>(), T, cnt.as<int>(), where.as<int>(), b,
-                                ix->ids_off.as<int64_t>(), (int)ix->n_lists, ix->twin_list.as<int32_t>(),
-                                ix->twin_off.as<int32_t>(), 0);
-            HIPCHECK(hipGetLastError());
-            HIPCHECK(hipDeviceSynchronize());
-            ix->twin_w = w;
-            ix->twin_unverified = ix->sharded;
-            if (!ix->sharded) {      // every list's codes are here: the table's two premises, checked (twins.hip)
-                HIPCHECK(hipMemsetAsync(cnt.p, 0, 4, 0));
-                tk_launch_twin_verify(ix->codes.as<uint4>(), ix->M / 2, ix->list_chunk_off.as<int64_t>(),
-                                      ix->ids_off.as<int64_t>(), (int)ix->n_lists, ix->twin_list.as<int32_t>(),
-                                      ix->twin_off.as<int32_t>(), w, T, cnt.as<int>(), 0);
-                int bad = 0;
-                HIPCHECK(hipMemcpy(&bad, cnt.p, 4, hipMemcpyDeviceToHost));
-                if (bad) {           // copies with different codes, or two in one list: the label-based test only
-                    ix->twin_w = 0;
-                    ix->twin_list.release();
-                    ix->twin_off.release();
-                }
-            }
-        }
+    TwinScratch t;
+    const int rc = build_twins_try(ix, label_bound, t);
+    if (rc != TK_OK || ix->twin_w == 0) {
+        ix->twin_w = 0;
+        ix->twin_unverified = false;
+        ix->twin_list.release();
+        ix->twin_off.release();
     }
-    cnt.release();
-    where.release();
-    return rc;
+    if (rc != TK_OK) (void)hipGetLastError();      // (an out-of-memory answer is sticky until read)
+    return TK_OK;
 }
 
 extern "C" int tk_index_twin_table(tk_index *ix, int64_t *rows, int *w, int32_t *list_out, int32_t *off_out)

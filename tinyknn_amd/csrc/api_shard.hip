@@ -853,6 +853,7 @@ static int shard_finish_filtered_impl(tk_index *ix, int slot, const float *q_dev
         Prof pf;
         TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf));
     }
+    w.ext_tables = nullptr;      // (the gathered tables were the batch's: the next one names its own)
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
@@ -914,6 +915,9 @@ extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_
         TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf, w.shard_plain,
                        TkSecond(), TkSecond(), w.shard_plain ? flag_dev : nullptr));
     }
+    // the caller's gathered-tables buffer (tk_index_shard_set_tables_dev) was this batch's: a later scan of the slot
+    // that brings its own probe lists must not read through a pointer the caller may have freed
+    w.ext_tables = nullptr;
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
@@ -985,5 +989,33 @@ extern "C" int tk_measure_gather_bandwidth(int64_t table_bytes, int row_bytes, i
     if (e1) (void)hipEventDestroy(e1);
     buf.release();
     out.release();
+    return rc;
+}
+
+// the library's exclusive prefix sum on host arrays (test plumbing: tests/test_scan_gpu.py)
+extern "C" int tk_scan_exclusive_host(const void *in_host, void *out_host, int64_t n, int is64)
+{
+    TRY(require_gpu());
+    ARGCHECK(n >= 0 && (n == 0 || (in_host && out_host)), "arrays");
+    if (n == 0) return TK_OK;
+    const size_t esz = is64 ? 8 : 4;
+    DevBuf in, out, tmp;
+    size_t tmp_bytes = 0;
+    int rc = in.ensure((size_t)n * esz);
+    if (rc == TK_OK) rc = out.ensure((size_t)n * esz);
+    if (rc == TK_OK)
+        rc = (is64 ? tk_scan_exclusive64(nullptr, &tmp_bytes, nullptr, nullptr, n, 0)
+                   : tk_scan_exclusive(nullptr, &tmp_bytes, nullptr, nullptr, n, 0)) ? fail(TK_ERR_HIP, "scan size query") : TK_OK;
+    if (rc == TK_OK) rc = tmp.ensure(tmp_bytes);
+    if (rc == TK_OK && hipMemcpy(in.p, in_host, (size_t)n * esz, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(TK_ERR_HIP, "copy in");
+    if (rc == TK_OK) {
+        const int e = is64 ? tk_scan_exclusive64(tmp.p, &tmp_bytes, in.as<long long>(), out.as<long long>(), n, 0)
+                           : tk_scan_exclusive(tmp.p, &tmp_bytes, in.as<int>(), out.as<int>(), n, 0);
+        if (e || hipDeviceSynchronize() != hipSuccess) rc = fail(TK_ERR_HIP, "scan");
+    }
+    if (rc == TK_OK && hipMemcpy(out_host, out.p, (size_t)n * esz, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(TK_ERR_HIP, "copy out");
+    in.release(); out.release(); tmp.release();
     return rc;
 }

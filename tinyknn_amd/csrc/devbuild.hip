@@ -8,7 +8,8 @@
 // rows in ascending row order, where numpy's unstable argsort leaves the order unspecified),
 // 16-row chunks packed into the Quick-ADC byte layout (_transform.py:4-77) directly in the
 // tiled order the scan kernels read.  api.hip drives these kernels (tk_index_build_dev).
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>      // radix_sort_pairs of the offline build only (ROCm's own primitives library)
 
 #include "kernels.h"
 
@@ -103,33 +104,142 @@ void tk_launch_remap_keys(int *keys, int64_t n, const int *remap, hipStream_t s)
     hipLaunchKernelGGL(remap_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, n, remap);
 }
 
-// stable sort of (list, row) pairs by list; tmp == NULL: size query
+// stable sort of (list, row) pairs by list; tmp == NULL: size query.  Offline build only (tk_index_build_dev).
 int tk_sort_pairs(void *tmp, size_t *tmp_bytes, const int *keys_in, int *keys_out, const int *vals_in,
                   int *vals_out, int64_t n, int bits, hipStream_t s)
 {
     size_t bytes = *tmp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out,
-                                                      (int)n, 0, bits, s);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                             (unsigned)bits, s);
     *tmp_bytes = bytes;
     return e == hipSuccess ? 0 : -1;
 }
 
-// exclusive prefix sum of n ints; tmp == NULL: size query
+// ---------------------------------------------------------------------------
+// Exclusive prefix sum in ONE launch (the per-batch sums of a list-sharded rank: segment positions, pair offsets).
+// Single pass with decoupled look-back: workgroups take tiles in ticket order (so every predecessor of a tile is
+// already running: the waits below always end), a tile publishes its AGGREGATE as soon as it is reduced and its
+// inclusive PREFIX once it knows what lies in front; a tile finds that by walking back 64 tiles at a time with
+// wave 0 — the first tile with a prefix ends the walk, the aggregates on the way are added.  State of a tile =
+// one 64-bit word (flag in the top two bits, value below: a single relaxed atomic publishes both).
+//   tmp layout: [0] ticket (unsigned), [8 ...) one uint64 per tile; zeroed by a memset in front of the kernel.
+#define TK_SCAN_THREADS 256
+#define TK_SCAN_ITEMS 8
+#define TK_SCAN_TILE (TK_SCAN_THREADS * TK_SCAN_ITEMS)
+#define TK_SCAN_AGG (1ull << 62)
+#define TK_SCAN_PFX (2ull << 62)
+#define TK_SCAN_VAL ((1ull << 62) - 1ull)
+
+template <typename T>
+__global__ __launch_bounds__(TK_SCAN_THREADS) void scan_exclusive_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                                         int64_t n, unsigned *ticket,
+                                                                         unsigned long long *state)
+{
+    __shared__ unsigned tile_s;
+    __shared__ long long wave_sum[TK_SCAN_THREADS / 64];
+    __shared__ long long excl_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) tile_s = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int64_t tile = tile_s;
+    const int64_t base = tile * TK_SCAN_TILE + (int64_t)tid * TK_SCAN_ITEMS;
+    long long v[TK_SCAN_ITEMS];
+    long long mine = 0;
+#pragma unroll
+    for (int i = 0; i < TK_SCAN_ITEMS; i++) {
+        v[i] = base + i < n ? (long long)in[base + i] : 0;
+        mine += v[i];
+    }
+    // inclusive scan of the threads' sums inside the wave
+    long long inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    long long wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < TK_SCAN_THREADS / 64; w++) {
+        wave_off += w < wave ? wave_sum[w] : 0;
+        total += wave_sum[w];
+    }
+    if (wave == 0) {
+        long long excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&state[0], TK_SCAN_PFX | ((unsigned long long)total & TK_SCAN_VAL),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&state[tile], TK_SCAN_AGG | ((unsigned long long)total & TK_SCAN_VAL),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t j = tile - 1;; j -= 64) {
+                const int64_t idx = j - lane;
+                unsigned long long st = TK_SCAN_PFX;                    // (in front of tile 0: a prefix of zero)
+                if (idx >= 0) {
+                    do {
+                        st = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((st >> 62) == 0);
+                }
+                const unsigned long long has_pfx = __ballot((st >> 62) == 2);
+                const int first = has_pfx ? __builtin_ctzll(has_pfx) : 64;
+                // sign-extend the 62-bit value (sums of non-negative counts here, but keep the arithmetic exact)
+                long long val = (long long)((st & TK_SCAN_VAL) << 2) >> 2;
+                val = lane <= first ? val : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
+                excl += val;
+                if (has_pfx) break;
+            }
+            if (lane == 0) __hip_atomic_store(&state[tile],
+                                              TK_SCAN_PFX | ((unsigned long long)(excl + total) & TK_SCAN_VAL),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) excl_s = excl;
+    }
+    __syncthreads();
+    long long run = excl_s + wave_off + (inc - mine);
+#pragma unroll
+    for (int i = 0; i < TK_SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = (T)run;
+        run += v[i];
+    }
+}
+
+static size_t scan_tmp_bytes(int64_t n)
+{
+    const int64_t tiles = (n + TK_SCAN_TILE - 1) / TK_SCAN_TILE;
+    return 8 + (size_t)(tiles > 0 ? tiles : 1) * 8;
+}
+
+template <typename T>
+static int scan_exclusive_impl(void *tmp, size_t *tmp_bytes, const T *in, T *out, int64_t n, hipStream_t s)
+{
+    const size_t need = scan_tmp_bytes(n);
+    if (!tmp) {
+        *tmp_bytes = need;
+        return 0;
+    }
+    if (*tmp_bytes < need) return -1;
+    if (n <= 0) return 0;
+    if (hipMemsetAsync(tmp, 0, need, s) != hipSuccess) return -1;
+    const int64_t tiles = (n + TK_SCAN_TILE - 1) / TK_SCAN_TILE;
+    hipLaunchKernelGGL(scan_exclusive_kernel<T>, dim3((unsigned)tiles), dim3(TK_SCAN_THREADS), 0, s, in, out, n,
+                       (unsigned *)tmp, (unsigned long long *)((char *)tmp + 8));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// exclusive prefix sum of n ints; tmp == NULL: size query.  in == out is allowed (a thread reads its items before
+// any thread of the grid writes them: tiles do not overlap).
 int tk_scan_exclusive(void *tmp, size_t *tmp_bytes, const int *in, int *out, int64_t n, hipStream_t s)
 {
-    size_t bytes = *tmp_bytes;
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, s);
-    *tmp_bytes = bytes;
-    return e == hipSuccess ? 0 : -1;
+    return scan_exclusive_impl<int>(tmp, tmp_bytes, in, out, n, s);
 }
 
 int tk_scan_exclusive64(void *tmp, size_t *tmp_bytes, const long long *in, long long *out, int64_t n,
                         hipStream_t s)
 {
-    size_t bytes = *tmp_bytes;
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, s);
-    *tmp_bytes = bytes;
-    return e == hipSuccess ? 0 : -1;
+    return scan_exclusive_impl<long long>(tmp, tmp_bytes, in, out, n, s);
 }
 
 __global__ void widen_ids_kernel(const int *__restrict__ rows, int64_t n, int64_t *__restrict__ ids)

@@ -116,25 +116,39 @@ def _copies_carry_one_code(ivf, n_lists):
     (ivf.py:77-102) and what the lane replay's TWIN form rests on (heap.hip).  The library checks it on the device
     where it holds every list's codes; a rank of a list-sharded index uploads only its own lists, so this is the
     same check on the host, over all lists, before the rank vouches (TK_OPT_TWIN_VOUCH)."""
+    # Two independent multilinear hashes (mod 2^64, fixed odd-seeded multipliers) per row instead of the M / 2 code bytes
+    # themselves: 16 B per stored row on every rank at construction, not 3 x M / 2 (a 100M-row build(n_probes=2) index
+    # is 200M stored rows).  Unequal codes hash alike with probability < 2^-100.
     labels, lists, sigs = [], [], []
+    mult = None
     for i in range(n_lists):
         td = ivf.pq_transformed_points[i]
         if isinstance(td, np.ndarray) or td.size == 0:
             continue
         pk = np.ascontiguousarray(td.packed, dtype=np.uint64)              # (chunks, M): per chunk M / 2 groups of 16 bytes
         P = pk.shape[1] // 2
-        rows = pk.view(np.uint8).reshape(pk.shape[0], P, 16).transpose(0, 2, 1).reshape(-1, P)[:td.size]
+        if mult is None or mult.shape[0] != P:
+            mult = np.random.RandomState(0x7151).randint(0, 2 ** 63, size=(P, 2), dtype=np.int64).astype(np.uint64) * 2 + 1
+        h = np.empty((td.size, 2), dtype=np.uint64)
+        by = pk.view(np.uint8).reshape(pk.shape[0], P, 16)                 # [chunk][pair][row of the chunk]
+        for lo in range(0, pk.shape[0], 4096):                              # (bounded temporaries)
+            part = by[lo:lo + 4096].transpose(0, 2, 1).reshape(-1, P)      # rows of these chunks, a code per row
+            n = min(part.shape[0], td.size - 16 * lo)
+            if n > 0:
+                h[16 * lo:16 * lo + n] = part[:n].astype(np.uint64) @ mult
         labels.append(np.asarray(ivf.ids[i], dtype=np.int64)[:td.size])
-        lists.append(np.full(td.size, i, dtype=np.int64))
-        sigs.append(rows)
+        lists.append(np.full(td.size, i, dtype=np.int32))
+        sigs.append(h)
     if not labels:
         return True
     labels, lists, sigs = np.concatenate(labels), np.concatenate(lists), np.concatenate(sigs)
     order = np.lexsort((lists, labels))
-    la, li, sg = labels[order], lists[order], sigs[order]
+    la, li = labels[order], lists[order]
     same = la[1:] == la[:-1]
     if (same & (li[1:] == li[:-1])).any():          # two copies in one list
         return False
+    del la, li
+    sg = sigs[order]
     return bool((sg[1:][same] == sg[:-1][same]).all())
 
 
