@@ -244,7 +244,9 @@ int tk_index_quiesce(tk_index *ix);
  * queries per wave, heap columns in LDS; pass_1 <= 574), or, for larger heaps, a
  * wave replays one query on packed 32-bit entries; otherwise the general kernel
  * (int64 labels + duplicate scan, one query per wave) runs.  1 = always the
- * general kernel.  2 = the packed wave kernel instead of the lane kernel.  All are
+ * general kernel.  2 = the packed wave kernel instead of the lane kernel.  3 = the
+ * wave-per-query register heap (heaps of <= 129 entries; automatic for small batches,
+ * TK_OPT_PAIR_NQ) for every batch size.  All are
  * bit-exact replays of _fast_pq_256.pyx:73-123; the switch exists for A/B timing
  * and for the parity tests. */
 int tk_index_set_heap_mode(tk_index *ix, int mode);
@@ -316,6 +318,11 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
  *                        only its own lists' codes (tk_index_set_lists_shard) cannot, and uses the table only behind
  *                        1 = "the caller has checked" (tinyknn_amd.DeviceIndex does, on the host).  0 (DEFAULT). */
 #define TK_OPT_TWIN_VOUCH 7
+/*   TK_OPT_PAIR_NQ       batches of up to this many queries (DEFAULT 256; 0 = never) replay their heaps one query per
+ *                        WAVE with the heap in registers, two nodes per lane (heaps of <= 129 entries: IVF.query's 111
+ *                        and its coarse top's 30 at the reference's bench settings, examples/bench.py:118-137): one
+ *                        query per call is ~760 dependent inserts, 0.47 of 0.54 ms in the lane kernel.  Same heap arrays. */
+#define TK_OPT_PAIR_NQ 8
 int tk_index_set_option(tk_index *ix, int option, int value);
 /* The table behind TK_OPT_REPLAY_TWIN (diagnostics, tests): *rows = stored rows (the length of the concatenated
  * ids), *w = other copies listed per row (0: no table — labels distinct, not int32, or one label stored more

@@ -49,7 +49,7 @@ def test_random_index_all_modes(oracle, seed):
     qn, qp = ivf._prepare(qs.copy())
     want = ox.query_batch(qn, c["k"], c["n_probes"])
     dev = ivf.device_index()
-    for heap_mode, scan_mode in ((0, 0), (1, 1), (2, 2), (0, 2)):
+    for heap_mode, scan_mode in ((0, 0), (1, 1), (2, 2), (0, 2), (3, 0)):
         dev.set_heap_mode(heap_mode)
         dev.set_scan_mode(scan_mode)
         got = dev.query_batch(qn, qp, c["k"], c["n_probes"])

@@ -348,6 +348,18 @@ def test_ivf_query_golden(tk, tag):
             np.testing.assert_array_equal(out, g[f"ids_p{n_probes}"])
         dev.set_option(_lib.OPT_REPLAY_LAZY, -1)
         dev.set_option(_lib.OPT_REPLAY_TWIN, 1)
+        # the wave-per-query replay with the heap in registers (heaps of up to 129 entries; the kernel of one query per
+        # call): forced, and as small batches get it by themselves at the product's default threshold
+        for mode, pair_nq in ((3, 0), (0, 256)):
+            dev.set_heap_mode(mode)
+            dev.set_option(_lib.OPT_PAIR_NQ, pair_nq)
+            out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
+            np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
+            np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"], err_msg=f"pair {mode} {pair_nq}")
+            np.testing.assert_array_equal(dbg["heap_val"], g[f"heap_val_p{n_probes}"])
+            np.testing.assert_array_equal(out, g[f"ids_p{n_probes}"])
+        dev.set_heap_mode(0)
+        dev.set_option(_lib.OPT_PAIR_NQ, 4)
         out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)
         np.testing.assert_array_equal(dbg["probes"], g[f"probes_p{n_probes}"])
         np.testing.assert_array_equal(dbg["heap_idx"], g[f"heap_idx_p{n_probes}"])
@@ -382,7 +394,8 @@ def test_ivf_vs_oracle_larger(tk, oracle):
                             [ivf.ids[i] for i in range(L)], ivf.data)
     qn, qp = ivf._prepare(qs.copy())
     for n_probes, heap_mode, scan_mode in ((1, 0, 2), (5, 0, 1), (10, 0, 2), (10, 1, 1), (10, 2, 2), (20, 0, 0),
-                                           (50, 0, 2), (50, 1, 1), (50, 2, 0)):
+                                           (50, 0, 2), (50, 1, 1), (50, 2, 0), (1, 3, 0), (5, 3, 2), (10, 3, 1),
+                                           (11, 3, 0), (20, 3, 0)):      # (3: register heap; beyond 129 entries: as 0)
         ivf.device_index().set_heap_mode(heap_mode)   # lane-per-query / wave-per-query replay
         ivf.device_index().set_scan_mode(scan_mode)   # query-major / list-major scan
         out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)
@@ -421,7 +434,7 @@ def test_ivf_saturating_and_duplicates(tk, oracle, build_probes):
     qn, qp = ivf._prepare(qs.copy())
     saw_sentinel = 0
     for n_probes in (3, 8, 20):
-        for heap_mode in (0, 1, 2):
+        for heap_mode in (0, 1, 2, 3):
             ivf.device_index().set_heap_mode(heap_mode)
             ivf.device_index().set_scan_mode(1 + heap_mode % 2)
             out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)

@@ -18,6 +18,10 @@ extern "C" tk_index *tk_index_create(void)
     // A/B: TINYKNN_PLAIN_SCAN=2 starts every index in mode 2 (plain always, repeating labels too)
     const char *e = getenv("TINYKNN_PLAIN_SCAN");
     if (e && e[0] == '2') ix->plain_mode = 2;
+    // the default of TK_OPT_PAIR_NQ (the test suite starts with a small one so that batches of a few hundred queries keep
+    // exercising the lane kernels)
+    e = getenv("TINYKNN_PAIR_NQ");
+    if (e && e[0] >= '0' && e[0] <= '9') ix->opt_pair_nq = atoi(e);
     return ix;
 }
 
@@ -341,6 +345,14 @@ bool twin_replay(const tk_index *ix, const Plan &p)
     return !ix->ids_unique && ix->twin_w > 0 && ix->opt_replay_twin == 1 && ix->heap_mode == 0 &&
            (!ix->twin_unverified || ix->twin_vouched) &&
            ix->total_ids < (1ll << 31) && p.cap * 16 <= 0xffffff && tk_lanes_twin_fits(p.R, p.S, ix->n_lists);
+}
+
+// the wave-per-query replay with the heap in registers (heap.hip: heap_replay_pair_kernel): small batches — ONE query
+// per call above all — where the lane kernel would spend a wave's round on a few lanes; heap_mode 3 forces it
+static bool pair_replay(const tk_index *ix, int64_t nq, int R)
+{
+    if (R > TK_PAIR_MAX_R) return false;
+    return ix->heap_mode == 3 || (ix->heap_mode == 0 && nq <= ix->opt_pair_nq);
 }
 
 static bool plain_possible(const tk_index *ix, const Plan &p)
@@ -734,7 +746,12 @@ int coarse_replay_probes(tk_index *ix, Work &w, const float *q_dev, int64_t nq, 
     // positions of one list against a fresh heap are distinct labels: lane-per-query
     const bool fast_c = ix->heap_mode != 1 && ix->center_chunks * 16 <= 0xffffff;
     const bool lanes_c = fast_c && ix->heap_mode == 0 && p.rescore <= TK_LANES_MAX_R;
-    if (fast_c && !lanes_c) {
+    if (fast_c && pair_replay(ix, nq, p.rescore)) {
+        tk_launch_heap_replay_pair(w.cdist.as<uint4>(), ix->center_chunks, nq, w.cmins.as<uint8_t>(), p.ccap_min,
+                                   ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2, ix->cslots_l.as<int64_t>(), 1,
+                                   nullptr, w.cheap_idx.as<int64_t>(), w.cheap_val.as<int32_t>(), p.rescore, 1, 1,
+                                   nullptr, 0, st);
+    } else if (fast_c && !lanes_c) {
         tk_launch_heap_replay_packed(w.cdist.as<uint4>(), ix->center_chunks, nq,
                                      ix->cslots_i.as<int>(), ix->cslots_i.as<int>() + 2,
                                      ix->cslots_l.as<int64_t>(), 1, nullptr,
@@ -921,7 +938,14 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
     const double blocks_per_query = (double)p.S * (double)ix->total_chunks / (double)ix->n_lists;
     const int lazy = ix->opt_replay_lazy >= 0 ? ix->opt_replay_lazy
                                               : (blocks_per_query >= (twin_replay(ix, p) ? 40.0 : 8.0) * p.R);
-    if (packed_ok && ix->ids_unique) {
+    if (packed_ok && !plain && pair_replay(ix, nq, p.R)) {
+        // one wave per query, heap in registers: position entries where labels are distinct (the queries whose probe
+        // list names a list twice: the duplicate test on labels, as every query of an index whose labels repeat)
+        tk_launch_heap_replay_pair(w.dist.as<uint4>(), p.cap, nq, w.mins.as<uint8_t>(), p.cap_min, slot_prefix, slot_n,
+                                   slot_loff, p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                   w.heap_val.as<int32_t>(), p.R, 1, 0, ix->ids_unique ? repeat_flag : nullptr,
+                                   ix->ids_unique ? 0 : 1, st);
+    } else if (packed_ok && ix->ids_unique) {
         const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
         if (!lanes)
             tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n,
@@ -1732,7 +1756,7 @@ extern "C" int tk_index_set_heap_mode(tk_index *ix, int mode)
 {
     IXLOCK(ix);
     ARGCHECK(ix, "null index");
-    ARGCHECK(mode >= 0 && mode <= 2, "mode");
+    ARGCHECK(mode >= 0 && mode <= 3, "mode");
     TRY(flush_pending(ix));
     ix->heap_mode = mode;
     return TK_OK;
@@ -1754,6 +1778,10 @@ extern "C" int tk_index_set_option(tk_index *ix, int option, int value)
         return TK_OK;
     case TK_OPT_PLAIN_LIMIT:
         ix->opt_plain_limit = value;
+        return TK_OK;
+    case TK_OPT_PAIR_NQ:
+        ARGCHECK(value >= 0, "TK_OPT_PAIR_NQ: >= 0");
+        ix->opt_pair_nq = value;
         return TK_OK;
     case TK_OPT_REPLAY_COUNT:
         ix->opt_replay_count = value != 0;
@@ -1783,7 +1811,7 @@ extern "C" int tk_index_set_scan_mode(tk_index *ix, int mode)
 {
     IXLOCK(ix);
     ARGCHECK(ix, "null index");
-    ARGCHECK(mode >= 0 && mode <= 2, "mode");
+    ARGCHECK(mode >= 0 && mode <= 3, "mode");
     TRY(flush_pending(ix));
     ix->scan_mode = mode;
     return TK_OK;
@@ -1793,7 +1821,7 @@ extern "C" int tk_index_set_plain_scan(tk_index *ix, int mode)
 {
     IXLOCK(ix);
     ARGCHECK(ix, "null index");
-    ARGCHECK(mode >= 0 && mode <= 2, "mode");
+    ARGCHECK(mode >= 0 && mode <= 3, "mode");
     TRY(flush_pending(ix));
     ix->plain_mode = mode;
     ix->plain_state = PLAIN_PROBE;

@@ -1481,6 +1481,297 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
 }
 
 // ---------------------------------------------------------------------------
+// Wave-per-query replay with the heap in REGISTERS, two nodes per lane: heaps of up to 129 entries (IVF.query at the
+// reference's bench settings: (n_probes + 1) k + 1 = 111; its coarse `top`: 2 n_probes + 10 = 30).  This is the kernel
+// of ONE query per call (examples/bench.py:118-137 times exactly that) and of small batches, where the lane kernel's
+// round of ~2 000 cycles serves a single lane: ~760 dependent inserts of one query were 0.47 of the call's 0.54 ms.
+//
+// Layout (tests/test_pair_heap_lemma.py restates it in numpy and checks it against the reference's loop): the root is
+// wave-uniform; lane L holds the two CHILDREN of node L — node 2L+1 in slot 0, node 2L+2 in slot 1.  "Which child of
+// node L is larger" (the left one on ties: `vl > v`, then `vr > nxt_val`, _fast_pq.pyx:297-300) is a comparison inside
+// the lane; one ballot B of it describes the whole max-child path, which `insert`'s sift follows whatever v is: node t
+// is on it iff every ancestor chose the child on the chain down to t — ((B ^ bits) & mask) == 0 with a per-lane constant
+// pair.  Values never rise along the path, so with CE[L] = the entry of node L's larger child
+//     root                                           <- CE[0]  if CE[0].v > v   else (label, v)
+//     larger child c of an on-path node L, CE[L].v > v <- CE[c]  if c < 64 and CE[c].v > v   else (label, v)
+// B, the path, CE and the cross-lane fetch of CE[c] (one ds_bpermute per register of an entry) are prepared BEHIND an
+// insert, before the next candidate is known; a compare and two selects per lane remain on the candidate's own chain.
+// Nodes >= R hold a value no candidate is below and are never taken.
+// Entries: POSITIONS (value8 << 24 | flat position24, one register per slot) where no label can repeat among a query's
+// lists; (value, label64) — three registers per slot — with the reference's duplicate test (`if i == indices[j]:
+// return`, :284-287, one ballot) where labels repeat (IVF.build(n_probes >= 2)) or a probe list names a list twice.
+#define TK_PAIR_LOW (-(1 << 20))
+
+struct PairLane {      // constants of lane L = node L: its ancestors (as lanes, all < 32) and the child each must choose
+    uint32_t anc_mask, anc_bits;
+};
+__device__ __forceinline__ PairLane pair_lane(int lane)
+{
+    PairLane K;
+    K.anc_mask = K.anc_bits = 0;
+    for (int t = lane; t > 0;) {
+        const int par = (t - 1) >> 1;
+        K.anc_mask |= 1u << par;
+        K.anc_bits |= (uint32_t)((t - 1) & 1) << par;
+        t = par;
+    }
+    return K;
+}
+
+// ---- position entries
+template <bool SIGNED>
+struct PairHeapPos {
+    uint32_t e0, e1, er;            // er: wave-uniform
+    // prepared behind every change
+    bool right, onp;
+    uint32_t ce, fe, ce0;
+    int cev, fev;
+    __device__ __forceinline__ void init(int lane, int R)
+    {
+        const uint32_t fresh = SIGNED ? 0x7fffffffu : 0xffffffffu;
+        const uint32_t lowest = SIGNED ? 0x80ffffffu : 0x00ffffffu;
+        er = fresh;
+        e0 = 2 * lane + 1 < R ? fresh : lowest;
+        e1 = 2 * lane + 2 < R ? fresh : lowest;
+    }
+    __device__ __forceinline__ void prepare(int lane, const PairLane &K)
+    {
+        const uint32_t lowest = SIGNED ? 0x80ffffffu : 0x00ffffffu;
+        const int v0 = entry_val<SIGNED>(e0), v1 = entry_val<SIGNED>(e1);
+        right = v1 > v0;
+        const uint32_t ball = (uint32_t)__builtin_amdgcn_ballot_w64(right);
+        onp = ((ball ^ K.anc_bits) & K.anc_mask) == 0;
+        ce = right ? e1 : e0;
+        cev = right ? v1 : v0;
+        const int c = 2 * lane + 1 + (int)right;
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((c & 63) << 2, (int)ce);
+        fe = c < 64 ? got : lowest;
+        fev = entry_val<SIGNED>(fe);
+        ce0 = __builtin_amdgcn_readlane(ce, 0);
+    }
+    __device__ __forceinline__ uint32_t bound() const { return er >> 24; }
+    __device__ __forceinline__ void insert(uint32_t e, int v, int lane, const PairLane &K)
+    {
+        const bool upd = onp && cev > v;
+        const uint32_t ne = fev > v ? fe : e;
+        e0 = (upd && !right) ? ne : e0;
+        e1 = (upd && right) ? ne : e1;
+        er = entry_val<SIGNED>(ce0) > v ? ce0 : e;
+        prepare(lane, K);
+    }
+};
+
+// ---- (value, label) entries with the duplicate test
+template <bool SIGNED>
+struct PairHeapLab {
+    int v0, v1, vr;
+    uint32_t lo0, lo1, lor, hi0, hi1, hir;
+    bool right, onp;
+    int cev, fev, cev0;
+    uint32_t clo, chi, flo, fhi, clo0, chi0;
+    __device__ __forceinline__ void init(int lane, int R)
+    {
+        const int fresh = SIGNED ? 127 : 255;
+        vr = fresh;
+        v0 = 2 * lane + 1 < R ? fresh : TK_PAIR_LOW;
+        v1 = 2 * lane + 2 < R ? fresh : TK_PAIR_LOW;
+        lo0 = lo1 = lor = hi0 = hi1 = hir = 0xffffffffu;       // label -1
+    }
+    __device__ __forceinline__ void prepare(int lane, const PairLane &K)
+    {
+        right = v1 > v0;
+        const uint32_t ball = (uint32_t)__builtin_amdgcn_ballot_w64(right);
+        onp = ((ball ^ K.anc_bits) & K.anc_mask) == 0;
+        cev = right ? v1 : v0;
+        clo = right ? lo1 : lo0;
+        chi = right ? hi1 : hi0;
+        const int c = 2 * lane + 1 + (int)right;
+        const int a = (c & 63) << 2;
+        const int gv = __builtin_amdgcn_ds_bpermute(a, cev);
+        const uint32_t gl = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)clo);
+        const uint32_t gh = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)chi);
+        fev = c < 64 ? gv : TK_PAIR_LOW;
+        flo = gl;
+        fhi = gh;
+        cev0 = __builtin_amdgcn_readlane(cev, 0);
+        clo0 = __builtin_amdgcn_readlane(clo, 0);
+        chi0 = __builtin_amdgcn_readlane(chi, 0);
+    }
+    __device__ __forceinline__ uint32_t bound() const { return (uint32_t)vr & 0xffu; }
+    // `if i == indices[j]: return` (:284-287): nodes >= R and fresh nodes hold -1, which no row carries
+    __device__ __forceinline__ bool holds(uint32_t llo, uint32_t lhi) const
+    {
+        const bool here = ((lo0 == llo) & (hi0 == lhi)) | ((lo1 == llo) & (hi1 == lhi));
+        return __builtin_amdgcn_ballot_w64(here) != 0 || (lor == llo && hir == lhi);
+    }
+    __device__ __forceinline__ void insert(uint32_t llo, uint32_t lhi, int v, int lane, const PairLane &K)
+    {
+        const bool upd = onp && cev > v;
+        const bool deeper = fev > v;
+        const int nv = deeper ? fev : v;
+        const uint32_t nl = deeper ? flo : llo, nh = deeper ? fhi : lhi;
+        const bool u0 = upd && !right, u1 = upd && right;
+        v0 = u0 ? nv : v0; lo0 = u0 ? nl : lo0; hi0 = u0 ? nh : hi0;
+        v1 = u1 ? nv : v1; lo1 = u1 ? nl : lo1; hi1 = u1 ? nh : hi1;
+        const bool rt = cev0 > v;
+        vr = rt ? cev0 : v; lor = rt ? clo0 : llo; hir = rt ? chi0 : lhi;
+        prepare(lane, K);
+    }
+};
+
+// One wave per query.  dist / mins / slot tables as heap_replay_packed_kernel; `flags`: queries that need the duplicate
+// test although labels are distinct (a probe list that names a list twice); dedupe_all: labels repeat in the index.
+template <bool SIGNED>
+__global__ __launch_bounds__(64) void heap_replay_pair_kernel(
+    const uint4 *__restrict__ dist, int64_t cap, const uint8_t *__restrict__ mins, int64_t cap_min,
+    const int *__restrict__ slot_prefix, const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off,
+    int S, const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx, int32_t *__restrict__ heap_val, int R,
+    int slots_uniform, const unsigned char *__restrict__ flags, int dedupe_all, int64_t nq)
+{
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    if (q >= nq) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int64_t qs = slots_uniform ? 0 : q;
+    const int *prefix = slot_prefix + qs * (S + 1);
+    const int *ns = slot_n + qs * S;
+    const int64_t *loffs = slot_label_off + qs * S;
+    const uint4 *drow = dist + q * cap;
+    const uint8_t *mrow = mins + q * cap_min;
+    const bool with_labels = dedupe_all || (flags && flags[q]);
+    const PairLane K = pair_lane(lane);
+    const int total = S > 0 ? prefix[S] : 0;
+    const uint4 never = SIGNED ? make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu)
+                               : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    PairHeapPos<SIGNED> HP;
+    PairHeapLab<SIGNED> HL;
+    HP.init(lane, R);
+    HL.init(lane, R);
+    if (with_labels) HL.prepare(lane, K); else HP.prepare(lane, K);
+    uint32_t bound = SIGNED ? 0x7fu : 0xffu;
+    // slot cursor (wave-uniform): flat blocks [c0, c1) belong to slot s
+    int s = 0, c0 = 0, c1 = S > 0 ? prefix[1] : 0;
+    // 64 blocks per step, each lane one block and its minimum; the next step's are requested before this one is replayed
+    uint4 nd = never;
+    uint32_t nm = SIGNED ? 0x7fu : 0xffu;
+    if (lane < total) { nd = drow[lane]; nm = mrow[lane]; }
+    for (int base = 0; base < total; base += 64) {
+        const uint4 dd = nd;
+        const uint32_t mn = nm;
+        nd = never;
+        nm = SIGNED ? 0x7fu : 0xffu;
+        if (base + 64 + lane < total) { nd = drow[base + 64 + lane]; nm = mrow[base + 64 + lane]; }
+        // blocks whose minimum is below the bound of now: a superset of what the reference enters (the bound only falls)
+        uint64_t mask = __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn, bound));
+        // labels of a voted block: lanes 0..15, one vector load, requested one voted block ahead
+        int j_pref = -1;
+        int64_t lab_pref = -2;
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int f = base + j;
+            while (f >= c1) {            // (empty lists: several steps)
+                s++;
+                c0 = c1;
+                c1 = prefix[s + 1];
+            }
+            const int n = ns[s];
+            const int rows = n - 16 * (f - c0);             // `pos < n`, _fast_pq_256.pyx:111
+            int64_t lab_cur = -2;
+            if (with_labels) {
+                const int64_t loff = loffs[s];
+                const int64_t inl = 16 * (int64_t)(f - c0) + lane;
+                if (j == j_pref) lab_cur = lab_pref;
+                else if (lane < 16 && inl < n) lab_cur = loff < 0 ? inl : labels[loff + inl];
+                if (mask) {                                 // the next voted block of this step (a superset: the bound may fall)
+                    j_pref = __builtin_ctzll(mask);
+                    const int f2 = base + j_pref;
+                    int s2 = s, a0 = c0, a1 = c1;
+                    while (f2 >= a1) { s2++; a0 = a1; a1 = prefix[s2 + 1]; }
+                    const int64_t loff2 = loffs[s2];
+                    const int64_t inl2 = 16 * (int64_t)(f2 - a0) + lane;
+                    lab_pref = -2;
+                    if (lane < 16 && inl2 < ns[s2]) lab_pref = loff2 < 0 ? inl2 : labels[loff2 + inl2];
+                }
+            }
+            const uint32_t d0 = __builtin_amdgcn_readlane(dd.x, j);
+            const uint32_t d1 = __builtin_amdgcn_readlane(dd.y, j);
+            const uint32_t d2 = __builtin_amdgcn_readlane(dd.z, j);
+            const uint32_t d3 = __builtin_amdgcn_readlane(dd.w, j);
+            // the reference's cmp_mask of this block against the bound captured at its start: row r in lane r
+            const uint32_t w = lane < 4 ? d0 : lane < 8 ? d1 : lane < 12 ? d2 : d3;
+            const uint32_t by = (w >> (8 * (lane & 3))) & 0xffu;
+            uint32_t bits = (uint32_t)__builtin_amdgcn_ballot_w64(lane < 16 && lane < rows && byte_lt<SIGNED>(by, bound));
+            if (!bits) continue;
+            const uint32_t pos0 = (uint32_t)(16 * f);
+            while (bits) {               // every passing row goes in, in row order, without a second look (:113-118)
+                const int r = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const uint32_t byr = __builtin_amdgcn_readlane(by, r);
+                const int v = SIGNED ? (int)(int8_t)byr : (int)byr;
+                if (with_labels) {
+                    const uint32_t llo = __builtin_amdgcn_readlane((uint32_t)lab_cur, r);
+                    const uint32_t lhi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)lab_cur >> 32), r);
+                    if (HL.holds(llo, lhi)) continue;
+                    HL.insert(llo, lhi, v, lane, K);
+                } else {
+                    HP.insert((byr << 24) | (pos0 + (uint32_t)r), v, lane, K);
+                }
+            }
+            bound = with_labels ? HL.bound() : HP.bound();                  // refresh behind the block, :123
+            if (mask) mask &= __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn, bound));
+        }
+    }
+    // heap arrays out, in the reference's layout: node 0 = the root, node 2L+1+slot = lane L's slot
+    int64_t *oi = heap_idx + q * R;
+    int32_t *ov = heap_val + q * R;
+    if (with_labels) {
+        if (lane == 0) { oi[0] = (int64_t)(((uint64_t)HL.hir << 32) | HL.lor); ov[0] = HL.vr; }
+        if (2 * lane + 1 < R) { oi[2 * lane + 1] = (int64_t)(((uint64_t)HL.hi0 << 32) | HL.lo0); ov[2 * lane + 1] = HL.v0; }
+        if (2 * lane + 2 < R) { oi[2 * lane + 2] = (int64_t)(((uint64_t)HL.hi1 << 32) | HL.lo1); ov[2 * lane + 2] = HL.v1; }
+        return;
+    }
+#pragma unroll
+    for (int slot = -1; slot < 2; slot++) {
+        const int t = slot < 0 ? 0 : 2 * lane + 1 + slot;
+        if (t >= R || (slot < 0 && lane != 0)) continue;
+        const uint32_t e = slot < 0 ? HP.er : slot == 0 ? HP.e0 : HP.e1;
+        const uint32_t pos = e & 0x00ffffffu;
+        int64_t label = -1;
+        if (pos != 0x00ffffffu) {          // the flat position back to (list, row): its label
+            const int fb = (int)(pos >> 4);
+            int lo = 0, hi = S;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (prefix[mid] <= fb) lo = mid; else hi = mid;
+            }
+            const int64_t inlist = (int64_t)pos - 16 * (int64_t)prefix[lo];
+            const int64_t loff = loffs[lo];
+            label = loff < 0 ? inlist : labels[loff + inlist];
+        }
+        oi[t] = label;
+        ov[t] = entry_val<SIGNED>(e);
+    }
+}
+
+// cap * 16 <= 0xffffff (position entries) is the caller's to check where labels are distinct
+void tk_launch_heap_replay_pair(const uint4 *dist, int64_t cap, int64_t nq, const uint8_t *mins, int64_t cap_min,
+                                const int *slot_prefix, const int *slot_n, const int64_t *slot_label_off, int S,
+                                const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R, int signd,
+                                int slots_uniform, const unsigned char *flags, int dedupe_all, hipStream_t s)
+{
+    if (nq == 0 || R == 0) return;
+    if (signd)
+        hipLaunchKernelGGL(heap_replay_pair_kernel<true>, dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,
+                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,
+                           dedupe_all, nq);
+    else
+        hipLaunchKernelGGL(heap_replay_pair_kernel<false>, dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,
+                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,
+                           dedupe_all, nq);
+}
+
+// ---------------------------------------------------------------------------
 __global__ void heap_fill_kernel(int64_t *heap_idx, int32_t *heap_val, int64_t count, int32_t v)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
