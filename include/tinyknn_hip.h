@@ -318,10 +318,12 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
  *                        only its own lists' codes (tk_index_set_lists_shard) cannot, and uses the table only behind
  *                        1 = "the caller has checked" (tinyknn_amd.DeviceIndex does, on the host).  0 (DEFAULT). */
 #define TK_OPT_TWIN_VOUCH 7
-/*   TK_OPT_PAIR_NQ       batches of up to this many queries (DEFAULT 256; 0 = never) replay their heaps one query per
- *                        WAVE with the heap in registers, two nodes per lane (heaps of <= 129 entries: IVF.query's 111
- *                        and its coarse top's 30 at the reference's bench settings, examples/bench.py:118-137): one
- *                        query per call is ~760 dependent inserts, 0.47 of 0.54 ms in the lane kernel.  Same heap arrays. */
+/*   TK_OPT_PAIR_NQ       batches of up to this many queries (DEFAULT 2048 one batch at a time, at most 256 in pipelined
+ *                        mode; 0 = never; environment TINYKNN_PAIR_NQ sets the default of new indexes) replay their heaps
+ *                        one query per WAVE with the heap in registers, two nodes per lane (heaps of <= 129 entries:
+ *                        IVF.query's 111 and its coarse top's 30 at the reference's bench settings,
+ *                        examples/bench.py:118-137): one query per call is ~760 dependent inserts, 0.47 of 0.54 ms in the
+ *                        lane kernel, 0.12 of 0.19 ms here.  Same heap arrays. */
 #define TK_OPT_PAIR_NQ 8
 int tk_index_set_option(tk_index *ix, int option, int value);
 /* The table behind TK_OPT_REPLAY_TWIN (diagnostics, tests): *rows = stored rows (the length of the concatenated

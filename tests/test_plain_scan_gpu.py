@@ -29,11 +29,13 @@ def limit_hook(tk):
 
 @pytest.mark.parametrize("tag", G6)
 @pytest.mark.parametrize("mode", ["auto", "rescan-all", "off"])
-def test_golden_ids_and_heaps(tk, tag, mode, limit_hook):
+@pytest.mark.parametrize("heap_mode", [0, 3])      # the lane replay / the wave-per-query register heap: both make the check
+def test_golden_ids_and_heaps(tk, tag, mode, limit_hook, heap_mode):
     from test_hip_parity import ivf_from_fixture
     g = golden(f"g6_ivf_{tag}.npz")
     ivf = ivf_from_fixture(tk, g)
     dev = ivf.device_index()
+    dev.set_heap_mode(heap_mode)
     dev.set_scan_mode(2)            # list-major: the form the plain kernel rides with
     dev.set_plain_scan("always" if mode != "off" else False)
     if mode == "rescan-all":

@@ -352,13 +352,21 @@ bool twin_replay(const tk_index *ix, const Plan &p)
 static bool pair_replay(const tk_index *ix, int64_t nq, int R)
 {
     if (R > TK_PAIR_MAX_R) return false;
-    return ix->heap_mode == 3 || (ix->heap_mode == 0 && nq <= ix->opt_pair_nq);
+    if (ix->heap_mode == 3) return true;
+    // One batch at a time the register heap wins up to ~10 000 queries (8 000: 0.30 against 0.69 ms,
+    // profiles/r06/query1_and_small_batches.txt) — but it fills every SIMD's issue slots, where the lane kernel leaves
+    // the chip to the scans of the batches beside it: with batches in flight (pipelined mode) the headline batch LOSES
+    // 38 % on it (25.9 -> 16.1 M queries/s).  So: the option's value one batch at a time, at most 256 when pipelined.
+    const int64_t limit = ix->depth > 1 ? (ix->opt_pair_nq < 256 ? ix->opt_pair_nq : 256) : ix->opt_pair_nq;
+    return ix->heap_mode == 0 && nq <= limit;
 }
 
 static bool plain_possible(const tk_index *ix, const Plan &p)
 {
     if (ix->plain_mode == 1 || !plain_env_on() || ix->sharded || p.S < 2 || !tk_plain_fits(ix->M)) return false;
-    if (ix->heap_mode != 0 || ix->scan_mode == 1 || p.cap * 16 > 0xffffff) return false;
+    // (heap_mode 3: the register heap makes the lemma's check as the lane kernel does)
+    if ((ix->heap_mode != 0 && !(ix->heap_mode == 3 && p.R <= TK_PAIR_MAX_R)) || ix->scan_mode == 1 || p.cap * 16 > 0xffffff)
+        return false;
     if (ix->ids_unique) return p.R <= TK_LANES_MAX_R;
     // repeating labels with the TWIN form of the lane replay: as with distinct labels
     if (twin_replay(ix, p)) return true;
@@ -938,13 +946,25 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
     const double blocks_per_query = (double)p.S * (double)ix->total_chunks / (double)ix->n_lists;
     const int lazy = ix->opt_replay_lazy >= 0 ? ix->opt_replay_lazy
                                               : (blocks_per_query >= (twin_replay(ix, p) ? 40.0 : 8.0) * p.R);
-    if (packed_ok && !plain && pair_replay(ix, nq, p.R)) {
+    if (packed_ok && pair_replay(ix, nq, p.R) && !(plain && plain_flag)) {
         // one wave per query, heap in registers: position entries where labels are distinct (the queries whose probe
-        // list names a list twice: the duplicate test on labels, as every query of an index whose labels repeat)
-        tk_launch_heap_replay_pair(w.dist.as<uint4>(), p.cap, nq, w.mins.as<uint8_t>(), p.cap_min, slot_prefix, slot_n,
-                                   slot_loff, p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                   w.heap_val.as<int32_t>(), p.R, 1, 0, ix->ids_unique ? repeat_flag : nullptr,
-                                   ix->ids_unique ? 0 : 1, st);
+        // list names a list twice: the duplicate test on labels, as every query of an index whose labels repeat).
+        // Behind the plain kernel: the lemma's check per query, as the lane kernel makes it (it does not depend on how the
+        // duplicate test is made: below the limit the plain values ARE the reference's); the queries that fail it and
+        // those flagged beforehand are scanned again exactly and replayed by the packed kernel with the duplicate test
+        if (tk_launch_heap_replay_pair(w.dist.as<uint4>(), p.cap, nq, w.mins.as<uint8_t>(), p.cap_min, slot_prefix, slot_n,
+                                       slot_loff, p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                       w.heap_val.as<int32_t>(), p.R, 1, 0, (plain || ix->ids_unique) ? repeat_flag : nullptr,
+                                       ix->ids_unique ? 0 : 1, st, slot_exact, qlim, plain ? w.flag_list.as<int>() : nullptr))
+            return fail(TK_ERR_HIP, "hipMemsetAsync(flag list) failed");
+        if (plain) {
+            rescan_flagged(ix, w, q0, nq, p, st, true);
+            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, -1, 1, st,
+                                         w.flag_list.as<int>(), w.flag_host);
+            plain_verdict_event(ix, w, nq, st);
+        }
     } else if (packed_ok && ix->ids_unique) {
         const bool lanes = ix->heap_mode == 0 && p.R <= TK_LANES_MAX_R;
         if (!lanes)

@@ -38,6 +38,8 @@
 //     64-lane compare + ballot, the sift-down runs wave-uniformly.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 // Heap state shared by the lanes of a wave lives in LDS and is accessed through
@@ -1619,35 +1621,23 @@ struct PairHeapLab {
     }
 };
 
-// One wave per query.  dist / mins / slot tables as heap_replay_packed_kernel; `flags`: queries that need the duplicate
-// test although labels are distinct (a probe list that names a list twice); dedupe_all: labels repeat in the index.
-template <bool SIGNED>
-__global__ __launch_bounds__(64) void heap_replay_pair_kernel(
-    const uint4 *__restrict__ dist, int64_t cap, const uint8_t *__restrict__ mins, int64_t cap_min,
-    const int *__restrict__ slot_prefix, const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off,
-    int S, const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx, int32_t *__restrict__ heap_val, int R,
-    int slots_uniform, const unsigned char *__restrict__ flags, int dedupe_all, int64_t nq)
+// The replay of one query by one wave: LABELS = the duplicate test on (value, label) entries, else position entries.
+// (Two instantiations called from one wave-uniform branch: as ONE loop with a run-time switch the compiler merged
+//  both heaps' registers and masks through every iteration — ~30 scalar moves per insert.)
+template <bool SIGNED, bool LABELS>
+__device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow, const uint8_t *__restrict__ mrow,
+                                                 const int *__restrict__ prefix, const int *__restrict__ ns,
+                                                 const int64_t *__restrict__ loffs, int S,
+                                                 const int64_t *__restrict__ labels, int64_t *__restrict__ oi,
+                                                 int32_t *__restrict__ ov, int R, int lane, int plain0, uint32_t &b_plain)
 {
-    const int lane = threadIdx.x;
-    const int64_t q = blockIdx.x;
-    if (q >= nq) return;
-    __builtin_amdgcn_s_setprio(3);
-    const int64_t qs = slots_uniform ? 0 : q;
-    const int *prefix = slot_prefix + qs * (S + 1);
-    const int *ns = slot_n + qs * S;
-    const int64_t *loffs = slot_label_off + qs * S;
-    const uint4 *drow = dist + q * cap;
-    const uint8_t *mrow = mins + q * cap_min;
-    const bool with_labels = dedupe_all || (flags && flags[q]);
     const PairLane K = pair_lane(lane);
     const int total = S > 0 ? prefix[S] : 0;
     const uint4 never = SIGNED ? make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu)
                                : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    PairHeapPos<SIGNED> HP;
-    PairHeapLab<SIGNED> HL;
-    HP.init(lane, R);
-    HL.init(lane, R);
-    if (with_labels) HL.prepare(lane, K); else HP.prepare(lane, K);
+    typename std::conditional<LABELS, PairHeapLab<SIGNED>, PairHeapPos<SIGNED>>::type H;
+    H.init(lane, R);
+    H.prepare(lane, K);
     uint32_t bound = SIGNED ? 0x7fu : 0xffu;
     // slot cursor (wave-uniform): flat blocks [c0, c1) belong to slot s
     int s = 0, c0 = 0, c1 = S > 0 ? prefix[1] : 0;
@@ -1663,7 +1653,7 @@ __global__ __launch_bounds__(64) void heap_replay_pair_kernel(
         if (base + 64 + lane < total) { nd = drow[base + 64 + lane]; nm = mrow[base + 64 + lane]; }
         // blocks whose minimum is below the bound of now: a superset of what the reference enters (the bound only falls)
         uint64_t mask = __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn, bound));
-        // labels of a voted block: lanes 0..15, one vector load, requested one voted block ahead
+        // LABELS: the labels of a voted block — lanes 0..15, one vector load — are requested one voted block ahead
         int j_pref = -1;
         int64_t lab_pref = -2;
         while (mask) {
@@ -1678,7 +1668,7 @@ __global__ __launch_bounds__(64) void heap_replay_pair_kernel(
             const int n = ns[s];
             const int rows = n - 16 * (f - c0);             // `pos < n`, _fast_pq_256.pyx:111
             int64_t lab_cur = -2;
-            if (with_labels) {
+            if (LABELS) {
                 const int64_t loff = loffs[s];
                 const int64_t inl = 16 * (int64_t)(f - c0) + lane;
                 if (j == j_pref) lab_cur = lab_pref;
@@ -1709,66 +1699,110 @@ __global__ __launch_bounds__(64) void heap_replay_pair_kernel(
                 bits &= bits - 1;
                 const uint32_t byr = __builtin_amdgcn_readlane(by, r);
                 const int v = SIGNED ? (int)(int8_t)byr : (int)byr;
-                if (with_labels) {
+                if constexpr (LABELS) {
                     const uint32_t llo = __builtin_amdgcn_readlane((uint32_t)lab_cur, r);
                     const uint32_t lhi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)lab_cur >> 32), r);
-                    if (HL.holds(llo, lhi)) continue;
-                    HL.insert(llo, lhi, v, lane, K);
+                    if (H.holds(llo, lhi)) continue;
+                    H.insert(llo, lhi, v, lane, K);
                 } else {
-                    HP.insert((byr << 24) | (pos0 + (uint32_t)r), v, lane, K);
+                    H.insert((byr << 24) | (pos0 + (uint32_t)r), v, lane, K);
                 }
             }
-            bound = with_labels ? HL.bound() : HP.bound();                  // refresh behind the block, :123
+            bound = H.bound();                                              // refresh behind the block, :123
+            b_plain = f < plain0 ? bound : b_plain;                         // (plain_scan.hip's lemma: the bound at the first plain block)
             if (mask) mask &= __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn, bound));
         }
     }
     // heap arrays out, in the reference's layout: node 0 = the root, node 2L+1+slot = lane L's slot
-    int64_t *oi = heap_idx + q * R;
-    int32_t *ov = heap_val + q * R;
-    if (with_labels) {
-        if (lane == 0) { oi[0] = (int64_t)(((uint64_t)HL.hir << 32) | HL.lor); ov[0] = HL.vr; }
-        if (2 * lane + 1 < R) { oi[2 * lane + 1] = (int64_t)(((uint64_t)HL.hi0 << 32) | HL.lo0); ov[2 * lane + 1] = HL.v0; }
-        if (2 * lane + 2 < R) { oi[2 * lane + 2] = (int64_t)(((uint64_t)HL.hi1 << 32) | HL.lo1); ov[2 * lane + 2] = HL.v1; }
-        return;
-    }
+    if constexpr (LABELS) {
+        if (lane == 0) { oi[0] = (int64_t)(((uint64_t)H.hir << 32) | H.lor); ov[0] = H.vr; }
+        if (2 * lane + 1 < R) { oi[2 * lane + 1] = (int64_t)(((uint64_t)H.hi0 << 32) | H.lo0); ov[2 * lane + 1] = H.v0; }
+        if (2 * lane + 2 < R) { oi[2 * lane + 2] = (int64_t)(((uint64_t)H.hi1 << 32) | H.lo1); ov[2 * lane + 2] = H.v1; }
+    } else {
 #pragma unroll
-    for (int slot = -1; slot < 2; slot++) {
-        const int t = slot < 0 ? 0 : 2 * lane + 1 + slot;
-        if (t >= R || (slot < 0 && lane != 0)) continue;
-        const uint32_t e = slot < 0 ? HP.er : slot == 0 ? HP.e0 : HP.e1;
-        const uint32_t pos = e & 0x00ffffffu;
-        int64_t label = -1;
-        if (pos != 0x00ffffffu) {          // the flat position back to (list, row): its label
-            const int fb = (int)(pos >> 4);
-            int lo = 0, hi = S;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (prefix[mid] <= fb) lo = mid; else hi = mid;
+        for (int slot = -1; slot < 2; slot++) {
+            const int t = slot < 0 ? 0 : 2 * lane + 1 + slot;
+            if (t >= R || (slot < 0 && lane != 0)) continue;
+            const uint32_t e = slot < 0 ? H.er : slot == 0 ? H.e0 : H.e1;
+            const uint32_t pos = e & 0x00ffffffu;
+            int64_t label = -1;
+            if (pos != 0x00ffffffu) {          // the flat position back to (list, row): its label
+                const int fb = (int)(pos >> 4);
+                int lo = 0, hi = S;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (prefix[mid] <= fb) lo = mid; else hi = mid;
+                }
+                const int64_t inlist = (int64_t)pos - 16 * (int64_t)prefix[lo];
+                const int64_t loff = loffs[lo];
+                label = loff < 0 ? inlist : labels[loff + inlist];
             }
-            const int64_t inlist = (int64_t)pos - 16 * (int64_t)prefix[lo];
-            const int64_t loff = loffs[lo];
-            label = loff < 0 ? inlist : labels[loff + inlist];
+            oi[t] = label;
+            ov[t] = entry_val<SIGNED>(e);
         }
-        oi[t] = label;
-        ov[t] = entry_val<SIGNED>(e);
     }
 }
 
-// cap * 16 <= 0xffffff (position entries) is the caller's to check where labels are distinct
-void tk_launch_heap_replay_pair(const uint4 *dist, int64_t cap, int64_t nq, const uint8_t *mins, int64_t cap_min,
-                                const int *slot_prefix, const int *slot_n, const int64_t *slot_label_off, int S,
-                                const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R, int signd,
-                                int slots_uniform, const unsigned char *flags, int dedupe_all, hipStream_t s)
+// One wave per query.  dist / mins / slot tables as heap_replay_packed_kernel; `flags`: queries that need the duplicate
+// test although labels are distinct (a probe list that names a list twice); dedupe_all: labels repeat in the index.
+// plain0_arr / qlim / flag_list (plain_scan.hip: the blocks from flat chunk plain0_arr[q] on carry clamp(plain sums)): the
+// replay checks the lemma's condition per query as the lane kernel does — bound at the first plain block <= qlim[q] —
+// and lists the queries that fail it, and those flagged beforehand, for the exact re-scan behind it (flags[q] = 2).
+template <bool SIGNED>
+__global__ __launch_bounds__(64) void heap_replay_pair_kernel(
+    const uint4 *__restrict__ dist, int64_t cap, const uint8_t *__restrict__ mins, int64_t cap_min,
+    const int *__restrict__ slot_prefix, const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off,
+    int S, const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx, int32_t *__restrict__ heap_val, int R,
+    int slots_uniform, unsigned char *__restrict__ flags, int dedupe_all, int64_t nq,
+    const int *__restrict__ plain0_arr, const int *__restrict__ qlim, int *__restrict__ flag_list)
 {
-    if (nq == 0 || R == 0) return;
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    if (q >= nq) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int64_t qs = slots_uniform ? 0 : q;
+    const bool flagged = flags && flags[q];
+    if (plain0_arr && flagged) {       // (its rows hold plain sums: left, with the queries that fail the check, to the re-scan)
+        if (lane == 0) flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
+        return;
+    }
+    const int plain0 = plain0_arr ? plain0_arr[q] : 0x7fffffff;
+    uint32_t b_plain = SIGNED ? 0x7fu : 0xffu;
+    const int *prefix = slot_prefix + qs * (S + 1);
+    if (dedupe_all || flagged)
+        pair_replay_body<SIGNED, true>(dist + q * cap, mins + q * cap_min, prefix, slot_n + qs * S,
+                                       slot_label_off + qs * S, S, labels, heap_idx + q * R, heap_val + q * R, R, lane,
+                                       plain0, b_plain);
+    else
+        pair_replay_body<SIGNED, false>(dist + q * cap, mins + q * cap_min, prefix, slot_n + qs * S,
+                                        slot_label_off + qs * S, S, labels, heap_idx + q * R, heap_val + q * R, R, lane,
+                                        plain0, b_plain);
+    if (SIGNED && plain0_arr && S > 0 && plain0 < prefix[S] && (int)(int8_t)b_plain > qlim[q] && lane == 0) {
+        flags[q] = 2;
+        flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
+    }
+}
+
+// cap * 16 <= 0xffffff (position entries) is the caller's to check where labels are distinct.  plain0 / qlim / flag_list:
+// all three or none (signed tables only); flag_list[0] is zeroed here, on the stream, in front of the kernel.
+int tk_launch_heap_replay_pair(const uint4 *dist, int64_t cap, int64_t nq, const uint8_t *mins, int64_t cap_min,
+                               const int *slot_prefix, const int *slot_n, const int64_t *slot_label_off, int S,
+                               const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R, int signd,
+                               int slots_uniform, unsigned char *flags, int dedupe_all, hipStream_t s,
+                               const int *plain0, const int *qlim, int *flag_list)
+{
+    if (nq == 0 || R == 0) return 0;
+    if (!plain0 || !qlim || !flag_list || !flags || !signd) plain0 = qlim = nullptr, flag_list = nullptr;
+    if (flag_list && hipMemsetAsync(flag_list, 0, 4, s) != hipSuccess) return -1;
     if (signd)
         hipLaunchKernelGGL(heap_replay_pair_kernel<true>, dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,
                            slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,
-                           dedupe_all, nq);
+                           dedupe_all, nq, plain0, qlim, flag_list);
     else
         hipLaunchKernelGGL(heap_replay_pair_kernel<false>, dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,
                            slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,
-                           dedupe_all, nq);
+                           dedupe_all, nq, plain0, qlim, flag_list);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------
