@@ -357,7 +357,8 @@ static bool pair_replay(const tk_index *ix, int64_t nq, int R)
     // profiles/r06/query1_and_small_batches.txt) — but it fills every SIMD's issue slots, where the lane kernel leaves
     // the chip to the scans of the batches beside it: with batches in flight (pipelined mode) the headline batch LOSES
     // 38 % on it (25.9 -> 16.1 M queries/s).  So: the option's value one batch at a time, at most 256 when pipelined.
-    const int64_t limit = ix->depth > 1 ? (ix->opt_pair_nq < 256 ? ix->opt_pair_nq : 256) : ix->opt_pair_nq;
+    // (a list-sharded index's depth is its number of workspace slots: the caller's batches, the option's value)
+    const int64_t limit = ix->depth > 1 && !ix->sharded ? (ix->opt_pair_nq < 256 ? ix->opt_pair_nq : 256) : ix->opt_pair_nq;
     return ix->heap_mode == 0 && nq <= limit;
 }
 
@@ -920,6 +921,28 @@ static void rescan_flagged(tk_index *ix, Work &w, int64_t q0, int64_t nq, const 
                           ix->order, st, list);
 }
 
+// The tail behind a lane (or register-heap) replay that rode with the plain kernel: the queries it flagged — the lemma's
+// check failed, or the probe list names a list twice — have been scanned again exactly (rescan_flagged) and are replayed
+// from fresh heaps with the reference's duplicate test; the flagged count goes to the page-locked word the host polls.
+// One wave per query either way; heaps of up to 129 entries take the register heap (a flagged query of the 100M x 128
+// index is ~1 300 inserts over 6 250 blocks: the packed kernel's LDS heap with its label scan per insert made ONE such
+// query a 1.2 ms tail behind a 1.9 ms replay of the other 9 999, profiles/r06/c5_flagged_tail.txt)
+static void replay_flagged_tail(tk_index *ix, Work &w, int64_t nq, const Plan &p, const int *slot_prefix, const int *slot_n,
+                                const int64_t *slot_loff, unsigned char *repeat_flag, hipStream_t st)
+{
+    if (p.R <= TK_PAIR_MAX_R && (ix->heap_mode == 0 || ix->heap_mode == 3) && ix->opt_pair_nq > 0) {
+        (void)tk_launch_heap_replay_pair(w.dist.as<uint4>(), p.cap, nq, w.mins.as<uint8_t>(), p.cap_min, slot_prefix, slot_n,
+                                         slot_loff, p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 0, st, nullptr, nullptr, nullptr,
+                                         1, w.flag_list.as<int>(), w.flag_host);
+        return;
+    }
+    tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
+                                 p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
+                                 w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, -1, 1, st,
+                                 w.flag_list.as<int>(), w.flag_host);
+}
+
 int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq, int k,
                       const Plan &p, int64_t *out_dev, hipStream_t st, Prof &pf, bool plain,
                       TkSecond q2, TkSecond out2, int *plain_flag)
@@ -946,23 +969,27 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
     const double blocks_per_query = (double)p.S * (double)ix->total_chunks / (double)ix->n_lists;
     const int lazy = ix->opt_replay_lazy >= 0 ? ix->opt_replay_lazy
                                               : (blocks_per_query >= (twin_replay(ix, p) ? 40.0 : 8.0) * p.R);
-    if (packed_ok && pair_replay(ix, nq, p.R) && !(plain && plain_flag)) {
+    if (packed_ok && pair_replay(ix, nq, p.R)) {
         // one wave per query, heap in registers: position entries where labels are distinct (the queries whose probe
         // list names a list twice: the duplicate test on labels, as every query of an index whose labels repeat).
         // Behind the plain kernel: the lemma's check per query, as the lane kernel makes it (it does not depend on how the
         // duplicate test is made: below the limit the plain values ARE the reference's); the queries that fail it and
-        // those flagged beforehand are scanned again exactly and replayed by the packed kernel with the duplicate test
+        // those flagged beforehand are scanned again exactly and replayed by the packed kernel with the duplicate test —
+        // or, on a list-sharded rank (plain_flag: the codes are elsewhere), raise the batch's flag word
         if (tk_launch_heap_replay_pair(w.dist.as<uint4>(), p.cap, nq, w.mins.as<uint8_t>(), p.cap_min, slot_prefix, slot_n,
                                        slot_loff, p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                        w.heap_val.as<int32_t>(), p.R, 1, 0, (plain || ix->ids_unique) ? repeat_flag : nullptr,
-                                       ix->ids_unique ? 0 : 1, st, slot_exact, qlim, plain ? w.flag_list.as<int>() : nullptr))
+                                       ix->ids_unique ? 0 : 1, st, slot_exact, qlim,
+                                       plain && !plain_flag ? w.flag_list.as<int>() : nullptr))
             return fail(TK_ERR_HIP, "hipMemsetAsync(flag list) failed");
-        if (plain) {
-            rescan_flagged(ix, w, q0, nq, p, st, true);
+        if (plain && plain_flag) {
+            tk_launch_shard_flag_plain(repeat_flag, nq, plain_flag, st);
             tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
                                          p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, -1, 1, st,
-                                         w.flag_list.as<int>(), w.flag_host);
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
+        } else if (plain) {
+            rescan_flagged(ix, w, q0, nq, p, st, true);
+            replay_flagged_tail(ix, w, nq, p, slot_prefix, slot_n, slot_loff, repeat_flag, st);
             plain_verdict_event(ix, w, nq, st);
         }
     } else if (packed_ok && ix->ids_unique) {
@@ -987,10 +1014,7 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
             // names a list twice: exact re-scan of both kinds (the lane replay listed them), then ONE launch of the
             // packed kernel with the duplicate test from fresh heaps (where labels are distinct the test never fires)
             rescan_flagged(ix, w, q0, nq, p, st, true);
-            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
-                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, -1, 1, st,
-                                         w.flag_list.as<int>(), w.flag_host);
+            replay_flagged_tail(ix, w, nq, p, slot_prefix, slot_n, slot_loff, repeat_flag, st);
             plain_verdict_event(ix, w, nq, st);
         } else if (plain) {
             rescan_flagged(ix, w, q0, nq, p, st);
@@ -1029,10 +1053,7 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
                                          w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 1, 1, st);
         } else if (plain) {         // (flags 1 and 2 alike: re-scan, one launch of the packed kernel)
             rescan_flagged(ix, w, q0, nq, p, st, true);
-            tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
-                                         p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, -1, 1, st,
-                                         w.flag_list.as<int>(), w.flag_host);
+            replay_flagged_tail(ix, w, nq, p, slot_prefix, slot_n, slot_loff, repeat_flag, st);
             plain_verdict_event(ix, w, nq, st);
         } else {
             tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,

@@ -1754,16 +1754,20 @@ __global__ __launch_bounds__(64) void heap_replay_pair_kernel(
     const int *__restrict__ slot_prefix, const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off,
     int S, const int64_t *__restrict__ labels, int64_t *__restrict__ heap_idx, int32_t *__restrict__ heap_val, int R,
     int slots_uniform, unsigned char *__restrict__ flags, int dedupe_all, int64_t nq,
-    const int *__restrict__ plain0_arr, const int *__restrict__ qlim, int *__restrict__ flag_list)
+    const int *__restrict__ plain0_arr, const int *__restrict__ qlim, int *__restrict__ flag_list, int only_flagged,
+    const int *__restrict__ count_src, volatile int *host_count)
 {
     const int lane = threadIdx.x;
     const int64_t q = blockIdx.x;
+    // (the count of the flagged queries to the page-locked word the host polls: plain_scan's state machine)
+    if (host_count && count_src && q == 0 && lane == 0) *host_count = count_src[0];
     if (q >= nq) return;
+    const bool flagged = flags && flags[q];
+    if (only_flagged && !flagged) return;      // the tail behind a lane replay: the queries it left (re-scanned exactly)
     __builtin_amdgcn_s_setprio(3);
     const int64_t qs = slots_uniform ? 0 : q;
-    const bool flagged = flags && flags[q];
-    if (plain0_arr && flagged) {       // (its rows hold plain sums: left, with the queries that fail the check, to the re-scan)
-        if (lane == 0) flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
+    if (plain0_arr && flagged) {       // (its rows hold plain sums: left, with the queries that fail the check, to the kernels behind)
+        if (lane == 0 && flag_list) flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
         return;
     }
     const int plain0 = plain0_arr ? plain0_arr[q] : 0x7fffffff;
@@ -1779,29 +1783,33 @@ __global__ __launch_bounds__(64) void heap_replay_pair_kernel(
                                         plain0, b_plain);
     if (SIGNED && plain0_arr && S > 0 && plain0 < prefix[S] && (int)(int8_t)b_plain > qlim[q] && lane == 0) {
         flags[q] = 2;
-        flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
+        if (flag_list) flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
     }
 }
 
-// cap * 16 <= 0xffffff (position entries) is the caller's to check where labels are distinct.  plain0 / qlim / flag_list:
-// all three or none (signed tables only); flag_list[0] is zeroed here, on the stream, in front of the kernel.
+// cap * 16 <= 0xffffff (position entries) is the caller's to check where labels are distinct.  plain0 / qlim (+ flags): both
+// or none (signed tables only); flag_list (optional: the failing queries listed for a re-scan) has its count zeroed here,
+// on the stream, in front of the kernel.  only_flagged: replay only the queries with flags[q] != 0 (the tail behind a lane
+// replay: queries it flagged, re-scanned exactly meanwhile) — with the duplicate test; count_src / host_count: count_src[0]
+// is copied to the page-locked *host_count (the flagged count the host polls).
 int tk_launch_heap_replay_pair(const uint4 *dist, int64_t cap, int64_t nq, const uint8_t *mins, int64_t cap_min,
                                const int *slot_prefix, const int *slot_n, const int64_t *slot_label_off, int S,
                                const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R, int signd,
                                int slots_uniform, unsigned char *flags, int dedupe_all, hipStream_t s,
-                               const int *plain0, const int *qlim, int *flag_list)
+                               const int *plain0, const int *qlim, int *flag_list, int only_flagged,
+                               const int *count_src, int *host_count)
 {
     if (nq == 0 || R == 0) return 0;
-    if (!plain0 || !qlim || !flag_list || !flags || !signd) plain0 = qlim = nullptr, flag_list = nullptr;
+    if (!plain0 || !qlim || !flags || !signd) plain0 = qlim = nullptr, flag_list = nullptr;
     if (flag_list && hipMemsetAsync(flag_list, 0, 4, s) != hipSuccess) return -1;
     if (signd)
         hipLaunchKernelGGL(heap_replay_pair_kernel<true>, dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,
                            slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,
-                           dedupe_all, nq, plain0, qlim, flag_list);
+                           dedupe_all, nq, plain0, qlim, flag_list, only_flagged, count_src, host_count);
     else
         hipLaunchKernelGGL(heap_replay_pair_kernel<false>, dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,
                            slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,
-                           dedupe_all, nq, plain0, qlim, flag_list);
+                           dedupe_all, nq, plain0, qlim, flag_list, only_flagged, count_src, host_count);
     return 0;
 }
 

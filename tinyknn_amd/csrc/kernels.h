@@ -206,7 +206,8 @@ int tk_launch_heap_replay_pair(const uint4 *dist, int64_t cap, int64_t nq, const
                                const int *slot_prefix, const int *slot_n, const int64_t *slot_label_off, int S,
                                const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R, int signd,
                                int slots_uniform, unsigned char *flags, int dedupe_all, hipStream_t s,
-                               const int *plain0 = nullptr, const int *qlim = nullptr, int *flag_list = nullptr);
+                               const int *plain0 = nullptr, const int *qlim = nullptr, int *flag_list = nullptr,
+                               int only_flagged = 0, const int *count_src = nullptr, int *host_count = nullptr);
 void tk_launch_heap_replay_packed(const uint4 *dist, int64_t cap, int64_t nq, const int *slot_prefix,
                                   const int *slot_n, const int64_t *slot_label_off, int S,
                                   const int64_t *labels, int64_t *heap_idx, int32_t *heap_val,
