@@ -1660,6 +1660,7 @@ def main():
     #    bounded sample of the same batch; also a full-size parity check of the ids
     cpu = None
     parity = None
+    query1 = None
     if not args.no_cpu and world == 1:
         cs = min(args.cpu_sample, args.nq)
         heap_parity = None
@@ -1703,6 +1704,31 @@ def main():
                               "sample": f"first {ps} raw queries, one Python-level query() per query as "
                                         f"examples/bench.py:118-137 times the reference; the per-query work is the C port's "
                                         f"(table build and rescoring in C, where the reference runs numpy), {tpy:.2f}s"}
+        # ... and the SAME protocol on the drop-in call of this library: `ivf.query(q)` per query (host preparation,
+        # H2D, the device pipeline with the wave-per-query register heap, D2H, one call at a time), checked row by row
+        # against the oracle's answers for the same queries
+        if args.workload != "c5" and hasattr(ivf, "query"):
+            try:
+                dev.set_pipeline(1)
+                nq1 = min(1000, args.nq)
+                for i in range(20):
+                    ivf.query(qs[i].copy(), args.k, n_probes=args.n_probes)
+                t1 = time.perf_counter()
+                got1 = [ivf.query(qs[i].copy(), args.k, n_probes=args.n_probes) for i in range(nq1)]
+                t_q1 = (time.perf_counter() - t1) / nq1
+                same1 = 0
+                for i in range(nq1):
+                    w1 = want[i] if i < cs else ox.query(qn[i], args.k, args.n_probes)
+                    w1 = np.asarray(w1)
+                    g1 = np.asarray(got1[i])
+                    w1 = w1[w1 != -1] if len(g1) < args.k else w1
+                    same1 += int(len(g1) == len(w1) and (g1 == w1).all())
+                query1 = {"ms_per_query": t_q1 * 1e3, "queries_per_s": 1.0 / t_q1, "rows": nq1, "identical_rows": same1,
+                          "cpu_oracle_ms_per_query": tpy / ps * 1e3,
+                          "protocol": "examples/bench.py:118-137: one ivf.query(q) per query in a Python loop, raw "
+                                      "float32 vector in, ids out, nothing in flight between calls"}
+            except Exception as e:      # noqa: BLE001 - an extra leg must not lose the line
+                query1 = {"error": repr(e)}
         if args.workload == "c5":
             ox_cleanup()
         cpu["note"] = ("value = C batch loop of the port (no per-query Python overhead: the STRONGER "
@@ -1832,8 +1858,11 @@ def main():
                            "rows": args.nq},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
+        "query1": query1,
         "sweep": sweep,
     }
+    if isinstance(query1, dict) and "ms_per_query" in query1:
+        line["query1_ms_per_query"] = query1["ms_per_query"]      # (scalar: the reference's own protocol on the drop-in call)
     # the other two chains of a batch, next to the scan kernel's entry (and their fractions as top-level scalars)
     if isinstance(line.get("roofline"), dict):
         line["roofline"]["replay"] = side_roofs.get("replay")

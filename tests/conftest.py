@@ -18,7 +18,7 @@ if os.path.join(ROOT, "scripts") not in sys.path:      # bench / test scaffoldin
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# Batches of up to TK_OPT_PAIR_NQ queries (product default 2048) replay their heaps one query per wave with the heap in
+# Batches of up to TK_OPT_PAIR_NQ queries (product default 8192) replay their heaps one query per wave with the heap in
 # registers.  Most tests here use batches of a few dozen to a few hundred queries and are ABOUT the lane kernels: start
 # every index of the suite with a threshold of 4 (single queries and tiny batches take the register heap everywhere;
 # tests/test_pair_replay_gpu.py and the heap_mode 3 legs cover it at every size, and at the product default).

@@ -350,7 +350,7 @@ def test_ivf_query_golden(tk, tag):
         dev.set_option(_lib.OPT_REPLAY_TWIN, 1)
         # the wave-per-query replay with the heap in registers (heaps of up to 129 entries; the kernel of one query per
         # call): forced, and as small batches get it by themselves at the product's default threshold
-        for mode, pair_nq in ((3, 0), (0, 2048)):
+        for mode, pair_nq in ((3, 0), (0, 8192)):
             dev.set_heap_mode(mode)
             dev.set_option(_lib.OPT_PAIR_NQ, pair_nq)
             out, dbg = dev.query_batch(g["qn"], g["qpq"], k, n_probes, debug=True)

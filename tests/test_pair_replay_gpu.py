@@ -1,6 +1,6 @@
 """The wave-per-query heap replay with the heap in registers (heap.hip: heap_replay_pair_kernel) — the kernel behind
 ONE query per call, which is what the reference's own bench times (examples/bench.py:118-137: `ivf.query(q)` in a
-Python loop), and behind small batches (TK_OPT_PAIR_NQ, product default 2048 one batch at a time).
+Python loop), and behind small batches (TK_OPT_PAIR_NQ, product default 8192 one batch at a time).
 
 Heap arrays (layout included), probe order and final ids against the oracle (ivf.py:106-163 through
 _fast_pq_256.pyx:73-123,188-210) for labels that are distinct and labels that repeat (IVF.build(n_probes=2): every
@@ -52,7 +52,7 @@ def test_small_batches_take_the_register_heap_and_match_the_oracle(built):
     dev = ivf.device_index()
     qn, qp = ivf._prepare(qs.copy())
     dev.set_heap_mode(0)
-    dev.set_option(_lib.OPT_PAIR_NQ, 256)         # (the product default is 2048; the suite starts indexes at 4: conftest.py)
+    dev.set_option(_lib.OPT_PAIR_NQ, 256)         # (the product default is 8192; the suite starts indexes at 4: conftest.py)
     try:
         # (k, n_probes): heaps of (n_probes + 1) k + 1 = 21, 61, 111, 121, 94, 129, 3 entries; coarse heaps 12 ... 70
         for k, n_probes in ((10, 1), (10, 5), (10, 10), (10, 11), (3, 30), (1, 127), (1, 1)):

@@ -356,7 +356,7 @@ static bool pair_replay(const tk_index *ix, int64_t nq, int R)
     // One batch at a time the register heap wins up to ~10 000 queries (8 000: 0.30 against 0.69 ms,
     // profiles/r06/query1_and_small_batches.txt) — but it fills every SIMD's issue slots, where the lane kernel leaves
     // the chip to the scans of the batches beside it: with batches in flight (pipelined mode) the headline batch LOSES
-    // 38 % on it (25.9 -> 16.1 M queries/s).  So: the option's value one batch at a time, at most 256 when pipelined.
+    // 38 % on it (25.9 -> 16.1 M queries/s).  So: the option's value one batch at a time, at most 256 when pipelined (default 8192: 8 000 queries 0.30 against 0.69 ms).
     // (a list-sharded index's depth is its number of workspace slots: the caller's batches, the option's value)
     const int64_t limit = ix->depth > 1 && !ix->sharded ? (ix->opt_pair_nq < 256 ? ix->opt_pair_nq : 256) : ix->opt_pair_nq;
     return ix->heap_mode == 0 && nq <= limit;

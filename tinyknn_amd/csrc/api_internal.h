@@ -192,7 +192,7 @@ struct tk_index {
     int max_list_chunks = 0;
     bool ids_unique = false;   // no label occurs twice => the lane-per-query replay is exact
     int heap_mode = 0;         // 0 auto (pair for small batches, lanes, else packed wave), 1 general wave, 2 packed wave, 3 pair
-    int opt_pair_nq = 2048;    // TK_OPT_PAIR_NQ: batches up to this many queries take the wave-per-query register heap
+    int opt_pair_nq = 8192;    // TK_OPT_PAIR_NQ: batches up to this many queries take the wave-per-query register heap
     bool have_pq = false, have_centers = false, have_lists = false, have_data = false;
     // list-sharded index: this rank stores the codes of the lists it owns;
     // list_chunk_off stays the GLOBAL layout (every rank derives the same distance rows),
