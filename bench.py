@@ -484,7 +484,7 @@ def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8, co=0):
         co = max(1, min(co or max(W, args.shard_coalesce), 131072 // args.nq))
         idx = ListShardedIndex(ivf, simulate=peers, depth=args.shard_depth, coarse="home", coalesce=co,
                                counts="device", plain={0: False, 1: True, 2: "two-phase", 3: "head"}[args.shard_plain],
-                               exchange="auto", tables=getattr(args, "shard_tables", "all"))
+                               exchange="auto")
         kind = idx._exchange_kind(args.k, args.n_probes, None)
         if getattr(args, "rank_share_exchange", "auto") != "auto":
             kind = args.rank_share_exchange
@@ -500,9 +500,7 @@ def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8, co=0):
             z = evs[0][0]
             out["stage_timeline_us"] = [[round(z.elapsed_time(e) * 1e3) for e in ev] for ev in evs]
             out["stage_timeline_is"] = "per batch: front start, front end, scan start, scan end, back end (us from the first)"
-        out.update(world=W, rank=0, tables=idx.tables if idx._tables_home() else "all",
-                   tables_is="home: a query's distance table is built on its home rank and all-gathered beside its probe "
-                             "list (M x 16 bytes per query); all: every rank builds every table",
+        out.update(world=W, rank=0,
                    what="ONE rank's share of a W-rank partition on this GPU, the peers' contributions recorded and "
                         "copied in (no links): per step of --nq shared queries")
         return out
@@ -1223,9 +1221,6 @@ def main():
                          "synchronisation), or SURVEY 8e's filtered records; both: dense is reported, the "
                          "filtered run beside it; auto: filtered where the lists are long against the heap "
                          "(size-weighted mean list >= 32 heap sizes: the 100M workload), dense otherwise")
-    ap.add_argument("--shard-tables", choices=["home", "all"], default="all",
-                    help="rank-share leg: distance tables on every rank (default), or built on a query's home rank and "
-                         "all-gathered (A/B: slower as one rank's share on one GPU)")
     ap.add_argument("--shard-coarse", choices=["home", "replicated"], default="home",
                     help="list-sharded leg: coarse stage of the home queries + probe all-gather, or of all "
                          "queries on every rank")

@@ -544,19 +544,6 @@ int tk_index_shard_resident(tk_index *ix, const int32_t *owner, int rank, int wo
 int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
                               int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                               int64_t *probes_home_dev, void *stream);
-/* The same with the distance tables built for the HOME queries only (fast_pq.py:186-222 once per query in the
- * whole job instead of once per query and rank): tables_home_dev (ceil(nq/world) x M x 16 bytes) and
- * limits_home_dev (ceil(nq/world) int32: the tables' limits for the plain-sum scan) are filled for the caller to
- * all-gather beside the probe lists; tk_index_shard_set_tables_dev then hands the gathered rows — query order,
- * world x ceil(nq/world) of them — to the scans of the slot, which read the tables where they lie (the buffer
- * belongs to the batch until it is done).  832 bytes per query on the links (M = 52) against a table build per
- * query on every rank. */
-int tk_index_shard_coarse_home_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
-                                   int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
-                                   int64_t *probes_home_dev, void *tables_home_dev, int32_t *limits_home_dev,
-                                   void *stream);
-int tk_index_shard_set_tables_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
-                                  const void *tables_all_dev, const int32_t *limits_all_dev, void *stream);
 int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev,
                             int q_pq_is_f64, int64_t nq, int k, int n_probes, int pass_1,
                             const int64_t *probes_all_dev, int64_t capacity, void *send_dev,
@@ -652,12 +639,26 @@ int tk_index_shard_usage(tk_index *ix, int slot, int64_t *max_stream_uint4);
 int tk_index_shard_bound_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
                              int64_t capacity, const void *scan_dev, uint8_t *bound_dev,
                              void *stream);
+/* ... and WITHOUT a host synchronisation (region_records >= 1; 0 = the compact form above, flag_dev / acc_dev
+ * may then be NULL): the records of home rank h go to records_dev[h * region_records, ...) (room for world *
+ * region_records records of 5 int32), so the all-to-all of the records has equal splits and can be enqueued
+ * before any count is known; the counts (counts_dev[0, world)) travel in their own equal-split all-to-all and
+ * are read by the home rank ON THE DEVICE: tk_index_shard_finish_filtered_dev with counts_recv_dev[world] takes
+ * the received regions (region s from source rank s; n_records is then ignored), with counts_recv_dev == NULL
+ * n_records compact records.  A home rank's records beyond region_records are dropped and *flag_dev |= 1 — the
+ * batch's overflow flag, handled like a `capacity` overflow (region_records = capacity can never overflow;
+ * callers trim it to what the batches need, multi_gpu.py).  Wire bytes: world * region_records * 20 per rank
+ * instead of the exact 20 * records.  acc_dev (or NULL): int64[3] kept by the caller across batches, updated
+ * atomically — [0] largest per-home count seen (what the regions must hold), [1] += records, [2] += blocks
+ * scored.  (Until round 6 the two forms were four entry points: ..._filter_regions_dev / ..._finish_regions_dev.) */
 int tk_index_shard_filter_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
                               int64_t capacity, const void *scan_dev, const uint8_t *bound_dev,
-                              int32_t *counts_dev, int32_t *records_dev, void *stream);
+                              int32_t *counts_dev, int32_t *records_dev, int64_t region_records,
+                              int *flag_dev, int64_t *acc_dev, void *stream);
 int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq,
                                        int k, int n_probes, int pass_1, const int32_t *records_dev,
-                                       int64_t n_records, int64_t *out_ids_home_dev, int *flag_dev,
+                                       int64_t n_records, const int32_t *counts_recv_dev,
+                                       int64_t region_records, int64_t *out_ids_home_dev, int *flag_dev,
                                        void *stream);
 /* The sharded scan in two phases, the second on the int8 matrix cores (tk_index_set_plain_scan's
  * kernel).  The plain sums are the reference's values for a query from the point where its heap's
@@ -689,27 +690,6 @@ int tk_index_shard_scan_rest_dev(tk_index *ix, int slot, int64_t nq, int k, int 
  * scored on the plain kernel, tiles of 32 of them, exact pair records of the slots behind the
  * first, queries (of all nq) whose bound let them go the plain way. */
 int tk_index_shard_plain_stats(tk_index *ix, int slot, int64_t *out4);
-/* The filtered exchange WITHOUT its host synchronisation: the records of home rank h go to
- * records_dev[h * region_records, ...) (room for world * region_records records of 5 int32), so the
- * all-to-all of the records has equal splits and can be enqueued before any count is known; the
- * counts (counts_dev[0, world)) travel in their own equal-split all-to-all and are read by the home
- * rank ON THE DEVICE: tk_index_shard_finish_regions_dev takes the received regions (region s from
- * source rank s) and counts_recv_dev[world].  A home rank's records beyond region_records are
- * dropped and *flag_dev |= 1 — the batch's overflow flag, handled like a `capacity` overflow
- * (region_records = capacity can never overflow: a region holds no more blocks than it has room
- * for; callers trim it to what the batches need, multi_gpu.py).  Wire bytes: world *
- * region_records * 20 per rank instead of the exact 20 * records.  acc_dev (or NULL): int64[3]
- * kept by the caller across batches, updated atomically — [0] largest per-home count seen (what
- * the regions must hold), [1] += records, [2] += blocks scored. */
-int tk_index_shard_filter_regions_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
-                                      int pass_1, int64_t capacity, const void *scan_dev,
-                                      const uint8_t *bound_dev, int32_t *counts_dev,
-                                      int32_t *records_dev, int64_t region_records, int *flag_dev,
-                                      int64_t *acc_dev, void *stream);
-int tk_index_shard_finish_regions_dev(tk_index *ix, int slot, const float *q_dev, int64_t nq, int k,
-                                      int n_probes, int pass_1, const int32_t *records_dev,
-                                      const int32_t *counts_recv_dev, int64_t region_records,
-                                      int64_t *out_ids_home_dev, int *flag_dev, void *stream);
 
 #ifdef __cplusplus
 }

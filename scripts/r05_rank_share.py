@@ -20,7 +20,6 @@ ap.add_argument("--co", type=int, default=0)
 ap.add_argument("--exchange", default="auto")
 ap.add_argument("--replay-lazy", type=int, default=-1, help="TK_OPT_REPLAY_LAZY of every engine (A/B)")
 ap.add_argument("--clusters", type=int, default=0)
-ap.add_argument("--tables", default="all", choices=["home", "all"])
 a = ap.parse_args()
 glove = a.workload == "glove"
 args = argparse.Namespace(n=a.n or (1183514 if glove else 25_000_000), d=100 if glove else 128,
@@ -28,7 +27,7 @@ args = argparse.Namespace(n=a.n or (1183514 if glove else 25_000_000), d=100 if 
                           metric="angular" if glove else "euclidean", data="glove-like", cache_dir="/tmp", fit_sample=100000,
                           data_file=None, nq=a.nq, k=10, n_probes=10, workload=a.workload, shard_depth=a.depth,
                           shard_plain=a.plain, warmup=5, steps=a.steps, windows=a.windows, backend="nccl", shard_coarse="home",
-                          shard_counts="device", rank_share=a.world, shard_coalesce=0, rank_share_exchange=a.exchange, shard_tables=a.tables)
+                          shard_counts="device", rank_share=a.world, shard_coalesce=0, rank_share_exchange=a.exchange)
 device = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 from tinyknn_amd import _lib

@@ -96,25 +96,10 @@ class SimulatedPeers:
         with t.cuda.stream(t.cuda.Stream()):
             p_all = None
             if coarse == "home":
-                # (the peers build their tables the round-4 way — all of them, each — which gives the same bytes; what
-                #  the live rank would RECEIVE is every rank's home rows: recorded once from this rank's clone)
                 homes = [t.zeros(qh * kc, dtype=t.int64, device="cuda") for _ in range(W)]
                 for r in range(W):
                     self._engine(r).coarse(0, qn, qp, k, n_probes, pass_1, homes[r])
                 p_all = t.cat(homes).contiguous()
-                tb = self._engine(me).table_bytes
-                t_all = t.zeros(W * qh * tb, dtype=t.uint8, device="cuda")
-                l_all = t.zeros(W * qh, dtype=t.int32, device="cuda")
-                for r in range(W):
-                    th = t.zeros(qh * tb, dtype=t.uint8, device="cuda")
-                    lh = t.zeros(qh, dtype=t.int32, device="cuda")
-                    ph = t.zeros(qh * kc, dtype=t.int64, device="cuda")
-                    self._engine(r).coarse_home(0, qn, qp, k, n_probes, pass_1, ph, th, lh)
-                    assert bool((ph == homes[r]).all())
-                    t_all[r * qh * tb:(r + 1) * qh * tb].copy_(th)
-                    l_all[r * qh:(r + 1) * qh].copy_(lh)
-                    self._engine(r).coarse(0, qn, qp, k, n_probes, pass_1, ph)      # (the scans below: own tables)
-                rec["t_all"], rec["l_all"] = t_all, l_all
             rec["p_all"] = p_all
             flag = t.zeros(1, dtype=t.int32, device="cuda")
             bound = None
@@ -184,10 +169,6 @@ class SimulatedPeers:
         n = inp.numel()
         if what == "probes":
             out.copy_(ctx["p_all"])
-        elif what == "tables":
-            out.copy_(ctx["t_all"])
-        elif what == "limits":
-            out.copy_(ctx["l_all"])
         # (ids: the other ranks' rows were written when the buffer was made, _buffers; their flag words — the last
         #  element of every rank's row — are what the recording pass saw: an overflow of a PEER's region makes the live
         #  rank grow its capacity and record again, as the gathered flag of a real world would)

@@ -580,10 +580,7 @@ def test_simulated_peers_one_rank_of_a_partition(oracle):
         peers = SimulatedPeers(ivf, world=world, rank=rank)
         lo, hi = peers.home_range(nq)
         for kw in (dict(exchange="dense"), dict(exchange="dense", plain="two-phase"), dict(exchange="filtered"),
-                   dict(exchange="dense", plain=False), dict(exchange="dense", plain="head"),
-                   # (tables="home": a query's table is built on its home rank and gathered; default: on every rank)
-                   dict(exchange="dense", tables="home"), dict(exchange="filtered", tables="home"),
-                   dict(exchange="dense", plain="head", tables="home")):
+                   dict(exchange="dense", plain=False), dict(exchange="dense", plain="head")):
             idx = ListShardedIndex(ivf, simulate=peers, depth=2, **kw)
             peers.reset()
             got = idx.query_prepared(qn_t, qp_t, 10, 6)

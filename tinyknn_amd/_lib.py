@@ -72,11 +72,6 @@ SIGNATURES = {
     "tk_index_shard_coarse_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p]),
-    "tk_index_shard_coarse_home_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tk_index_shard_set_tables_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
-                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_shard_scan_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -96,23 +91,17 @@ SIGNATURES = {
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_shard_filter_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                             C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p]),
+                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_shard_finish_filtered_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
-                                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
-                                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+                                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_shard_plain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tk_index_shard_plain_stats": (C.c_int, [C.c_void_p, C.c_int, _i64p]),
     "tk_index_shard_scan_first_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_index_shard_scan_rest_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tk_index_shard_plain_stats": (C.c_int, [C.c_void_p, C.c_int, _i64p]),
-    "tk_index_shard_filter_regions_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
-                                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tk_index_shard_finish_regions_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
-                                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tk_measure_read_bandwidth": (C.c_int, [C.c_int64, C.c_int, _f64p]),
     "tk_measure_gather_bandwidth": (C.c_int, [C.c_int64, C.c_int, C.c_int64, C.c_int, _f64p]),
     "tk_scan_exclusive_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),

@@ -112,7 +112,6 @@ struct Work {
     int64_t shard_nq = 0, shard_capacity = 0;
     // list-sharded batch whose tables were built by the queries' HOME ranks and all-gathered by the caller
     // (tk_index_shard_coarse_home_dev / tk_index_shard_set_tables_dev): the gathered rows, in the caller's buffer
-    const uint4 *ext_tables = nullptr;
     bool shard_first = false;       // tk_index_shard_scan_first_dev ran: _rest_dev is owed
     bool shard_plain = false;       // tk_index_shard_scan_plain_dev filled the send buffer: the home replay checks the lemma
     bool shard_head = false;        // tk_index_shard_scan_head_dev ran: _scan_plain_dev(bound_dev) is owed
@@ -292,7 +291,7 @@ struct Prof {
 };
 
 // the distance tables a batch's scans read: the workspace's, or the gathered rows of a list-sharded batch
-inline const uint4 *tables_of(const Work &w) { return w.ext_tables ? w.ext_tables : w.tables.as<uint4>(); }
+inline const uint4 *tables_of(const Work &w) { return w.tables.as<uint4>(); }
 
 // ---- api_index.hip, used by the other files
 int flush_pending(tk_index *ix);

@@ -96,49 +96,29 @@ static int reserve_shard_plain(tk_index *ix, Work &w, int64_t nq, const Plan &p)
 // Coarse stage sharded by HOME rank: tables for all nq queries (every rank scores segments of
 // every query), coarse scan + replay + rescoring only for this rank's ceil(nq/world) home
 // queries; the caller all-gathers the probe lists and hands them to tk_index_shard_scan_dev.
-// tables_home_dev == NULL: as above.  Otherwise (tk_index_shard_coarse_home_dev) the tables are built for the HOME
-// queries only and leave, with their limits, in the caller's buffers for an all-gather: a rank of W then builds
-// nq / W tables instead of nq (a W = 8 rank of the GloVe-shaped index: 0.14 ms of its 80 000-query batch).
 static int shard_coarse_impl(tk_index *ix, int slot, const float *q_dev, const void *q_pq_dev, int q_pq_is_f64,
-                             int64_t nq, int k, int n_probes, int pass_1, int64_t *probes_home_dev,
-                             void *tables_home_dev, int32_t *limits_home_dev, void *stream)
+                             int64_t nq, int k, int n_probes, int pass_1, int64_t *probes_home_dev, void *stream)
 {
     Plan p;
     TRY(make_plan(ix, k, n_probes, pass_1, p));
     int64_t qh = 0;
     TRY(shard_args(ix, slot, nq, 1, p, qh));
     ARGCHECK(probes_home_dev, "probes buffer");
-    ARGCHECK(!tables_home_dev || limits_home_dev, "tables and limits leave together");
     Work &w = ix->works[(size_t)slot];
     hipStream_t st = (hipStream_t)stream;
     TRY(reserve_shard(ix, w, nq, qh, p));
-    w.ext_tables = nullptr;
     Prof pf;
     // (the limits C of all nq tables ride in the table launch's shadow where a plain form may follow)
     const bool limits = shard_plain_possible(ix, p);
-    if (limits || tables_home_dev) TRY(reserve_shard_plain(ix, w, nq, p));
+    if (limits) TRY(reserve_shard_plain(ix, w, nq, p));
     const int64_t q0 = (int64_t)ix->rank * qh;
     int64_t nqh = nq - q0;
     nqh = nqh < 0 ? 0 : (nqh > qh ? qh : nqh);
-    const size_t esz = q_pq_is_f64 ? 8 : 4;
-    if (!tables_home_dev) {
-        TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, limits));
-    } else {
-        // rows past nq: zero tables with the limit of "never plain" (defined for the all-gather; no query reads them)
-        HIPCHECK(hipMemsetAsync(tables_home_dev, 0, (size_t)qh * ix->M * 16, st));
-        HIPCHECK(hipMemsetAsync(limits_home_dev, 0x80, (size_t)qh * 4, st));
-        if (nqh > 0) {
-            TRY(stage_tables(ix, w, (const char *)q_pq_dev + (size_t)q0 * ix->dq * esz, q_pq_is_f64, nqh, st, pf, true,
-                             TkSecond(), q0));
-            HIPCHECK(hipMemcpyAsync(tables_home_dev, w.tables.as<uint8_t>() + (size_t)q0 * ix->M * 16,
-                                    (size_t)nqh * ix->M * 16, hipMemcpyDeviceToDevice, st));
-            HIPCHECK(hipMemcpyAsync(limits_home_dev, w.qlim.as<int>() + q0, (size_t)nqh * 4, hipMemcpyDeviceToDevice, st));
-        }
-    }
+    TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, limits));
     // rows past nq: list 0 (never read by a consumer; defined for the all-gather)
     HIPCHECK(hipMemsetAsync(probes_home_dev, 0, (size_t)qh * p.kc * 8, st));
     if (nqh > 0) {
-        if (!tables_home_dev && coarse_units(ix, nqh))     // identity pairs of the home range (stage_tables wrote those of all nq)
+        if (coarse_units(ix, nqh))     // identity pairs of the home range (stage_tables wrote those of all nq)
             tk_launch_identity_pairs(nqh, (int)ix->center_chunks, w.c_pair_off.as<int>(),
                                      w.c_unit_prefix.as<int>(), w.c_pair_q.as<int>(),
                                      w.c_pair_f0.as<int>(), st);
@@ -155,39 +135,7 @@ extern "C" int tk_index_shard_coarse_dev(tk_index *ix, int slot, const float *q_
                                          void *stream)
 {
     IXLOCK(ix);
-    return shard_coarse_impl(ix, slot, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, probes_home_dev,
-                             nullptr, nullptr, stream);
-}
-
-extern "C" int tk_index_shard_coarse_home_dev(tk_index *ix, int slot, const float *q_dev,
-                                              const void *q_pq_dev, int q_pq_is_f64, int64_t nq, int k,
-                                              int n_probes, int pass_1, int64_t *probes_home_dev,
-                                              void *tables_home_dev, int32_t *limits_home_dev, void *stream)
-{
-    IXLOCK(ix);
-    ARGCHECK(tables_home_dev && limits_home_dev, "tables / limits buffers");
-    return shard_coarse_impl(ix, slot, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, probes_home_dev,
-                             tables_home_dev, limits_home_dev, stream);
-}
-
-// The gathered tables of a batch (world x ceil(nq / world) rows of M x 16 bytes, in query order) and their limits:
-// the scans of this slot read the tables where they lie (the caller keeps the buffer until the batch is done);
-// the limits — 4 bytes per query — are copied into the workspace.
-extern "C" int tk_index_shard_set_tables_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes, int pass_1,
-                                             const void *tables_all_dev, const int32_t *limits_all_dev, void *stream)
-{
-    IXLOCK(ix);
-    Plan p;
-    TRY(make_plan(ix, k, n_probes, pass_1, p));
-    int64_t qh = 0;
-    TRY(shard_args(ix, slot, nq, 1, p, qh));
-    ARGCHECK(tables_all_dev && limits_all_dev, "tables / limits buffers");
-    Work &w = ix->works[(size_t)slot];
-    TRY(reserve_shard(ix, w, nq, qh, p));
-    TRY(reserve_shard_plain(ix, w, nq, p));
-    w.ext_tables = (const uint4 *)tables_all_dev;
-    HIPCHECK(hipMemcpyAsync(w.qlim.p, limits_all_dev, (size_t)nq * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return TK_OK;
+    return shard_coarse_impl(ix, slot, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, probes_home_dev, stream);
 }
 
 extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_dev,
@@ -215,7 +163,6 @@ extern "C" int tk_index_shard_scan_dev(tk_index *ix, int slot, const float *q_de
         coarse_slots(ix, w, probes, nq, p, w.u_count.as<int>(), owner, ix->rank, st);
     } else {
         // replicated coarse stage: every rank derives every probe list itself
-        w.ext_tables = nullptr;
         TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
         launch_coarse_scan(ix, w, nq, p, st);
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf));
@@ -308,7 +255,6 @@ extern "C" int tk_index_shard_scan_head_dev(tk_index *ix, int slot, const float 
     if (probes) {
         coarse_slots(ix, w, probes, nq, p, nullptr, owner, ix->rank, st);
     } else {
-        w.ext_tables = nullptr;
         TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, true));
         launch_coarse_scan(ix, w, nq, p, st);
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, nullptr, owner, ix->rank, st, pf));
@@ -436,7 +382,6 @@ extern "C" int tk_index_shard_scan_plain_dev(tk_index *ix, int slot, const float
         // tables and their limits: tk_index_shard_coarse_dev; the probe lists arrive gathered
         coarse_slots(ix, w, probes, nq, p, w.u_count.as<int>(), owner, ix->rank, st, true);
     } else {
-        w.ext_tables = nullptr;
         TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf, true));
         launch_coarse_scan(ix, w, nq, p, st);
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, w.u_count.as<int>(), owner, ix->rank, st, pf, true));
@@ -560,7 +505,6 @@ extern "C" int tk_index_shard_scan_first_dev(tk_index *ix, int slot, const float
     if (probes) {
         coarse_slots(ix, w, probes, nq, p, nullptr, owner, ix->rank, st);
     } else {
-        w.ext_tables = nullptr;
         TRY(stage_tables(ix, w, q_pq_dev, q_pq_is_f64, nq, st, pf));
         launch_coarse_scan(ix, w, nq, p, st);
         TRY(stage_coarse_rest(ix, w, q_dev, nq, p, nullptr, owner, ix->rank, st, pf));
@@ -795,34 +739,28 @@ static int shard_filter_impl(tk_index *ix, int slot, int64_t nq, int k, int n_pr
     return TK_OK;
 }
 
+// records_dev: the blocks below the bound as 20-byte records grouped by home rank.  region_records == 0: compact
+// (variable splits: counts_dev read on the host before the all-to-all; flag_dev / acc_dev may be NULL).
+// region_records >= 1: the records of home rank h at records_dev[h * region_records ...] (room for world *
+// region_records records): the all-to-all that follows has EQUAL splits, so no rank has to read a count on the
+// host before it can enqueue it — counts_dev[0, world) travel beside the records and the home rank reads them on
+// the device (tk_index_shard_finish_filtered_dev with counts_recv_dev).  More than region_records records for one
+// home rank: the rest is dropped and *flag_dev |= 1, the overflow flag of the batch (the caller repeats it with
+// larger regions, as with `capacity`).  acc_dev (or NULL): three int64 the caller keeps across batches — [0] =
+// largest counts_dev[h] seen (atomic max: what the regions have to hold), [1] += records, [2] += blocks scored.
 extern "C" int tk_index_shard_filter_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
                                          int pass_1, int64_t capacity, const void *scan_dev,
                                          const uint8_t *bound_dev, int32_t *counts_dev,
-                                         int32_t *records_dev, void *stream)
-{
-    IXLOCK(ix);
-    return shard_filter_impl(ix, slot, nq, k, n_probes, pass_1, capacity, scan_dev, bound_dev, counts_dev,
-                             records_dev, 0, nullptr, nullptr, stream);
-}
-
-// The same with the records of home rank h at records_dev[h * region_records ...] (room for world *
-// region_records records): the all-to-all that follows has EQUAL splits, so no rank has to read
-// a count on the host before it can enqueue it — counts_dev[0, world) travel beside the records and
-// the home rank reads them on the device (tk_index_shard_finish_regions_dev).  More than
-// region_records records for one home rank: the rest is dropped and *flag_dev |= 1, the overflow
-// flag of the batch (the caller repeats it with larger regions, as with `capacity`).
-// acc_dev (or NULL): three int64 the caller keeps across batches — [0] = largest counts_dev[h] seen
-// (atomic max: what the regions have to hold), [1] += records, [2] += blocks scored.
-extern "C" int tk_index_shard_filter_regions_dev(tk_index *ix, int slot, int64_t nq, int k, int n_probes,
-                                                 int pass_1, int64_t capacity, const void *scan_dev,
-                                                 const uint8_t *bound_dev, int32_t *counts_dev,
-                                                 int32_t *records_dev, int64_t region_records,
-                                                 int *flag_dev, int64_t *acc_dev, void *stream)
+                                         int32_t *records_dev, int64_t region_records,
+                                         int *flag_dev, int64_t *acc_dev, void *stream)
 {
     IXLOCK(ix);
     ARGCHECK(ix && ix->sharded, "not a list-sharded index");
-    ARGCHECK(region_records >= 1 && region_records * ix->world < (1ll << 31) && flag_dev,
+    ARGCHECK(region_records == 0 || (region_records >= 1 && region_records * ix->world < (1ll << 31) && flag_dev),
              "region_records (x world must stay below 2^31) / flag buffer");
+    if (region_records == 0)
+        return shard_filter_impl(ix, slot, nq, k, n_probes, pass_1, capacity, scan_dev, bound_dev, counts_dev,
+                                 records_dev, 0, nullptr, nullptr, stream);
     return shard_filter_impl(ix, slot, nq, k, n_probes, pass_1, capacity, scan_dev, bound_dev, counts_dev,
                              records_dev, region_records, flag_dev, acc_dev, stream);
 }
@@ -853,36 +791,27 @@ static int shard_finish_filtered_impl(tk_index *ix, int slot, const float *q_dev
         Prof pf;
         TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf));
     }
-    w.ext_tables = nullptr;      // (the gathered tables were the batch's: the next one names its own)
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }
 
+// counts_recv_dev == NULL: records_dev holds n_records compact records.  Otherwise: `world` regions of region_records
+// records as the equal-split all-to-all delivered them (region s from source rank s); counts_recv_dev[s] of them are
+// real (the all-to-all of the senders' counts_dev[0, world), on the device: no host synchronisation anywhere in the
+// batch); n_records is ignored.
 extern "C" int tk_index_shard_finish_filtered_dev(tk_index *ix, int slot, const float *q_dev,
                                                   int64_t nq, int k, int n_probes, int pass_1,
                                                   const int32_t *records_dev, int64_t n_records,
+                                                  const int32_t *counts_recv_dev, int64_t region_records,
                                                   int64_t *out_ids_home_dev, int *flag_dev,
                                                   void *stream)
 {
     IXLOCK(ix);
-    return shard_finish_filtered_impl(ix, slot, q_dev, nq, k, n_probes, pass_1, records_dev, n_records,
-                                      nullptr, 0, out_ids_home_dev, flag_dev, stream);
-}
-
-// records_dev: world regions of region_records records as the equal-split all-to-all delivered
-// them (region s from source rank s); counts_recv_dev[s] of them are real (the all-to-all of the
-// senders' counts_dev[0, world), on the device: no host synchronisation anywhere in the batch)
-extern "C" int tk_index_shard_finish_regions_dev(tk_index *ix, int slot, const float *q_dev,
-                                                 int64_t nq, int k, int n_probes, int pass_1,
-                                                 const int32_t *records_dev,
-                                                 const int32_t *counts_recv_dev,
-                                                 int64_t region_records, int64_t *out_ids_home_dev,
-                                                 int *flag_dev, void *stream)
-{
-    IXLOCK(ix);
     ARGCHECK(ix && ix->sharded, "not a list-sharded index");
-    ARGCHECK(counts_recv_dev && region_records >= 1 && region_records * ix->world < (1ll << 31),
-             "counts / region_records");
+    if (!counts_recv_dev)
+        return shard_finish_filtered_impl(ix, slot, q_dev, nq, k, n_probes, pass_1, records_dev, n_records,
+                                          nullptr, 0, out_ids_home_dev, flag_dev, stream);
+    ARGCHECK(region_records >= 1 && region_records * ix->world < (1ll << 31), "counts / region_records");
     return shard_finish_filtered_impl(ix, slot, q_dev, nq, k, n_probes, pass_1, records_dev,
                                       region_records * ix->world, counts_recv_dev, region_records,
                                       out_ids_home_dev, flag_dev, stream);
@@ -915,9 +844,7 @@ extern "C" int tk_index_shard_finish_dev(tk_index *ix, int slot, const float *q_
         TRY(stage_back(ix, w, q_dev + q0 * ix->d, q0, nqh, k, p, out_ids_home_dev, st, pf, w.shard_plain,
                        TkSecond(), TkSecond(), w.shard_plain ? flag_dev : nullptr));
     }
-    // the caller's gathered-tables buffer (tk_index_shard_set_tables_dev) was this batch's: a later scan of the slot
-    // that brings its own probe lists must not read through a pointer the caller may have freed
-    w.ext_tables = nullptr;
+
     HIPCHECK(hipGetLastError());
     return TK_OK;
 }

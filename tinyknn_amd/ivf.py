@@ -470,25 +470,6 @@ class DeviceIndex:
             self._h, int(slot), qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
             int(pass_1 or 0), probes_home_ptr, stream))
 
-    def shard_coarse_home_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1,
-                              probes_home_ptr, tables_home_ptr, limits_home_ptr, stream=0):
-        """Tables + limits + coarse stage of this rank's home queries only (tk_index_shard_coarse_home_dev);
-        the caller all-gathers probe lists, tables and limits and calls shard_set_tables_dev."""
-        _lib.check(_lib.lib().tk_index_shard_coarse_home_dev(
-            self._h, int(slot), qn_ptr, qpq_ptr, int(qpq_is_f64), nq, int(k), int(n_probes),
-            int(pass_1 or 0), probes_home_ptr, tables_home_ptr, limits_home_ptr, stream))
-
-    def shard_set_tables_dev(self, slot, nq, k, n_probes, pass_1, tables_all_ptr, limits_all_ptr, stream=0):
-        """The gathered tables / limits of a batch for the scans of the slot (tk_index_shard_set_tables_dev)."""
-        _lib.check(_lib.lib().tk_index_shard_set_tables_dev(
-            self._h, int(slot), nq, int(k), int(n_probes), int(pass_1 or 0), tables_all_ptr, limits_all_ptr,
-            stream))
-
-    @property
-    def M(self):
-        """PQ blocks per vector (a distance table is M x 16 bytes)"""
-        return self.dq // self.dpb
-
     def shard_scan_dev(self, slot, qn_ptr, qpq_ptr, qpq_is_f64, nq, k, n_probes, pass_1, capacity,
                        send_ptr, flag_ptr, stream=0, probes_all_ptr=None):
         """Scan of the owned segments into the send buffer (tk_index_shard_scan_dev);
@@ -560,17 +541,17 @@ class DeviceIndex:
 
     def shard_filter_dev(self, slot, nq, k, n_probes, pass_1, capacity, scan_ptr, bound_ptr,
                          counts_ptr, records_ptr, stream=0):
-        """Blocks below the bound as records grouped by home rank (tk_index_shard_filter_dev)."""
+        """Blocks below the bound as records grouped by home rank, compact (tk_index_shard_filter_dev, region 0)."""
         _lib.check(_lib.lib().tk_index_shard_filter_dev(
             self._h, int(slot), nq, int(k), int(n_probes), int(pass_1 or 0), int(capacity),
-            scan_ptr, bound_ptr, counts_ptr, records_ptr, stream))
+            scan_ptr, bound_ptr, counts_ptr, records_ptr, 0, None, None, stream))
 
     def shard_finish_filtered_dev(self, slot, qn_ptr, nq, k, n_probes, pass_1, records_ptr,
                                   n_records, out_ptr, flag_ptr, stream=0):
-        """Received records -> rows, replay, rescoring (tk_index_shard_finish_filtered_dev)."""
+        """Received compact records -> rows, replay, rescoring (tk_index_shard_finish_filtered_dev)."""
         _lib.check(_lib.lib().tk_index_shard_finish_filtered_dev(
             self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0), records_ptr,
-            int(n_records), out_ptr, flag_ptr, stream))
+            int(n_records), None, 0, out_ptr, flag_ptr, stream))
 
     def shard_plain(self, k, n_probes, pass_1=None):
         """Does the two-phase scan with the matrix-core kernel apply (tk_index_shard_plain)?"""
@@ -603,18 +584,18 @@ class DeviceIndex:
 
     def shard_filter_regions_dev(self, slot, nq, k, n_probes, pass_1, capacity, scan_ptr, bound_ptr,
                                  counts_ptr, records_ptr, region, flag_ptr, acc_ptr=None, stream=0):
-        """... into fixed regions of `region` records per home rank (tk_index_shard_filter_regions_dev)."""
-        _lib.check(_lib.lib().tk_index_shard_filter_regions_dev(
+        """... into fixed regions of `region` records per home rank (tk_index_shard_filter_dev, region >= 1)."""
+        _lib.check(_lib.lib().tk_index_shard_filter_dev(
             self._h, int(slot), nq, int(k), int(n_probes), int(pass_1 or 0), int(capacity),
             scan_ptr, bound_ptr, counts_ptr, records_ptr, int(region), flag_ptr, acc_ptr, stream))
 
     def shard_finish_regions_dev(self, slot, qn_ptr, nq, k, n_probes, pass_1, records_ptr,
                                  counts_recv_ptr, region, out_ptr, flag_ptr, stream=0):
         """Received regions + their counts on the device -> rows, replay, rescoring
-        (tk_index_shard_finish_regions_dev)."""
-        _lib.check(_lib.lib().tk_index_shard_finish_regions_dev(
+        (tk_index_shard_finish_filtered_dev with the received counts)."""
+        _lib.check(_lib.lib().tk_index_shard_finish_filtered_dev(
             self._h, int(slot), qn_ptr, nq, int(k), int(n_probes), int(pass_1 or 0), records_ptr,
-            counts_recv_ptr, int(region), out_ptr, flag_ptr, stream))
+            0, counts_recv_ptr, int(region), out_ptr, flag_ptr, stream))
 
     def replay_stats(self):
         """What the lane replays of the probed lists did since set_option(OPT_REPLAY_COUNT, 1) / the last call

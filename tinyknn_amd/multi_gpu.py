@@ -165,20 +165,6 @@ class _HipShardEngine:
         self.dev.shard_coarse_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
                                   qn.shape[0], k, n_probes, pass_1, probes_home.data_ptr(), stream=st)
 
-    def coarse_home(self, slot, qn, qp, k, n_probes, pass_1, probes_home, tables_home, limits_home):
-        """... with the tables (and their limits) of the HOME queries only, left for an all-gather"""
-        import torch
-        st = torch.cuda.current_stream().cuda_stream
-        self.dev.shard_coarse_home_dev(slot, qn.data_ptr(), qp.data_ptr(), qp.dtype == torch.float64,
-                                       qn.shape[0], k, n_probes, pass_1, probes_home.data_ptr(),
-                                       tables_home.data_ptr(), limits_home.data_ptr(), stream=st)
-
-    def set_tables(self, slot, nq, k, n_probes, pass_1, tables_all, limits_all):
-        import torch
-        st = torch.cuda.current_stream().cuda_stream
-        self.dev.shard_set_tables_dev(slot, nq, k, n_probes, pass_1, tables_all.data_ptr(), limits_all.data_ptr(),
-                                      stream=st)
-
     @property
     def table_bytes(self):
         return self.dev.M * 16
@@ -318,7 +304,7 @@ class ListShardedIndex:
 
     def __init__(self, ivf, group=None, engine=None, depth=1, owner=None, list_sizes=None,
                  coarse="home", coalesce=1, exchange="dense", calibrate=True, force_collectives=None,
-                 counts="device", plain=True, simulate=None, tables="all"):
+                 counts="device", plain=True, simulate=None):
         import os
         import torch
         import torch.distributed as dist
@@ -356,15 +342,6 @@ class ListShardedIndex:
         self._check_same_index(ivf)
         assert coarse in ("home", "replicated")
         self.coarse = coarse
-        # tables: "all" (default) — every rank builds every query's distance table; "home" — a table is built once,
-        # on its query's home rank, and travels beside its probe list (M x 16 bytes per query: 832 for M = 52;
-        # tk_index_shard_coarse_home_dev / _set_tables_dev; only with the home-sharded coarse stage and the HIP
-        # engine).  Measured as one rank's share of W = 8 on one GPU (GloVe-shaped, 80 000 queries per batch, the
-        # gather played by device copies): 0.115-0.117 ms per step at home against 0.112 on every rank — the
-        # 0.14 ms table build of a batch is not what a rank waits for, and on real links the gather adds 58 MB to
-        # the 134 MB of the dense exchange (profiles/r05/rank_share_tables_home_vs_all.txt).
-        assert tables in ("home", "all")
-        self.tables = tables
         assert exchange in ("dense", "filtered", "auto")
         self.exchange = exchange
         sz = self.list_sizes.astype(np.float64)
@@ -408,7 +385,6 @@ class ListShardedIndex:
         self.capacity = {}          # (nq, n_probes) -> uint4 per region, grows on overflow
         self._bufs = {}
         self._pbufs = {}
-        self._tbufs = {}
         self._fbufs = {}
         self._calls = 0
         self._multi = self.device == "cuda" and depth > 1      # batches in flight
@@ -759,37 +735,15 @@ class ListShardedIndex:
         self.engine.scan_rest(slot, qn, k, n_probes, pass_1, capacity, b["send"], b["bound"])
         return b["bound"]
 
-    def _tables_home(self):
-        return (self.tables == "home" and self.coarse == "home" and self.world > 1
-                and hasattr(self.engine, "coarse_home"))
-
-    def _table_buffers(self, slot, nq):
-        if self._tbufs.get(slot, (None,))[0] != nq:
-            t, W = self.torch, self.world
-            if slot in self._tbufs:     # a batch of this slot may still read the old buffers on its stream: held until join()
-                self._inflight_inputs.append(self._tbufs[slot])
-            qh = -(-nq // W)
-            tb = self.engine.table_bytes
-            self._tbufs[slot] = (nq, t.empty(qh * tb, dtype=t.uint8, device=self.device),
-                                 t.empty(W * qh * tb, dtype=t.uint8, device=self.device),
-                                 t.empty(qh, dtype=t.int32, device=self.device),
-                                 t.empty(W * qh, dtype=t.int32, device=self.device))
-        return self._tbufs[slot][1:]
-
     def _coarse_home(self, slot, qn, qp, k, n_probes, pass_1):
-        """The home-sharded coarse stage of a batch + the all-gathers behind it; returns the gathered probe lists."""
+        """The home-sharded coarse stage of a batch + the all-gather behind it; returns the gathered probe lists.
+        (Every rank builds every query's distance table.  Building a table only on its query's home rank and
+        all-gathering it — 832 bytes per query at M = 52 — was built and measured in round 5: 0.115–0.117 against
+        0.112 ms per step as one rank's share of W = 8, 58 MB more per batch on the links; removed in round 6.)"""
         nq = qn.shape[0]
         p_home, p_all = self._probe_buffers(slot, nq, n_probes)
-        if self._tables_home():
-            t_home, t_all, l_home, l_all = self._table_buffers(slot, nq)
-            self.engine.coarse_home(slot, qn, qp, k, n_probes, pass_1, p_home, t_home, l_home)
-            self._all_gather(p_all, p_home, "probes")
-            self._all_gather(t_all, t_home, "tables")
-            self._all_gather(l_all, l_home, "limits")
-            self.engine.set_tables(slot, nq, k, n_probes, pass_1, t_all, l_all)
-        else:
-            self.engine.coarse(slot, qn, qp, k, n_probes, pass_1, p_home)
-            self._all_gather(p_all, p_home, "probes")
+        self.engine.coarse(slot, qn, qp, k, n_probes, pass_1, p_home)
+        self._all_gather(p_all, p_home, "probes")
         return p_all
 
     def _probe_buffers(self, slot, nq, n_probes):
