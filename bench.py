@@ -1191,6 +1191,8 @@ def main():
     ap.add_argument("--data", choices=["glove-like", "sift-like", "sift-clustered"], default="glove-like",
                     help="synthetic stand-in: Gaussian clusters, or |N(0,1)|*40 clipped to [0,218]")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
+    ap.add_argument("--sort-queries", choices=["none", "probe", "probe-xcd"], default="none",
+                    help="A/B: order every batch's queries by their nearest coarse centre before the upload")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
     ap.add_argument("--rescore-form", type=int, default=2, help="TK_OPT_RESCORE_FORM (A/B): 2 = 32-row tiles, 1 = 64-row, 0 = row per lane")
     ap.add_argument("--scan-form", type=int, default=0,
@@ -1340,6 +1342,20 @@ def main():
     batches = []
     for b in range(N_BATCHES):
         qs_b = make_batch(b)
+        if args.sort_queries != "none":
+            # A/B (round 6): the batch's queries ordered by the coarse centre nearest to them (the first probed list,
+            # approximately) — neighbours in the batch then rescore overlapping candidate rows; "probe-xcd": ... and
+            # dealt out so that workgroup b of a one-workgroup-per-query kernel (XCD b % 8) gets sorted position
+            # (b % 8) * (nq / 8) + b / 8, i.e. each XCD's L2 sees one contiguous eighth of the sorted batch
+            qn_tmp, _ = ivf._prepare(qs_b.copy())
+            key = np.argmax(qn_tmp @ ivf.active_centers.T, axis=1) if ang else \
+                np.argmin(((qn_tmp[:, None, :8] - ivf.active_centers[None, :, :8]) ** 2).sum(-1), axis=1)
+            order = np.argsort(key, kind="stable")
+            if args.sort_queries == "probe-xcd":
+                nq8 = len(order) // 8
+                pos = (np.arange(8 * nq8) % 8) * nq8 + np.arange(8 * nq8) // 8
+                order = np.concatenate([order[:8 * nq8][pos], order[8 * nq8:]])
+            qs_b = np.ascontiguousarray(qs_b[order])
         t_prep = time.perf_counter()
         qn_b, qp_b = ivf._prepare(qs_b.copy())
         t_prep = time.perf_counter() - t_prep

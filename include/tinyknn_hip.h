@@ -245,7 +245,7 @@ int tk_index_quiesce(tk_index *ix);
  * wave replays one query on packed 32-bit entries; otherwise the general kernel
  * (int64 labels + duplicate scan, one query per wave) runs.  1 = always the
  * general kernel.  2 = the packed wave kernel instead of the lane kernel.  3 = the
- * wave-per-query register heap (heaps of <= 129 entries; automatic for small batches,
+ * wave-per-query register heap (heaps of <= 513 entries; automatic for small batches,
  * TK_OPT_PAIR_NQ) for every batch size.  All are
  * bit-exact replays of _fast_pq_256.pyx:73-123; the switch exists for A/B timing
  * and for the parity tests. */
@@ -320,11 +320,16 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
 #define TK_OPT_TWIN_VOUCH 7
 /*   TK_OPT_PAIR_NQ       batches of up to this many queries (DEFAULT 8192 one batch at a time, at most 256 in pipelined
  *                        mode; 0 = never; environment TINYKNN_PAIR_NQ sets the default of new indexes) replay their heaps
- *                        one query per WAVE with the heap in registers, two nodes per lane (heaps of <= 129 entries:
- *                        IVF.query's 111 and its coarse top's 30 at the reference's bench settings,
+ *                        one query per WAVE with the heap in registers, two / four / eight nodes per lane (heaps of <= 129 /
+ *                        257 / 513 entries: IVF.query's 111 and its coarse top's 30 at the reference's bench settings,
  *                        examples/bench.py:118-137): one query per call is ~760 dependent inserts, 0.47 of 0.54 ms in the
  *                        lane kernel, 0.12 of 0.19 ms here.  Same heap arrays. */
 #define TK_OPT_PAIR_NQ 8
+/*   TK_OPT_LABELS24      the register heap's duplicate test (labels that repeat, IVF.build(n_probes >= 2); a probe list
+ *                        that names a list twice): 1 (DEFAULT) = on entries value8 << 24 | label24 — one register per
+ *                        slot, as with positions — where every label of the index is below 0xffffff (16.7 M rows);
+ *                        0 = always on (value, label64) entries, three registers per slot (what larger indexes get). */
+#define TK_OPT_LABELS24 9
 int tk_index_set_option(tk_index *ix, int option, int value);
 /* The table behind TK_OPT_REPLAY_TWIN (diagnostics, tests): *rows = stored rows (the length of the concatenated
  * ids), *w = other copies listed per row (0: no table — labels distinct, not int32, or one label stored more

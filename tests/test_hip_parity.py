@@ -395,7 +395,7 @@ def test_ivf_vs_oracle_larger(tk, oracle):
     qn, qp = ivf._prepare(qs.copy())
     for n_probes, heap_mode, scan_mode in ((1, 0, 2), (5, 0, 1), (10, 0, 2), (10, 1, 1), (10, 2, 2), (20, 0, 0),
                                            (50, 0, 2), (50, 1, 1), (50, 2, 0), (1, 3, 0), (5, 3, 2), (10, 3, 1),
-                                           (11, 3, 0), (20, 3, 0)):      # (3: register heap; beyond 129 entries: as 0)
+                                           (11, 3, 0), (20, 3, 0), (50, 3, 2)):      # (3: the register heap: 2 / 4 / 8 nodes per lane)
         ivf.device_index().set_heap_mode(heap_mode)   # lane-per-query / wave-per-query replay
         ivf.device_index().set_scan_mode(scan_mode)   # query-major / list-major scan
         out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)
@@ -434,7 +434,10 @@ def test_ivf_saturating_and_duplicates(tk, oracle, build_probes):
     qn, qp = ivf._prepare(qs.copy())
     saw_sentinel = 0
     for n_probes in (3, 8, 20):
-        for heap_mode in (0, 1, 2, 3):
+        for heap_mode in (0, 1, 2, 3, 4):      # (4: the register heap with label64 entries instead of label24)
+            from tinyknn_amd import _lib
+            ivf.device_index().set_option(_lib.OPT_LABELS24, 0 if heap_mode == 4 else 1)
+            heap_mode = min(heap_mode, 3)
             ivf.device_index().set_heap_mode(heap_mode)
             ivf.device_index().set_scan_mode(1 + heap_mode % 2)
             out, dbg = ivf.device_index().query_batch(qn, qp, 10, n_probes, debug=True)

@@ -108,3 +108,90 @@ def test_pair_layout_insert_on_falling_and_constant_streams(oracle):
                 H.insert(step, v)
             gi, gv = H.arrays()
             assert (gi == wi).all() and (gv == wv).all(), (R, kind)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G groups of node pairs per lane (heap.hip: the same kernel for heaps of up to 128 G + 1 entries — G = 2: 257, the
+# heap of n_probes <= 24 at k = 10): lane L, group g holds the children of node t = 64 g + L.  The path is still one
+# ballot per group; a node's ancestors are all below 64 G / 2, i.e. in the lower half of the groups; CE[c] of the
+# chosen child c = 2 t + 1 + right lives in lane c & 63 of group c >> 6 (if c < 64 G).
+class GroupHeap:
+    def __init__(self, R, fresh, G):
+        assert 1 <= R <= 128 * G + 1
+        self.R, self.G = R, G
+        t = np.arange(64 * G)                       # internal-node slots: node t's children pair
+        self.v = np.full((2, 64 * G), SENT, dtype=np.int64)
+        self.i = np.full((2, 64 * G), -1, dtype=np.int64)
+        for s in (0, 1):
+            self.v[s][2 * t + 1 + s < R] = fresh
+        self.rv, self.ri = fresh, -1
+        self.anc = []                               # per node t: list of (ancestor a, bit the ancestor must have chosen)
+        for node in range(64 * G):
+            ch, x = [], node
+            while x > 0:
+                par = (x - 1) // 2
+                ch.append((par, (x - 1) & 1))
+                x = par
+            self.anc.append(ch)
+
+    def insert(self, label, v):
+        G, R = self.G, self.R
+        t = np.arange(64 * G)
+        live = np.stack([2 * t + 1 < R, 2 * t + 2 < R])
+        if self.ri == label or ((self.i == label) & live).any():
+            return
+        B = self.v[1] > self.v[0]                   # G ballots of 64 bits, concatenated
+        onpath = np.array([all(bool(B[a]) == bool(bit) for a, bit in self.anc[n]) for n in t])
+        ch = B.astype(int)
+        cv = np.where(B, self.v[1], self.v[0])
+        ci = np.where(B, self.i[1], self.i[0])
+        c = 2 * t + 1 + ch
+        has = c < 64 * G
+        fv = np.where(has, cv[np.minimum(c, 64 * G - 1)], SENT)
+        fi = np.where(has, ci[np.minimum(c, 64 * G - 1)], -1)
+        upd = onpath & (cv > v)
+        nv = np.where(fv > v, fv, v)
+        ni = np.where(fv > v, fi, label)
+        new_root = (cv[0], ci[0]) if cv[0] > v else (v, label)
+        for s in (0, 1):
+            sel = upd & (ch == s)
+            self.v[s] = np.where(sel, nv, self.v[s])
+            self.i[s] = np.where(sel, ni, self.i[s])
+        self.rv, self.ri = new_root
+
+    def arrays(self):
+        idx, val = np.empty(self.R, np.int64), np.empty(self.R, np.int32)
+        idx[0], val[0] = self.ri, self.rv
+        for n in range(1, self.R):
+            idx[n], val[n] = self.i[(n - 1) & 1][(n - 1) >> 1], self.v[(n - 1) & 1][(n - 1) >> 1]
+        return idx, val
+
+
+def test_group_layout_ancestors_live_in_the_lower_groups():
+    """What the kernel's per-lane constants rest on: the ancestors of internal node t < 64 G are all < 32 G."""
+    for G in (1, 2, 4):
+        for node in range(64 * G):
+            x = node
+            while x > 0:
+                x = (x - 1) // 2
+                assert x < 32 * G
+
+
+@pytest.mark.parametrize("G,R", [(2, 130), (2, 131), (2, 193), (2, 211), (2, 256), (2, 257), (2, 111), (4, 258), (4, 511), (4, 513)])
+@pytest.mark.parametrize("spread", [3, 60])
+def test_group_layout_insert_equals_the_loop(oracle, G, R, spread):
+    rng = np.random.RandomState(R * 7 + spread + G)
+    for signd in (True, False):
+        wi, wv = np.zeros(R, np.int64), np.zeros(R, np.int32)
+        oracle.init_heap(wi, wv, signd)
+        H = GroupHeap(R, int(wv[0]), G)
+        lo = -128 if signd else 0
+        for step in range(900):
+            base = int(wv[0])
+            v = int(np.clip(base - rng.randint(0, spread) + (rng.randint(0, 6) if step % 11 == 0 else 0), lo, lo + 255))
+            label = int(wi[rng.randint(R)]) if step % 17 == 5 and wi.max() >= 0 else step
+            oracle.insert(wi, wv, label, v)
+            H.insert(label, v)
+            if step % 7 == 0 or step > 880:
+                gi, gv = H.arrays()
+                assert (gi == wi).all() and (gv == wv).all(), (G, R, signd, step)

@@ -5,7 +5,7 @@ Python loop), and behind small batches (TK_OPT_PAIR_NQ, product default 8192 one
 Heap arrays (layout included), probe order and final ids against the oracle (ivf.py:106-163 through
 _fast_pq_256.pyx:73-123,188-210) for labels that are distinct and labels that repeat (IVF.build(n_probes=2): every
 row in two lists, the duplicate test of `insert` on (value, label) entries), at every batch size up to the threshold,
-heaps of 1 ... 129 entries, both coarse (2 n_probes + 10 entries) and list replays; the CPU lemma for the
+heaps of 1 ... 513 entries (two, four and eight nodes per lane), both coarse (2 n_probes + 10 entries) and list replays; the CPU lemma for the
 two-nodes-per-lane formulation is tests/test_pair_heap_lemma.py."""
 import numpy as np
 import pytest
@@ -58,13 +58,18 @@ def test_small_batches_take_the_register_heap_and_match_the_oracle(built):
         for k, n_probes in ((10, 1), (10, 5), (10, 10), (10, 11), (3, 30), (1, 127), (1, 1)):
             for lo, hi in ((0, 1), (1, 4), (4, 68), (0, 300)):      # (300 > 256: the lane kernel's batch beside them)
                 check_batch(dev, ox, qn, qp, k, n_probes, lo, hi)
-        # beyond 129 entries the register heap does not apply: the other kernels answer, same arrays
-        check_batch(dev, ox, qn, qp, 10, 20, 0, 40)
+        # four nodes per lane (heaps of 130 ... 257 entries: n_probes 12 ... 24 at k = 10) and eight (... 513: n_probes <= 50)
+        for k, n_probes in ((10, 12), (10, 20), (10, 24), (2, 127), (10, 25), (10, 50), (4, 127)):
+            for lo, hi in ((0, 1), (1, 70)):
+                check_batch(dev, ox, qn, qp, k, n_probes, lo, hi)
+        # beyond 513 entries the register heap does not apply: the other kernels answer, same arrays
+        check_batch(dev, ox, qn, qp, 10, 60, 0, 40)
     finally:
         dev.set_option(_lib.OPT_PAIR_NQ, 4)
 
 
 def test_forced_for_every_batch_size(built):
+    from tinyknn_amd import _lib
     ivf, ox, qs = built
     dev = ivf.device_index()
     qn, qp = ivf._prepare(qs.copy())
@@ -73,7 +78,13 @@ def test_forced_for_every_batch_size(built):
         for scan_mode in (1, 2):
             dev.set_scan_mode(scan_mode)
             check_batch(dev, ox, qn, qp, 10, 10, 0, 300)
+        # the duplicate test on (value, label64) entries — what an index of more than 16.7 M rows gets — instead of
+        # value8 << 24 | label24: two, four and eight nodes per lane
+        dev.set_option(_lib.OPT_LABELS24, 0)
+        for n_probes in (10, 20, 40):
+            check_batch(dev, ox, qn, qp, 10, n_probes, 0, 120)
     finally:
+        dev.set_option(_lib.OPT_LABELS24, 1)
         dev.set_heap_mode(0)
         dev.set_scan_mode(0)
 

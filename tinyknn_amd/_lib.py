@@ -33,7 +33,7 @@ _f64p = C.POINTER(C.c_double)
 # name -> (restype, argtypes); mirrors include/tinyknn_hip.h one to one
 # tk_index_set_option
 OPT_SCAN_FORM, OPT_RESCORE_FORM, OPT_PLAIN_LIMIT, OPT_REPLAY_LAZY, OPT_REPLAY_COUNT, OPT_REPLAY_TWIN, OPT_TWIN_VOUCH = 1, 2, 3, 4, 5, 6, 7
-OPT_PAIR_NQ = 8
+OPT_PAIR_NQ, OPT_LABELS24 = 8, 9
 
 SIGNATURES = {
     "tk_last_error": (C.c_char_p, []),

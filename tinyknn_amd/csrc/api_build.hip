@@ -244,6 +244,7 @@ extern "C" int tk_index_build_dev(tk_index *ix, int normalise, const float *all_
     tk_launch_widen_ids(rows2.as<int>(), T, ix->ids.as<int64_t>(), 0);
     HIPCHECK(hipGetLastError());
     ix->ids_unique = kp == 1;       // one list per row: no label can repeat
+    ix->labels24 = ix->N < 0x00ffffff;      // (labels are row numbers)
     ix->have_ids32 = false;
     if (kp > 1) {                   // the lane replay's duplicate test reads the labels as int32
         TRY(ix->ids32.ensure((size_t)T * 4));
@@ -326,6 +327,7 @@ extern "C" tk_index *tk_index_clone_shard(tk_index *src, const int32_t *owner, i
     ix->ids.borrow(src->ids);
     ix->ids32.borrow(src->ids32);
     ix->have_ids32 = src->have_ids32;
+    ix->labels24 = src->labels24;
     ix->twin_list.borrow(src->twin_list);
     ix->twin_off.borrow(src->twin_off);
     ix->twin_w = src->twin_w;

@@ -263,8 +263,12 @@ static int set_lists_impl(tk_index *ix, const int64_t *list_sizes, const uint64_
     ix->max_list_chunks = (int)maxc;
     ix->have_lists = true;
     {   // labels that repeat: where every row's other copies are (the lane replay's duplicate test)
-        int64_t mx = -1;
-        for (int64_t i = 0; i < ioff[L]; i++) mx = ids[i] > mx ? ids[i] : mx;
+        int64_t mx = -1, mn = 0;
+        for (int64_t i = 0; i < ioff[L]; i++) {
+            mx = ids[i] > mx ? ids[i] : mx;
+            mn = ids[i] < mn ? ids[i] : mn;
+        }
+        ix->labels24 = mn >= 0 && mx < 0x00ffffff;
         TRY(build_twins(ix, mx + 1));
     }
     return TK_OK;
@@ -933,8 +937,8 @@ static void replay_flagged_tail(tk_index *ix, Work &w, int64_t nq, const Plan &p
     if (p.R <= TK_PAIR_MAX_R && (ix->heap_mode == 0 || ix->heap_mode == 3) && ix->opt_pair_nq > 0) {
         (void)tk_launch_heap_replay_pair(w.dist.as<uint4>(), p.cap, nq, w.mins.as<uint8_t>(), p.cap_min, slot_prefix, slot_n,
                                          slot_loff, p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
-                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, 0, st, nullptr, nullptr, nullptr,
-                                         1, w.flag_list.as<int>(), w.flag_host);
+                                         w.heap_val.as<int32_t>(), p.R, 1, 0, repeat_flag, (ix->labels24 && ix->opt_labels24) ? 2 : 0, st, nullptr,
+                                         nullptr, nullptr, 1, w.flag_list.as<int>(), w.flag_host);
         return;
     }
     tk_launch_heap_replay_packed(w.dist.as<uint4>(), p.cap, nq, slot_prefix, slot_n, slot_loff,
@@ -979,7 +983,7 @@ int stage_back(tk_index *ix, Work &w, const float *q_dev, int64_t q0, int64_t nq
         if (tk_launch_heap_replay_pair(w.dist.as<uint4>(), p.cap, nq, w.mins.as<uint8_t>(), p.cap_min, slot_prefix, slot_n,
                                        slot_loff, p.S, ix->ids.as<int64_t>(), w.heap_idx.as<int64_t>(),
                                        w.heap_val.as<int32_t>(), p.R, 1, 0, (plain || ix->ids_unique) ? repeat_flag : nullptr,
-                                       ix->ids_unique ? 0 : 1, st, slot_exact, qlim,
+                                       (ix->ids_unique ? 0 : 1) | ((ix->labels24 && ix->opt_labels24) ? 2 : 0), st, slot_exact, qlim,
                                        plain && !plain_flag ? w.flag_list.as<int>() : nullptr))
             return fail(TK_ERR_HIP, "hipMemsetAsync(flag list) failed");
         if (plain && plain_flag) {
@@ -1823,6 +1827,9 @@ extern "C" int tk_index_set_option(tk_index *ix, int option, int value)
     case TK_OPT_PAIR_NQ:
         ARGCHECK(value >= 0, "TK_OPT_PAIR_NQ: >= 0");
         ix->opt_pair_nq = value;
+        return TK_OK;
+    case TK_OPT_LABELS24:
+        ix->opt_labels24 = value != 0;
         return TK_OK;
     case TK_OPT_REPLAY_COUNT:
         ix->opt_replay_count = value != 0;

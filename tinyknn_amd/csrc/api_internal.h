@@ -179,6 +179,8 @@ struct tk_index {
     // lists
     DevBuf list_chunk_off, list_n, ids_off, ids, codes, ids32;
     bool have_ids32 = false;   // every label fits int32: the lane kernel can run the duplicate test
+    bool labels24 = false;     // every label is in [0, 0xffffff): the register heap's duplicate test on one register per slot
+    int opt_labels24 = 1;      // TK_OPT_LABELS24: 0 = (value, label64) entries even where the labels would fit (tests)
     // repeating labels: where the other copies of every stored row are (twins.hip); twin_w = copies - 1, 0 = no table
     DevBuf twin_list, twin_off;
     int twin_w = 0;

@@ -1552,6 +1552,13 @@ struct PairHeapPos {
         ce0 = __builtin_amdgcn_readlane(ce, 0);
     }
     __device__ __forceinline__ uint32_t bound() const { return er >> 24; }
+    // entries value8 << 24 | label24 (labels below 0xffffff): `if i == indices[j]: return` (:284-287) on the low 24 bits —
+    // fresh nodes and nodes >= R hold 0xffffff, which no row carries
+    __device__ __forceinline__ bool holds24(uint32_t l24) const
+    {
+        const bool here = (((e0 ^ l24) & 0x00ffffffu) == 0) | (((e1 ^ l24) & 0x00ffffffu) == 0);
+        return __builtin_amdgcn_ballot_w64(here) != 0 || ((er ^ l24) & 0x00ffffffu) == 0;
+    }
     __device__ __forceinline__ void insert(uint32_t e, int v, int lane, const PairLane &K)
     {
         const bool upd = onp && cev > v;
@@ -1621,26 +1628,227 @@ struct PairHeapLab {
     }
 };
 
+// ---- G groups of node pairs per lane: heaps of up to 128 G + 1 entries (G = 2: 257 — n_probes <= 24 at k = 10; G = 4: 513 —
+// n_probes <= 50).  Lane L, group g holds the children of node t = 64 g + L.  One ballot per group describes the path; the
+// ancestors of an internal node are all below 32 G (the lower half of the groups), so a node's on-path test is a mask test
+// against the ballots of those groups with per-lane constants; the chosen child c = 2 t + 1 + right of a node of group g
+// has its own pair in lane c & 63 of group c >> 6 in {2g, 2g+1, 2g+2} (c < 64 G), else it is a leaf.  Formulation checked
+// on the CPU for G = 1, 2, 4 (tests/test_pair_heap_lemma.py: GroupHeap).  G = 1 keeps the structs above (same arithmetic,
+// written out: the kernel of the smallest heaps is the one that matters most).
+template <int G>
+struct GroupLane {
+    static constexpr int GA = G >= 2 ? G / 2 : 1;      // groups that hold ancestors
+    uint32_t m_lo[G][GA], m_hi[G][GA], b_lo[G][GA], b_hi[G][GA];
+};
+template <int G>
+__device__ __forceinline__ GroupLane<G> group_lane(int lane)
+{
+    GroupLane<G> K;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+#pragma unroll
+        for (int a = 0; a < GroupLane<G>::GA; a++) K.m_lo[g][a] = K.m_hi[g][a] = K.b_lo[g][a] = K.b_hi[g][a] = 0;
+        for (int t = 64 * g + lane; t > 0;) {
+            const int par = (t - 1) >> 1;
+            const uint32_t bit = (uint32_t)((t - 1) & 1);
+            const int a = par >> 6, l = par & 63;       // a < GA by construction
+#pragma unroll
+            for (int aa = 0; aa < GroupLane<G>::GA; aa++)
+                if (aa == a) {
+                    if (l < 32) { K.m_lo[g][aa] |= 1u << l; K.b_lo[g][aa] |= bit << l; }
+                    else { K.m_hi[g][aa] |= 1u << (l - 32); K.b_hi[g][aa] |= bit << (l - 32); }
+                }
+            t = par;
+        }
+    }
+    return K;
+}
+
+template <bool SIGNED, int G>
+struct GroupHeapPos {
+    static constexpr int GROUPS = G;
+    uint32_t e0[G], e1[G], er;
+    bool right[G], onp[G];
+    uint32_t ce[G], fe[G], ce0;
+    __device__ __forceinline__ void init(int lane, int R)
+    {
+        const uint32_t fresh = SIGNED ? 0x7fffffffu : 0xffffffffu;
+        const uint32_t lowest = SIGNED ? 0x80ffffffu : 0x00ffffffu;
+        er = fresh;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            e0[g] = 2 * (64 * g + lane) + 1 < R ? fresh : lowest;
+            e1[g] = 2 * (64 * g + lane) + 2 < R ? fresh : lowest;
+        }
+    }
+    __device__ __forceinline__ void prepare(int lane, const GroupLane<G> &K)
+    {
+        const uint32_t lowest = SIGNED ? 0x80ffffffu : 0x00ffffffu;
+        uint64_t B[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            right[g] = entry_val<SIGNED>(e1[g]) > entry_val<SIGNED>(e0[g]);
+            B[g] = __builtin_amdgcn_ballot_w64(right[g]);
+            ce[g] = right[g] ? e1[g] : e0[g];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            uint32_t bad = 0;
+#pragma unroll
+            for (int a = 0; a < GroupLane<G>::GA; a++)
+                bad |= (((uint32_t)B[a] ^ K.b_lo[g][a]) & K.m_lo[g][a]) | (((uint32_t)(B[a] >> 32) ^ K.b_hi[g][a]) & K.m_hi[g][a]);
+            onp[g] = bad == 0;
+            const int c = 2 * (64 * g + lane) + 1 + (int)right[g];
+            const int a4 = (c & 63) << 2;
+            uint32_t f = lowest;
+#pragma unroll
+            for (int sg = 2 * g; sg <= 2 * g + 2; sg++)
+                if (sg < G) {
+                    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)ce[sg]);
+                    f = (c >> 6) == sg ? got : f;
+                }
+            fe[g] = f;
+        }
+        ce0 = __builtin_amdgcn_readlane(ce[0], 0);
+    }
+    __device__ __forceinline__ uint32_t bound() const { return er >> 24; }
+    __device__ __forceinline__ bool holds24(uint32_t l24) const
+    {
+        bool here = false;
+#pragma unroll
+        for (int g = 0; g < G; g++) here |= (((e0[g] ^ l24) & 0x00ffffffu) == 0) | (((e1[g] ^ l24) & 0x00ffffffu) == 0);
+        return __builtin_amdgcn_ballot_w64(here) != 0 || ((er ^ l24) & 0x00ffffffu) == 0;
+    }
+    __device__ __forceinline__ void insert(uint32_t e, int v, int lane, const GroupLane<G> &K)
+    {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const bool upd = onp[g] && entry_val<SIGNED>(ce[g]) > v;
+            const uint32_t ne = entry_val<SIGNED>(fe[g]) > v ? fe[g] : e;
+            e0[g] = (upd && !right[g]) ? ne : e0[g];
+            e1[g] = (upd && right[g]) ? ne : e1[g];
+        }
+        er = entry_val<SIGNED>(ce0) > v ? ce0 : e;
+        prepare(lane, K);
+    }
+    __device__ __forceinline__ uint32_t slot_entry(int g, int slot) const { return slot ? e1[g] : e0[g]; }
+};
+
+template <bool SIGNED, int G>
+struct GroupHeapLab {
+    static constexpr int GROUPS = G;
+    int v0[G], v1[G], vr;
+    uint32_t lo0[G], lo1[G], hi0[G], hi1[G], lor, hir;
+    bool right[G], onp[G];
+    int cev[G], fev[G], cev0;
+    uint32_t clo[G], chi[G], flo[G], fhi[G], clo0, chi0;
+    __device__ __forceinline__ void init(int lane, int R)
+    {
+        const int fresh = SIGNED ? 127 : 255;
+        vr = fresh;
+        lor = hir = 0xffffffffu;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            v0[g] = 2 * (64 * g + lane) + 1 < R ? fresh : TK_PAIR_LOW;
+            v1[g] = 2 * (64 * g + lane) + 2 < R ? fresh : TK_PAIR_LOW;
+            lo0[g] = lo1[g] = hi0[g] = hi1[g] = 0xffffffffu;       // label -1
+        }
+    }
+    __device__ __forceinline__ void prepare(int lane, const GroupLane<G> &K)
+    {
+        uint64_t B[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            right[g] = v1[g] > v0[g];
+            B[g] = __builtin_amdgcn_ballot_w64(right[g]);
+            cev[g] = right[g] ? v1[g] : v0[g];
+            clo[g] = right[g] ? lo1[g] : lo0[g];
+            chi[g] = right[g] ? hi1[g] : hi0[g];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            uint32_t bad = 0;
+#pragma unroll
+            for (int a = 0; a < GroupLane<G>::GA; a++)
+                bad |= (((uint32_t)B[a] ^ K.b_lo[g][a]) & K.m_lo[g][a]) | (((uint32_t)(B[a] >> 32) ^ K.b_hi[g][a]) & K.m_hi[g][a]);
+            onp[g] = bad == 0;
+            const int c = 2 * (64 * g + lane) + 1 + (int)right[g];
+            const int a4 = (c & 63) << 2;
+            int fv = TK_PAIR_LOW;
+            uint32_t fl = 0xffffffffu, fh = 0xffffffffu;
+#pragma unroll
+            for (int sg = 2 * g; sg <= 2 * g + 2; sg++)
+                if (sg < G) {
+                    const int gv = __builtin_amdgcn_ds_bpermute(a4, cev[sg]);
+                    const uint32_t gl = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)clo[sg]);
+                    const uint32_t gh = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)chi[sg]);
+                    const bool here = (c >> 6) == sg;
+                    fv = here ? gv : fv; fl = here ? gl : fl; fh = here ? gh : fh;
+                }
+            fev[g] = fv; flo[g] = fl; fhi[g] = fh;
+        }
+        cev0 = __builtin_amdgcn_readlane(cev[0], 0);
+        clo0 = __builtin_amdgcn_readlane(clo[0], 0);
+        chi0 = __builtin_amdgcn_readlane(chi[0], 0);
+    }
+    __device__ __forceinline__ uint32_t bound() const { return (uint32_t)vr & 0xffu; }
+    __device__ __forceinline__ bool holds(uint32_t llo, uint32_t lhi) const
+    {
+        bool here = false;
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            here |= ((lo0[g] == llo) & (hi0[g] == lhi)) | ((lo1[g] == llo) & (hi1[g] == lhi));
+        return __builtin_amdgcn_ballot_w64(here) != 0 || (lor == llo && hir == lhi);
+    }
+    __device__ __forceinline__ void insert(uint32_t llo, uint32_t lhi, int v, int lane, const GroupLane<G> &K)
+    {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const bool upd = onp[g] && cev[g] > v;
+            const bool deeper = fev[g] > v;
+            const int nv = deeper ? fev[g] : v;
+            const uint32_t nl = deeper ? flo[g] : llo, nh = deeper ? fhi[g] : lhi;
+            const bool u0 = upd && !right[g], u1 = upd && right[g];
+            v0[g] = u0 ? nv : v0[g]; lo0[g] = u0 ? nl : lo0[g]; hi0[g] = u0 ? nh : hi0[g];
+            v1[g] = u1 ? nv : v1[g]; lo1[g] = u1 ? nl : lo1[g]; hi1[g] = u1 ? nh : hi1[g];
+        }
+        const bool rt = cev0 > v;
+        vr = rt ? cev0 : v; lor = rt ? clo0 : llo; hir = rt ? chi0 : lhi;
+        prepare(lane, K);
+    }
+};
+
 // The replay of one query by one wave: LABELS = the duplicate test on (value, label) entries, else position entries.
 // (Two instantiations called from one wave-uniform branch: as ONE loop with a run-time switch the compiler merged
 //  both heaps' registers and masks through every iteration — ~30 scalar moves per insert.)
-template <bool SIGNED, bool LABELS>
+// KIND 0: position entries (no label can repeat among the query's lists); 1: (value, label64) entries with the duplicate
+// test; 2: the duplicate test on value8 << 24 | label24 entries (every label of the index below 0xffffff: one register per
+// slot as with positions — the reference's default build, IVF.build(n_probes=2), of anything up to 16.7 M rows)
+template <bool SIGNED, int KIND, int G>
 __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow, const uint8_t *__restrict__ mrow,
                                                  const int *__restrict__ prefix, const int *__restrict__ ns,
                                                  const int64_t *__restrict__ loffs, int S,
                                                  const int64_t *__restrict__ labels, int64_t *__restrict__ oi,
                                                  int32_t *__restrict__ ov, int R, int lane, int plain0, uint32_t &b_plain)
 {
-    const PairLane K = pair_lane(lane);
+    // G = 1 (heaps <= 129): the written-out structs; G = 2 / 4: the same arithmetic over G groups of pairs per lane
+    typename std::conditional<G == 1, PairLane, GroupLane<G>>::type K;
+    if constexpr (G == 1) K = pair_lane(lane); else K = group_lane<G>(lane);
     const int total = S > 0 ? prefix[S] : 0;
     const uint4 never = SIGNED ? make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu)
                                : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    typename std::conditional<LABELS, PairHeapLab<SIGNED>, PairHeapPos<SIGNED>>::type H;
+    constexpr bool LABELS = KIND == 1;          // three registers per slot
+    constexpr bool NEEDS_LABELS = KIND != 0;    // the candidate rows' labels are loaded
+    typename std::conditional<G == 1,
+                              typename std::conditional<LABELS, PairHeapLab<SIGNED>, PairHeapPos<SIGNED>>::type,
+                              typename std::conditional<LABELS, GroupHeapLab<SIGNED, G>, GroupHeapPos<SIGNED, G>>::type>::type H;
     H.init(lane, R);
     H.prepare(lane, K);
     uint32_t bound = SIGNED ? 0x7fu : 0xffu;
-    // slot cursor (wave-uniform): flat blocks [c0, c1) belong to slot s
+    // slot cursor (wave-uniform): flat blocks [c0, c1) belong to slot s, a list of n_s rows with its labels at loff_s
     int s = 0, c0 = 0, c1 = S > 0 ? prefix[1] : 0;
+    int n_s = S > 0 ? ns[0] : 0;
+    int64_t loff_s = S > 0 ? loffs[0] : -1;
     // 64 blocks per step, each lane one block and its minimum; the next step's are requested before this one is replayed
     uint4 nd = never;
     uint32_t nm = SIGNED ? 0x7fu : 0xffu;
@@ -1653,7 +1861,25 @@ __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow,
         if (base + 64 + lane < total) { nd = drow[base + 64 + lane]; nm = mrow[base + 64 + lane]; }
         // blocks whose minimum is below the bound of now: a superset of what the reference enters (the bound only falls)
         uint64_t mask = __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn, bound));
-        // LABELS: the labels of a voted block — lanes 0..15, one vector load — are requested one voted block ahead
+        // The labels of a voted block — lanes 0..15, one vector load — are requested one voted block ahead (two ahead was
+        // measured: no gain).  The slot's row count and label offset live in registers and change only where the cursor
+        // steps into the next list: read through `ns[s]` / `loffs[s]` per voted block they were a scalar load each in
+        // front of every block's cmp_mask — the build(n_probes=2) index (labels: three such loads per voted block) spent
+        // 0.28 ms in this replay against 0.09 for distinct labels.
+        auto load_labels = [&](int f2) -> int64_t {       // block f2 >= the cursor's block
+            int a0 = c0, n2 = n_s;
+            int64_t loff2 = loff_s;
+            if (f2 >= c1) {                               // (rare: the next voted block lies in a later list)
+                int s2 = s, a1 = c1;
+                while (f2 >= a1) { s2++; a0 = a1; a1 = prefix[s2 + 1]; }
+                n2 = ns[s2];
+                loff2 = loffs[s2];
+            }
+            const int64_t inl2 = 16 * (int64_t)(f2 - a0) + lane;
+            int64_t l = -2;
+            if (lane < 16 && inl2 < n2) l = loff2 < 0 ? inl2 : labels[loff2 + inl2];
+            return l;
+        };
         int j_pref = -1;
         int64_t lab_pref = -2;
         while (mask) {
@@ -1664,24 +1890,17 @@ __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow,
                 s++;
                 c0 = c1;
                 c1 = prefix[s + 1];
+                n_s = ns[s];
+                loff_s = loffs[s];
             }
-            const int n = ns[s];
-            const int rows = n - 16 * (f - c0);             // `pos < n`, _fast_pq_256.pyx:111
+            const int rows = n_s - 16 * (f - c0);           // `pos < n`, _fast_pq_256.pyx:111
             int64_t lab_cur = -2;
-            if (LABELS) {
-                const int64_t loff = loffs[s];
-                const int64_t inl = 16 * (int64_t)(f - c0) + lane;
-                if (j == j_pref) lab_cur = lab_pref;
-                else if (lane < 16 && inl < n) lab_cur = loff < 0 ? inl : labels[loff + inl];
+            if (NEEDS_LABELS) {
+                lab_cur = j == j_pref ? lab_pref : load_labels(f);
+                j_pref = -1;
                 if (mask) {                                 // the next voted block of this step (a superset: the bound may fall)
                     j_pref = __builtin_ctzll(mask);
-                    const int f2 = base + j_pref;
-                    int s2 = s, a0 = c0, a1 = c1;
-                    while (f2 >= a1) { s2++; a0 = a1; a1 = prefix[s2 + 1]; }
-                    const int64_t loff2 = loffs[s2];
-                    const int64_t inl2 = 16 * (int64_t)(f2 - a0) + lane;
-                    lab_pref = -2;
-                    if (lane < 16 && inl2 < ns[s2]) lab_pref = loff2 < 0 ? inl2 : labels[loff2 + inl2];
+                    lab_pref = load_labels(base + j_pref);
                 }
             }
             const uint32_t d0 = __builtin_amdgcn_readlane(dd.x, j);
@@ -1704,6 +1923,10 @@ __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow,
                     const uint32_t lhi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)lab_cur >> 32), r);
                     if (H.holds(llo, lhi)) continue;
                     H.insert(llo, lhi, v, lane, K);
+                } else if constexpr (KIND == 2) {
+                    const uint32_t l24 = __builtin_amdgcn_readlane((uint32_t)lab_cur, r) & 0x00ffffffu;
+                    if (H.holds24(l24)) continue;
+                    H.insert((byr << 24) | l24, v, lane, K);
                 } else {
                     H.insert((byr << 24) | (pos0 + (uint32_t)r), v, lane, K);
                 }
@@ -1713,32 +1936,44 @@ __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow,
             if (mask) mask &= __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn, bound));
         }
     }
-    // heap arrays out, in the reference's layout: node 0 = the root, node 2L+1+slot = lane L's slot
-    if constexpr (LABELS) {
+    // heap arrays out, in the reference's layout: node 0 = the root, node 2 t + 1 + slot = the slot of lane L, group g (t = 64 g + L)
+    auto resolve = [&](uint32_t e) -> int64_t {      // a flat position back to (list, row): its label (KIND 2: the label itself)
+        const uint32_t pos = e & 0x00ffffffu;
+        if (pos == 0x00ffffffu) return -1;
+        if (KIND == 2) return (int64_t)pos;
+        const int fb = (int)(pos >> 4);
+        int lo = 0, hi = S;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= fb) lo = mid; else hi = mid;
+        }
+        const int64_t inlist = (int64_t)pos - 16 * (int64_t)prefix[lo];
+        const int64_t loff = loffs[lo];
+        return loff < 0 ? inlist : labels[loff + inlist];
+    };
+    if constexpr (G == 1 && LABELS) {
         if (lane == 0) { oi[0] = (int64_t)(((uint64_t)H.hir << 32) | H.lor); ov[0] = H.vr; }
         if (2 * lane + 1 < R) { oi[2 * lane + 1] = (int64_t)(((uint64_t)H.hi0 << 32) | H.lo0); ov[2 * lane + 1] = H.v0; }
         if (2 * lane + 2 < R) { oi[2 * lane + 2] = (int64_t)(((uint64_t)H.hi1 << 32) | H.lo1); ov[2 * lane + 2] = H.v1; }
-    } else {
+    } else if constexpr (G == 1) {
+        if (lane == 0) { oi[0] = resolve(H.er); ov[0] = entry_val<SIGNED>(H.er); }
+        if (2 * lane + 1 < R) { oi[2 * lane + 1] = resolve(H.e0); ov[2 * lane + 1] = entry_val<SIGNED>(H.e0); }
+        if (2 * lane + 2 < R) { oi[2 * lane + 2] = resolve(H.e1); ov[2 * lane + 2] = entry_val<SIGNED>(H.e1); }
+    } else if constexpr (LABELS) {
+        if (lane == 0) { oi[0] = (int64_t)(((uint64_t)H.hir << 32) | H.lor); ov[0] = H.vr; }
 #pragma unroll
-        for (int slot = -1; slot < 2; slot++) {
-            const int t = slot < 0 ? 0 : 2 * lane + 1 + slot;
-            if (t >= R || (slot < 0 && lane != 0)) continue;
-            const uint32_t e = slot < 0 ? H.er : slot == 0 ? H.e0 : H.e1;
-            const uint32_t pos = e & 0x00ffffffu;
-            int64_t label = -1;
-            if (pos != 0x00ffffffu) {          // the flat position back to (list, row): its label
-                const int fb = (int)(pos >> 4);
-                int lo = 0, hi = S;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (prefix[mid] <= fb) lo = mid; else hi = mid;
-                }
-                const int64_t inlist = (int64_t)pos - 16 * (int64_t)prefix[lo];
-                const int64_t loff = loffs[lo];
-                label = loff < 0 ? inlist : labels[loff + inlist];
-            }
-            oi[t] = label;
-            ov[t] = entry_val<SIGNED>(e);
+        for (int g = 0; g < G; g++) {
+            const int t0 = 2 * (64 * g + lane) + 1;
+            if (t0 < R) { oi[t0] = (int64_t)(((uint64_t)H.hi0[g] << 32) | H.lo0[g]); ov[t0] = H.v0[g]; }
+            if (t0 + 1 < R) { oi[t0 + 1] = (int64_t)(((uint64_t)H.hi1[g] << 32) | H.lo1[g]); ov[t0 + 1] = H.v1[g]; }
+        }
+    } else {
+        if (lane == 0) { oi[0] = resolve(H.er); ov[0] = entry_val<SIGNED>(H.er); }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int t0 = 2 * (64 * g + lane) + 1;
+            if (t0 < R) { oi[t0] = resolve(H.e0[g]); ov[t0] = entry_val<SIGNED>(H.e0[g]); }
+            if (t0 + 1 < R) { oi[t0 + 1] = resolve(H.e1[g]); ov[t0 + 1] = entry_val<SIGNED>(H.e1[g]); }
         }
     }
 }
@@ -1748,7 +1983,7 @@ __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow,
 // plain0_arr / qlim / flag_list (plain_scan.hip: the blocks from flat chunk plain0_arr[q] on carry clamp(plain sums)): the
 // replay checks the lemma's condition per query as the lane kernel does — bound at the first plain block <= qlim[q] —
 // and lists the queries that fail it, and those flagged beforehand, for the exact re-scan behind it (flags[q] = 2).
-template <bool SIGNED>
+template <bool SIGNED, int G>
 __global__ __launch_bounds__(64) void heap_replay_pair_kernel(
     const uint4 *__restrict__ dist, int64_t cap, const uint8_t *__restrict__ mins, int64_t cap_min,
     const int *__restrict__ slot_prefix, const int *__restrict__ slot_n, const int64_t *__restrict__ slot_label_off,
@@ -1773,14 +2008,19 @@ __global__ __launch_bounds__(64) void heap_replay_pair_kernel(
     const int plain0 = plain0_arr ? plain0_arr[q] : 0x7fffffff;
     uint32_t b_plain = SIGNED ? 0x7fu : 0xffu;
     const int *prefix = slot_prefix + qs * (S + 1);
-    if (dedupe_all || flagged)
-        pair_replay_body<SIGNED, true>(dist + q * cap, mins + q * cap_min, prefix, slot_n + qs * S,
-                                       slot_label_off + qs * S, S, labels, heap_idx + q * R, heap_val + q * R, R, lane,
-                                       plain0, b_plain);
+    // dedupe_all: bit 0 = every query takes the duplicate test (labels repeat in the index), bit 1 = every label is below 0xffffff
+    const uint4 *drow = dist + q * cap;
+    const uint8_t *mrow = mins + q * cap_min;
+    const int *ns = slot_n + qs * S;
+    const int64_t *loffs = slot_label_off + qs * S;
+    int64_t *oi = heap_idx + q * R;
+    int32_t *ov = heap_val + q * R;
+    if (!((dedupe_all & 1) || flagged))
+        pair_replay_body<SIGNED, 0, G>(drow, mrow, prefix, ns, loffs, S, labels, oi, ov, R, lane, plain0, b_plain);
+    else if (dedupe_all & 2)
+        pair_replay_body<SIGNED, 2, G>(drow, mrow, prefix, ns, loffs, S, labels, oi, ov, R, lane, plain0, b_plain);
     else
-        pair_replay_body<SIGNED, false>(dist + q * cap, mins + q * cap_min, prefix, slot_n + qs * S,
-                                        slot_label_off + qs * S, S, labels, heap_idx + q * R, heap_val + q * R, R, lane,
-                                        plain0, b_plain);
+        pair_replay_body<SIGNED, 1, G>(drow, mrow, prefix, ns, loffs, S, labels, oi, ov, R, lane, plain0, b_plain);
     if (SIGNED && plain0_arr && S > 0 && plain0 < prefix[S] && (int)(int8_t)b_plain > qlim[q] && lane == 0) {
         flags[q] = 2;
         if (flag_list) flag_list[1 + atomicAdd(&flag_list[0], 1)] = (int)q;
@@ -1802,14 +2042,16 @@ int tk_launch_heap_replay_pair(const uint4 *dist, int64_t cap, int64_t nq, const
     if (nq == 0 || R == 0) return 0;
     if (!plain0 || !qlim || !flags || !signd) plain0 = qlim = nullptr, flag_list = nullptr;
     if (flag_list && hipMemsetAsync(flag_list, 0, 4, s) != hipSuccess) return -1;
-    if (signd)
-        hipLaunchKernelGGL(heap_replay_pair_kernel<true>, dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,
-                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,
-                           dedupe_all, nq, plain0, qlim, flag_list, only_flagged, count_src, host_count);
-    else
-        hipLaunchKernelGGL(heap_replay_pair_kernel<false>, dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,
-                           slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,
-                           dedupe_all, nq, plain0, qlim, flag_list, only_flagged, count_src, host_count);
+#define TK_LAUNCH_PAIR(S_, G_)                                                                                           \
+    hipLaunchKernelGGL((heap_replay_pair_kernel<S_, G_>), dim3((unsigned)nq), dim3(64), 0, s, dist, cap, mins, cap_min,  \
+                       slot_prefix, slot_n, slot_label_off, S, labels, heap_idx, heap_val, R, slots_uniform, flags,     \
+                       dedupe_all, nq, plain0, qlim, flag_list, only_flagged, count_src, host_count)
+    // two nodes per lane up to 129 entries, four up to 257 (n_probes <= 24 at k = 10), eight up to 513 (n_probes <= 50)
+    if (R <= 129) { if (signd) TK_LAUNCH_PAIR(true, 1); else TK_LAUNCH_PAIR(false, 1); }
+    else if (R <= 257) { if (signd) TK_LAUNCH_PAIR(true, 2); else TK_LAUNCH_PAIR(false, 2); }
+    else if (R <= TK_PAIR_MAX_R) { if (signd) TK_LAUNCH_PAIR(true, 4); else TK_LAUNCH_PAIR(false, 4); }
+    else return -1;
+#undef TK_LAUNCH_PAIR
     return 0;
 }
 

@@ -197,11 +197,12 @@ int tk_launch_heap_replay_lanes(const uint4 *dist, int64_t cap, int64_t nq, cons
 // R*12 with `dedupe`: int64 labels per slot + the reference's duplicate-label test,
 // for labels that can repeat).  flags/run_if: only queries with flags[q] == run_if
 // (flags may be NULL).  cap*16 < 2^24 (no dedupe) / R < 2^24.
-// Wave-per-query replay with the heap in registers, two nodes per lane (heap.hip): R <= TK_PAIR_MAX_R, fresh heaps;
+// Wave-per-query replay with the heap in registers, two / four / eight nodes per lane for heaps of up to 129 / 257 / 513
+// entries (heap.hip): R <= TK_PAIR_MAX_R, fresh heaps;
 // position entries where labels are distinct (cap * 16 <= 0xffffff), the reference's duplicate test on (value, label)
 // entries for the queries with flags[q] != 0 or for every query (dedupe_all).  The kernel of one query per call.
 // plain0 / qlim / flag_list: the per-query check of plain_scan.hip's lemma, as tk_launch_heap_replay_lanes makes it.
-#define TK_PAIR_MAX_R 129
+#define TK_PAIR_MAX_R 513
 int tk_launch_heap_replay_pair(const uint4 *dist, int64_t cap, int64_t nq, const uint8_t *mins, int64_t cap_min,
                                const int *slot_prefix, const int *slot_n, const int64_t *slot_label_off, int S,
                                const int64_t *labels, int64_t *heap_idx, int32_t *heap_val, int R, int signd,
