@@ -43,6 +43,10 @@ PINNED = {
     # (one wave per SIMD is all a replay gets: 157 - 314 waves on 1024 SIMDs)
     ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb0ELb1EE"): (144, 3),
     ("heap.hip", "heap_replay_lanes_kernelILb1ELb0ELi64ELb1ELb1EE"): (96, 4),
+    # the register heap (one query per wave; round 6): two / four / eight nodes per lane, no LDS
+    ("heap.hip", "heap_replay_pair_kernelILb1ELi1EE"): (48, 8),
+    ("heap.hip", "heap_replay_pair_kernelILb1ELi2EE"): (64, 7),
+    ("heap.hip", "heap_replay_pair_kernelILb1ELi4EE"): (112, 4),
     ("heap.hip", "heap_replay_packed_kernelILb1ELb0EE"): (64, 8),
     ("heap.hip", "heap_replay_packed_kernelILb1ELb1EE"): (64, 8),
 }
@@ -58,7 +62,11 @@ NO_SCRATCH_FILES = ("adc_scan.hip", "plain_scan.hip", "tables.hip", "rescore.hip
 SGPR_SPILLS_OK = {"heap_replay_lanes_kernelILb1ELb1ELi32ELb0ELb0EE": 48, "heap_replay_lanes_kernelILb0ELb1ELi32ELb0ELb0EE": 48,
                   "heap_replay_lanes_kernelILb1ELb0ELi64ELb0ELb1EE": 24, "heap_replay_lanes_kernelILb0ELb0ELi64ELb0ELb1EE": 24,
                   "heap_replay_lanes_kernelILb1ELb0ELi64ELb1ELb1EE": 24, "heap_replay_lanes_kernelILb0ELb0ELi64ELb1ELb1EE": 24,
-                  "scan_plain_wave_kernelILi26ELb0EE": 16}
+                  "scan_plain_wave_kernelILi26ELb0EE": 16,
+                  # the register heap with four / eight nodes per lane (heaps of 130 ... 513 entries): its lane masks (one
+                  # per group and role) outnumber the SGPRs; the two-node form of the common heaps (<= 129) has none
+                  "heap_replay_pair_kernelILb1ELi2EE": 16, "heap_replay_pair_kernelILb0ELi2EE": 16,
+                  "heap_replay_pair_kernelILb1ELi4EE": 96, "heap_replay_pair_kernelILb0ELi4EE": 96}
 
 
 def _usage(fname):

@@ -1866,20 +1866,23 @@ __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow,
         // steps into the next list: read through `ns[s]` / `loffs[s]` per voted block they were a scalar load each in
         // front of every block's cmp_mask — the build(n_probes=2) index (labels: three such loads per voted block) spent
         // 0.28 ms in this replay against 0.09 for distinct labels.
-        auto load_labels = [&](int f2) -> int64_t {       // block f2 >= the cursor's block
-            int a0 = c0, n2 = n_s;
-            int64_t loff2 = loff_s;
-            if (f2 >= c1) {                               // (rare: the next voted block lies in a later list)
-                int s2 = s, a1 = c1;
-                while (f2 >= a1) { s2++; a0 = a1; a1 = prefix[s2 + 1]; }
-                n2 = ns[s2];
-                loff2 = loffs[s2];
-            }
-            const int64_t inl2 = 16 * (int64_t)(f2 - a0) + lane;
-            int64_t l = -2;
-            if (lane < 16 && inl2 < n2) l = loff2 < 0 ? inl2 : labels[loff2 + inl2];
-            return l;
-        };
+        // (a macro, not a lambda: a closure over c0 / n_s / loff_s by reference whose body selects between them and
+        //  freshly loaded values went to scratch — 12 bytes per lane, tests/test_kernel_resources.py)
+#define TK_LOAD_LABELS(out_, f2_)                                                          \
+        {                                                                                  \
+            const int f2__ = (f2_);                                                        \
+            int a0__ = c0, n2__ = n_s;                                                     \
+            int64_t loff2__ = loff_s;                                                      \
+            if (f2__ >= c1) {       /* (rare: the next voted block lies in a later list) */ \
+                int s2__ = s, a1__ = c1;                                                   \
+                while (f2__ >= a1__) { s2__++; a0__ = a1__; a1__ = prefix[s2__ + 1]; }     \
+                n2__ = ns[s2__];                                                           \
+                loff2__ = loffs[s2__];                                                     \
+            }                                                                              \
+            const int64_t inl2__ = 16 * (int64_t)(f2__ - a0__) + lane;                     \
+            (out_) = -2;                                                                   \
+            if (lane < 16 && inl2__ < n2__) (out_) = loff2__ < 0 ? inl2__ : labels[loff2__ + inl2__]; \
+        }
         int j_pref = -1;
         int64_t lab_pref = -2;
         while (mask) {
@@ -1896,11 +1899,12 @@ __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow,
             const int rows = n_s - 16 * (f - c0);           // `pos < n`, _fast_pq_256.pyx:111
             int64_t lab_cur = -2;
             if (NEEDS_LABELS) {
-                lab_cur = j == j_pref ? lab_pref : load_labels(f);
+                if (j == j_pref) lab_cur = lab_pref;
+                else TK_LOAD_LABELS(lab_cur, f)
                 j_pref = -1;
                 if (mask) {                                 // the next voted block of this step (a superset: the bound may fall)
                     j_pref = __builtin_ctzll(mask);
-                    lab_pref = load_labels(base + j_pref);
+                    TK_LOAD_LABELS(lab_pref, base + j_pref)
                 }
             }
             const uint32_t d0 = __builtin_amdgcn_readlane(dd.x, j);
@@ -1936,6 +1940,7 @@ __device__ __forceinline__ void pair_replay_body(const uint4 *__restrict__ drow,
             if (mask) mask &= __builtin_amdgcn_ballot_w64(byte_lt<SIGNED>(mn, bound));
         }
     }
+#undef TK_LOAD_LABELS
     // heap arrays out, in the reference's layout: node 0 = the root, node 2 t + 1 + slot = the slot of lane L, group g (t = 64 g + L)
     auto resolve = [&](uint32_t e) -> int64_t {      // a flat position back to (list, row): its label (KIND 2: the label itself)
         const uint32_t pos = e & 0x00ffffffu;
