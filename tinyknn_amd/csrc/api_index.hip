@@ -1439,6 +1439,18 @@ static int pipe_begin(tk_index *ix, Pending &b, hipStream_t caller, hipStream_t 
     if (!ix->front_stream) HIPCHECK(shared_front_stream(&ix->front_stream));
     b.sf = ix->front_stream;
     b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
+    if (ix->capturing) {
+        // A captured pipeline is replayed by ROCm's graph executor on TWO hardware queues whatever it captured
+        // (profiles/r05/hipgraph_replay_queues.txt), one of them 96 % busy with four captured chains.  Captured on THREE —
+        // the front chain on the caller's stream in front of the scans, the two replay streams as they are — the same
+        // executor gives 16.2 instead of 14.7 M queries/s (identical rows); on two (one replay stream) 13.9 M; with three
+        // or four replay streams less (profiles/r06/hipgraph_captured_streams.txt).
+        // TINYKNN_GRAPH_STREAMS (A/B): 4 = as stream-launched, 3 (default) = front chain on the caller's stream, 2 = ... and
+        // one replay stream
+        static const int gs = [] { const char *e = getenv("TINYKNN_GRAPH_STREAMS"); return e ? atoi(e) : 3; }();
+        if (gs == 2 || gs == 3) b.sf = caller;
+        if (gs == 2) b.sl = ix->lat_streams[0];
+    }
     ix->calls++;
     hipEvent_t *evs[] = {&w.tables_done, &w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
     for (hipEvent_t *e : evs)
