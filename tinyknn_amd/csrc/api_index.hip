@@ -1449,7 +1449,7 @@ static int pipe_begin(tk_index *ix, Pending &b, hipStream_t caller, hipStream_t 
         // one replay stream
         static const int gs = [] { const char *e = getenv("TINYKNN_GRAPH_STREAMS"); return e ? atoi(e) : 3; }();
         if (gs == 2 || gs == 3) b.sf = caller;
-        if (gs == 2) b.sl = ix->lat_streams[0];
+        if (gs == 2 || gs == 5) b.sl = ix->lat_streams[0];      // (5: front stream as it is, one replay stream)
     }
     ix->calls++;
     hipEvent_t *evs[] = {&w.tables_done, &w.coarse_scanned, &w.front_done, &w.scanned, &w.done};
