@@ -27,6 +27,9 @@ ap.add_argument("--k-neighbours", type=int, default=10)
 ap.add_argument("--metric", choices=["euclidean", "angular"], default="angular")
 ap.add_argument("--a", type=float, default=1.0, help="n_clusters = int(a * sqrt(n))")
 ap.add_argument("--build-probes", type=int, nargs="+", default=[1])
+ap.add_argument("--per-query", type=int, default=0,
+                help="also time this many queries ONE ivf.query(q) per call, exactly as the reference's loop does "
+                     "(examples/bench.py:118-137); printed on its own line")
 args = ap.parse_args()
 
 np.random.seed(10)
@@ -66,4 +69,12 @@ for build_probes in args.build_probes:
         recall = float(np.mean([len(set(t) & set(g)) / k for t, g in zip(truth, found[:1000])]))
         print(f"Recall{k}@{k}:", recall)
         print("Queries/second:", qps)
+        if args.per_query:
+            m = min(args.per_query, len(queries))
+            for q in queries[:8]:
+                ivf.query(q.copy(), k=k, n_probes=n_probes)
+            t0 = time.time()
+            for q in queries[:m]:
+                ivf.query(q.copy(), k=k, n_probes=n_probes)
+            print("(one ivf.query(q) per call) queries/second:", m / (time.time() - t0))
         n_probes += int(n_probes ** 0.5)

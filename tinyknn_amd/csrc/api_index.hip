@@ -1439,7 +1439,7 @@ static int pipe_begin(tk_index *ix, Pending &b, hipStream_t caller, hipStream_t 
     if (!ix->front_stream) HIPCHECK(shared_front_stream(&ix->front_stream));
     b.sf = ix->front_stream;
     b.sl = ix->lat_streams[ix->calls % (uint64_t)ix->depth];
-    if (ix->capturing) {
+    if (ix->capturing) {      // (stream-launched, this arrangement loses a fifth: 20.7 against 25.7 M queries/s, same box)
         // A captured pipeline is replayed by ROCm's graph executor on TWO hardware queues whatever it captured
         // (profiles/r05/hipgraph_replay_queues.txt), one of them 96 % busy with four captured chains.  Captured on THREE —
         // the front chain on the caller's stream in front of the scans, the two replay streams as they are — the same
