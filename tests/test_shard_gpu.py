@@ -555,12 +555,15 @@ def test_one_phase_scan_golden(tag, world):
             np.testing.assert_array_equal(ids, g[f"ids_p{n_probes}"])
 
 
-def test_simulated_peers_one_rank_of_a_partition(oracle):
+@pytest.mark.parametrize("pair_nq", ["4", "100000"])
+def test_simulated_peers_one_rank_of_a_partition(oracle, pair_nq, monkeypatch):
     """ListShardedIndex(simulate=SimulatedPeers(...)): ONE rank of a W-rank partition with the other
     ranks' contributions recorded from clone shards on the same device — its home rows are the
-    unsharded rows, for every rank, dense (one- and two-phase) and filtered exchange, tables built on every rank (the default)
-    or at home and gathered, with batches in flight; the unsharded index stays usable beside
-    the clones."""
+    unsharded rows, for every rank, dense (one- and two-phase) and filtered exchange, with batches in flight;
+    the unsharded index stays usable beside the clones.  pair_nq: the home queries' replays by the lane kernel
+    (the suite's default threshold) and by the wave-per-query register heap (every handle made in this test:
+    the check of the plain scan's lemma then raises the batch's flag word from that kernel)."""
+    monkeypatch.setenv("TINYKNN_PAIR_NQ", pair_nq)
     import torch
     from tinyknn_amd import IVF, FastPQ
     from tinyknn_amd.multi_gpu import ListShardedIndex
