@@ -631,7 +631,9 @@ class DeviceIndex:
         _lib.check(_lib.lib().tk_index_set_pipeline(self._h, int(depth)))
 
     def set_option(self, option, value):
-        """Per-index A/B and test options (tk_index_set_option): _lib.OPT_SCAN_FORM,
+        """Per-index A/B and test options (tk_index_set_option): _lib.OPT_PAIR_NQ (batches of up to this many queries
+        replay their heaps one query per wave, heap in registers: 8192 one batch at a time, at most 256 pipelined),
+        _lib.OPT_LABELS24, _lib.OPT_SCAN_FORM,
         _lib.OPT_RESCORE_FORM, _lib.OPT_PLAIN_LIMIT, _lib.OPT_REPLAY_LAZY, _lib.OPT_REPLAY_COUNT,
         _lib.OPT_REPLAY_TWIN."""
         _lib.check(_lib.lib().tk_index_set_option(self._h, int(option), int(value)))
@@ -660,7 +662,9 @@ class DeviceIndex:
         _lib.check(_lib.lib().tk_index_quiesce(self._h))
 
     def set_heap_mode(self, mode):
-        """0: automatic (lane-per-query), 1: general wave kernel, 2: packed wave kernel."""
+        """0: automatic (small batches: one query per wave with the heap in registers — _lib.OPT_PAIR_NQ; else one
+        query per lane), 1: general wave kernel, 2: packed wave kernel, 3: the register heap for every batch size
+        (heaps of up to 513 entries)."""
         _lib.check(_lib.lib().tk_index_set_heap_mode(self._h, int(mode)))
 
     def set_scan_mode(self, mode):
