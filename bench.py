@@ -325,13 +325,26 @@ def build_index_c5(args, device):
     from tinyknn_amd import IVF, FastPQ
     t0 = time.time()
     cent = np.random.RandomState(args.seed).randn(3000, args.d).astype(np.float32)
+    sigma = 0.7
+    micro = int(getattr(args, "c5_micro", 0) or 0)
+    if micro > 0:
+        # A second stand-in (round 6; the default stays what rounds 2-5 measured): isotropic noise of sigma 0.7 in all 128
+        # dimensions around 3000 centres leaves a 128-bit PQ code nothing to tell a cluster's 33 000 rows apart by
+        # (Recall10@10 0.195 at n_probes 10).  Here every cluster is `micro` micro-clusters (centre + 0.7 N(0, 1)) of
+        # ~N / (3000 micro) rows each with a noise of --c5-sigma around them: local structure a code can resolve, as real
+        # descriptor sets have — the same generator, kernels, sizes and list lengths, at a recall one would run at.
+        off = np.random.RandomState(args.seed + 1).randn(3000 * micro, args.d).astype(np.float32)
+        cent = (np.repeat(cent, micro, axis=0) + np.float32(0.7) * off).astype(np.float32)
+        sigma = float(args.c5_sigma)
+    args.c5_point_sigma = sigma
     ivf = IVF("euclidean", args.n_clusters, FastPQ(2))
     # The FIT (k-means on the GPU: atomics; ortho_group / k-means of FastPQ.fit: numpy's global RNG)
     # is not bit-reproducible from run to run, and a list-sharded index needs every rank to hold
     # the SAME centres and codebook: rank 0 fits first (main() orders the ranks) and leaves the
     # fitted parameters in the cache directory; the other ranks load them.  The BUILD from those
     # parameters is deterministic (seeded generator, stable sort) and runs on every rank.
-    fit_cache = os.path.join(args.cache_dir, f"tinyknn_bench_c5fit_n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}.npz")
+    fit_cache = os.path.join(args.cache_dir, f"tinyknn_bench_c5fit_n{args.n}_d{args.d}_c{args.n_clusters}_s{args.seed}"
+                             + (f"_m{micro}_g{sigma}" if micro > 0 else "") + ".npz")
     if os.path.exists(fit_cache):
         z = np.load(fit_cache)
         ivf.all_centers = z["all_centers"]
@@ -341,7 +354,7 @@ def build_index_c5(args, device):
         log(f"[bench] c5 fit loaded from {fit_cache}")
     else:
         ns = min(args.n, 1_000_000)
-        sample = synth_rows_host(ns, args.d, args.seed, cent, 0.7)   # rows 0..ns: a uniform sample of the clusters
+        sample = synth_rows_host(ns, args.d, args.seed, cent, sigma)   # rows 0..ns: a uniform sample of the clusters
         ivf.all_centers = quick_kmeans(sample, args.n_clusters, 6, args.seed, device).astype(np.float32)
         ivf.pq.fit(sample[:30000])
         del sample
@@ -353,7 +366,7 @@ def build_index_c5(args, device):
         except OSError as e:
             log(f"[bench] could not cache the c5 fit: {e}")
         log(f"[bench] c5 fit done in {time.time() - t0:.1f}s")
-    ivf.build_resident(args.n, args.d, args.seed, cent, 0.7)
+    ivf.build_resident(args.n, args.d, args.seed, cent, sigma)
     sz = ivf.list_sizes
     log(f"[bench] c5 index built on the device in {time.time() - t0:.1f}s: {len(sz)} lists of "
         f"{sz.min()}..{sz.max()} rows, codes {int(((sz + 15) // 16).sum()) * 16 * (ivf.pq.centers.shape[1] // 4) / 1e6:.0f} MB, "
@@ -1191,6 +1204,10 @@ def main():
     ap.add_argument("--data", choices=["glove-like", "sift-like", "sift-clustered"], default="glove-like",
                     help="synthetic stand-in: Gaussian clusters, or |N(0,1)|*40 clipped to [0,218]")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
+    ap.add_argument("--c5-micro", type=int, default=0,
+                    help="--workload c5: every one of the 3000 clusters as this many micro-clusters (0: the stand-in of "
+                         "rounds 2-5, isotropic noise around 3000 centres)")
+    ap.add_argument("--c5-sigma", type=float, default=0.15, help="point noise around a micro-cluster's centre (--c5-micro)")
     ap.add_argument("--sort-queries", choices=["none", "probe", "probe-xcd"], default="none",
                     help="A/B: order every batch's queries by their nearest coarse centre before the upload")
     ap.add_argument("--scan-mode", type=int, default=0, help="tk_index_set_scan_mode (A/B)")
@@ -1336,7 +1353,7 @@ def main():
         if real_queries is not None:       # the file's queries, rotated by a quarter per batch
             return np.roll(real_queries, -b * (len(real_queries) // N_BATCHES), axis=0)[:args.nq].copy()
         if args.workload == "c5":
-            return synth_rows_host(args.nq, args.d, args.seed + 100 + rank + 1000 * b, cent, 0.7)
+            return synth_rows_host(args.nq, args.d, args.seed + 100 + rank + 1000 * b, cent, getattr(args, "c5_point_sigma", 0.7))
         return synth_queries(cent, args.nq, args.seed + 100 + rank + 1000 * b, kind=args.data)
 
     batches = []
@@ -1823,7 +1840,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8 (saturating PQ sums) + f32 (tables, rescoring)",
         "data": "synthetic" if not args.data_file else f"file {os.path.basename(args.data_file)}",
-        "config": {"workload": ("c5 (BASELINE configs[4] on one GPU): 3000 Gaussian clusters sigma 0.7 generated in "
+        "config": {"workload": ("c5 (BASELINE configs[4] on one GPU): " +
+                                (f"3000 x {args.c5_micro} micro-clusters (centre + 0.7 N(0,1)), point noise sigma {args.c5_sigma}, "
+                                 if args.workload == "c5" and args.c5_micro > 0 else "") +
+                                "3000 Gaussian clusters sigma 0.7 generated in "
                                 "HBM (seeded counter-based generator), index built on the device, PQ rotated to 64 "
                                 "dims, euclidean, "
                                 if args.workload == "c5" else
