@@ -513,12 +513,49 @@ def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8, co=0):
             z = evs[0][0]
             out["stage_timeline_us"] = [[round(z.elapsed_time(e) * 1e3) for e in ev] for ev in evs]
             out["stage_timeline_is"] = "per batch: front start, front end, scan start, scan end, back end (us from the first)"
+        # What the links would have to carry (xGMI: 7 links x ~153 GB/s per GPU, point to point): this rank's
+        # INBOUND bytes per sharded batch — the other W - 1 ranks' regions of the equal-split all-to-all, the probe lists
+        # and the ids — and the rate that needs at the period measured here WITHOUT links.
+        ex = r["exchange"]
+        per_step = (W - 1) / W * (ex["all_to_all_bytes_per_rank_per_step"] + ex["probe_all_gather_bytes_per_rank_per_step"]
+                                  + ex["all_gather_bytes_per_rank_per_step"])
+        out["links"] = {kind: {"inbound_MB_per_batch": per_step * co / 1e6,
+                               "GBps_needed_at_the_measured_period": per_step / (r["ms_per_step"] * 1e-3) / 1e9,
+                               "GBps_needed_at_0.7_efficiency": None}}
+        if getattr(args, "rank_share_exchange", "auto") == "auto" and kind == "dense" and args.workload != "c5":
+            # ... and the filtered exchange beside it (records of the blocks below the bound after the first list,
+            # fixed regions): fewer bytes, more kernels — decided by the bytes, not by the one-rank rate
+            try:
+                idx2 = ListShardedIndex(ivf, simulate=peers, depth=args.shard_depth, coarse="home", coalesce=co,
+                                        counts="device", plain={0: False, 1: True, 2: "two-phase", 3: "head"}[args.shard_plain],
+                                        exchange="filtered")
+                peers.reset()
+                r2 = _list_sharded_run(args, idx2, device, 1, 0, qn_t, qp_t, want, co, "filtered", sim=peers)
+                e2 = r2["exchange"]
+                # (regions travel whole: world x region records x 20 B per rank and exchange, + the counts)
+                reg_bytes = W * e2.get("record_region", 0) * 20 / co
+                ps2 = (W - 1) / W * (reg_bytes + e2["probe_all_gather_bytes_per_rank_per_step"] + e2["all_gather_bytes_per_rank_per_step"]
+                                     + args.nq) + 0.0
+                out["links"]["filtered"] = {"inbound_MB_per_batch": ps2 * co / 1e6, "ms_per_step": r2["ms_per_step"],
+                                            "identical_rows_vs_replica": r2["identical_rows_vs_replica"],
+                                            "GBps_needed_at_the_measured_period": ps2 / (r2["ms_per_step"] * 1e-3) / 1e9,
+                                            "records_held_MB_per_batch": e2.get("records_held_bytes_per_rank_per_step", 0) * co / 1e6}
+            except Exception as e:      # noqa: BLE001 - an extra figure must not lose the leg
+                out["links"]["filtered"] = {"error": repr(e)}
         out.update(world=W, rank=0,
                    what="ONE rank's share of a W-rank partition on this GPU, the peers' contributions recorded and "
                         "copied in (no links): per step of --nq shared queries")
         return out
     finally:
         peers.close()
+
+
+def _links_at_target(rs):
+    """rank_share leg: the all-to-all rate each exchange would need on the links at 0.7 strong-scaling efficiency."""
+    co = max(1, int(rs.get("steps_coalesced_per_exchange", 1)))
+    for v in (rs.get("links") or {}).values():
+        if isinstance(v, dict) and "inbound_MB_per_batch" in v:
+            v["GBps_needed_at_0.7_efficiency"] = v["inbound_MB_per_batch"] * 1e6 / co / (rs["target_ms_per_step_at_0.7_efficiency"] * 1e-3) / 1e9
 
 
 def _list_sharded_run(args, idx, device, world, rank, qn_t, qp_t, want, co, kind, sim=None):
@@ -1914,6 +1951,7 @@ def main():
             rs["unsharded_ms_per_step_over_W"] = line["ms_per_step"] / W
             rs["target_ms_per_step_at_0.7_efficiency"] = line["ms_per_step"] / (0.7 * W)
             rs["implied_strong_scaling_efficiency_without_links"] = line["ms_per_step"] / W / rs["ms_per_step"]
+            _links_at_target(rs)
             line["rank_share_W%d" % W] = rs
             line["rank_share_W%d_ms_per_step" % W] = rs["ms_per_step"]
             line["rank_share_W%d_implied_efficiency_without_links" % W] = rs["implied_strong_scaling_efficiency_without_links"]
@@ -1968,6 +2006,7 @@ def main():
                     rs["unsharded_ms_per_step_over_W"] = line["ms_per_step"] / W
                     rs["target_ms_per_step_at_0.7_efficiency"] = line["ms_per_step"] / (0.7 * W)
                     rs["implied_strong_scaling_efficiency_without_links"] = line["ms_per_step"] / W / rs["ms_per_step"]
+                    _links_at_target(rs)
                     line[key + "_ms_per_step"] = rs["ms_per_step"]
                     line[key + "_implied_efficiency_without_links"] = rs["implied_strong_scaling_efficiency_without_links"]
         if world > 1:
