@@ -223,3 +223,31 @@ def test_copies_carry_one_code_host_check():
     ivf.ids[1] = ivf.ids[1].copy()
     ivf.ids[1][1] = ivf.ids[1][0]
     assert not _copies_carry_one_code(ivf, L)
+
+
+def test_failed_plain_check_is_demoted_one_level_at_a_time():
+    """ListShardedIndex._note_plain_failure (bit 4 of a batch's flag word): one-phase -> head form -> two-phase -> an error,
+    never the same form again (every rank sees the same gathered flag, so every rank takes the same step)."""
+    from tinyknn_amd.multi_gpu import ListShardedIndex
+    idx = ListShardedIndex.__new__(ListShardedIndex)
+    idx._plain_failed, idx._head_failed = set(), set()
+    idx._one_phase = idx._head_phase = True
+    idx._exchange_kind = lambda k, n_probes, pass_1: "dense"
+    idx._use_plain = lambda k, n_probes, pass_1: True
+    a, b = (10, 10, None), (10, 5, None)
+    assert idx._scan_form(*a) == "one" and idx._scan_form(*b) == "one"
+    idx._note_plain_failure({a})
+    assert idx._scan_form(*a) == "head" and idx._scan_form(*b) == "one"
+    idx._note_plain_failure({a})
+    assert idx._scan_form(*a) == "two"
+    with pytest.raises(RuntimeError, match="every scan form"):
+        idx._note_plain_failure({a})
+    # an engine without the head form: straight to two-phase, then the error
+    idx2 = ListShardedIndex.__new__(ListShardedIndex)
+    idx2._plain_failed, idx2._head_failed = set(), set()
+    idx2._one_phase, idx2._head_phase = True, False
+    idx2._exchange_kind, idx2._use_plain = idx._exchange_kind, idx._use_plain
+    idx2._note_plain_failure({a})
+    assert idx2._scan_form(*a) == "two"
+    with pytest.raises(RuntimeError):
+        idx2._note_plain_failure({a})
