@@ -522,7 +522,7 @@ def rank_share_leg(args, ivf, device, qn_t, qp_t, want, W=8, co=0):
         out["links"] = {kind: {"inbound_MB_per_batch": per_step * co / 1e6,
                                "GBps_needed_at_the_measured_period": per_step / (r["ms_per_step"] * 1e-3) / 1e9,
                                "GBps_needed_at_0.7_efficiency": None}}
-        if getattr(args, "rank_share_exchange", "auto") == "auto" and kind == "dense" and args.workload != "c5":
+        if getattr(args, "rank_share_links", "dense") == "both" and kind == "dense" and args.workload != "c5":
             # ... and the filtered exchange beside it (records of the blocks below the bound after the first list,
             # fixed regions): fewer bytes, more kernels — decided by the bytes, not by the one-rank rate
             try:
@@ -1241,6 +1241,9 @@ def main():
     ap.add_argument("--data", choices=["glove-like", "sift-like", "sift-clustered"], default="glove-like",
                     help="synthetic stand-in: Gaussian clusters, or |N(0,1)|*40 clipped to [0,218]")
     ap.add_argument("--heap-mode", type=int, default=0, help="tk_index_set_heap_mode (A/B)")
+    ap.add_argument("--rank-share-links", choices=["dense", "both"], default="dense",
+                    help="rank-share leg: `both` also runs the filtered exchange for the links table (+1 minute; "
+                         "profiles/r06/rank_share_links.txt)")
     ap.add_argument("--c5-micro", type=int, default=0,
                     help="--workload c5: every one of the 3000 clusters as this many micro-clusters (0: the stand-in of "
                          "rounds 2-5, isotropic noise around 3000 centres)")
