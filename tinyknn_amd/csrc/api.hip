@@ -140,10 +140,23 @@ extern "C" int tk_query_pq(const uint64_t *data, int64_t chunks, int M, int64_t 
     TRY(S.mins.ensure((size_t)cap_min));
     tk_launch_scan_flat(S.tiled.as<uint4>(), chunks, M, S.tables.as<uint4>(), 1, S.out.as<uint4>(),
                         chunks, S.mins.as<uint8_t>(), cap_min, signd, order, st);
-    tk_launch_heap_replay(S.out.as<uint4>(), chunks, 1, S.slots_i.as<int>(),
-                          S.slots_i.as<int>() + 2, S.slots_l.as<int64_t>(), 1,
-                          S.labels.as<int64_t>(), S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R,
-                          signd, 1, nullptr, st, S.mins.as<uint8_t>(), cap_min);
+    // A FRESH heap of up to 513 entries (init_heap's arrays: the first query_pq of a DistanceTable.top / IVF.query): the
+    // wave-per-query replay with the heap in registers (heap.hip: heap_replay_pair_kernel; position entries without labels,
+    // (value, label64) entries with the reference's duplicate test with them) instead of the general kernel's LDS heap —
+    // ~300 instead of ~2 000 cycles per insert.  Same arrays out.
+    bool fresh_heap = R <= TK_PAIR_MAX_R && chunks * 16 <= 0xffffff;
+    for (int i = 0; i < R && fresh_heap; i++) fresh_heap = indices[i] == -1 && vals[i] == (signd ? 127 : 255);
+    if (fresh_heap) {
+        if (tk_launch_heap_replay_pair(S.out.as<uint4>(), chunks, 1, S.mins.as<uint8_t>(), cap_min, S.slots_i.as<int>(),
+                                       S.slots_i.as<int>() + 2, S.slots_l.as<int64_t>(), 1, S.labels.as<int64_t>(),
+                                       S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R, signd, 1, nullptr, labels ? 1 : 0, st))
+            return fail(TK_ERR_HIP, "heap_replay_pair_kernel launch failed");
+    } else {
+        tk_launch_heap_replay(S.out.as<uint4>(), chunks, 1, S.slots_i.as<int>(),
+                              S.slots_i.as<int>() + 2, S.slots_l.as<int64_t>(), 1,
+                              S.labels.as<int64_t>(), S.hidx.as<int64_t>(), S.hval.as<int32_t>(), R,
+                              signd, 1, nullptr, st, S.mins.as<uint8_t>(), cap_min);
+    }
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(indices, S.hidx.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(vals, S.hval.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
@@ -389,8 +402,41 @@ extern "C" int tk_codes_query(tk_codes *c, int64_t n, const uint64_t *tables, in
     // set): one table copy from pinned memory, the scan, ONE launch that replays with the heap in
     // registers and writes it to pinned memory (heap.hip, flat_top_one_kernel).  The head is
     // ~sqrt(R chunks) blocks: about as many again pass its bound.
-    bool fresh = !labels && chunks >= 4096 && R <= 64 && (size_t)c->M * 16 <= 32 * 1024;
-    for (int i = 0; i < R && fresh; i++) fresh = indices[i] == -1 && vals[i] == (signd ? 127 : 255);
+    bool fresh_heap = !labels && R <= TK_PAIR_MAX_R && (size_t)c->M * 16 <= 32 * 1024;
+    for (int i = 0; i < R && fresh_heap; i++) fresh_heap = indices[i] == -1 && vals[i] == (signd ? 127 : 255);
+    const bool fresh = fresh_heap && chunks >= 4096 && R <= 64;
+    if (fresh_heap && !fresh && chunks * 16 <= 0xffffff) {
+        // A fresh heap of up to 513 entries over a shorter array (DistanceTable.top of one query over a few thousand to a
+        // million rows, examples/example.py: 16 000 rows, R = 2 k + 10 = 30): table in through pinned memory, the scan, the
+        // wave-per-query replay with the heap in registers (heap.hip: heap_replay_pair_kernel, position entries — positions
+        // ARE the labels here), the heap written straight to pinned memory: 4 operations instead of 11, ~300 instead of
+        // ~2 000 cycles per insert.
+        if (!c->pin) HIPCHECK(hipHostMalloc(&c->pin, 64 * 1024, hipHostMallocDefault));
+        TRY(c->slots_i.ensure(3 * sizeof(int)));
+        TRY(c->slots_l.ensure(sizeof(int64_t)));
+        unsigned char *pin = (unsigned char *)c->pin;
+        int64_t *pidx = (int64_t *)(pin + 32 * 1024);
+        int32_t *pval = (int32_t *)(pin + 32 * 1024 + (size_t)TK_PAIR_MAX_R * 8);
+        int *psl = (int *)(pin + 32 * 1024 + (((size_t)TK_PAIR_MAX_R * 12 + 15) & ~(size_t)15));      // slot table: prefix[0..1], n, label offset
+        memcpy(pin, tables, (size_t)c->M * 16);
+        const int64_t nclamp = n > (int64_t)0x7fffffff ? 0x7fffffff : (n < 0 ? 0 : n);
+        psl[0] = 0; psl[1] = (int)chunks; psl[2] = (int)nclamp; psl[3] = 0;
+        ((int64_t *)(psl + 4))[0] = -1;
+        HIPCHECK(hipMemcpyAsync(c->tables.p, pin, (size_t)c->M * 16, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(c->slots_i.p, psl, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(c->slots_l.p, psl + 4, sizeof(int64_t), hipMemcpyHostToDevice, st));
+        tk_launch_scan_flat(c->tiled.as<uint4>(), chunks, c->M, c->tables.as<uint4>(), 1,
+                            c->out.as<uint4>(), chunks, c->mins.as<uint8_t>(), cap_min, signd, order, st);
+        if (tk_launch_heap_replay_pair(c->out.as<uint4>(), chunks, 1, c->mins.as<uint8_t>(), cap_min, c->slots_i.as<int>(),
+                                       c->slots_i.as<int>() + 2, c->slots_l.as<int64_t>(), 1, nullptr, pidx, pval, R, signd,
+                                       1, nullptr, 0, st))
+            return fail(TK_ERR_HIP, "heap_replay_pair_kernel launch failed");
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(st));
+        memcpy(indices, pidx, (size_t)R * 8);
+        memcpy(vals, pval, (size_t)R * 4);
+        return TK_OK;
+    }
     if (fresh) {
         if (!c->pin) HIPCHECK(hipHostMalloc(&c->pin, 64 * 1024, hipHostMallocDefault));
         TRY(c->cdist.ensure((size_t)chunks * 16));
