@@ -43,6 +43,16 @@ HBM_PEAK_GBPS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
+
+_T0 = [time.time()]
+
+
+def lap(what):
+    """stderr: seconds since the previous lap (where a run's wall time goes, leg by leg)."""
+    now = time.time()
+    log(f"[bench] {what}: {now - _T0[0]:.1f}s")
+    _T0[0] = now
+
 COMPACT_LIMIT = 4096     # bytes of the FINAL stdout line (the driver keeps a bounded tail of stdout)
 
 
@@ -204,6 +214,39 @@ def synth(n, nq, d, seed, n_centres=300, sigma=0.7, kind="glove-like"):
     return X, cent
 
 
+def save_atomic(path, write):
+    """write(file object) into `path` by way of a private name + rename: ranks and child runs that share the
+    cache directory never read a half-written file."""
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    try:
+        with open(tmp, "wb") as f:
+            write(f)
+        os.replace(tmp, path)
+    except OSError as e:
+        log(f"[bench] could not cache {os.path.basename(path)}: {e}")
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+
+
+def synth_cached(args):
+    """synth() of the run's data set, kept as a .npy beside the index cache: the profiler child runs and the sweep's
+    second build over the same rows load it instead of drawing 118M normals again (7 s each)."""
+    path = os.path.join(args.cache_dir, f"tinyknn_bench_rows_n{args.n}_d{args.d}_s{args.seed}_{args.data}.npy")
+    cent = np.random.RandomState(args.seed).randn(300, args.d)      # synth()'s first draw
+    if os.path.exists(path):
+        try:
+            X = np.load(path)
+            if X.shape == (args.n, args.d) and X.dtype == np.float32:
+                return X, cent
+        except (OSError, ValueError):
+            pass
+    X, cent = synth(args.n, 0, args.d, args.seed, kind=args.data)
+    save_atomic(path, lambda f: np.save(f, X))
+    return X, cent
+
+
 def synth_queries(cent, nq, seed, sigma=0.7, kind="glove-like"):
     rng = np.random.RandomState(seed)
     d = cent.shape[1]
@@ -259,7 +302,7 @@ def build_index(args, device, X=None):
     cache = os.path.join(args.cache_dir, f"tinyknn_bench_{tag}.npz")
     cent = None
     if X is None:
-        X, cent = synth(args.n, 0, args.d, args.seed, kind=args.data)
+        X, cent = synth_cached(args)
     ang = args.metric == "angular"
     ivf = IVF(args.metric, args.n_clusters, FastPQ(2))
     if os.path.exists(cache):
@@ -269,12 +312,12 @@ def build_index(args, device, X=None):
         ivf.pq.R = z["R"] if "R" in z else None
         ivf.active_centers = z["active_centers"]
         ivf.pq_transformed_centers = TransformedData(int(z["center_size"]), z["center_codes"])
-        sizes = z["list_sizes"]
+        sizes, codes, ids = z["list_sizes"], z["list_codes"], z["ids"]      # (an NpzFile reads the member at EVERY z[...])
         coff = np.concatenate([[0], np.cumsum((sizes + 15) // 16)])
         ioff = np.concatenate([[0], np.cumsum(sizes)])
-        ivf.pq_transformed_points = [TransformedData(int(sizes[i]), z["list_codes"][coff[i]:coff[i + 1]])
+        ivf.pq_transformed_points = [TransformedData(int(sizes[i]), codes[coff[i]:coff[i + 1]])
                                      for i in range(len(sizes))]
-        ivf.ids = [z["ids"][ioff[i]:ioff[i + 1]] for i in range(len(sizes))]
+        ivf.ids = [ids[ioff[i]:ioff[i + 1]] for i in range(len(sizes))]
         ivf.data = X / np.linalg.norm(X, axis=1, keepdims=True) if ang else X
         log(f"[bench] index loaded from {cache}")
         return ivf, cent
@@ -291,16 +334,14 @@ def build_index(args, device, X=None):
     ivf.build(X, n_probes=args.build_probes, device=True)   # build.hip: same lists and codes as numpy
     log(f"[bench] build done in {time.time() - t0:.1f}s")
     L = len(ivf.active_centers)
-    try:
-        extra = {} if ivf.pq.R is None else {"R": ivf.pq.R}
-        np.savez(cache, pq_centers=ivf.pq.centers, sqrt_n_blocks=ivf.pq.sqrt_n_blocks, **extra,
-                 active_centers=ivf.active_centers, center_size=ivf.pq_transformed_centers.size,
-                 center_codes=ivf.pq_transformed_centers.packed,
-                 list_sizes=np.array([ivf.pq_transformed_points[i].size for i in range(L)], np.int64),
-                 list_codes=np.concatenate([ivf.pq_transformed_points[i].packed for i in range(L)]),
-                 ids=np.concatenate([np.asarray(ivf.ids[i], np.int64) for i in range(L)]))
-    except OSError as e:
-        log(f"[bench] could not cache the index: {e}")
+    extra = {} if ivf.pq.R is None else {"R": ivf.pq.R}
+    save_atomic(cache, lambda f: np.savez(
+        f, pq_centers=ivf.pq.centers, sqrt_n_blocks=ivf.pq.sqrt_n_blocks, **extra,
+        active_centers=ivf.active_centers, center_size=ivf.pq_transformed_centers.size,
+        center_codes=ivf.pq_transformed_centers.packed,
+        list_sizes=np.array([ivf.pq_transformed_points[i].size for i in range(L)], np.int64),
+        list_codes=np.concatenate([ivf.pq_transformed_points[i].packed for i in range(L)]),
+        ids=np.concatenate([np.asarray(ivf.ids[i], np.int64) for i in range(L)])))
     return ivf, cent
 
 
@@ -933,7 +974,7 @@ def pick_kernel(stats, sub):
 
 def measure_traffic(args, plain_on=True):
     """HBM bytes per scan launch from PMC counters, measured NOW: two child runs of this script
-    under rocprofv3 (--pmc FETCH_SIZE, then --pmc WRITE_SIZE: they do not fit one pass), one
+    under rocprofv3 (--pmc FETCH_SIZE, then --pmc WRITE_SIZE SQ_INSTS_VALU: the two sizes do not fit one pass), one
     batch in flight so that the list scan and the coarse scan are separate launches.  gfx950
     correction of MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half the bytes of wide coalesced
     reads -> x2; WRITE_SIZE exact; both in KiB."""
@@ -945,10 +986,12 @@ def measure_traffic(args, plain_on=True):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not found"
     me = os.path.abspath(__file__)
-    tot = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+    mode = {"TINYKNN_PLAIN_SCAN": "2"} if plain_on else {"TINYKNN_PLAIN_SCAN": "0"}
+
+    def one_pass(counters):
+        """One child run under --pmc `counters`: {counter: {scan launch: mean value per launch}}."""
         tmp = tempfile.mkdtemp(prefix="tk_pmc_")
-        cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", tmp, "--", sys.executable, me,
+        cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", tmp, "--", sys.executable, me,
                "--steps", "3", "--warmup", "1", "--warmup-seconds", "0", "--windows", "1", "--pipeline", "1",
                "--profile-only", "--shard", "none", "--cache-dir", args.cache_dir,
                "--workload", args.workload, "--n", str(args.n), "--d", str(args.d),
@@ -958,10 +1001,9 @@ def measure_traffic(args, plain_on=True):
         try:
             # the child answers 4 batches: too few for the plain path to prove itself (probe, wait, on).
             # It runs in the state the parent's timed region settled in — always plain, or never.
-            mode = {"TINYKNN_PLAIN_SCAN": "2"} if plain_on else {"TINYKNN_PLAIN_SCAN": "0"}
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", **mode), stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=600, check=True)
-            acc = {}
+            acc = {c: {} for c in counters}
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     name = r["Kernel_Name"]
@@ -970,25 +1012,37 @@ def measure_traffic(args, plain_on=True):
                     key = ("plain" if "scan_plain" in name else
                            "units2" if "scan_units2_kernel" in name else
                            "units" if "scan_units_kernel" in name else None)
-                    if r["Counter_Name"] == c and key:
-                        acc.setdefault(key + ("_coarse" if key == "units" and
-                                              name.split("(")[0].rstrip(">").rstrip().endswith("true") else ""),
-                                       []).append(float(r["Counter_Value"]))
-            if not acc:
-                if c == "SQ_INSTS_VALU":     # an extra: the traffic figure stands without it
-                    tot[c] = None
-                    continue
-                return None, f"no scan kernel rows in the {c} pass"
-            tot[c] = sum(sum(v) / len(v) for v in acc.values())     # every scan launch of a batch, KiB
-            measure_traffic.parts = getattr(measure_traffic, "parts", {})
-            measure_traffic.parts[c] = {k_: sum(v) / len(v) for k_, v in acc.items()}
-        except Exception as e:     # noqa: BLE001 - profiling is an extra
-            if c == "SQ_INSTS_VALU":
-                tot[c] = None
-                continue
-            return None, f"{c} pass failed: {e!r}"
+                    if r["Counter_Name"] in acc and key:
+                        acc[r["Counter_Name"]].setdefault(
+                            key + ("_coarse" if key == "units" and
+                                   name.split("(")[0].rstrip(">").rstrip().endswith("true") else ""),
+                            []).append(float(r["Counter_Value"]))
+            return {c: {k_: sum(v) / len(v) for k_, v in a.items()} for c, a in acc.items()}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+
+    # FETCH_SIZE takes 3 of the L2's 4 counters and WRITE_SIZE 2: two passes.  SQ_INSTS_VALU (an extra: the
+    # traffic figure stands without it) is a counter of another block and rides with WRITE_SIZE.
+    tot = {"SQ_INSTS_VALU": None}
+    measure_traffic.parts = {}
+    for counters in (("FETCH_SIZE",), ("WRITE_SIZE", "SQ_INSTS_VALU")):
+        try:
+            got = one_pass(counters)
+            if not got[counters[0]] and len(counters) > 1:
+                got = one_pass(counters[:1])
+        except Exception as e:     # noqa: BLE001 - profiling is an extra
+            if len(counters) == 1:
+                return None, f"{counters[0]} pass failed: {e!r}"
+            try:
+                got = one_pass(counters[:1])
+            except Exception as e2:     # noqa: BLE001
+                return None, f"{counters[0]} pass failed: {e2!r}"
+        if not got[counters[0]]:
+            return None, f"no scan kernel rows in the {counters[0]} pass"
+        for c, parts in got.items():
+            if parts:
+                tot[c] = sum(parts.values())     # every scan launch of a batch (KiB for the two sizes)
+                measure_traffic.parts[c] = parts
     measure_traffic.valu_insts = tot["SQ_INSTS_VALU"]      # wave-instructions, list + coarse scan
     return (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024, \
         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this script in this run (pipeline 1: plain " \
@@ -1068,13 +1122,15 @@ def sweep_leg(args, ivf, dev, batches, qp_is_f64, stream, device, cent):
     out = {"protocol": "pipelined mode, %d steps x 4 windows per point, median window behind the first; parity: the "
                        "first %d rows of batch 0 against oracle/tinyknn_oracle.c" % (40, rows), "points": []}
 
+    oxs = {}
+
     def point(label, ivf_, dev_, batches_, f64, n_probes, extra=None):
         e = {"config": label, "n_probes": n_probes}
         try:
             e.update(timed_rate(dev_, batches_, f64, args.nq, args.k, n_probes, stream, args.pipeline, args.coalesce))
             torch.cuda.synchronize()
             got = batches_[0]["out"].cpu().numpy()[:rows]
-            ox = oracle_index(ivf_)
+            ox = oxs.get(id(ivf_)) or oxs.setdefault(id(ivf_), oracle_index(ivf_))
             tc = time.perf_counter()
             want = ox.query_batch(batches_[0]["qn"][:rows], args.k, n_probes)
             e["cpu_oracle_queries_per_s"] = rows / (time.perf_counter() - tc)
@@ -1088,6 +1144,7 @@ def sweep_leg(args, ivf, dev, batches, qp_is_f64, stream, device, cent):
     for np_ in (1, 5, 20, 50):
         point("headline index", ivf, dev, batches, qp_is_f64, np_)
     dev.set_pipeline(1)
+    lap("side roofs; sweep: n_probes 1 / 5 / 20 / 50 on the headline index")
 
     def other_index(label, **over):
         a2 = argparse.Namespace(**dict(vars(args), **over))
@@ -1106,6 +1163,8 @@ def sweep_leg(args, ivf, dev, batches, qp_is_f64, stream, device, cent):
               extra=lambda d_: {"plain_scan_state": (d_.plain_stats() or {}).get("state")})
         dev2.set_pipeline(1)
         dev2.close()
+        oxs.clear()
+        lap("sweep: " + label[:40])
 
     try:
         other_index("IVF.build(n_probes=2): the reference's default build (ivf.py:53), every point in two lists",
@@ -1380,7 +1439,9 @@ def main():
         ivf, cent = build_index(args, device)
     if world > 1 and rank == 0:
         dist.barrier()
+    lap("imports, data, index fit + build (or cache load)")
     dev = ivf.device_index()
+    lap("index upload (tk_index_set_lists, tk_index_set_data)")
     M = ivf.pq.centers.shape[1] // 2
 
     # -- this rank's batches, normalised on the host exactly like ivf.py:125-127.  The timed loop
@@ -1497,6 +1558,7 @@ def main():
     plain_ms_timed = getattr(dev, "last_plain_kernel_ms", 0.0)      # HIP events around the plain kernel alone
     plain_stats_timed = dev.plain_stats()       # of the last batch of the timed region (a pair of steps when coalescing)
     raw_leg = None if args.profile_only else raw_stream_leg(args, dev, qs, out_dev, device, world)
+    lap("queries, warm-up, timed region, raw stream leg")
     # the same kernels with ONE batch in flight (no co-running batches), for reference
     dev.set_pipeline(1)
     dev.reserve(args.nq, args.k, args.n_probes)
@@ -1666,8 +1728,11 @@ def main():
     kstats, kstats_src = None, "not run"
     plain_on_timed = bool(plain_stats_timed and plain_stats_timed.get("plain_units"))
     if args.traffic == "auto" and (default_wl or args.workload == "c5") and world == 1 and not args.data_file:
+        lap("hipgraph leg, stage and isolated timings")
         traffic, traffic_src = measure_traffic(args, plain_on_timed)
+        lap("PMC traffic child runs")
         kstats, kstats_src = kernel_stats_child(args, plain_on_timed)
+        lap("kernel-stats child run")
     hbm_leg = None
     if not args.no_hbm_leg and world == 1:
         try:
@@ -1802,6 +1867,7 @@ def main():
         cpu["note"] = ("value = C batch loop of the port (no per-query Python overhead: the STRONGER "
                        "baseline); python_loop = the reference's own measurement protocol")
 
+    lap("hbm-scale leg, recall, CPU baseline, query1")
     # -- the two biggest consumers of GPU time beside the scan, each against the resource that binds it
     side_roofs = {}
     try:
@@ -1960,6 +2026,7 @@ def main():
             line["rank_share_W%d_implied_efficiency_without_links" % W] = rs["implied_strong_scaling_efficiency_without_links"]
         except Exception as e:      # noqa: BLE001 - an extra leg must not lose the line
             line["rank_share_W%d" % args.rank_share] = {"error": repr(e)}
+    lap("rank-share leg")
     if isinstance(raw_leg, dict) and "queries_per_s" in raw_leg:
         line["raw_in_ids_out_queries_per_s"] = raw_leg["queries_per_s"]      # (scalar: kept by the driver's parsed record)
     if shard_w1 and not do_shard:
@@ -2032,6 +2099,7 @@ def main():
             line["roofline"] = dict(line["replica"]["roofline"],
                                     note="scan launch of the REPLICA region (the sharded leg runs the same "
                                          "kernel on this rank's 1/%d of the (query, list) segments)" % world)
+    lap("list-sharded legs")
     emit(line)
     if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
