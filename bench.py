@@ -1290,7 +1290,9 @@ def main():
     ap.add_argument("--n-probes", type=int, default=10)
     ap.add_argument("--seed", type=int, default=10)
     ap.add_argument("--fit-sample", type=int, default=100000)
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=120000,
+                    help="queries timed on the CPU oracle (one core, ~10 s at the default) and compared row by row: the "
+                         "distinct batches of the timed region, then more batches of the same generator")
     ap.add_argument("--recall-sample", type=int, default=1000)
     ap.add_argument("--cache-dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--no-cpu", action="store_true")
@@ -1348,7 +1350,7 @@ def main():
     ap.add_argument("--traffic", choices=["auto", "none"], default="auto",
                     help="auto: HBM bytes of the scan launch from rocprofv3 --pmc child runs of this "
                          "script (N = 1, default workload only)")
-    ap.add_argument("--py-cpu-sample", type=int, default=300,
+    ap.add_argument("--py-cpu-sample", type=int, default=3000,
                     help="queries of the per-query Python-loop CPU baseline (examples/bench.py:118-137)")
     ap.add_argument("--profile-only", action="store_true",
                     help="stop after the timed region + the isolated stages (profiler runs)")
@@ -1690,6 +1692,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     got = out_dev.cpu().numpy()
+    got_all = [b_["out"].cpu().numpy() for b_ in batches]      # every distinct batch of the timed region
 
     do_shard = args.shard == "lists" or (args.shard == "auto" and world > 1)
     # N = 1, default workload: the list-sharded leg as a ONE-rank rehearsal, every exchange through RCCL
@@ -1814,13 +1817,50 @@ def main():
             heap_parity = {"queries": hs, "identical_probe_lists": same_p, "identical_heap_arrays": same_h}
         else:
             ox = oracle_index(ivf)
-        tc = time.perf_counter()
-        want = ox.query_batch(qn[:cs], args.k, args.n_probes)
-        tcpu = time.perf_counter() - tc
+        # The sample: the distinct batches of the timed region (their rows as the timed region left them), then further
+        # batches of the same generator answered by the same pipelined calls — --cpu-sample queries in all (default
+        # 120 000: ~10 s of one host core), EVERY row compared.
+        cs_all = cs if args.workload == "c5" else max(1, args.cpu_sample)
+        n_b = (cs_all + args.nq - 1) // args.nq
+        sample_q, sample_got = [], []
+        extra = []
+        for b_ in range(n_b):
+            m = min(args.nq, cs_all - b_ * args.nq)
+            if b_ < N_BATCHES:
+                sample_q.append(batches[b_]["qn"][:m])
+                sample_got.append((got if b_ == 0 else got_all[b_])[:m])
+            else:
+                qn_x, qp_x = ivf._prepare(make_batch(b_).copy())
+                extra.append(dict(m=m, qn=qn_x, q_dev=torch.from_numpy(qn_x).to(device),
+                                  qp_dev=torch.from_numpy(np.ascontiguousarray(qp_x)).to(device),
+                                  out=torch.full((args.nq, args.k), -1, dtype=torch.int64, device=device)))
+        if extra:
+            dev.set_pipeline(args.pipeline)
+            dev.set_coalesce(args.coalesce if args.pipeline > 1 else 1)
+            for x in extra:
+                dev.query_batch_dev(x["q_dev"].data_ptr(), x["qp_dev"].data_ptr(), qp_is_f64, args.nq, args.k,
+                                    args.n_probes, x["out"].data_ptr(), stream=stream)
+            dev.join(stream)
+            torch.cuda.synchronize()
+            for x in extra:
+                sample_q.append(x["qn"][:x["m"]])
+                sample_got.append(x["out"].cpu().numpy()[:x["m"]])
+            del extra
+        tcpu, same_rows, want = 0.0, 0, None
+        for q_b, g_b in zip(sample_q, sample_got):
+            tc = time.perf_counter()
+            want_b = ox.query_batch(q_b, args.k, args.n_probes)
+            tcpu += time.perf_counter() - tc
+            same_rows += int((want_b == g_b).all(axis=1).sum())
+            if want is None:
+                want = want_b
+        cs = sum(len(q_b) for q_b in sample_q)
         cpu = {"value": cs / tcpu, "unit": "queries/s", "cores": 1, "kind": "port",
-               "sample": f"first {cs} queries of the same batch, oracle/tinyknn_oracle.c "
-                         f"(AVX2 pshufb scan + sequential heap), {tcpu:.2f}s"}
-        parity = {"queries_checked": cs, "identical_rows": int((want == got[:cs]).all(axis=1).sum())}
+               "sample": (f"first {cs} queries of the same batch" if n_b == 1 else
+                          f"{cs} queries = {n_b} batches of the same workload (the {min(n_b, N_BATCHES)} distinct batches of "
+                          f"the timed region{'' if n_b <= N_BATCHES else ' + %d more of the same generator' % (n_b - N_BATCHES)})") +
+                         f", oracle/tinyknn_oracle.c (AVX2 pshufb scan + sequential heap), {tcpu:.2f}s"}
+        parity = {"queries_checked": cs, "identical_rows": same_rows}
         if heap_parity:
             parity.update(heap_parity)
         # like-for-like with examples/bench.py:118-137: ONE Python-level query() per query
@@ -1851,7 +1891,7 @@ def main():
                 t_q1 = (time.perf_counter() - t1) / nq1
                 same1 = 0
                 for i in range(nq1):
-                    w1 = want[i] if i < cs else ox.query(qn[i], args.k, args.n_probes)
+                    w1 = want[i] if i < len(want) else ox.query(qn[i], args.k, args.n_probes)
                     w1 = np.asarray(w1)
                     g1 = np.asarray(got1[i])
                     w1 = w1[w1 != -1] if len(g1) < args.k else w1
