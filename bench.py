@@ -240,7 +240,7 @@ def synth_cached(args):
             X = np.load(path)
             if X.shape == (args.n, args.d) and X.dtype == np.float32:
                 return X, cent
-        except (OSError, ValueError):
+        except Exception:      # noqa: BLE001 - a damaged cache file is regenerated, whatever numpy says about it
             pass
     X, cent = synth(args.n, 0, args.d, args.seed, kind=args.data)
     save_atomic(path, lambda f: np.save(f, X))
@@ -1208,6 +1208,12 @@ def roofline_entry(args, M, pst, plain_ms, stages, iso_stages, scan_bytes, n_pro
                          "the first lists + whole lists of the queries that stay exact + the coarse scan — at the issue "
                          "rate measured for this instruction mix (profiles/r02_valu_issue_rate_microbench.txt)"
                          % (args.nq * lb)}
+    if exact and exact["frac"] and exact["frac"] > 1.0:
+        # the PMC child run and the kernel-trace child run did not launch the same thing (a batch cut into sub-batches:
+        # the trace's average is over launches of different sizes) — no fraction is formed from the two
+        exact["frac_not_formed"] = ("instructions of one launch of the PMC run against the average duration of the "
+                                    "trace run's launches, which differ in size: %.2f" % exact["frac"])
+        exact["frac"] = None
     common = {"traffic_source": traffic_src, "device_copy_GBps_measured": copy_gbps,
               "device_read_GBps_measured": read_gbps, "launches_timed": n_prof,
               "launch_covers": "%d step(s) = %d queries" % (lb, args.nq * lb),

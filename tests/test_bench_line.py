@@ -99,3 +99,32 @@ def test_emit_prints_the_detail_first_and_the_compact_line_last(tmp_path):
     check(last, full)
     with open(tmp_path / "detail.json") as f:
         assert json.load(f)["list_sharded"]["queries_per_s"] == full["list_sharded"]["queries_per_s"]
+
+
+def test_bench_caches_round_trip(tmp_path):
+    """The index / rows caches of bench.py: written by rename (no half-written file is ever visible under the final
+    name), rows read back equal to synth()'s, a damaged or mis-shaped file regenerated instead of trusted."""
+    import argparse
+    import numpy as np
+    import bench
+    a = argparse.Namespace(cache_dir=str(tmp_path), n=3000, d=20, seed=10, data="glove-like")
+    X1, c1 = bench.synth_cached(a)
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert files == ["tinyknn_bench_rows_n3000_d20_s10_glove-like.npy"], files      # (no .tmp left behind)
+    X2, c2 = bench.synth_cached(a)
+    X3, c3 = bench.synth(a.n, 0, a.d, a.seed, kind=a.data)
+    assert np.array_equal(X1, X3) and np.array_equal(X2, X3) and np.array_equal(c1, c3) and np.array_equal(c2, c3)
+    # a file of another shape under the same name (a stale cache) is not trusted
+    np.save(tmp_path / files[0], np.zeros((5, 5), dtype=np.float32))
+    X4, _ = bench.synth_cached(a)
+    assert np.array_equal(X4, X3)
+    # a truncated file neither
+    (tmp_path / files[0]).write_bytes(b"\x93NUMPY\x01\x00garbage")
+    X5, _ = bench.synth_cached(a)
+    assert np.array_equal(X5, X3)
+    # save_atomic: a failing writer leaves neither the final name nor the private one
+    def boom(f):
+        f.write(b"half")
+        raise OSError("disk full")
+    bench.save_atomic(str(tmp_path / "x.bin"), boom)
+    assert not (tmp_path / "x.bin").exists() and not list(tmp_path.glob("x.bin.*"))
