@@ -306,21 +306,25 @@ def build_index(args, device, X=None):
     ang = args.metric == "angular"
     ivf = IVF(args.metric, args.n_clusters, FastPQ(2))
     if os.path.exists(cache):
-        z = np.load(cache)
-        ivf.pq.centers = z["pq_centers"]
-        ivf.pq.sqrt_n_blocks = float(z["sqrt_n_blocks"])
-        ivf.pq.R = z["R"] if "R" in z else None
-        ivf.active_centers = z["active_centers"]
-        ivf.pq_transformed_centers = TransformedData(int(z["center_size"]), z["center_codes"])
-        sizes, codes, ids = z["list_sizes"], z["list_codes"], z["ids"]      # (an NpzFile reads the member at EVERY z[...])
-        coff = np.concatenate([[0], np.cumsum((sizes + 15) // 16)])
-        ioff = np.concatenate([[0], np.cumsum(sizes)])
-        ivf.pq_transformed_points = [TransformedData(int(sizes[i]), codes[coff[i]:coff[i + 1]])
-                                     for i in range(len(sizes))]
-        ivf.ids = [ids[ioff[i]:ioff[i + 1]] for i in range(len(sizes))]
-        ivf.data = X / np.linalg.norm(X, axis=1, keepdims=True) if ang else X
-        log(f"[bench] index loaded from {cache}")
-        return ivf, cent
+        try:
+            z = np.load(cache)
+            ivf.pq.centers = z["pq_centers"]
+            ivf.pq.sqrt_n_blocks = float(z["sqrt_n_blocks"])
+            ivf.pq.R = z["R"] if "R" in z else None
+            ivf.active_centers = z["active_centers"]
+            ivf.pq_transformed_centers = TransformedData(int(z["center_size"]), z["center_codes"])
+            sizes, codes, ids = z["list_sizes"], z["list_codes"], z["ids"]      # (an NpzFile reads the member at EVERY z[...])
+            coff = np.concatenate([[0], np.cumsum((sizes + 15) // 16)])
+            ioff = np.concatenate([[0], np.cumsum(sizes)])
+            ivf.pq_transformed_points = [TransformedData(int(sizes[i]), codes[coff[i]:coff[i + 1]])
+                                         for i in range(len(sizes))]
+            ivf.ids = [ids[ioff[i]:ioff[i + 1]] for i in range(len(sizes))]
+            ivf.data = X / np.linalg.norm(X, axis=1, keepdims=True) if ang else X
+            log(f"[bench] index loaded from {cache}")
+            return ivf, cent
+        except Exception as e:      # noqa: BLE001 - a damaged cache file: fit and build again
+            log(f"[bench] cache {cache} not usable ({e!r}): building")
+            ivf = IVF(args.metric, args.n_clusters, FastPQ(2))
     t0 = time.time()
     rng = np.random.RandomState(args.seed + 1)
     sample = X[rng.choice(len(X), min(len(X), args.fit_sample), replace=False)]
