@@ -127,6 +127,12 @@ def compact_line(line, detail_file=None):
                 k.startswith("rank_share_W") or k.startswith("roofline_") or k.startswith("list_sharded_")
                 or k.startswith("raw_in_ids_out") or k.startswith("query1_")):
             out[k] = _r(v)
+    hs = line.get("roofline_hbm_scale")
+    if isinstance(hs, dict) and hs.get("frac") is not None:
+        # the exact code scan where it streams HBM (1 GiB of codes, one query: every byte fetched once): GB/s and the fraction
+        # of the 8 TB/s peak (north_star's ">= 60 % on the code-scan kernel" reads on this shape)
+        out["scan_hbm_stream"] = {"GBps": _r(hs.get("GBps"), 5), "frac": _r(hs.get("frac"), 4),
+                                  "frac_of_read_only_kernel": _r(hs.get("frac_of_measured_read_only_kernel"), 4)}
     g = line.get("hipgraph")
     if isinstance(g, dict) and g.get("queries_per_s") and line.get("value"):
         out["hipgraph_queries_per_s"] = _r(g["queries_per_s"])
@@ -158,7 +164,7 @@ def compact_line(line, detail_file=None):
         out["query1"] = _pick(q1, "ms_per_query", "queries_per_s", "identical_rows", "rows", "cpu_oracle_ms_per_query", nd=4)
     out["detail"] = detail_file
     # hard guard: drop optional keys, least important first, until the line fits
-    for drop in ("sweep_points", "query1", "replica", "list_sharded", "hipgraph_identical_to_stream_launch",
+    for drop in ("sweep_points", "query1", "scan_hbm_stream", "replica", "list_sharded", "hipgraph_identical_to_stream_launch",
                  "hipgraph_queries_per_s", "detail"):
         if len(json.dumps(out, allow_nan=False)) <= COMPACT_LIMIT:
             break
