@@ -1391,7 +1391,7 @@ def main():
     ap.add_argument("--warmup-seconds", type=float, default=0.5,
                     help="warm up for at least this long, whatever --warmup says")
     ap.add_argument("--windows", type=int, default=0,
-                    help="windows of --steps steps in the timed region (0: ~600 steps in all, 3..15 windows); "
+                    help="windows of --steps steps in the timed region (0: ~2400 steps in all, 3..61 windows); "
                          "ms_per_step is the median window")
     ap.add_argument("--data-file", default=None,
                     help=".npy of float vectors (GloVe-100, SIFT-1M ...): the protocol of examples/bench.py:67-70 "
@@ -1547,7 +1547,10 @@ def main():
     # one) — the windows behind the first measure what a server that keeps submitting sustains,
     # the whole-region figure (fill and drain included) is reported beside it as `drained`.
     K = args.steps
-    n_win = args.windows if args.windows > 0 else max(3, min(15, -(-600 // K)))
+    # (round 6: ~2 400 steps — 61 windows of the driver's 20 — instead of ~600: the four streams fall into and out of a slower
+    #  phase that lasts 40-100+ ms at a time; the median of half a second sees both where 0.12 s saw one)
+    target_steps = 600 if args.workload == "c5" else 2400
+    n_win = args.windows if args.windows > 0 else max(3, min(61, -(-target_steps // K)))
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
     for e in evs:
         e.record()              # materialises the HIP event; the library re-records it
