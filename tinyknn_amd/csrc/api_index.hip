@@ -1610,8 +1610,12 @@ static int query_batch_dev_impl(tk_index *ix, const float *q_dev, const void *q_
         return coalesce_call(ix, p, q_dev, q_pq_dev, q_pq_is_f64, nq, k, n_probes, pass_1, out_ids_dev,
                              out_ids_pinned, done_ev, caller);
     if (ix->held) TRY(launch_held(ix));
-    for (int64_t o = 0; o < nq; o += ms) {
-        int64_t sub = nq - o < ms ? nq - o : ms;
+    // a batch beyond one workspace goes in EQUAL parts (30 000 queries at 100M x 128, 22 500 to a workspace: 2 x 15 000,
+    // not 22 500 + 7 500 — the small rest fell below the list-major scan's threshold and took the query-major kernel)
+    const int64_t parts = nq > ms ? (nq + ms - 1) / ms : 1;
+    const int64_t part = (nq + parts - 1) / parts;
+    for (int64_t o = 0; o < nq; o += part) {
+        int64_t sub = nq - o < part ? nq - o : part;
         Work &w = ix->works[ix->calls % ix->works.size()];
         Pending b;
         b.w = &w;
