@@ -190,7 +190,9 @@ int tk_index_query_batch(tk_index *ix, const float *q, const void *q_pq, int q_p
                          int64_t *out_probes, int64_t *out_heap_idx, int32_t *out_heap_val);
 
 /* Same with device-resident inputs/outputs, enqueued on `stream`, no sync.  Large
- * batches are processed in sub-batches whose distance buffers stay under 16 GB (TINYKNN_WORKSPACE_GB).
+ * batches are processed in sub-batches whose distance buffers stay under 16 GB (TINYKNN_WORKSPACE_GB):
+ * EQUAL parts of at most tk_index_max_sub_batch queries, each through the pipeline by itself (calls that fit one
+ * workspace are what pairs up under tk_index_set_coalesce).
  * An index handle serves one caller at a time: its entry points take a per-handle lock, so
  * calls from several threads are serialised (the reference's kernels are nogil and re-entrant
  * on distinct buffers; use one handle per thread for concurrency). */
