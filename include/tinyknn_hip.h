@@ -320,8 +320,8 @@ int tk_index_plain_stats(tk_index *ix, int64_t *out8);
  *                        only its own lists' codes (tk_index_set_lists_shard) cannot, and uses the table only behind
  *                        1 = "the caller has checked" (tinyknn_amd.DeviceIndex does, on the host).  0 (DEFAULT). */
 #define TK_OPT_TWIN_VOUCH 7
-/*   TK_OPT_PAIR_NQ       batches of up to this many queries (DEFAULT 8192 one batch at a time, at most 256 in pipelined
- *                        mode; 0 = never; environment TINYKNN_PAIR_NQ sets the default of new indexes) replay their heaps
+/*   TK_OPT_PAIR_NQ       batches of up to this many queries (DEFAULT 8192 one batch at a time, at most 4096 per launch — a pair
+ *                        of calls of 2048 — in pipelined mode; 0 = never; environment TINYKNN_PAIR_NQ sets the default of new indexes) replay their heaps
  *                        one query per WAVE with the heap in registers, two / four / eight nodes per lane (heaps of <= 129 /
  *                        257 / 513 entries: IVF.query's 111 and its coarse top's 30 at the reference's bench settings,
  *                        examples/bench.py:118-137): one query per call is ~760 dependent inserts, 0.47 of 0.54 ms in the

@@ -34,12 +34,17 @@ def setup(oracle):
     return torch, out
 
 
+@pytest.mark.parametrize("pair_nq", [4, 8192])
 @pytest.mark.parametrize("tag", ["an100", "eu64"])
-def test_pairs_of_calls_are_the_rows_of_separate_calls(setup, tag):
+def test_pairs_of_calls_are_the_rows_of_separate_calls(setup, tag, pair_nq):
+    """pair_nq: the suite's default (4: the lane kernels replay) and the product's (8192: launches of up to 4 096 queries
+    — every pair here — replay through the register heap with batches in flight)."""
+    from tinyknn_amd import _lib
     torch, fx = setup
     ivf, ox, qn, qp = fx[tag]
     f64 = qp.dtype != np.float32
     dev = ivf.device_index()
+    dev.set_option(_lib.OPT_PAIR_NQ, pair_nq)
     dev.set_pipeline(2)
     dev.set_coalesce(2)
     st = torch.cuda.current_stream().cuda_stream
@@ -81,6 +86,7 @@ def test_pairs_of_calls_are_the_rows_of_separate_calls(setup, tag):
         torch.cuda.synchronize()
         np.testing.assert_array_equal(o.cpu().numpy(), want[p][a:b])
     dev.set_pipeline(1)
+    dev.set_option(_lib.OPT_PAIR_NQ, 4)
 
 
 def test_streaming_session_over_a_coalescing_index(setup):

@@ -360,9 +360,13 @@ static bool pair_replay(const tk_index *ix, int64_t nq, int R)
     // One batch at a time the register heap wins up to ~10 000 queries (8 000: 0.30 against 0.69 ms,
     // profiles/r06/query1_and_small_batches.txt) — but it fills every SIMD's issue slots, where the lane kernel leaves
     // the chip to the scans of the batches beside it: with batches in flight (pipelined mode) the headline batch LOSES
-    // 38 % on it (25.9 -> 16.1 M queries/s).  So: the option's value one batch at a time, at most 256 when pipelined (default 8192: 8 000 queries 0.30 against 0.69 ms).
+    // 38 % on it (25.9 -> 16.1 M queries/s).  With batches in flight it pays up to ~4 000 queries per LAUNCH (a pair of
+    // calls of 2 000): calls of 500 / 1 000 / 2 000 queries 2.7 -> 7.3, 5.1 -> 11.6, 9.5 -> 14.1 M queries/s, calls of
+    // 4 000 (launches of 8 000) 15.9 -> 15.5 (profiles/r06/queries_per_call_sweep.txt).  So: the option's value one
+    // batch at a time (default 8 192), at most 4 096 per launch when pipelined (TINYKNN_PAIR_NQ_PIPE: A/B).
     // (a list-sharded index's depth is its number of workspace slots: the caller's batches, the option's value)
-    const int64_t limit = ix->depth > 1 && !ix->sharded ? (ix->opt_pair_nq < 256 ? ix->opt_pair_nq : 256) : ix->opt_pair_nq;
+    static const int64_t pipe_cap = [] { const char *e = getenv("TINYKNN_PAIR_NQ_PIPE"); return e ? atoll(e) : 4096ll; }();
+    const int64_t limit = ix->depth > 1 && !ix->sharded ? (ix->opt_pair_nq < pipe_cap ? ix->opt_pair_nq : pipe_cap) : ix->opt_pair_nq;
     return ix->heap_mode == 0 && nq <= limit;
 }
 

@@ -632,7 +632,7 @@ class DeviceIndex:
 
     def set_option(self, option, value):
         """Per-index A/B and test options (tk_index_set_option): _lib.OPT_PAIR_NQ (batches of up to this many queries
-        replay their heaps one query per wave, heap in registers: 8192 one batch at a time, at most 256 pipelined),
+        replay their heaps one query per wave, heap in registers: 8192 one batch at a time, at most 4096 per launch pipelined),
         _lib.OPT_LABELS24, _lib.OPT_SCAN_FORM,
         _lib.OPT_RESCORE_FORM, _lib.OPT_PLAIN_LIMIT, _lib.OPT_REPLAY_LAZY, _lib.OPT_REPLAY_COUNT,
         _lib.OPT_REPLAY_TWIN."""
