@@ -1,3 +1,5 @@
+# small pipelined calls (500 ... 4 000 queries per call, pairs of calls per launch): the register heap's limit with batches in flight,
+# 256 (until round 6) against 8 192, in turn (TINYKNN_PAIR_NQ_PIPE); the default became 4 096 per launch
 O=gpurun_out/r06; mkdir -p $O
 FLAGS="--steps 20 --warmup 5 --sweep none --traffic none --no-hbm-leg --shard none --cpu-sample 2000"
 for nq in 500 1000 2000 4000; do for cap in 256 8192 256 8192; do
